@@ -1,0 +1,128 @@
+"""ctypes binding of libcdrl_hip.so (C ABI in include/cdrl.h).
+
+The product path has NO CPU fallback: if the HIP library is missing the import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcdrl_hip.so')
+
+
+class CdrlError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('road', C.c_int32), ('vehicle', C.c_int32), ('navigation', C.c_int32), ('A', C.c_int32),
+                ('stem', C.c_int32), ('stage_c', C.c_int32 * 3), ('stage_n', C.c_int32 * 3), ('last', C.c_int32),
+                ('feat', C.c_int32), ('rnn_image', C.c_int32), ('rnn_small', C.c_int32), ('dyn', C.c_int32),
+                ('head', C.c_int32), ('exp_scale', C.c_float)]
+
+
+class ParamInfo(C.Structure):
+    _fields_ = [('name', C.c_char * 64), ('shape', C.c_int32 * 4), ('ndim', C.c_int32), ('trainable', C.c_int32),
+                ('numel', C.c_int64), ('offset', C.c_int64)]
+
+
+class HParams(C.Structure):
+    _fields_ = [('policy_lr', C.c_float), ('value_lr', C.c_float), ('dynamics_lr', C.c_float),
+                ('clip_ratio', C.c_float), ('entropy_coef', C.c_float), ('clip_norm_policy', C.c_float),
+                ('clip_norm_value', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float)]
+
+
+_fp = C.c_void_p   # device pointers travel as plain addresses
+
+
+class PolicyBatch(C.Structure):
+    _fields_ = [(n, _fp) for n in ('image', 'road', 'vehicle', 'navigation', 'advantages', 'old_log_prob', 'speed',
+                                   'similarity', 'u', 'du_dalpha', 'du_dbeta')]
+
+
+class ValueBatch(C.Structure):
+    _fields_ = [(n, _fp) for n in ('image', 'road', 'vehicle', 'navigation', 'returns', 'speed', 'similarity')]
+
+
+TRUNK, POLICY, VALUE, OLD_POLICY = 0, 1, 2, 3
+BUF_DYNAMICS, BUF_IMG_FEAT, BUF_METRICS_P, BUF_METRICS_V, BUF_AUX_P, BUF_AUX_V, BUF_LIN_P, BUF_LIN_V = range(8)
+
+_i, _i64, _f, _d, _sz = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+_L = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/cdrl.h
+PROTOTYPES = {
+    'cdrl_last_error': (C.c_char_p, []),
+    'cdrl_version': (_i, []),
+    'cdrl_config_default': (None, [C.POINTER(Config)]),
+    'cdrl_learner_create': (_i, [C.POINTER(Config), C.POINTER(_L)]),
+    'cdrl_learner_destroy': (None, [_L]),
+    'cdrl_learner_param_count': (_i, [_L, _i]),
+    'cdrl_learner_param_info': (_i, [_L, _i, _i, C.POINTER(ParamInfo)]),
+    'cdrl_learner_region_offset': (_i64, [_L, _i, _i]),
+    'cdrl_learner_region_elems': (_i64, [_L, _i, _i]),
+    'cdrl_learner_params_total': (_i64, [_L]),
+    'cdrl_learner_grads_total': (_i64, [_L]),
+    'cdrl_learner_workspace_bytes': (_sz, [_L]),
+    'cdrl_learner_bind': (_i, [_L, _fp, _fp, _fp, _fp, _fp, _sz]),
+    'cdrl_learner_set_hparams': (_i, [_L, C.POINTER(HParams), _fp]),
+    'cdrl_learner_reset_optimizer_steps': (_i, [_L, _fp]),
+    'cdrl_learner_policy_forward_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
+    'cdrl_learner_policy_apply': (_i, [_L, _fp]),
+    'cdrl_learner_value_forward_backward': (_i, [_L, C.POINTER(ValueBatch), _f, _fp]),
+    'cdrl_learner_value_apply': (_i, [_L, _fp]),
+    'cdrl_learner_update_old_policy': (_i, [_L, _fp]),
+    'cdrl_learner_predict': (_i, [_L, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    'cdrl_learner_trunk_forward_train': (_i, [_L, _fp, _fp, _fp, _fp, _fp]),
+    'cdrl_learner_get_buffer': (_i, [_L, _i, C.POINTER(_fp), C.POINTER(_i64)]),
+    'cdrl_gae_returns': (_i, [_fp, _fp, _i, _d, _d, _f, _fp, _fp, _fp, _fp, _fp, _fp]),
+    'cdrl_gemm_nn': (_i, [_fp, _i, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
+    'cdrl_gemm_tn_workspace_elems': (_i64, [_i, _i, _i]),
+    'cdrl_gemm_tn': (_i, [_fp, _i, _i, _fp, _i, _i, _fp, _i, _i, _i, _fp, _i, _fp]),
+    'cdrl_stem_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),
+    'cdrl_stem_bwd_workspace_doubles': (_i64, [_i, _i, _i, _i, _i]),
+    'cdrl_stem_bwd_filter': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp]),
+    'cdrl_dwconv_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),
+    'cdrl_dwconv_bwd_data': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),
+    'cdrl_dwconv_bwd_workspace_doubles': (_i64, [_i, _i, _i, _i, _i]),
+    'cdrl_dwconv_bwd_filter': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp]),
+    'cdrl_maxpool_fwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    'cdrl_maxpool_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    'cdrl_bn_train_fwd': (_i, [_fp, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _fp, _fp, _fp]),
+    'cdrl_bn_train_bwd': (_i, [_fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
+    'cdrl_beta_ppo_loss': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _f, _fp, _fp, _fp, _fp, _fp]),
+    'cdrl_value_loss': (_i, [_fp, _fp, _fp, _fp, _i, _f, _f, _fp, _fp, _fp, _fp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libcdrl_hip.so; raises ImportError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950). There is no CPU fallback for the learner hot path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().cdrl_last_error()
+        raise CdrlError(f'{what} failed (rc={rc}): {msg.decode() if msg else ""}')
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,373 @@
+// BatchNorm family + small elementwise kernels (gfx950).
+//
+// Reference semantics: Keras BatchNormalization applied **per time slice** with shared
+// gamma/beta (reference core/architectures.py:44-57).  Rows of one time
+// slice are contiguous (frame order f = t*B + b), so a statistics group is a row range.
+//
+// All kernels here are HBM-bound column-mapped streams: blockDim = (CX channel lanes, CY row
+// lanes); consecutive lanes touch consecutive channels of one NHWC pixel (coalesced), and the
+// per-channel reductions finish with an LDS tree over the CY row lanes.  Partial sums are kept
+// in double so that E[x^2]-E[x]^2 and the (sum dz, sum dz*xhat) pair are exact to fp32 output
+// precision and bit-wise deterministic (fixed reduction order, no atomics).
+#include "colreduce.h"
+
+namespace cdrl {
+
+#define BN_EPS 1e-3f
+
+struct StatsF {
+    View y;
+    __device__ void operator()(int, int64_t row, int c, double* acc) const {
+        double v = (double)y.p[row * y.ld + y.coff + c];
+        acc[0] += v;
+        acc[1] += v * v;
+    }
+};
+
+int colstats(View y, int G, int Mg, int C, double* part, hipStream_t st) {
+    StatsF f{y};
+    return launch_colreduce<2>(f, G, Mg, C, part, st);
+}
+
+struct SumF {
+    View x;
+    __device__ void operator()(int, int64_t row, int c, double* acc) const {
+        acc[0] += (double)x.p[row * x.ld + x.coff + c];
+    }
+};
+
+int colsum(View x, int rows, int C, double* part, hipStream_t st) {
+    SumF f{x};
+    return launch_colreduce<1>(f, 1, rows, C, part, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward finalize: stats[0]=mean, [1]=invstd, [2]=scale, [3]=shift, each [G][C]
+// ------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ mov_mean, float* __restrict__ mov_var, int bessel,
+                                   int training, float* __restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float gm = gamma[c], bt = beta[c];
+    const int GC = G * C;
+    if (!training) {
+        const float mean = mov_mean[c];
+        const float invstd = (float)(1.0 / sqrt((double)mov_var[c] + (double)BN_EPS));
+        for (int g = 0; g < G; ++g) {
+            stats[0 * GC + g * C + c] = mean;
+            stats[1 * GC + g * C + c] = invstd;
+            stats[2 * GC + g * C + c] = gm * invstd;
+            stats[3 * GC + g * C + c] = bt - mean * gm * invstd;
+        }
+        return;
+    }
+    float mm = mov_mean[c], mv = mov_var[c];
+    const double n = (double)Mg;
+    const float corr = (bessel && Mg > 1) ? (float)(n / (n - 1.0)) : 1.0f;
+    for (int g = 0; g < G; ++g) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            s += part[(((int64_t)g * nb + b) * 2 + 0) * C + c];
+            q += part[(((int64_t)g * nb + b) * 2 + 1) * C + c];
+        }
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float meanf = (float)mean, varf = (float)var;
+        const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+        stats[0 * GC + g * C + c] = meanf;
+        stats[1 * GC + g * C + c] = invstd;
+        stats[2 * GC + g * C + c] = gm * invstd;
+        stats[3 * GC + g * C + c] = bt - meanf * gm * invstd;
+        // Keras: moving -= (moving - value) * (1 - momentum), once per time slice (t ascending)
+        mm = mm - (mm - meanf) * 0.01f;
+        mv = mv - (mv - varf * corr) * 0.01f;
+    }
+    mov_mean[c] = mm;
+    mov_var[c] = mv;
+}
+
+int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* gamma, const float* beta,
+                float* mov_mean, float* mov_var, int bessel, int training, float* stats, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, part, nb, G, Mg, C, gamma, beta,
+                       mov_mean, mov_var, bessel, training, stats);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward apply
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float apply_act(float z, int act) {
+    if (act == ACT_RELU6) return fminf(fmaxf(z, 0.0f), 6.0f);
+    return z;
+}
+
+__global__ void __launch_bounds__(256) bn_apply_kernel(View y, int Mg, int C, int rb, int GC,
+                                                       const float* __restrict__ stats, int act, View dst,
+                                                       int shuffle_ctot) {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int g = blockIdx.y;
+    const int r0 = blockIdx.x * rb;
+    const int r1 = min(r0 + rb, Mg);
+    for (int c = tx; c < C; c += CX) {
+        float sc = 1.0f, sh = 0.0f;
+        if (stats) {
+            sc = stats[2 * GC + g * C + c];
+            sh = stats[3 * GC + g * C + c];
+        }
+        int dc = dst.coff + c;
+        if (shuffle_ctot) dc = shuffle_dst(dc, shuffle_ctot);
+        for (int r = r0 + ty; r < r1; r += CY) {
+            const int64_t row = (int64_t)g * Mg + r;
+            const float v = y.p[row * y.ld + y.coff + c];
+            dst.p[row * dst.ld + dc] = apply_act(fmaf(sc, v, sh), act);
+        }
+    }
+}
+
+int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
+             hipStream_t st) {
+    ColGeom g = col_geom(Mg, C, 1024);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(g.nb, G), dim3(g.cx, g.cy), 0, st, y, Mg, C, g.rb, G * C, stats, act,
+                       dst, shuffle_ctot);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+struct BnBwdReduceF {
+    View da;
+    int shuffle_ctot;
+    View y;
+    const float* stats;
+    int GC, C, act;
+    __device__ void operator()(int g, int64_t row, int c, double* acc) const {
+        int dc = da.coff + c;
+        if (shuffle_ctot) dc = shuffle_dst(dc, shuffle_ctot);
+        float d = da.p[row * da.ld + dc];
+        const float v = y.p[row * y.ld + y.coff + c];
+        const float mean = stats[0 * GC + g * C + c], invstd = stats[1 * GC + g * C + c];
+        if (act == ACT_RELU6) {
+            const float z = fmaf(stats[2 * GC + g * C + c], v, stats[3 * GC + g * C + c]);
+            if (!(z > 0.0f && z < 6.0f)) d = 0.0f;
+        }
+        const float xh = (v - mean) * invstd;
+        acc[0] += (double)d;
+        acc[1] += (double)d * (double)xh;
+    }
+};
+
+int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
+                  double* part, hipStream_t st) {
+    BnBwdReduceF f{da, shuffle_ctot, y, stats, G * C, C, act};
+    return launch_colreduce<2>(f, G, Mg, C, part, st);
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
+                                       const float* __restrict__ stats, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int GC = G * C;
+    double dg = 0.0, db = 0.0;
+    const double n = (double)Mg;
+    for (int g = 0; g < G; ++g) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            s += part[(((int64_t)g * nb + b) * 2 + 0) * C + c];
+            q += part[(((int64_t)g * nb + b) * 2 + 1) * C + c];
+        }
+        db += s;
+        dg += q;
+        coef[0 * GC + g * C + c] = stats[2 * GC + g * C + c];   // k1 = gamma * invstd
+        coef[1 * GC + g * C + c] = (float)(s / n);              // k2 = mean(dz)
+        coef[2 * GC + g * C + c] = (float)(q / n);              // k3 = mean(dz * xhat)
+    }
+    dgamma[c] = (float)dg;      // shared gamma/beta: summed over the T applications (Appendix E)
+    dbeta[c] = (float)db;
+}
+
+int bn_bwd_finalize(const double* part, int nb, int G, int Mg, int C, const float* stats, float* dgamma,
+                    float* dbeta, float* coef, hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, part, nb, G, Mg, C, stats, dgamma,
+                       dbeta, coef);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+struct BnBwdApplyF {
+    View da;
+    int shuffle_ctot;
+    View y;
+    const float* stats;
+    const float* coef;
+    int GC, C, act;
+    float* dy;
+    __device__ void operator()(int g, int64_t row, int c, double* acc) const {
+        int dc = da.coff + c;
+        if (shuffle_ctot) dc = shuffle_dst(dc, shuffle_ctot);
+        float d = da.p[row * da.ld + dc];
+        const float v = y.p[row * y.ld + y.coff + c];
+        const float mean = stats[0 * GC + g * C + c], invstd = stats[1 * GC + g * C + c];
+        if (act == ACT_RELU6) {
+            const float z = fmaf(stats[2 * GC + g * C + c], v, stats[3 * GC + g * C + c]);
+            if (!(z > 0.0f && z < 6.0f)) d = 0.0f;
+        }
+        const float xh = (v - mean) * invstd;
+        const float k1 = coef[0 * GC + g * C + c], k2 = coef[1 * GC + g * C + c], k3 = coef[2 * GC + g * C + c];
+        const float o = k1 * (d - k2 - xh * k3);
+        dy[row * C + c] = o;
+        acc[0] += (double)o;
+    }
+};
+
+int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, const float* coef,
+                 int act, float* dy, double* part2, hipStream_t st) {
+    BnBwdApplyF f{da, shuffle_ctot, y, stats, coef, G * C, C, act, dy};
+    return launch_colreduce<1>(f, G, Mg, C, part2, st);
+}
+
+__global__ void reduce_partials_kernel(const double* __restrict__ part, int nparts, int n, int64_t stride,
+                                       float* __restrict__ out, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * stride + i];
+    out[i] = accumulate ? out[i] + (float)s : (float)s;
+}
+
+int reduce_partials(const double* part, int nparts, int n, int64_t stride, float* out, int accumulate,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, nparts, n, stride, out,
+                       accumulate);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) gather_view_kernel(View src, int shuffle_ctot, int rows, int C, int rb,
+                                                          View dst, int accumulate) {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int r0 = blockIdx.x * rb;
+    const int r1 = min(r0 + rb, rows);
+    for (int c = tx; c < C; c += CX) {
+        int sc = src.coff + c;
+        if (shuffle_ctot) sc = shuffle_dst(sc, shuffle_ctot);
+        for (int r = r0 + ty; r < r1; r += CY) {
+            const float v = src.p[(int64_t)r * src.ld + sc];
+            float* d = &dst.p[(int64_t)r * dst.ld + dst.coff + c];
+            *d = accumulate ? *d + v : v;
+        }
+    }
+}
+
+int gather_view(View src, int shuffle_ctot, int rows, int C, View dst, int accumulate, hipStream_t st) {
+    ColGeom g = col_geom(rows, C, 4096);
+    hipLaunchKernelGGL(gather_view_kernel, dim3(g.nb), dim3(g.cx, g.cy), 0, st, src, shuffle_ctot, rows, C, g.rb, dst,
+                       accumulate);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// dense activations (relu6 for feature nets, swish6 for the control branches)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void act_fwd_kernel(const float* __restrict__ z, float* __restrict__ a, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = z[i];
+        float o = x;
+        if (act == ACT_RELU6) o = fminf(fmaxf(x, 0.0f), 6.0f);
+        else if (act == ACT_SWISH6) o = fminf(x * sigmoidf_(x), 6.0f);      // rl/utils.py:420-421
+        else if (act == ACT_TANH) o = tanhf(x);
+        else if (act == ACT_SIGMOID) o = sigmoidf_(x);
+        a[i] = o;
+    }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ z, const float* __restrict__ da, float* __restrict__ dz,
+                               int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = z[i];
+        float d = da[i];
+        if (act == ACT_RELU6) {
+            if (!(x > 0.0f && x < 6.0f)) d = 0.0f;
+        } else if (act == ACT_SWISH6) {
+            const float s = sigmoidf_(x);
+            d = (x * s < 6.0f) ? d * (s * (1.0f + x * (1.0f - s))) : 0.0f;
+        } else if (act == ACT_TANH) {
+            const float t = tanhf(x);
+            d *= (1.0f - t * t);
+        } else if (act == ACT_SIGMOID) {
+            const float s = sigmoidf_(x);
+            d *= s * (1.0f - s);
+        }
+        dz[i] = d;
+    }
+}
+
+static inline int flat_grid(int64_t n) {
+    int64_t b = cdiv64(n, 256);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int act_fwd(const float* z, float* a, int64_t n, int act, hipStream_t st) {
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(flat_grid(n)), dim3(256), 0, st, z, a, n, act);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+int act_bwd(const float* z, const float* da, float* dz, int64_t n, int act, hipStream_t st) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(flat_grid(n)), dim3(256), 0, st, z, da, dz, n, act);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+int fill(float* p, int64_t n, float v, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(flat_grid(n)), dim3(256), 0, st, p, n, v);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// (B,T,D) -> rows t*B+b
+__global__ void permute_bt_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int T, int D,
+                                  int inverse) {
+    const int64_t n = (int64_t)B * T * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t bt = i / D;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const int64_t j = ((int64_t)t * B + b) * D + d;
+        if (inverse) dst[i] = src[j];
+        else dst[j] = src[i];
+    }
+}
+
+int permute_bt(const float* src, float* dst, int B, int T, int D, hipStream_t st) {
+    hipLaunchKernelGGL(permute_bt_kernel, dim3(flat_grid((int64_t)B * T * D)), dim3(256), 0, st, src, dst, B, T, D, 0);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+int permute_tb_bwd(const float* src, float* dst, int B, int T, int D, hipStream_t st) {
+    hipLaunchKernelGGL(permute_bt_kernel, dim3(flat_grid((int64_t)B * T * D)), dim3(256), 0, st, src, dst, B, T, D, 1);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cdrl

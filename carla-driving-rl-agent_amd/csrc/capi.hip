@@ -1,0 +1,344 @@
+// extern "C" surface of libcdrl_hip.so (declared in include/cdrl.h).
+#include <string.h>
+
+#include <new>
+
+#include "../../include/cdrl.h"
+#include "engine.h"
+
+using namespace cdrl;
+
+struct cdrl_learner {
+    Learner* impl;
+};
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define CHECK_L(l)                         \
+    if (!(l) || !(l)->impl) {              \
+        cdrl::set_error("null learner");   \
+        return -1;                         \
+    }
+
+extern "C" {
+
+const char* cdrl_last_error(void) { return cdrl::last_error(); }
+int cdrl_version(void) { return CDRL_VERSION; }
+
+void cdrl_config_default(cdrl_config* c) {
+    if (!c) return;
+    Config d;
+    c->B = d.B; c->T = d.T; c->H = d.H; c->W = d.W;
+    c->road = d.road; c->vehicle = d.vehicle; c->navigation = d.navigation; c->A = d.A;
+    c->stem = d.stem;
+    for (int i = 0; i < 3; ++i) { c->stage_c[i] = d.stage_c[i]; c->stage_n[i] = d.stage_n[i]; }
+    c->last = d.last; c->feat = d.feat; c->rnn_image = d.rnn_image; c->rnn_small = d.rnn_small;
+    c->dyn = d.dyn; c->head = d.head; c->exp_scale = d.exp_scale;
+}
+
+int cdrl_learner_create(const cdrl_config* c, cdrl_learner** out) {
+    if (!c || !out) {
+        cdrl::set_error("cdrl_learner_create: null argument");
+        return -1;
+    }
+    if (c->B < 1 || c->T < 1 || c->H < 35 || c->W < 35 || c->A < 1 || c->A > 8) {
+        cdrl::set_error("cdrl_learner_create: bad geometry B=%d T=%d H=%d W=%d A=%d", c->B, c->T, c->H, c->W, c->A);
+        return -1;
+    }
+    for (int i = 0; i < 3; ++i)
+        if (c->stage_c[i] % 4 != 0 || c->stage_n[i] < 1) {
+            cdrl::set_error("cdrl_learner_create: stage channels must be multiples of 4");
+            return -1;
+        }
+    Config d;
+    d.B = c->B; d.T = c->T; d.H = c->H; d.W = c->W;
+    d.road = c->road; d.vehicle = c->vehicle; d.navigation = c->navigation; d.A = c->A;
+    d.stem = c->stem;
+    for (int i = 0; i < 3; ++i) { d.stage_c[i] = c->stage_c[i]; d.stage_n[i] = c->stage_n[i]; }
+    d.last = c->last; d.feat = c->feat; d.rnn_image = c->rnn_image; d.rnn_small = c->rnn_small;
+    d.dyn = c->dyn; d.head = c->head; d.exp_scale = c->exp_scale;
+    cdrl_learner* l = new (std::nothrow) cdrl_learner;
+    if (!l) return -3;
+    l->impl = new (std::nothrow) Learner(d);
+    if (!l->impl) {
+        delete l;
+        return -3;
+    }
+    *out = l;
+    return 0;
+}
+
+void cdrl_learner_destroy(cdrl_learner* l) {
+    if (!l) return;
+    delete l->impl;
+    delete l;
+}
+
+int cdrl_learner_param_count(const cdrl_learner* l, int model) {
+    CHECK_L(l);
+    if (model == CDRL_OLD_POLICY) model = CDRL_POLICY;
+    if (model < 0 || model > 2) return -1;
+    return (int)l->impl->params(model).size();
+}
+
+int cdrl_learner_param_info(const cdrl_learner* l, int model, int index, cdrl_param_info* out) {
+    CHECK_L(l);
+    if (model == CDRL_OLD_POLICY) model = CDRL_POLICY;
+    if (model < 0 || model > 2 || !out) return -1;
+    const auto& v = l->impl->params(model);
+    if (index < 0 || index >= (int)v.size()) {
+        cdrl::set_error("param index %d out of range", index);
+        return -1;
+    }
+    const ParamInfo& p = v[index];
+    memset(out, 0, sizeof(*out));
+    strncpy(out->name, p.name.c_str(), sizeof(out->name) - 1);
+    for (int i = 0; i < 4; ++i) out->shape[i] = p.shape[i];
+    out->ndim = p.ndim;
+    out->trainable = p.trainable;
+    out->numel = p.numel;
+    out->offset = p.off;
+    return 0;
+}
+
+int64_t cdrl_learner_region_offset(const cdrl_learner* l, int model, int trainable) {
+    CHECK_L(l);
+    return trainable ? l->impl->tr_offset(model) : l->impl->st_offset(model);
+}
+
+int64_t cdrl_learner_region_elems(const cdrl_learner* l, int model, int trainable) {
+    CHECK_L(l);
+    if (model == CDRL_OLD_POLICY) model = CDRL_POLICY;
+    return trainable ? l->impl->trainable_elems(model) : l->impl->state_elems(model);
+}
+
+int64_t cdrl_learner_params_total(const cdrl_learner* l) {
+    CHECK_L(l);
+    return l->impl->params_total();
+}
+
+int64_t cdrl_learner_grads_total(const cdrl_learner* l) {
+    CHECK_L(l);
+    return l->impl->grads_total();
+}
+
+size_t cdrl_learner_workspace_bytes(const cdrl_learner* l) {
+    if (!l || !l->impl) return 0;
+    return l->impl->workspace_bytes();
+}
+
+int cdrl_learner_bind(cdrl_learner* l, float* params, float* grads, float* adam_m, float* adam_v, void* workspace,
+                      size_t workspace_bytes) {
+    CHECK_L(l);
+    Buffers b;
+    b.params = params;
+    b.grads = grads;
+    b.adam_m = adam_m;
+    b.adam_v = adam_v;
+    b.workspace = workspace;
+    b.workspace_bytes = workspace_bytes;
+    return l->impl->bind(b);
+}
+
+int cdrl_learner_set_hparams(cdrl_learner* l, const cdrl_hparams* hp, void* stream) {
+    CHECK_L(l);
+    if (!hp) return -1;
+    DevHP* h = l->impl->host_hp();
+    h->lr_policy = hp->policy_lr;
+    h->lr_value = hp->value_lr;
+    h->lr_dynamics = hp->dynamics_lr;
+    h->clip_ratio = hp->clip_ratio;
+    h->entropy_coef = hp->entropy_coef;
+    h->clip_norm_policy = hp->clip_norm_policy;
+    h->clip_norm_value = hp->clip_norm_value;
+    h->beta1 = hp->beta1;
+    h->beta2 = hp->beta2;
+    h->eps = hp->eps;
+    return l->impl->upload_hp(S(stream));
+}
+
+int cdrl_learner_reset_optimizer_steps(cdrl_learner* l, void* stream) {
+    CHECK_L(l);
+    return l->impl->reset_counters(S(stream));
+}
+
+int cdrl_learner_policy_forward_backward(cdrl_learner* l, const cdrl_policy_batch* b, float grad_scale, void* stream) {
+    CHECK_L(l);
+    if (!b) return -1;
+    PolicyBatch pb{b->image, b->road, b->vehicle, b->navigation, b->advantages, b->old_log_prob,
+                   b->speed, b->similarity, b->u, b->du_dalpha, b->du_dbeta};
+    if (!pb.adv || !pb.old_logp || !pb.speed || !pb.similarity || !pb.u) {
+        cdrl::set_error("policy batch: null tensor");
+        return -1;
+    }
+    return l->impl->policy_forward_backward(pb, grad_scale, S(stream));
+}
+
+int cdrl_learner_policy_apply(cdrl_learner* l, void* stream) {
+    CHECK_L(l);
+    return l->impl->policy_apply(S(stream));
+}
+
+int cdrl_learner_value_forward_backward(cdrl_learner* l, const cdrl_value_batch* b, float grad_scale, void* stream) {
+    CHECK_L(l);
+    if (!b) return -1;
+    ValueBatch vb{b->image, b->road, b->vehicle, b->navigation, b->returns, b->speed, b->similarity};
+    if (!vb.returns || !vb.speed || !vb.similarity) {
+        cdrl::set_error("value batch: null tensor");
+        return -1;
+    }
+    return l->impl->value_forward_backward(vb, grad_scale, S(stream));
+}
+
+int cdrl_learner_value_apply(cdrl_learner* l, void* stream) {
+    CHECK_L(l);
+    return l->impl->value_apply(S(stream));
+}
+
+int cdrl_learner_update_old_policy(cdrl_learner* l, void* stream) {
+    CHECK_L(l);
+    return l->impl->update_old_policy(S(stream));
+}
+
+int cdrl_learner_predict(cdrl_learner* l, const float* image, const float* road, const float* vehicle,
+                         const float* navigation, float* dist_out, float* value_out, float* dynamics_out, void* stream) {
+    CHECK_L(l);
+    if (!dist_out || !value_out) return -1;
+    return l->impl->predict(image, road, vehicle, navigation, dist_out, value_out, dynamics_out, S(stream));
+}
+
+int cdrl_learner_trunk_forward_train(cdrl_learner* l, const float* image, const float* road, const float* vehicle,
+                                     const float* navigation, void* stream) {
+    CHECK_L(l);
+    return l->impl->trunk_forward_train(image, road, vehicle, navigation, S(stream));
+}
+
+int cdrl_learner_get_buffer(const cdrl_learner* l, int which, float** ptr, int64_t* elems) {
+    CHECK_L(l);
+    if (!ptr || !elems) return -1;
+    const Config& c = l->impl->config();
+    switch (which) {
+        case CDRL_BUF_DYNAMICS: *ptr = l->impl->dyn_out(); *elems = (int64_t)c.B * c.dyn; break;
+        case CDRL_BUF_IMG_FEAT: *ptr = l->impl->img_feat(); *elems = (int64_t)c.B * c.T * c.last; break;
+        case CDRL_BUF_METRICS_P: *ptr = l->impl->metrics_policy(); *elems = 16; break;
+        case CDRL_BUF_METRICS_V: *ptr = l->impl->metrics_value(); *elems = 16; break;
+        case CDRL_BUF_AUX_P: *ptr = l->impl->policy_aux(); *elems = (int64_t)c.B * 4 * c.A; break;
+        case CDRL_BUF_AUX_V: *ptr = l->impl->value_aux(); *elems = (int64_t)c.B * 2; break;
+        case CDRL_BUF_LIN_P: *ptr = l->impl->policy_lin(); *elems = (int64_t)c.B * (2 * c.A + 2); break;
+        case CDRL_BUF_LIN_V: *ptr = l->impl->value_lin(); *elems = (int64_t)c.B * 4; break;
+        default: cdrl::set_error("unknown buffer id %d", which); return -1;
+    }
+    return 0;
+}
+
+int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double gamma, double lambda, float scale,
+                     float* returns, float* returns_be, float* adv_raw, float* adv, double* scratch, void* stream) {
+    if (!rewards || !values_be || !returns || !returns_be || !adv_raw || !adv || !scratch) {
+        cdrl::set_error("cdrl_gae_returns: null argument");
+        return -1;
+    }
+    return gae_returns(rewards, values_be, N, gamma, lambda, scale, returns, returns_be, adv_raw, adv, scratch, S(stream));
+}
+
+int cdrl_gemm_nn(const float* A, int lda, int a_coff, const float* B, int sbk, int sbn, const float* bias, float* C,
+                 int ldc, int c_coff, int M, int N, int K, int accumulate, void* stream) {
+    return gemm_nn(make_view(const_cast<float*>(A), lda, a_coff), B, sbk, sbn, bias, make_view(C, ldc, c_coff), M, N, K,
+                   accumulate, S(stream));
+}
+
+int64_t cdrl_gemm_tn_workspace_elems(int M, int N, int K) { return gemm_tn_part_elems(M, N, K); }
+
+int cdrl_gemm_tn(const float* A, int lda, int a_coff, const float* D, int ldd, int d_coff, float* out, int M, int N,
+                 int K, float* workspace, int accumulate, void* stream) {
+    return gemm_tn(make_view(const_cast<float*>(A), lda, a_coff), make_view(const_cast<float*>(D), ldd, d_coff), out, M, N,
+                   K, workspace, accumulate, S(stream));
+}
+
+int cdrl_stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
+                  void* stream) {
+    return stem_fwd(x, w, bias, y, B, T, H, W, Cout, S(stream));
+}
+
+int64_t cdrl_stem_bwd_workspace_doubles(int B, int T, int H, int W, int Cout) {
+    return stem_bwd_part_elems(B, T, H, W, Cout);
+}
+
+int cdrl_stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,
+                         double* workspace, void* stream) {
+    return stem_bwd_filter(x, dy, dw, db, B, T, H, W, Cout, workspace, S(stream));
+}
+
+int cdrl_dwconv_fwd(const float* a, const float* w, const float* bias, float* y, int N, int H, int W, int C, int stride,
+                    void* stream) {
+    return dw_fwd(make_view(const_cast<float*>(a), C), w, bias, y, N, H, W, C, stride, S(stream));
+}
+
+int cdrl_dwconv_bwd_data(const float* dy, const float* w, float* da, int N, int H, int W, int C, int stride, void* stream) {
+    return dw_bwd_data(dy, w, make_view(da, C), N, H, W, C, stride, 0, S(stream));
+}
+
+int64_t cdrl_dwconv_bwd_workspace_doubles(int N, int H, int W, int C, int stride) {
+    return dw_bwd_part_elems(N, H, W, C, stride);
+}
+
+int cdrl_dwconv_bwd_filter(const float* a, const float* dy, float* dw, float* db, int N, int H, int W, int C, int stride,
+                           double* workspace, void* stream) {
+    return dw_bwd_filter(make_view(const_cast<float*>(a), C), dy, dw, db, N, H, W, C, stride, workspace, S(stream));
+}
+
+int cdrl_maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, void* stream) {
+    return maxpool_fwd(a, p, argmax, N, H, W, C, S(stream));
+}
+
+int cdrl_maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H, int W, int C, void* stream) {
+    return maxpool_bwd(argmax, dp, da, N, H, W, C, S(stream));
+}
+
+int cdrl_bn_train_fwd(const float* y, int G, int Mg, int C, const float* gamma, const float* beta, float* moving_mean,
+                      float* moving_var, int bessel, int relu6, float* out, int out_ld, int out_coff, int shuffle_ctot,
+                      float* stats, double* workspace, void* stream) {
+    View yv = make_view(const_cast<float*>(y), C);
+    const int nb = col_geom(Mg, C).nb;
+    CDRL_TRY(colstats(yv, G, Mg, C, workspace, S(stream)));
+    CDRL_TRY(bn_finalize(workspace, nb, G, Mg, C, gamma, beta, moving_mean, moving_var, bessel, 1, stats, S(stream)));
+    return bn_apply(yv, G, Mg, C, stats, relu6 ? ACT_RELU6 : ACT_NONE, make_view(out, out_ld, out_coff), shuffle_ctot,
+                    S(stream));
+}
+
+int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, const float* y, int G, int Mg,
+                      int C, const float* stats, int relu6, float* dgamma, float* dbeta, float* dy, float* coef,
+                      double* workspace, void* stream) {
+    View yv = make_view(const_cast<float*>(y), C);
+    View dv = make_view(const_cast<float*>(dout), dout_ld, dout_coff);
+    const int nb = col_geom(Mg, C).nb;
+    const int act = relu6 ? ACT_RELU6 : ACT_NONE;
+    CDRL_TRY(bn_bwd_reduce(dv, shuffle_ctot, yv, G, Mg, C, stats, act, workspace, S(stream)));
+    CDRL_TRY(bn_bwd_finalize(workspace, nb, G, Mg, C, stats, dgamma, dbeta, coef, S(stream)));
+    return bn_bwd_apply(dv, shuffle_ctot, yv, G, Mg, C, stats, coef, act, dy, workspace, S(stream));
+}
+
+int cdrl_beta_ppo_loss(const float* lin, const float* adv, const float* old_logp, const float* speed,
+                       const float* similarity, const float* u, const float* du_da, const float* du_db, float clip_ratio,
+                       float entropy_coef, int B, int A, float grad_scale, float* dlin, float* metrics, float* aux,
+                       float* hp_scratch16, void* stream) {
+    DevHP h;
+    memset(&h, 0, sizeof(h));
+    h.clip_ratio = clip_ratio;
+    h.entropy_coef = entropy_coef;
+    CDRL_HIP(hipMemcpyAsync(hp_scratch16, &h, sizeof(h), hipMemcpyHostToDevice, S(stream)));
+    PolicyLossArgs a;
+    a.lin = lin; a.adv = adv; a.old_logp = old_logp; a.speed = speed; a.similarity = similarity;
+    a.u = u; a.du_da = du_da; a.du_db = du_db; a.hp = hp_scratch16; a.dlin = dlin; a.metrics = metrics; a.aux = aux;
+    a.B = B; a.A = A; a.inv_world = grad_scale;
+    return policy_loss(a, S(stream));
+}
+
+int cdrl_value_loss(const float* lin, const float* returns, const float* speed, const float* similarity, int B,
+                    float exp_scale, float grad_scale, float* dlin, float* metrics, float* values, void* stream) {
+    ValueLossArgs a;
+    a.lin = lin; a.returns = returns; a.speed = speed; a.similarity = similarity; a.dlin = dlin; a.metrics = metrics;
+    a.values = values; a.B = B; a.exp_scale = exp_scale; a.inv_world = grad_scale;
+    return value_loss(a, S(stream));
+}
+
+}  // extern "C"

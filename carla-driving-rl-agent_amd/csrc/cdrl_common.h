@@ -1,0 +1,83 @@
+// Common device/host helpers for libcdrl_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace cdrl {
+
+// Channels-last 2-D view: element (row r, channel c) lives at p[r*ld + coff + c].
+// A "row" is one pixel of one frame; frames are ordered f = t*B + b so that the rows of
+// one BatchNorm statistics group (one time slice) are contiguous.
+struct View {
+    float* p;
+    int ld;
+    int coff;
+};
+
+__host__ __device__ inline View make_view(float* p, int ld, int coff = 0) {
+    View v;
+    v.p = p;
+    v.ld = ld;
+    v.coff = coff;
+    return v;
+}
+
+enum Act : int { ACT_NONE = 0, ACT_RELU6 = 1, ACT_SWISH6 = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
+
+// De-interleaving channel shuffle of the reference (core/architectures.py:109-118, F7):
+// concat index i -> output channel (i & 1) * (C/2) + (i >> 1).
+__host__ __device__ inline int shuffle_dst(int i, int ctot) { return (i & 1) * (ctot >> 1) + (i >> 1); }
+
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define CDRL_HIP(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            cdrl::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return -2;                                                                         \
+        }                                                                                      \
+    } while (0)
+
+#define CDRL_LAUNCH_CHECK() CDRL_HIP(hipGetLastError())
+
+#define CDRL_TRY(expr)            \
+    do {                          \
+        int _r = (expr);          \
+        if (_r != 0) return _r;   \
+    } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+inline int pow2ceil(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// Geometry of the "column-mapped" kernels: blockDim = (CX channel lanes, CY row lanes), 256 threads.
+struct ColGeom {
+    int cx, cy;     // block dims
+    int rb;         // rows per block
+    int nb;         // blocks per group
+};
+
+inline ColGeom col_geom(int rows_per_group, int C, int max_blocks_per_group = 128) {
+    ColGeom g;
+    g.cx = pow2ceil(C);
+    if (g.cx < 32) g.cx = 32;
+    if (g.cx > 256) g.cx = 256;
+    g.cy = 256 / g.cx;
+    int rb = cdiv(rows_per_group, max_blocks_per_group);
+    int minrb = g.cy * 4;
+    if (rb < minrb) rb = minrb;
+    rb = cdiv(rb, g.cy) * g.cy;
+    g.rb = rb;
+    g.nb = cdiv(rows_per_group, rb);
+    return g;
+}
+
+}  // namespace cdrl

@@ -1,0 +1,147 @@
+// Internal C++ launch API of libcdrl_hip.so.  Every function enqueues work on `st`, never
+// allocates, never synchronises, and returns 0 on success (<0: see cdrl::last_error()).
+#pragma once
+#include "cdrl_common.h"
+
+namespace cdrl {
+
+// ---------------------------------------------------------------- BatchNorm family (bn.hip)
+// Per-group column statistics of y (rows grouped contiguously: group g = rows [g*Mg,(g+1)*Mg)).
+// part layout: [G][nb][2][C] (sum, sum of squares); nb from col_geom(Mg, C).
+int colstats(View y, int G, int Mg, int C, double* part, hipStream_t st);
+// Turns partials (training) or moving statistics (inference) into per-(group,channel) mean /
+// invstd / scale / shift and applies the T sequential EMA updates.
+int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* gamma, const float* beta,
+                float* mov_mean, float* mov_var, int bessel, int training, float* stats /*[4][G][C]*/,
+                hipStream_t st);
+// dst = act(scale*y + shift); optional de-interleave shuffle on the destination channel index.
+// stats == nullptr -> plain copy.
+int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
+             hipStream_t st);
+// Backward: reduce (sum dz, sum dz*xhat) -> part [G][nb][2][C]
+int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
+                  double* part, hipStream_t st);
+// dgamma/dbeta (+= over groups; `accumulate` keeps previous content) and coefficients coef[3][G][C]
+int bn_bwd_finalize(const double* part, int nb, int G, int Mg, int C, const float* stats, float* dgamma,
+                    float* dbeta, float* coef, hipStream_t st);
+// dy = k1*(dz - k2 - xhat*k3) (dense [G*Mg][C]); also column sums of dy -> part2 [G][nb][C]
+int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats,
+                 const float* coef, int act, float* dy, double* part2, hipStream_t st);
+// out[i] (+)= sum_p part[p*stride + i], i < n
+int reduce_partials(const double* part, int nparts, int n, int64_t stride, float* out, int accumulate,
+                    hipStream_t st);
+// column sums of a view: part [nb][C] with nb = col_geom(rows, C).nb
+int colsum(View x, int rows, int C, double* part, hipStream_t st);
+// dst(view) = src(view) gathered through the shuffle map on the *source* (backward of shuffle)
+int gather_view(View src, int shuffle_ctot, int rows, int C, View dst, int accumulate, hipStream_t st);
+// elementwise activation on dense [n] arrays
+int act_fwd(const float* z, float* a, int64_t n, int act, hipStream_t st);
+int act_bwd(const float* z, const float* da, float* dz, int64_t n, int act, hipStream_t st);
+int fill(float* p, int64_t n, float v, hipStream_t st);
+// (B,T,D) -> (T*B, D)
+int permute_bt(const float* src, float* dst, int B, int T, int D, hipStream_t st);
+int permute_tb_bwd(const float* src, float* dst, int B, int T, int D, hipStream_t st);
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+// C[M,N] (view) (+)= A[M,K] (view) * B(k,n) + bias[n];  B(k,n) = Bp[k*sbk + n*sbn].
+// fp32 MFMA (v_mfma_f32_32x32x2_f32): results are bit-identical to a k-ordered fmaf chain.
+int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C, int M, int N, int K,
+            int accumulate, hipStream_t st);
+// Cout[K,N] = sum_m A[m,K]^T * D[m,N]  (split over M; partial buffer `part` >= gemm_tn_part_elems)
+int64_t gemm_tn_part_elems(int M, int N, int K);
+int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st);
+
+// ---------------------------------------------------------------- convolutions (conv.hip)
+// x: (B,T,H,W,3) reference layout -> y: [(t*B+b)][Ho][Wo][Cout], 3x3 stride 2 valid.
+int stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
+             hipStream_t st);
+int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout);
+int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,
+                    double* part, hipStream_t st);
+// depthwise 3x3, TF 'SAME' (asymmetric) padding, stride 1|2.  N = frames.
+int dw_fwd(View a, const float* w, const float* bias, float* y, int N, int H, int W, int C, int stride,
+           hipStream_t st);
+int dw_bwd_data(const float* dy, const float* w, View da, int N, int H, int W, int C, int stride, int accumulate,
+                hipStream_t st);
+int64_t dw_bwd_part_elems(int N, int H, int W, int C, int stride);
+int dw_bwd_filter(View a, const float* dy, float* dw, float* db, int N, int H, int W, int C, int stride,
+                  double* part, hipStream_t st);
+int maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, hipStream_t st);
+int maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H, int W, int C, hipStream_t st);
+// mean over the P pixels of each frame: a [N][P][C] -> out [N][C]
+int gap_fwd(const float* a, float* out, int N, int P, int C, hipStream_t st);
+int gap_bwd(const float* dout, float* da, int N, int P, int C, hipStream_t st);
+
+// ---------------------------------------------------------------- GRU (rnn.hip)
+// gates of step t: xp,hp [B][3u]; hprev [B][u]; saves z,r,hh; writes hnew
+int gru_gates_fwd(const float* xp, const float* hp, const float* hprev, float* z, float* r, float* hh, float* hnew,
+                  int B, int u, hipStream_t st);
+int gru_gates_bwd(const float* dh, const float* z, const float* r, const float* hh, const float* hp,
+                  const float* hprev, float* dxp, float* dhp, float* dhprev, int B, int u, hipStream_t st);
+
+// ---------------------------------------------------------------- losses (loss.hip)
+struct PolicyLossArgs {
+    const float* lin;        // [B][2A+2] linear head outputs: alpha_pre(A) beta_pre(A) similarity_pre speed_pre
+    const float* adv;        // [B]
+    const float* old_logp;   // [B][A]
+    const float* speed;      // [B]
+    const float* similarity; // [B]
+    const float* u;          // [B][A] Beta samples (or stored actions)
+    const float* du_da;      // [B][A] or nullptr
+    const float* du_db;      // [B][A] or nullptr
+    const float* hp;         // device hyper-parameter block (DevHP)
+    float* dlin;             // [B][2A+2]
+    float* metrics;          // [16]
+    float* aux;              // optional [B][4A]: alpha, beta, log_prob, entropy
+    int B, A;
+    float inv_world;         // gradient scale for data-parallel averaging (1/world_size)
+};
+int policy_loss(const PolicyLossArgs& a, hipStream_t st);
+struct ValueLossArgs {
+    const float* lin;        // [B][4]: base_pre, exp_pre, speed_pre, similarity_pre
+    const float* returns;    // [B][2]
+    const float* speed;
+    const float* similarity;
+    float* dlin;             // [B][4]
+    float* metrics;          // [16]
+    float* values;           // optional [B][2]
+    int B;
+    float exp_scale;
+    float inv_world;
+};
+int value_loss(const ValueLossArgs& a, hipStream_t st);
+// inference heads: alpha,beta,(mean,std) and value(base,exp) from linear outputs
+int policy_dist(const float* lin, float* out /*[B][4A]: alpha,beta,mean,std*/, int B, int A, hipStream_t st);
+int value_act(const float* lin, float* out /*[B][4] base,exp,speed,sim*/, int B, float exp_scale, hipStream_t st);
+
+// ---------------------------------------------------------------- optimiser (optim.hip)
+// Device hyper-parameter block, refreshed by the host before each step (graph-replay safe).
+struct DevHP {
+    float lr_policy, lr_value, lr_dynamics;
+    float clip_ratio, entropy_coef;
+    float clip_norm_policy, clip_norm_value;   // <= 0 : no clipping
+    float beta1, beta2, eps;
+    int t_policy, t_value, t_dynamics;         // Adam step counters (incremented on device)
+    int pad[3];
+};
+struct TensorSeg {      // one parameter tensor inside a flat arena
+    int64_t off;
+    int64_t n;
+    int first_chunk;    // index of its first 1024-element chunk in the chunk table
+    int nchunks;
+};
+// sq-norm per tensor -> norms[ntensors]; deterministic two-stage reduction
+int tensor_sqnorms(const float* g, const TensorSeg* segs_dev, int ntensors, const int* chunk_tensor_dev,
+                   const int64_t* chunk_off_dev, int nchunks, double* chunk_part, float* sqnorms, hipStream_t st);
+// which: 0 policy, 1 value, 2 dynamics
+int clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const int* chunk_tensor_dev,
+              const int64_t* chunk_off_dev, int nchunks, const TensorSeg* segs_dev, const float* sqnorms /*or null*/,
+              DevHP* hp, int which, hipStream_t st);
+int adam_tick(DevHP* hp, int which, hipStream_t st);
+
+// ---------------------------------------------------------------- GAE (gae.hip)
+// rewards [N+1] (bootstrap appended), values_be [N+1][2] -> returns_be [N][2], returns [N], adv_raw [N], adv [N]
+int gae_returns(const float* rewards, const float* values_be, int N, double gamma, double lambda, float scale,
+                float* returns, float* returns_be, float* adv_raw, float* adv, double* scratch, hipStream_t st);
+
+}  // namespace cdrl

@@ -1,0 +1,378 @@
+// Spatial kernels of the image tower (gfx950): 3x3/s2 stem conv, depthwise 3x3, max-pool, GAP.
+//
+// Layout: NHWC dense, frames ordered f = t*B + b.  All kernels are HBM-bound streams with
+// channel-fastest lane mapping (coalesced along C); reductions (filter gradients) reuse the
+// column-mapped skeleton with double partials (deterministic, no atomics).
+// TF 'SAME' padding is asymmetric for stride 2 on even sizes:
+// pad_before = floor(total/2).
+#include "colreduce.h"
+
+namespace cdrl {
+
+__host__ __device__ inline int same_out(int n, int s) { return (n + s - 1) / s; }
+__host__ __device__ inline int same_pad_before(int n, int s) {
+    const int out = (n + s - 1) / s;
+    int tot = (out - 1) * s + 3 - n;
+    if (tot < 0) tot = 0;
+    return tot / 2;
+}
+
+// ------------------------------------------------------------------------------------------
+// stem: Conv2D(24, 3, strides=2, 'valid') on the (B,T,H,W,3) observation tensor
+// (reference core/architectures.py:159).  Output frame index = t*B + b.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                       int T, int H, int W, int Ho, int Wo, int Cout) {
+    extern __shared__ float ws[];      // [27][Cout] + [Cout]
+    for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) ws[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) ws[27 * Cout + i] = bias[i];
+    __syncthreads();
+    const int64_t total = (int64_t)B * T * Ho * Wo * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        int64_t pix = i / Cout;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int f = (int)(pix / Ho);
+        const int t = f / B, b = f % B;
+        const float* xp = x + ((((int64_t)b * T + t) * H + 2 * oy) * W + 2 * ox) * 3;
+        float acc = ws[27 * Cout + co];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+                    acc = fmaf(xp[((int64_t)ky * W + kx) * 3 + ci], ws[((ky * 3 + kx) * 3 + ci) * Cout + co], acc);
+        y[i] = acc;
+    }
+}
+
+int stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
+             hipStream_t st) {
+    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    const int64_t total = (int64_t)B * T * Ho * Wo * Cout;
+    int64_t nb = cdiv64(total, 256 * 4);
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)nb), dim3(256), (27 * Cout + Cout) * sizeof(float), st, x, w, bias,
+                       y, B, T, H, W, Ho, Wo, Cout);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+struct StemBwdF {
+    const float* x;
+    const float* dy;
+    int B, T, H, W, Ho, Wo, Cout;
+    __device__ void operator()(int, int64_t row, int c, double* acc) const {
+        const int ox = (int)(row % Wo);
+        int64_t r = row / Wo;
+        const int oy = (int)(r % Ho);
+        const int f = (int)(r / Ho);
+        const int t = f / B, b = f % B;
+        const float* xp = x + ((((int64_t)b * T + t) * H + 2 * oy) * W + 2 * ox) * 3;
+        const double d = (double)dy[row * Cout + c];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+                    acc[(ky * 3 + kx) * 3 + ci] += (double)xp[((int64_t)ky * W + kx) * 3 + ci] * d;
+        acc[27] += d;
+    }
+};
+
+int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout) {
+    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    ColGeom g = col_geom(B * T * Ho * Wo, Cout);
+    return (int64_t)g.nb * 28 * Cout;
+}
+
+int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,
+                    double* part, hipStream_t st) {
+    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    const int rows = B * T * Ho * Wo;
+    StemBwdF f{x, dy, B, T, H, W, Ho, Wo, Cout};
+    CDRL_TRY(launch_colreduce<28>(f, 1, rows, Cout, part, st));
+    ColGeom g = col_geom(rows, Cout);
+    CDRL_TRY(reduce_partials(part, g.nb, 27 * Cout, (int64_t)28 * Cout, dw, 0, st));
+    CDRL_TRY(reduce_partials(part + 27 * Cout, g.nb, Cout, (int64_t)28 * Cout, db, 0, st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// depthwise 3x3 (reference core/architectures.py:132,138); kernel layout (3,3,C,1) -> [9][C]
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dw_fwd_kernel(View a, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ y, int rows, int H, int W, int Ho, int Wo, int C,
+                                                     int s, int pt, int pl, int rb) {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int r0 = blockIdx.x * rb;
+    const int r1 = min(r0 + rb, rows);
+    for (int c = tx; c < C; c += CX) {
+        float wk[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = w[k * C + c];
+        const float bv = bias[c];
+        for (int r = r0 + ty; r < r1; r += CY) {
+            const int ox = r % Wo;
+            const int q = r / Wo;
+            const int oy = q % Ho;
+            const int n = q / Ho;
+            float acc = bv;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * s + ky - pt;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * s + kx - pl;
+                    if (ix < 0 || ix >= W) continue;
+                    const int64_t irow = ((int64_t)n * H + iy) * W + ix;
+                    acc = fmaf(a.p[irow * a.ld + a.coff + c], wk[ky * 3 + kx], acc);
+                }
+            }
+            y[(int64_t)r * C + c] = acc;
+        }
+    }
+}
+
+int dw_fwd(View a, const float* w, const float* bias, float* y, int N, int H, int W, int C, int stride,
+           hipStream_t st) {
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    const int rows = N * Ho * Wo;
+    ColGeom g = col_geom(rows, C, 2048);
+    hipLaunchKernelGGL(dw_fwd_kernel, dim3(g.nb), dim3(g.cx, g.cy), 0, st, a, w, bias, y, rows, H, W, Ho, Wo, C, stride,
+                       same_pad_before(H, stride), same_pad_before(W, stride), g.rb);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) dw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                          View da, int rows, int H, int W, int Ho, int Wo, int C, int s,
+                                                          int pt, int pl, int rb, int accumulate) {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int r0 = blockIdx.x * rb;
+    const int r1 = min(r0 + rb, rows);
+    for (int c = tx; c < C; c += CX) {
+        float wk[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = w[k * C + c];
+        for (int r = r0 + ty; r < r1; r += CY) {
+            const int ix = r % W;
+            const int q = r / W;
+            const int iy = q % H;
+            const int n = q / H;
+            float acc = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int ny = iy + pt - ky;
+                if (ny < 0 || (ny % s) != 0) continue;
+                const int oy = ny / s;
+                if (oy >= Ho) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int nx = ix + pl - kx;
+                    if (nx < 0 || (nx % s) != 0) continue;
+                    const int ox = nx / s;
+                    if (ox >= Wo) continue;
+                    acc = fmaf(dy[(((int64_t)n * Ho + oy) * Wo + ox) * C + c], wk[ky * 3 + kx], acc);
+                }
+            }
+            float* d = &da.p[(int64_t)r * da.ld + da.coff + c];
+            *d = accumulate ? *d + acc : acc;
+        }
+    }
+}
+
+int dw_bwd_data(const float* dy, const float* w, View da, int N, int H, int W, int C, int stride, int accumulate,
+                hipStream_t st) {
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    const int rows = N * H * W;
+    ColGeom g = col_geom(rows, C, 2048);
+    hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(g.nb), dim3(g.cx, g.cy), 0, st, dy, w, da, rows, H, W, Ho, Wo, C, stride,
+                       same_pad_before(H, stride), same_pad_before(W, stride), g.rb, accumulate);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+struct DwBwdFilterF {
+    View a;
+    const float* dy;
+    int H, W, Ho, Wo, C, s, pt, pl;
+    __device__ void operator()(int, int64_t row, int c, double* acc) const {
+        const int ox = (int)(row % Wo);
+        const int64_t q = row / Wo;
+        const int oy = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        const float d = dy[row * C + c];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * s + ky - pt;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * s + kx - pl;
+                if (ix < 0 || ix >= W) continue;
+                const int64_t irow = ((int64_t)n * H + iy) * W + ix;
+                acc[ky * 3 + kx] += (double)(a.p[irow * a.ld + a.coff + c] * d);
+            }
+        }
+        acc[9] += (double)d;
+    }
+};
+
+int64_t dw_bwd_part_elems(int N, int H, int W, int C, int stride) {
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    ColGeom g = col_geom(N * Ho * Wo, C);
+    return (int64_t)g.nb * 10 * C;
+}
+
+int dw_bwd_filter(View a, const float* dy, float* dw, float* db, int N, int H, int W, int C, int stride,
+                  double* part, hipStream_t st) {
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    const int rows = N * Ho * Wo;
+    DwBwdFilterF f{a, dy, H, W, Ho, Wo, C, stride, same_pad_before(H, stride), same_pad_before(W, stride)};
+    CDRL_TRY(launch_colreduce<10>(f, 1, rows, C, part, st));
+    ColGeom g = col_geom(rows, C);
+    CDRL_TRY(reduce_partials(part, g.nb, 9 * C, (int64_t)10 * C, dw, 0, st));
+    CDRL_TRY(reduce_partials(part + 9 * C, g.nb, C, (int64_t)10 * C, db, 0, st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPooling2D(3, 2, 'same') (reference core/architectures.py:161); padding never wins.
+// argmax (first maximum in (ky,kx) scan order) is saved as one byte per output element.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ a, float* __restrict__ p,
+                                                          uint8_t* __restrict__ argmax, int rows, int H, int W, int Ho,
+                                                          int Wo, int C, int pt, int pl, int rb) {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int r0 = blockIdx.x * rb;
+    const int r1 = min(r0 + rb, rows);
+    for (int c = tx; c < C; c += CX) {
+        for (int r = r0 + ty; r < r1; r += CY) {
+            const int ox = r % Wo;
+            const int q = r / Wo;
+            const int oy = q % Ho;
+            const int n = q / Ho;
+            float best = -INFINITY;
+            int bi = 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * 2 + ky - pt;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * 2 + kx - pl;
+                    if (ix < 0 || ix >= W) continue;
+                    const float v = a[(((int64_t)n * H + iy) * W + ix) * C + c];
+                    if (v > best) {
+                        best = v;
+                        bi = ky * 3 + kx;
+                    }
+                }
+            }
+            p[(int64_t)r * C + c] = best;
+            if (argmax) argmax[(int64_t)r * C + c] = (uint8_t)bi;
+        }
+    }
+}
+
+int maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, hipStream_t st) {
+    const int Ho = same_out(H, 2), Wo = same_out(W, 2);
+    const int rows = N * Ho * Wo;
+    ColGeom g = col_geom(rows, C, 2048);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(g.nb), dim3(g.cx, g.cy), 0, st, a, p, argmax, rows, H, W, Ho, Wo, C,
+                       same_pad_before(H, 2), same_pad_before(W, 2), g.rb);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const uint8_t* __restrict__ argmax, const float* __restrict__ dp,
+                                                          float* __restrict__ da, int rows, int H, int W, int Ho, int Wo,
+                                                          int C, int pt, int pl, int rb) {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int r0 = blockIdx.x * rb;
+    const int r1 = min(r0 + rb, rows);
+    for (int c = tx; c < C; c += CX) {
+        for (int r = r0 + ty; r < r1; r += CY) {
+            const int ix = r % W;
+            const int q = r / W;
+            const int iy = q % H;
+            const int n = q / H;
+            float acc = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int ny = iy + pt - ky;
+                if (ny < 0 || (ny & 1)) continue;
+                const int oy = ny >> 1;
+                if (oy >= Ho) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int nx = ix + pl - kx;
+                    if (nx < 0 || (nx & 1)) continue;
+                    const int ox = nx >> 1;
+                    if (ox >= Wo) continue;
+                    const int64_t o = (((int64_t)n * Ho + oy) * Wo + ox) * C + c;
+                    if (argmax[o] == (uint8_t)(ky * 3 + kx)) acc += dp[o];
+                }
+            }
+            da[(int64_t)r * C + c] = acc;
+        }
+    }
+}
+
+int maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H, int W, int C, hipStream_t st) {
+    const int Ho = same_out(H, 2), Wo = same_out(W, 2);
+    const int rows = N * H * W;
+    ColGeom g = col_geom(rows, C, 2048);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(g.nb), dim3(g.cx, g.cy), 0, st, argmax, dp, da, rows, H, W, Ho, Wo, C,
+                       same_pad_before(H, 2), same_pad_before(W, 2), g.rb);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// GlobalAveragePooling2D (reference core/architectures.py:172)
+// ------------------------------------------------------------------------------------------
+__global__ void gap_fwd_kernel(const float* __restrict__ a, float* __restrict__ out, int N, int P, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * C) return;
+    const int c = (int)(i % C);
+    const int64_t n = i / C;
+    float s = 0.0f;
+    for (int p = 0; p < P; ++p) s += a[(n * P + p) * C + c];
+    out[i] = s / (float)P;
+}
+
+int gap_fwd(const float* a, float* out, int N, int P, int C, hipStream_t st) {
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3((unsigned)cdiv64((int64_t)N * C, 256)), dim3(256), 0, st, a, out, N, P, C);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void gap_bwd_kernel(const float* __restrict__ dout, float* __restrict__ da, int N, int P, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * P * C) return;
+    const int c = (int)(i % C);
+    const int64_t n = i / ((int64_t)P * C);
+    da[i] = dout[n * C + c] / (float)P;
+}
+
+int gap_bwd(const float* dout, float* da, int N, int P, int C, hipStream_t st) {
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3((unsigned)cdiv64((int64_t)N * P * C, 256)), dim3(256), 0, st, dout, da, N, P,
+                       C);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cdrl

@@ -1,0 +1,190 @@
+// Learner engine: owns the layer graph of CARLANetwork (trunk + policy / old-policy / value
+// heads), the flat parameter-arena layout and the workspace plan for one batch size.
+#pragma once
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "cdrl_kernels.h"
+
+namespace cdrl {
+
+struct Config {
+    int B = 1, T = 4, H = 90, W = 120;
+    int road = 9, vehicle = 4, navigation = 5, A = 2;
+    int stem = 24;
+    int stage_c[3] = {116, 232, 464};
+    int stage_n[3] = {4, 8, 4};
+    int last = 768;
+    int feat = 16;
+    int rnn_image = 256, rnn_small = 32;
+    int dyn = 512;
+    int head = 320;
+    float exp_scale = 6.0f;
+};
+
+enum Model : int { M_TRUNK = 0, M_POLICY = 1, M_VALUE = 2, M_OLD_POLICY = 3 };
+
+struct ParamInfo {
+    std::string name;
+    int shape[4] = {1, 1, 1, 1};
+    int ndim = 1;
+    int64_t numel = 0;
+    int trainable = 1;
+    int model = 0;
+    int64_t off = 0;      // element offset inside the model's trainable / state region
+};
+
+struct Buffers {
+    float* params = nullptr;     // [policy_tr | trunk_tr | value_tr | policy_st | trunk_st | value_st | old_tr | old_st]
+    float* grads = nullptr;      // [policy_tr | trunk_tr | value_tr]
+    float* adam_m = nullptr;
+    float* adam_v = nullptr;
+    void* workspace = nullptr;
+    size_t workspace_bytes = 0;
+};
+
+struct PolicyBatch {
+    const float *image, *road, *vehicle, *navigation;       // (B,T,...) reference layout
+    const float *adv, *old_logp, *speed, *similarity, *u, *du_da, *du_db;
+};
+struct ValueBatch {
+    const float *image, *road, *vehicle, *navigation;
+    const float *returns, *speed, *similarity;
+};
+
+struct Op {
+    std::function<int(hipStream_t, int)> fwd;
+    std::function<int(hipStream_t)> bwd;
+};
+
+class Learner {
+public:
+    explicit Learner(const Config& cfg);
+    ~Learner();
+
+    const Config& config() const { return cfg_; }
+    const std::vector<ParamInfo>& params(int model) const { return infos_[model]; }
+    int64_t trainable_elems(int model) const { return tr_size_[model]; }
+    int64_t state_elems(int model) const { return st_size_[model]; }
+    // element offsets of the regions inside Buffers::params / grads
+    int64_t tr_offset(int model) const;
+    int64_t st_offset(int model) const;
+    int64_t params_total() const;
+    int64_t grads_total() const { return tr_size_[0] + tr_size_[1] + tr_size_[2]; }
+    size_t workspace_bytes() const { return ws_bytes_; }
+
+    int bind(const Buffers& b);
+    DevHP* host_hp() { return &hp_host_; }
+    int upload_hp(hipStream_t st);          // host hp block (lr, clip...) -> device, keeps device counters
+    int reset_counters(hipStream_t st);
+
+    int policy_forward_backward(const PolicyBatch& b, float inv_world, hipStream_t st);
+    int policy_apply(hipStream_t st);
+    int value_forward_backward(const ValueBatch& b, float inv_world, hipStream_t st);
+    int value_apply(hipStream_t st);
+    int update_old_policy(hipStream_t st);
+    // inference: trunk (moving stats) + old_policy + value heads
+    int predict(const float* image, const float* road, const float* vehicle, const float* navigation,
+                float* dist_out /*[B][4A]*/, float* value_out /*[B][4]*/, float* dyn_out /*[B][dyn] or null*/,
+                hipStream_t st);
+    // training-mode forward only (parity tests): returns pointers inside the workspace
+    int trunk_forward_train(const float* image, const float* road, const float* vehicle, const float* navigation,
+                            hipStream_t st);
+    float* dyn_out() const { return dyn_.p; }
+    float* img_feat() const { return feat_.p; }
+    float* metrics_policy() const { return metrics_p_; }
+    float* metrics_value() const { return metrics_v_; }
+    float* policy_aux() const { return aux_p_; }
+    float* value_aux() const { return aux_v_; }
+    float* policy_lin() const { return lin_p_.p; }
+    float* value_lin() const { return lin_v_.p; }
+    DevHP* dev_hp() const { return hp_dev_; }
+
+private:
+    struct Tens {
+        float* p = nullptr;
+        float* g = nullptr;
+        int rows = 0, C = 0;
+        View v(int coff = 0) const { return make_view(p, C, coff); }
+        View gv(int coff = 0) const { return make_view(g, C, coff); }
+    };
+    struct PRef {
+        float* p = nullptr;
+        float* g = nullptr;
+    };
+    struct BnRec {
+        int G, Mg, C, nb;
+    };
+
+    // --- building
+    void build(bool dry);
+    float* alloc(size_t n);
+    double* alloc_d(size_t n);
+    Tens tens(int rows, int C, bool grad = true);
+    PRef param(int model, const std::string& name, std::initializer_list<int> shape, bool trainable);
+    void build_trunk(std::vector<Op>& ops);
+    void build_head(std::vector<Op>& ops, int model, const std::string& prefix, Tens& lin, int nheads,
+                    const int* head_dims, const char* const* head_names);
+    BnRec add_bn(std::vector<Op>& ops, int model, const std::string& prefix, View x, int G, int Mg, int C, bool bessel,
+                 int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx);
+    void add_pw(std::vector<Op>& ops, const std::string& prefix, View in, int rows, int Cin, int Cout, float* y,
+                float* dy, View din, int din_acc, BnRec bn_after);
+    void add_dw(std::vector<Op>& ops, const std::string& prefix, View in, int N, int H, int W, int C, int stride,
+                float* y, float* dy, View din, int din_acc);
+    void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
+                   View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);
+    void add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,
+                 bool need_dx);
+    void note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn_f);
+
+    int run_fwd(std::vector<Op>& ops, hipStream_t st, int training);
+    int run_bwd(std::vector<Op>& ops, hipStream_t st);
+    int set_inputs(const float* image, const float* road, const float* vehicle, const float* navigation);
+
+    Config cfg_;
+    std::vector<ParamInfo> infos_[3];
+    std::unordered_map<std::string, int> index_[3];
+    int64_t tr_size_[3] = {0, 0, 0}, st_size_[3] = {0, 0, 0};
+    bool table_frozen_ = false;
+
+    Buffers buf_;
+    bool dry_ = true;
+    char* ws_base_ = nullptr;
+    size_t ws_off_ = 0, ws_bytes_ = 0;
+    // scratch maxima (from the dry build) and pointers
+    size_t max_part_ = 0, max_part2_ = 0, max_dy_ = 0, max_tn_ = 0;
+    double *part_ = nullptr, *part2_ = nullptr;
+    float *dy_ = nullptr, *tn_part_ = nullptr;
+
+    std::vector<Op> trunk_ops_, policy_ops_, value_ops_, old_policy_ops_;
+    // live input pointers (read by the first ops through these slots)
+    const float* in_image_ = nullptr;
+    const float* in_road_ = nullptr;
+    const float* in_vehicle_ = nullptr;
+    const float* in_navigation_ = nullptr;
+
+    Tens dyn_, feat_, lin_p_, lin_v_, lin_old_;
+    float *metrics_p_ = nullptr, *metrics_v_ = nullptr, *aux_p_ = nullptr, *aux_v_ = nullptr;
+    DevHP hp_host_;
+    DevHP* hp_dev_ = nullptr;
+    DevHP* hp_stage_ = nullptr;     // pinned host staging
+    // optimiser tables (device, inside workspace)
+    struct SegTable {
+        TensorSeg* segs = nullptr;
+        int* chunk_tensor = nullptr;
+        int64_t* chunk_off = nullptr;
+        int ntensors = 0, nchunks = 0;
+        double* chunk_part = nullptr;
+        float* sqnorms = nullptr;
+        std::vector<TensorSeg> h_segs;
+        std::vector<int> h_chunk_tensor;
+        std::vector<int64_t> h_chunk_off;
+    } seg_[3];
+    void build_seg_tables();
+    int upload_seg_tables();
+    bool tables_uploaded_ = false;
+};
+
+}  // namespace cdrl

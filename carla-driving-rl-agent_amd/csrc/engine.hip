@@ -1,0 +1,700 @@
+// Learner engine implementation (host side, gfx950 kernels from the sibling .hip files).
+//
+// Mirrors the structure built by the reference's Keras graph builders:
+//   trunk  = dynamics_layers            (reference core/networks.py:37-56)
+//            shufflenet_v2 over T slices (core/architectures.py:30-173)
+//            feature_net x3             (core/architectures.py:9-27)
+//   heads  = control_branch + policy / value heads (core/networks.py:59-66,115-137,255-275)
+//   steps  = get_*_gradients / apply_*_gradients   (core/carla_agent.py:351-388,430-463;
+//                                                    rl/agents/ppo.py:238-275)
+// Frames are ordered f = t*B + b, so each per-time-slice BatchNorm group is a contiguous row
+// range (F6); split / concat / channel_shuffle never materialise on their own: they are views
+// (ld, channel offset) plus a destination-index permutation in the BN-apply store (F7).
+#include "engine.h"
+
+#include <string.h>
+
+namespace cdrl {
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int same_out_h(int n, int s) { return (n + s - 1) / s; }
+
+Learner::Learner(const Config& cfg) : cfg_(cfg) {
+    memset(&hp_host_, 0, sizeof(hp_host_));
+    hp_host_.lr_policy = 3e-4f;
+    hp_host_.lr_value = 3e-4f;
+    hp_host_.lr_dynamics = 3e-4f;
+    hp_host_.clip_ratio = 0.2f;
+    hp_host_.entropy_coef = 1.0f;
+    hp_host_.clip_norm_policy = 1.0f;
+    hp_host_.clip_norm_value = 1.0f;
+    hp_host_.beta1 = 0.9f;
+    hp_host_.beta2 = 0.999f;
+    hp_host_.eps = 1e-7f;
+    build(true);
+    table_frozen_ = true;
+    build_seg_tables();
+}
+
+Learner::~Learner() {
+    if (hp_stage_) (void)hipHostFree(hp_stage_);
+}
+
+int64_t Learner::tr_offset(int model) const {
+    switch (model) {
+        case M_POLICY: return 0;
+        case M_TRUNK: return tr_size_[M_POLICY];
+        case M_VALUE: return tr_size_[M_POLICY] + tr_size_[M_TRUNK];
+        default: return grads_total() + st_size_[0] + st_size_[1] + st_size_[2];      // old policy trainable
+    }
+}
+
+int64_t Learner::st_offset(int model) const {
+    const int64_t base = grads_total();
+    switch (model) {
+        case M_POLICY: return base;
+        case M_TRUNK: return base + st_size_[M_POLICY];
+        case M_VALUE: return base + st_size_[M_POLICY] + st_size_[M_TRUNK];
+        default: return tr_offset(M_OLD_POLICY) + tr_size_[M_POLICY];                  // old policy state
+    }
+}
+
+int64_t Learner::params_total() const { return st_offset(M_OLD_POLICY) + st_size_[M_POLICY]; }
+
+// ------------------------------------------------------------------------------------------
+// allocation helpers
+// ------------------------------------------------------------------------------------------
+float* Learner::alloc(size_t n) {
+    const size_t bytes = align_up(n * sizeof(float), 256);
+    float* p = dry_ ? nullptr : reinterpret_cast<float*>(ws_base_ + ws_off_);
+    ws_off_ += bytes;
+    return p;
+}
+
+double* Learner::alloc_d(size_t n) {
+    const size_t bytes = align_up(n * sizeof(double), 256);
+    double* p = dry_ ? nullptr : reinterpret_cast<double*>(ws_base_ + ws_off_);
+    ws_off_ += bytes;
+    return p;
+}
+
+Learner::Tens Learner::tens(int rows, int C, bool grad) {
+    Tens t;
+    t.rows = rows;
+    t.C = C;
+    t.p = alloc((size_t)rows * C);
+    if (grad) t.g = alloc((size_t)rows * C);
+    return t;
+}
+
+Learner::PRef Learner::param(int model, const std::string& name, std::initializer_list<int> shape, bool trainable) {
+    const int tm = model == M_OLD_POLICY ? (int)M_POLICY : model;
+    int idx;
+    auto it = index_[tm].find(name);
+    if (it == index_[tm].end()) {
+        if (table_frozen_ || model == M_OLD_POLICY) {
+            set_error("unknown parameter %s", name.c_str());
+            return PRef();
+        }
+        ParamInfo pi;
+        pi.name = name;
+        pi.ndim = (int)shape.size();
+        int64_t n = 1;
+        int k = 0;
+        for (int d : shape) {
+            pi.shape[k++] = d;
+            n *= d;
+        }
+        pi.numel = n;
+        pi.trainable = trainable ? 1 : 0;
+        pi.model = tm;
+        int64_t& sz = trainable ? tr_size_[tm] : st_size_[tm];
+        pi.off = sz;
+        sz += (n + 3) / 4 * 4;           // 16-byte aligned tensor starts
+        idx = (int)infos_[tm].size();
+        infos_[tm].push_back(pi);
+        index_[tm][name] = idx;
+    } else {
+        idx = it->second;
+    }
+    PRef r;
+    if (dry_) return r;
+    const ParamInfo& pi = infos_[tm][idx];
+    if (pi.trainable) {
+        r.p = buf_.params + tr_offset(model) + pi.off;
+        if (model != M_OLD_POLICY) r.g = buf_.grads + tr_offset(model) + pi.off;
+    } else {
+        r.p = buf_.params + st_offset(model) + pi.off;
+    }
+    return r;
+}
+
+void Learner::note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn_f) {
+    if (part_d > max_part_) max_part_ = part_d;
+    if (part2_d > max_part2_) max_part2_ = part2_d;
+    if (dy_f > max_dy_) max_dy_ = dy_f;
+    if (tn_f > max_tn_) max_tn_ = tn_f;
+}
+
+// ------------------------------------------------------------------------------------------
+// op builders
+// ------------------------------------------------------------------------------------------
+Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::string& prefix, View x, int G, int Mg, int C,
+                               bool bessel, int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx) {
+    PRef gamma = param(model, prefix + ".gamma", {C}, true);
+    PRef beta = param(model, prefix + ".beta", {C}, true);
+    PRef mm = param(model, prefix + ".moving_mean", {C}, false);
+    PRef mv = param(model, prefix + ".moving_var", {C}, false);
+    float* stats = alloc((size_t)4 * G * C);
+    float* coef = alloc((size_t)3 * G * C);
+    const int nb = col_geom(Mg, C).nb;
+    note_scratch((size_t)G * nb * 2 * C, (size_t)G * nb * C, 0, 0);
+    BnRec rec{G, Mg, C, nb};
+    const int bes = bessel ? 1 : 0;
+    Op op;
+    op.fwd = [=](hipStream_t st, int training) -> int {
+        if (training) CDRL_TRY(colstats(x, G, Mg, C, part_, st));
+        CDRL_TRY(bn_finalize(part_, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
+        return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st);
+    };
+    op.bwd = [=](hipStream_t st) -> int {
+        CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, part_, st));
+        CDRL_TRY(bn_bwd_finalize(part_, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
+        return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, part2_, st);
+    };
+    ops.push_back(op);
+    return rec;
+}
+
+void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, int rows, int Cin, int Cout, float* y,
+                     float* dy, View din, int din_acc, BnRec bn_after) {
+    PRef w = param(M_TRUNK, prefix + ".w", {1, 1, Cin, Cout}, true);
+    PRef b = param(M_TRUNK, prefix + ".b", {Cout}, true);
+    note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin));
+    Op op;
+    op.fwd = [=](hipStream_t st, int) -> int {
+        return gemm_nn(in, w.p, Cout, 1, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
+    };
+    op.bwd = [=](hipStream_t st) -> int {
+        // bias gradient = column sums of dy, already reduced per block by bn_bwd_apply
+        CDRL_TRY(reduce_partials(part2_, bn_after.G * bn_after.nb, Cout, Cout, b.g, 0, st));
+        if (din.p) CDRL_TRY(gemm_nn(make_view(dy, Cout), w.p, 1, Cout, nullptr, din, rows, Cin, Cout, din_acc, st));
+        return gemm_tn(in, make_view(dy, Cout), w.g, rows, Cout, Cin, tn_part_, 0, st);
+    };
+    ops.push_back(op);
+}
+
+void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, int N, int H, int W, int C, int stride,
+                     float* y, float* dy, View din, int din_acc) {
+    PRef w = param(M_TRUNK, prefix + ".w", {3, 3, C, 1}, true);
+    PRef b = param(M_TRUNK, prefix + ".b", {C}, true);
+    const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
+    note_scratch((size_t)dw_bwd_part_elems(N, H, W, C, stride), 0, (size_t)N * Ho * Wo * C, 0);
+    Op op;
+    op.fwd = [=](hipStream_t st, int) -> int { return dw_fwd(in, w.p, b.p, y, N, H, W, C, stride, st); };
+    op.bwd = [=](hipStream_t st) -> int {
+        CDRL_TRY(dw_bwd_data(dy, w.p, din, N, H, W, C, stride, din_acc, st));
+        return dw_bwd_filter(in, dy, w.g, b.g, N, H, W, C, stride, part_, st);
+    };
+    ops.push_back(op);
+}
+
+void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N,
+                        int act, View out, View dout, View din, int din_acc, bool need_din, const char*) {
+    PRef w = param(model, prefix + ".w", {K, N}, true);
+    PRef b = param(model, prefix + ".b", {N}, true);
+    float *z = nullptr, *dz = nullptr;
+    if (act != ACT_NONE) {
+        z = alloc((size_t)M * N);
+        dz = alloc((size_t)M * N);
+    }
+    note_scratch((size_t)col_geom(M, N).nb * N, 0, 0, (size_t)gemm_tn_part_elems(M, N, K));
+    const int nb = col_geom(M, N).nb;
+    Op op;
+    op.fwd = [=](hipStream_t st, int) -> int {
+        if (act == ACT_NONE) return gemm_nn(in, w.p, N, 1, b.p, out, M, N, K, 0, st);
+        CDRL_TRY(gemm_nn(in, w.p, N, 1, b.p, make_view(z, N), M, N, K, 0, st));
+        return act_fwd(z, out.p, (int64_t)M * N, act, st);
+    };
+    op.bwd = [=](hipStream_t st) -> int {
+        View dzv = dout;
+        if (act != ACT_NONE) {
+            CDRL_TRY(act_bwd(z, dout.p, dz, (int64_t)M * N, act, st));
+            dzv = make_view(dz, N);
+        }
+        CDRL_TRY(colsum(dzv, M, N, part_, st));
+        CDRL_TRY(reduce_partials(part_, nb, N, N, b.g, 0, st));
+        if (need_din) CDRL_TRY(gemm_nn(dzv, w.p, 1, N, nullptr, din, M, K, N, din_acc, st));
+        return gemm_tn(in, dzv, w.g, M, N, K, tn_part_, 0, st);
+    };
+    ops.push_back(op);
+}
+
+void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,
+                      bool need_dx) {
+    const int B = cfg_.B, T = cfg_.T, U3 = 3 * u;
+    PRef Kp = param(M_TRUNK, name + ".kernel", {In, U3}, true);
+    PRef Rp = param(M_TRUNK, name + ".recurrent", {u, U3}, true);
+    PRef bp = param(M_TRUNK, name + ".bias", {2, U3}, true);
+    float* XP = alloc((size_t)T * B * U3);
+    float* HP = alloc((size_t)T * B * U3);
+    float* Z = alloc((size_t)T * B * u);
+    float* R = alloc((size_t)T * B * u);
+    float* HH = alloc((size_t)T * B * u);
+    float* Hs = alloc((size_t)(T + 1) * B * u);
+    float* dXP = alloc((size_t)T * B * U3);
+    float* dHP = alloc((size_t)T * B * U3);
+    float* dHa = alloc((size_t)B * u);
+    float* dHb = alloc((size_t)B * u);
+    note_scratch((size_t)col_geom(T * B, U3).nb * U3, 0, 0,
+                 (size_t)std::max(gemm_tn_part_elems(T * B, U3, In), gemm_tn_part_elems(T * B, U3, u)));
+    const int nbc = col_geom(T * B, U3).nb;
+    View xv = x.v();
+    View xg = x.gv();
+    Op op;
+    op.fwd = [=](hipStream_t st, int) -> int {
+        CDRL_TRY(fill(Hs, (int64_t)B * u, 0.0f, st));
+        CDRL_TRY(gemm_nn(xv, Kp.p, U3, 1, bp.p, make_view(XP, U3), T * B, U3, In, 0, st));
+        for (int t = 0; t < T; ++t) {
+            float* h = Hs + (size_t)t * B * u;
+            float* hp = HP + (size_t)t * B * U3;
+            CDRL_TRY(gemm_nn(make_view(h, u), Rp.p, U3, 1, bp.p + U3, make_view(hp, U3), B, U3, u, 0, st));
+            CDRL_TRY(gru_gates_fwd(XP + (size_t)t * B * U3, hp, h, Z + (size_t)t * B * u, R + (size_t)t * B * u,
+                                   HH + (size_t)t * B * u, Hs + (size_t)(t + 1) * B * u, B, u, st));
+        }
+        return bn_apply(make_view(Hs + (size_t)T * B * u, u), 1, B, u, nullptr, ACT_NONE, out, 0, st);
+    };
+    op.bwd = [=](hipStream_t st) -> int {
+        CDRL_TRY(gather_view(dout, 0, B, u, make_view(dHa, u), 0, st));
+        float* cur = dHa;
+        float* nxt = dHb;
+        for (int t = T - 1; t >= 0; --t) {
+            float* dhp = dHP + (size_t)t * B * U3;
+            CDRL_TRY(gru_gates_bwd(cur, Z + (size_t)t * B * u, R + (size_t)t * B * u, HH + (size_t)t * B * u,
+                                   HP + (size_t)t * B * U3, Hs + (size_t)t * B * u, dXP + (size_t)t * B * U3, dhp, nxt, B,
+                                   u, st));
+            CDRL_TRY(gemm_nn(make_view(dhp, U3), Rp.p, 1, U3, nullptr, make_view(nxt, u), B, u, U3, 1, st));
+            float* tmp = cur;
+            cur = nxt;
+            nxt = tmp;
+        }
+        CDRL_TRY(gemm_tn(xv, make_view(dXP, U3), Kp.g, T * B, U3, In, tn_part_, 0, st));
+        CDRL_TRY(colsum(make_view(dXP, U3), T * B, U3, part_, st));
+        CDRL_TRY(reduce_partials(part_, nbc, U3, U3, bp.g, 0, st));
+        CDRL_TRY(gemm_tn(make_view(Hs, u), make_view(dHP, U3), Rp.g, T * B, U3, u, tn_part_, 0, st));
+        CDRL_TRY(colsum(make_view(dHP, U3), T * B, U3, part_, st));
+        CDRL_TRY(reduce_partials(part_, nbc, U3, U3, bp.g + U3, 0, st));
+        if (need_dx) CDRL_TRY(gemm_nn(make_view(dXP, U3), Kp.p, 1, U3, nullptr, xg, T * B, In, U3, 0, st));
+        return 0;
+    };
+    ops.push_back(op);
+}
+
+// ------------------------------------------------------------------------------------------
+// graph construction
+// ------------------------------------------------------------------------------------------
+void Learner::build_trunk(std::vector<Op>& ops) {
+    const Config& c = cfg_;
+    const int B = c.B, T = c.T, N = B * T;
+    const int Hs = (c.H - 3) / 2 + 1, Ws = (c.W - 3) / 2 + 1;
+    auto bnrec = [](int G, int Mg, int C) { return BnRec{G, Mg, C, col_geom(Mg, C).nb}; };
+
+    // ---- stem (core/architectures.py:159-161)
+    {
+        Tens y = tens(N * Hs * Ws, c.stem, false);
+        Tens a = tens(N * Hs * Ws, c.stem);
+        PRef w = param(M_TRUNK, "img.stem.conv.w", {3, 3, 3, c.stem}, true);
+        PRef b = param(M_TRUNK, "img.stem.conv.b", {c.stem}, true);
+        note_scratch((size_t)stem_bwd_part_elems(B, T, c.H, c.W, c.stem), 0, (size_t)N * Hs * Ws * c.stem, 0);
+        Op op;
+        const int H = c.H, W = c.W, Cs = c.stem;
+        op.fwd = [=](hipStream_t st, int) -> int { return stem_fwd(in_image_, w.p, b.p, y.p, B, T, H, W, Cs, st); };
+        op.bwd = [=](hipStream_t st) -> int { return stem_bwd_filter(in_image_, dy_, w.g, b.g, B, T, H, W, Cs, part_, st); };
+        ops.push_back(op);
+        add_bn(ops, M_TRUNK, "img.stem.bn", y.v(), T, B * Hs * Ws, c.stem, true, ACT_RELU6, a.v(), 0, a.gv(), 0, dy_);
+        const int Hp = same_out_h(Hs, 2), Wp = same_out_h(Ws, 2);
+        Tens pool = tens(N * Hp * Wp, c.stem);
+        uint8_t* argmax = reinterpret_cast<uint8_t*>(alloc(((size_t)N * Hp * Wp * c.stem + 3) / 4));
+        Op mp;
+        mp.fwd = [=](hipStream_t st, int) -> int { return maxpool_fwd(a.p, pool.p, argmax, N, Hs, Ws, Cs, st); };
+        mp.bwd = [=](hipStream_t st) -> int { return maxpool_bwd(argmax, pool.g, a.g, N, Hs, Ws, Cs, st); };
+        ops.push_back(mp);
+
+        // ---- stages (core/architectures.py:120-151,164-167)
+        Tens X = pool;
+        int curH = Hp, curW = Wp, curC = c.stem;
+        for (int s = 0; s < 3; ++s) {
+            for (int u = 0; u < c.stage_n[s]; ++u) {
+                const int stride = u == 0 ? 2 : 1;
+                const int C = c.stage_c[s];
+                const int sc_c = stride == 2 ? curC : curC / 2;
+                const int main_in = stride == 2 ? curC : curC - sc_c;
+                const int main_off = stride == 2 ? 0 : sc_c;
+                const int mid = C / 2, main_out = C - sc_c;
+                const int Ho = stride == 2 ? same_out_h(curH, 2) : curH, Wo = stride == 2 ? same_out_h(curW, 2) : curW;
+                const int rows_in = N * curH * curW, rows_out = N * Ho * Wo;
+                const int Mg_in = B * curH * curW, Mg_out = B * Ho * Wo;
+                const std::string pre = "img.s" + std::to_string(s) + ".u" + std::to_string(u);
+                Tens out = tens(rows_out, C);
+                if (stride == 1) {
+                    Op cp;                      // shortcut half: identity through concat + shuffle
+                    View src = X.v(0), dst = out.v(0), gsrc = out.gv(0), gdst = X.gv(0);
+                    cp.fwd = [=](hipStream_t st, int) -> int {
+                        return bn_apply(src, 1, rows_in, sc_c, nullptr, ACT_NONE, dst, C, st);
+                    };
+                    cp.bwd = [=](hipStream_t st) -> int { return gather_view(gsrc, C, rows_in, sc_c, gdst, 0, st); };
+                    ops.push_back(cp);
+                }
+                Tens y1 = tens(rows_in, mid, false), a1 = tens(rows_in, mid);
+                add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, dy_, X.gv(main_off),
+                       stride == 2 ? 1 : 0, bnrec(T, Mg_in, mid));
+                add_bn(ops, M_TRUNK, pre + ".bn1", y1.v(), T, Mg_in, mid, true, ACT_RELU6, a1.v(), 0, a1.gv(), 0, dy_);
+                Tens y2 = tens(rows_out, mid, false), a2 = tens(rows_out, mid);
+                add_dw(ops, pre + ".dw", a1.v(), N, curH, curW, mid, stride, y2.p, dy_, a1.gv(), 0);
+                add_bn(ops, M_TRUNK, pre + ".bn2", y2.v(), T, Mg_out, mid, true, ACT_NONE, a2.v(), 0, a2.gv(), 0, dy_);
+                Tens y3 = tens(rows_out, main_out, false);
+                add_pw(ops, pre + ".pw2", a2.v(), rows_out, mid, main_out, y3.p, dy_, a2.gv(), 0, bnrec(T, Mg_out, main_out));
+                add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C,
+                       out.gv(sc_c), C, dy_);
+                if (stride == 2) {
+                    Tens ys1 = tens(rows_out, sc_c, false), b1 = tens(rows_out, sc_c);
+                    add_dw(ops, pre + ".sc_dw", X.v(0), N, curH, curW, sc_c, 2, ys1.p, dy_, X.gv(0), 0);
+                    add_bn(ops, M_TRUNK, pre + ".sc_bn1", ys1.v(), T, Mg_out, sc_c, true, ACT_NONE, b1.v(), 0, b1.gv(), 0,
+                           dy_);
+                    Tens ys2 = tens(rows_out, sc_c, false);
+                    add_pw(ops, pre + ".sc_pw", b1.v(), rows_out, sc_c, sc_c, ys2.p, dy_, b1.gv(), 0, bnrec(T, Mg_out, sc_c));
+                    add_bn(ops, M_TRUNK, pre + ".sc_bn2", ys2.v(), T, Mg_out, sc_c, true, ACT_RELU6, out.v(0), C, out.gv(0),
+                           C, dy_);
+                }
+                X = out;
+                curH = Ho;
+                curW = Wo;
+                curC = C;
+            }
+        }
+        // ---- head conv + GAP (core/architectures.py:170-172)
+        const int P = curH * curW, rows = N * P;
+        Tens yh = tens(rows, c.last, false), ah = tens(rows, c.last);
+        add_pw(ops, "img.head.conv", X.v(), rows, curC, c.last, yh.p, dy_, X.gv(), 0, bnrec(T, B * P, c.last));
+        add_bn(ops, M_TRUNK, "img.head.bn", yh.v(), T, B * P, c.last, true, ACT_RELU6, ah.v(), 0, ah.gv(), 0, dy_);
+        feat_ = tens(N, c.last);
+        Tens feat = feat_;
+        const int Cl = c.last;
+        Op gp;
+        gp.fwd = [=](hipStream_t st, int) -> int { return gap_fwd(ah.p, feat.p, N, P, Cl, st); };
+        gp.bwd = [=](hipStream_t st) -> int { return gap_bwd(feat.g, ah.g, N, P, Cl, st); };
+        ops.push_back(gp);
+    }
+
+    // ---- feature nets (core/architectures.py:9-27)
+    const char* fnames[3] = {"road", "vehicle", "navigation"};
+    const int fdims[3] = {c.road, c.vehicle, c.navigation};
+    Tens fout[3];
+    for (int i = 0; i < 3; ++i) {
+        const std::string nm = fnames[i];
+        const int D = fdims[i];
+        Tens xin = tens(N, D, false);
+        Op pin;
+        const int which = i;
+        pin.fwd = [=](hipStream_t st, int) -> int {
+            const float* src = which == 0 ? in_road_ : (which == 1 ? in_vehicle_ : in_navigation_);
+            return permute_bt(src, xin.p, B, T, D, st);
+        };
+        pin.bwd = [](hipStream_t) -> int { return 0; };
+        ops.push_back(pin);
+        Tens a0 = tens(N, c.feat), n0 = tens(N, c.feat), a1 = tens(N, c.feat), n1 = tens(N, c.feat);
+        add_dense(ops, M_TRUNK, nm + ".fc0", xin.v(), N, D, c.feat, ACT_RELU6, a0.v(), a0.gv(), View{nullptr, 0, 0}, 0,
+                  false, "glorot");
+        add_bn(ops, M_TRUNK, nm + ".bn0", a0.v(), T, B, c.feat, false, ACT_NONE, n0.v(), 0, n0.gv(), 0, a0.g);
+        add_dense(ops, M_TRUNK, nm + ".fc1", n0.v(), N, c.feat, c.feat, ACT_RELU6, a1.v(), a1.gv(), n0.gv(), 0, true,
+                  "glorot");
+        add_bn(ops, M_TRUNK, nm + ".bn1", a1.v(), T, B, c.feat, false, ACT_NONE, n1.v(), 0, n1.gv(), 0, a1.g);
+        fout[i] = n1;
+    }
+
+    // ---- GRUs + concat + BN + Dense (core/networks.py:44-56)
+    const int catC = c.rnn_image + 3 * c.rnn_small;
+    Tens cat = tens(B, catC);
+    add_gru(ops, "gru_image", feat_, c.last, c.rnn_image, cat.v(0), cat.gv(0), true);
+    for (int i = 0; i < 3; ++i)
+        add_gru(ops, std::string("gru_") + fnames[i], fout[i], c.feat, c.rnn_small, cat.v(c.rnn_image + i * c.rnn_small),
+                cat.gv(c.rnn_image + i * c.rnn_small), true);
+    Tens ncat = tens(B, catC);
+    add_bn(ops, M_TRUNK, "dyn.bn", cat.v(), 1, B, catC, false, ACT_NONE, ncat.v(), 0, ncat.gv(), 0, cat.g);
+    dyn_ = tens(B, c.dyn);
+    add_dense(ops, M_TRUNK, "dyn.fc", ncat.v(), B, catC, c.dyn, ACT_NONE, dyn_.v(), dyn_.gv(), ncat.gv(), 0, true, "glorot");
+}
+
+void Learner::build_head(std::vector<Op>& ops, int model, const std::string& prefix, Tens& lin, int nheads,
+                         const int* head_dims, const char* const* head_names) {
+    const Config& c = cfg_;
+    const int B = c.B;
+    Tens n0 = tens(B, c.dyn), a0 = tens(B, c.head), n1 = tens(B, c.head), a1 = tens(B, c.head);
+    add_bn(ops, model, prefix + ".bn0", dyn_.v(), 1, B, c.dyn, false, ACT_NONE, n0.v(), 0, n0.gv(), 0, dyn_.g);
+    add_dense(ops, model, prefix + ".fc0", n0.v(), B, c.dyn, c.head, ACT_SWISH6, a0.v(), a0.gv(), n0.gv(), 0, true, "glorot");
+    add_bn(ops, model, prefix + ".bn1", a0.v(), 1, B, c.head, false, ACT_NONE, n1.v(), 0, n1.gv(), 0, a0.g);
+    add_dense(ops, model, prefix + ".fc1", n1.v(), B, c.head, c.head, ACT_SWISH6, a1.v(), a1.gv(), n1.gv(), 0, true, "glorot");
+    int L = 0;
+    for (int i = 0; i < nheads; ++i) L += head_dims[i];
+    lin = tens(B, L);
+    int off = 0;
+    for (int i = 0; i < nheads; ++i) {
+        add_dense(ops, model, prefix + "." + head_names[i], a1.v(), B, c.head, head_dims[i], ACT_NONE, lin.v(off),
+                  lin.gv(off), a1.gv(), i < nheads - 1 ? 1 : 0, true, "glorot");
+        off += head_dims[i];
+    }
+}
+
+void Learner::build(bool dry) {
+    dry_ = dry;
+    ws_off_ = 0;
+    trunk_ops_.clear();
+    policy_ops_.clear();
+    value_ops_.clear();
+    old_policy_ops_.clear();
+    if (!dry) {
+        part_ = alloc_d(max_part_);
+        part2_ = alloc_d(max_part2_);
+        dy_ = alloc(max_dy_);
+        tn_part_ = alloc(max_tn_);
+    }
+    build_trunk(trunk_ops_);
+    const int A = cfg_.A;
+    const int pdims[4] = {A, A, 1, 1};
+    const char* const pnames[4] = {"alpha", "beta", "similarity", "speed"};
+    build_head(policy_ops_, M_POLICY, "pi", lin_p_, 4, pdims, pnames);
+    const int vdims[4] = {1, 1, 1, 1};
+    const char* const vnames[4] = {"base", "exp", "speed", "similarity"};
+    build_head(value_ops_, M_VALUE, "v", lin_v_, 4, vdims, vnames);
+    build_head(old_policy_ops_, M_OLD_POLICY, "pi", lin_old_, 4, pdims, pnames);
+    metrics_p_ = alloc(16);
+    metrics_v_ = alloc(16);
+    aux_p_ = alloc((size_t)cfg_.B * 4 * A);
+    aux_v_ = alloc((size_t)cfg_.B * 2);
+    hp_dev_ = reinterpret_cast<DevHP*>(alloc(sizeof(DevHP) / sizeof(float) + 4));
+    // optimiser tables
+    for (int m = 1; m <= 2; ++m) {
+        SegTable& s = seg_[m];
+        int nt = 0;
+        int64_t nch = 0;
+        for (const ParamInfo& pi : infos_[m])
+            if (pi.trainable) {
+                ++nt;
+                nch += (pi.numel + 1023) / 1024;
+            }
+        s.segs = reinterpret_cast<TensorSeg*>(alloc((size_t)nt * sizeof(TensorSeg) / sizeof(float)));
+        s.chunk_tensor = reinterpret_cast<int*>(alloc((size_t)nch));
+        s.chunk_off = reinterpret_cast<int64_t*>(alloc((size_t)nch * 2));
+        s.chunk_part = alloc_d((size_t)nch);
+        s.sqnorms = alloc((size_t)nt);
+    }
+    if (dry) {
+        // scratch goes first in the real layout; account for it here
+        ws_off_ += align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
+                   align_up(max_dy_ * sizeof(float), 256) + align_up(max_tn_ * sizeof(float), 256);
+        ws_bytes_ = ws_off_ + 4096;
+    }
+}
+
+void Learner::build_seg_tables() {
+    for (int m = 1; m <= 2; ++m) {
+        SegTable& s = seg_[m];
+        s.h_segs.clear();
+        s.h_chunk_tensor.clear();
+        s.h_chunk_off.clear();
+        for (const ParamInfo& pi : infos_[m]) {
+            if (!pi.trainable) continue;
+            TensorSeg seg;
+            seg.off = pi.off;
+            seg.n = pi.numel;
+            seg.first_chunk = (int)s.h_chunk_tensor.size();
+            seg.nchunks = (int)((pi.numel + 1023) / 1024);
+            for (int k = 0; k < seg.nchunks; ++k) {
+                s.h_chunk_tensor.push_back((int)s.h_segs.size());
+                s.h_chunk_off.push_back(pi.off + (int64_t)k * 1024);
+            }
+            s.h_segs.push_back(seg);
+        }
+        s.ntensors = (int)s.h_segs.size();
+        s.nchunks = (int)s.h_chunk_tensor.size();
+    }
+}
+
+int Learner::upload_seg_tables() {
+    for (int m = 1; m <= 2; ++m) {
+        SegTable& s = seg_[m];
+        CDRL_HIP(hipMemcpy(s.segs, s.h_segs.data(), s.h_segs.size() * sizeof(TensorSeg), hipMemcpyHostToDevice));
+        CDRL_HIP(hipMemcpy(s.chunk_tensor, s.h_chunk_tensor.data(), s.h_chunk_tensor.size() * sizeof(int),
+                           hipMemcpyHostToDevice));
+        CDRL_HIP(hipMemcpy(s.chunk_off, s.h_chunk_off.data(), s.h_chunk_off.size() * sizeof(int64_t),
+                           hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int Learner::bind(const Buffers& b) {
+    if (!b.params || !b.grads || !b.adam_m || !b.adam_v || !b.workspace) {
+        set_error("bind: null buffer");
+        return -1;
+    }
+    if (b.workspace_bytes < ws_bytes_) {
+        set_error("bind: workspace too small (%zu < %zu)", b.workspace_bytes, ws_bytes_);
+        return -1;
+    }
+    buf_ = b;
+    ws_base_ = reinterpret_cast<char*>(b.workspace);
+    build(false);
+    if (ws_off_ > b.workspace_bytes) {
+        set_error("bind: internal workspace overflow");
+        return -1;
+    }
+    CDRL_TRY(upload_seg_tables());
+    if (!hp_stage_) CDRL_HIP(hipHostMalloc(reinterpret_cast<void**>(&hp_stage_), sizeof(DevHP), 0));
+    CDRL_HIP(hipMemcpy(hp_dev_, &hp_host_, sizeof(DevHP), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int Learner::upload_hp(hipStream_t st) {
+    // only the float block (lr / clip / entropy / betas); the Adam counters stay device-resident
+    memcpy(hp_stage_, &hp_host_, sizeof(DevHP));
+    CDRL_HIP(hipMemcpyAsync(hp_dev_, hp_stage_, offsetof(DevHP, t_policy), hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+int Learner::reset_counters(hipStream_t st) {
+    CDRL_HIP(hipMemsetAsync(reinterpret_cast<char*>(hp_dev_) + offsetof(DevHP, t_policy), 0, 3 * sizeof(int), st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// execution
+// ------------------------------------------------------------------------------------------
+int Learner::run_fwd(std::vector<Op>& ops, hipStream_t st, int training) {
+    for (Op& op : ops) CDRL_TRY(op.fwd(st, training));
+    return 0;
+}
+
+int Learner::run_bwd(std::vector<Op>& ops, hipStream_t st) {
+    for (size_t i = ops.size(); i-- > 0;) CDRL_TRY(ops[i].bwd(st));
+    return 0;
+}
+
+int Learner::set_inputs(const float* image, const float* road, const float* vehicle, const float* navigation) {
+    if (!ws_base_) {
+        set_error("learner not bound");
+        return -1;
+    }
+    if (!image || !road || !vehicle || !navigation) {
+        set_error("null state input");
+        return -1;
+    }
+    in_image_ = image;
+    in_road_ = road;
+    in_vehicle_ = vehicle;
+    in_navigation_ = navigation;
+    return 0;
+}
+
+int Learner::trunk_forward_train(const float* image, const float* road, const float* vehicle, const float* navigation,
+                                 hipStream_t st) {
+    CDRL_TRY(set_inputs(image, road, vehicle, navigation));
+    return run_fwd(trunk_ops_, st, 1);
+}
+
+int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipStream_t st) {
+    CDRL_TRY(set_inputs(b.image, b.road, b.vehicle, b.navigation));
+    CDRL_TRY(run_fwd(trunk_ops_, st, 1));
+    CDRL_TRY(run_fwd(policy_ops_, st, 1));
+    PolicyLossArgs a;
+    a.lin = lin_p_.p;
+    a.adv = b.adv;
+    a.old_logp = b.old_logp;
+    a.speed = b.speed;
+    a.similarity = b.similarity;
+    a.u = b.u;
+    a.du_da = b.du_da;
+    a.du_db = b.du_db;
+    a.hp = reinterpret_cast<const float*>(hp_dev_);
+    a.dlin = lin_p_.g;
+    a.metrics = metrics_p_;
+    a.aux = aux_p_;
+    a.B = cfg_.B;
+    a.A = cfg_.A;
+    a.inv_world = inv_world;
+    CDRL_TRY(policy_loss(a, st));
+    CDRL_TRY(run_bwd(policy_ops_, st));
+    return run_bwd(trunk_ops_, st);
+}
+
+int Learner::value_forward_backward(const ValueBatch& b, float inv_world, hipStream_t st) {
+    CDRL_TRY(set_inputs(b.image, b.road, b.vehicle, b.navigation));
+    CDRL_TRY(run_fwd(trunk_ops_, st, 1));
+    CDRL_TRY(run_fwd(value_ops_, st, 1));
+    ValueLossArgs a;
+    a.lin = lin_v_.p;
+    a.returns = b.returns;
+    a.speed = b.speed;
+    a.similarity = b.similarity;
+    a.dlin = lin_v_.g;
+    a.metrics = metrics_v_;
+    a.values = aux_v_;
+    a.B = cfg_.B;
+    a.exp_scale = cfg_.exp_scale;
+    a.inv_world = inv_world;
+    CDRL_TRY(value_loss(a, st));
+    CDRL_TRY(run_bwd(value_ops_, st));
+    return run_bwd(trunk_ops_, st);
+}
+
+int Learner::update_old_policy(hipStream_t st) {
+    // old_policy.set_weights(policy.get_weights()): all weights incl. BN moving statistics
+    // (reference core/networks.py:281-285)
+    CDRL_HIP(hipMemcpyAsync(buf_.params + tr_offset(M_OLD_POLICY), buf_.params + tr_offset(M_POLICY),
+                            tr_size_[M_POLICY] * sizeof(float), hipMemcpyDeviceToDevice, st));
+    CDRL_HIP(hipMemcpyAsync(buf_.params + st_offset(M_OLD_POLICY), buf_.params + st_offset(M_POLICY),
+                            st_size_[M_POLICY] * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int Learner::policy_apply(hipStream_t st) {
+    // order: trunk Adam (unclipped, F9) -> clip -> old_policy <- policy -> policy Adam
+    const int64_t to = tr_offset(M_TRUNK), po = tr_offset(M_POLICY);
+    CDRL_TRY(clip_adam(buf_.params + to, buf_.grads + to, buf_.adam_m + to, buf_.adam_v + to, tr_size_[M_TRUNK], nullptr,
+                       nullptr, 0, nullptr, nullptr, hp_dev_, 2, st));
+    CDRL_TRY(adam_tick(hp_dev_, 2, st));
+    SegTable& s = seg_[M_POLICY];
+    CDRL_TRY(tensor_sqnorms(buf_.grads + po, s.segs, s.ntensors, s.chunk_tensor, s.chunk_off, s.nchunks, s.chunk_part,
+                            s.sqnorms, st));
+    CDRL_TRY(update_old_policy(st));
+    CDRL_TRY(clip_adam(buf_.params + po, buf_.grads + po, buf_.adam_m + po, buf_.adam_v + po, tr_size_[M_POLICY],
+                       s.chunk_tensor, s.chunk_off, s.nchunks, s.segs, s.sqnorms, hp_dev_, 0, st));
+    return adam_tick(hp_dev_, 0, st);
+}
+
+int Learner::value_apply(hipStream_t st) {
+    const int64_t to = tr_offset(M_TRUNK), vo = tr_offset(M_VALUE);
+    CDRL_TRY(clip_adam(buf_.params + to, buf_.grads + to, buf_.adam_m + to, buf_.adam_v + to, tr_size_[M_TRUNK], nullptr,
+                       nullptr, 0, nullptr, nullptr, hp_dev_, 2, st));
+    CDRL_TRY(adam_tick(hp_dev_, 2, st));
+    SegTable& s = seg_[M_VALUE];
+    CDRL_TRY(tensor_sqnorms(buf_.grads + vo, s.segs, s.ntensors, s.chunk_tensor, s.chunk_off, s.nchunks, s.chunk_part,
+                            s.sqnorms, st));
+    CDRL_TRY(clip_adam(buf_.params + vo, buf_.grads + vo, buf_.adam_m + vo, buf_.adam_v + vo, tr_size_[M_VALUE],
+                       s.chunk_tensor, s.chunk_off, s.nchunks, s.segs, s.sqnorms, hp_dev_, 1, st));
+    return adam_tick(hp_dev_, 1, st);
+}
+
+int Learner::predict(const float* image, const float* road, const float* vehicle, const float* navigation,
+                     float* dist_out, float* value_out, float* dyn_out, hipStream_t st) {
+    CDRL_TRY(set_inputs(image, road, vehicle, navigation));
+    CDRL_TRY(run_fwd(trunk_ops_, st, 0));
+    CDRL_TRY(run_fwd(old_policy_ops_, st, 0));
+    CDRL_TRY(policy_dist(lin_old_.p, dist_out, cfg_.B, cfg_.A, st));
+    CDRL_TRY(run_fwd(value_ops_, st, 0));
+    CDRL_TRY(value_act(lin_v_.p, value_out, cfg_.B, cfg_.exp_scale, st));
+    if (dyn_out)
+        CDRL_HIP(hipMemcpyAsync(dyn_out, dyn_.p, (size_t)cfg_.B * cfg_.dyn * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+}  // namespace cdrl

@@ -1,0 +1,254 @@
+// fp32 MFMA GEMMs for gfx950 (CDNA4): v_mfma_f32_32x32x2_f32, 64-lane wavefronts.
+//
+// Used for every GEMM-shaped op of the learner (K4 pointwise convs, K8 dense layers, K10 GRU
+// projections).  The f32-input MFMA is an exact k-ordered fmaf chain, so the
+// results carry plain fp32 rounding (needed for the 1e-4 parity bar) at the matrix-core rate.
+//
+//   gemm_nn : C[M,N] (+)= A[M,K] * B(k,n) + bias     (forward, backward-data via strided B)
+//   gemm_tn : W[K,N]  = sum_m A[m,K]^T D[m,N]        (backward-filter; split over M, two-stage
+//                                                      deterministic reduction, no atomics)
+//
+// Tiling: 256-thread workgroups = 4 wavefronts.  gemm_nn: 128 x (32*NT) output tile, every
+// wave owns 32 rows x NT 32x32 accumulators; A/B staged through LDS in BK=32 slices (A tile
+// padded to 33 floats per row -> conflict-free ds_read_b32 for the MFMA A fragment, B fragment
+// reads are lane-consecutive).  Awkward channel counts (24/58/92/116/232/464) are zero-padded in
+// LDS only; HBM tensors stay dense NHWC.
+#include "cdrl_kernels.h"
+
+namespace cdrl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BM 128
+#define BK 32
+
+template <int NT>
+__global__ void __launch_bounds__(256) gemm_nn_kernel(View A, const float* __restrict__ Bp, int sbk, int sbn,
+                                                      const float* __restrict__ bias, View C, int M, int N, int K,
+                                                      int accumulate) {
+    constexpr int BN = 32 * NT;
+    __shared__ float As[BM][BK + 1];
+    __shared__ float Bs[BK][BN];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    const int lrow = lane & 31, lk = lane >> 5;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        // stage A: 128 x 32
+#pragma unroll
+        for (int i = 0; i < (BM * BK) / 256; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 5, kk = idx & 31;
+            const int64_t m = m0 + r;
+            float v = 0.0f;
+            if (m < M && (k0 + kk) < K) v = A.p[m * A.ld + A.coff + k0 + kk];
+            As[r][kk] = v;
+        }
+        // stage B: 32 x BN
+#pragma unroll
+        for (int i = 0; i < (BK * BN) / 256; ++i) {
+            const int idx = tid + 256 * i;
+            const int kk = idx / BN, nn = idx % BN;
+            float v = 0.0f;
+            if ((k0 + kk) < K && (n0 + nn) < N) v = Bp[(int64_t)(k0 + kk) * sbk + (int64_t)(n0 + nn) * sbn];
+            Bs[kk][nn] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = As[wave * 32 + lrow][kk + lk];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float b = Bs[kk + lk][j * 32 + lrow];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 32 + lrow;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < M) {
+                float* c = &C.p[m * C.ld + C.coff + n];
+                float v = acc[j][r] + bv;
+                if (accumulate) v += *c;
+                *c = v;
+            }
+        }
+    }
+}
+
+int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C, int M, int N, int K,
+            int accumulate, hipStream_t st) {
+    if (M <= 0 || N <= 0) return 0;
+    int nt = cdiv(N, 32);
+    if (nt > 4) nt = 4;
+    // balance column blocks: e.g. N=232 -> 2 blocks of 4 tiles; N=92 -> 1 block of 3 tiles
+    const int ncb = cdiv(N, 32 * nt);
+    nt = cdiv(cdiv(N, ncb), 32);
+    dim3 grid(cdiv(M, BM), cdiv(N, 32 * nt)), block(256);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(gemm_nn_kernel<1>, grid, block, 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+        case 2: hipLaunchKernelGGL(gemm_nn_kernel<2>, grid, block, 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+        case 3: hipLaunchKernelGGL(gemm_nn_kernel<3>, grid, block, 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+        default: hipLaunchKernelGGL(gemm_nn_kernel<4>, grid, block, 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+    }
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// TN: W[K,N] = A^T D, reduction over M.
+// Block output tile: (32*KT) x (32*NTL) <= 128x128; the KT*NTL 32x32 MFMA tiles are dealt
+// round-robin to the 4 waves (<= 4 tiles = 64 accumulator VGPRs per wave).
+// ------------------------------------------------------------------------------------------
+#define TN_BM 32
+
+struct TnPlan {
+    int kt, ntl;        // 32-wide tiles per block along K and N
+    int gy, gz;         // blocks along K and N
+    int nsplit;         // blocks along M
+    int rows_per;       // rows per split (multiple of TN_BM)
+};
+
+static TnPlan tn_plan(int M, int N, int K) {
+    TnPlan p;
+    p.gy = cdiv(K, 128);
+    p.gz = cdiv(N, 128);
+    p.kt = cdiv(cdiv(K, p.gy), 32);
+    p.ntl = cdiv(cdiv(N, p.gz), 32);
+    int target = 1024 / (p.gy * p.gz);
+    if (target < 1) target = 1;
+    int ns = M / 256;
+    if (ns > target) ns = target;
+    if (ns < 1) ns = 1;
+    p.rows_per = cdiv(cdiv(M, ns), TN_BM) * TN_BM;
+    p.nsplit = cdiv(M, p.rows_per);
+    return p;
+}
+
+int64_t gemm_tn_part_elems(int M, int N, int K) {
+    TnPlan p = tn_plan(M, N, K);
+    return (int64_t)p.nsplit * K * N;
+}
+
+template <int KT, int NTL>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(View A, View D, float* __restrict__ part, int M, int N, int K,
+                                                      int rows_per) {
+    constexpr int TK = 32 * KT, TNn = 32 * NTL;
+    constexpr int NTILES = KT * NTL;
+    constexpr int PER_WAVE = (NTILES + 3) / 4;
+    __shared__ float As[TN_BM][TK];
+    __shared__ float Ds[TN_BM][TNn];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lcol = lane & 31, lk = lane >> 5;
+    const int k0 = blockIdx.y * TK, n0 = blockIdx.z * TNn;
+    const int64_t mbeg = (int64_t)blockIdx.x * rows_per;
+    int64_t mend = mbeg + rows_per;
+    if (mend > M) mend = M;
+    f32x16 acc[PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    for (int64_t m0 = mbeg; m0 < mend; m0 += TN_BM) {
+        for (int idx = tid; idx < TN_BM * TK; idx += 256) {
+            const int r = idx / TK, kk = idx % TK;
+            const int64_t m = m0 + r;
+            float v = 0.0f;
+            if (m < mend && (k0 + kk) < K) v = A.p[m * A.ld + A.coff + k0 + kk];
+            As[r][kk] = v;
+        }
+        for (int idx = tid; idx < TN_BM * TNn; idx += 256) {
+            const int r = idx / TNn, nn = idx % TNn;
+            const int64_t m = m0 + r;
+            float v = 0.0f;
+            if (m < mend && (n0 + nn) < N) v = D.p[m * D.ld + D.coff + n0 + nn];
+            Ds[r][nn] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int tile = wave + 4 * j;
+            if (tile < NTILES) {
+                const int ki = tile / NTL, nj = tile % NTL;
+#pragma unroll
+                for (int mm = 0; mm < TN_BM; mm += 2) {
+                    const float a = As[mm + lk][ki * 32 + lcol];
+                    const float b = Ds[mm + lk][nj * 32 + lcol];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = part + (int64_t)blockIdx.x * K * N;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int tile = wave + 4 * j;
+        if (tile < NTILES) {
+            const int ki = tile / NTL, nj = tile % NTL;
+            const int n = n0 + nj * 32 + lcol;
+            if (n < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = k0 + ki * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (k < K) out[(int64_t)k * N + n] = acc[j][r];
+                }
+            }
+        }
+    }
+}
+
+__global__ void tn_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
+                                 int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < nsplit; ++p) s += (double)part[(int64_t)p * n + i];
+    out[i] = accumulate ? out[i] + (float)s : (float)s;
+}
+
+template <int KT>
+static void launch_tn(int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp) {
+    switch (ntl) {
+        case 1: hipLaunchKernelGGL((gemm_tn_kernel<KT, 1>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
+        case 2: hipLaunchKernelGGL((gemm_tn_kernel<KT, 2>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
+        case 3: hipLaunchKernelGGL((gemm_tn_kernel<KT, 3>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
+        default: hipLaunchKernelGGL((gemm_tn_kernel<KT, 4>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
+    }
+}
+
+int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st) {
+    TnPlan p = tn_plan(M, N, K);
+    dim3 grid(p.nsplit, p.gy, p.gz);
+    switch (p.kt) {
+        case 1: launch_tn<1>(p.ntl, grid, st, A, D, part, M, N, K, p.rows_per); break;
+        case 2: launch_tn<2>(p.ntl, grid, st, A, D, part, M, N, K, p.rows_per); break;
+        case 3: launch_tn<3>(p.ntl, grid, st, A, D, part, M, N, K, p.rows_per); break;
+        default: launch_tn<4>(p.ntl, grid, st, A, D, part, M, N, K, p.rows_per); break;
+    }
+    CDRL_LAUNCH_CHECK();
+    const int64_t n = (int64_t)K * N;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, part, p.nsplit, n, Cout,
+                       accumulate);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cdrl

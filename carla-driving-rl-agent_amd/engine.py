@@ -1,0 +1,260 @@
+"""LearnerEngine: thin Python owner of a `cdrl_learner` handle.
+
+PyTorch is used for device memory (parameter arenas, Adam state, workspace), streams and
+`torch.distributed` only; every arithmetic step of the learner runs in libcdrl_hip.so.
+"""
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import TRUNK, POLICY, VALUE, OLD_POLICY
+
+MODEL_IDS = dict(trunk=TRUNK, policy=POLICY, value=VALUE, old_policy=OLD_POLICY)
+
+
+def make_config(B, T=4, H=90, W=120, road=9, vehicle=4, navigation=5, A=2, **kw) -> _lib.Config:
+    lib = _lib.load()
+    cfg = _lib.Config()
+    lib.cdrl_config_default(C.byref(cfg))
+    cfg.B, cfg.T, cfg.H, cfg.W = B, T, H, W
+    cfg.road, cfg.vehicle, cfg.navigation, cfg.A = road, vehicle, navigation, A
+    for k, v in kw.items():
+        if k in ('stage_c', 'stage_n'):
+            for i in range(3):
+                getattr(cfg, k)[i] = v[i]
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+class ParamTable:
+    """Variable inventory of one model (trunk / policy / value) as reported by the engine."""
+
+    def __init__(self, lib, handle, model):
+        self.entries = []
+        n = lib.cdrl_learner_param_count(handle, model)
+        for i in range(n):
+            pi = _lib.ParamInfo()
+            _lib.check(lib.cdrl_learner_param_info(handle, model, i, C.byref(pi)), 'param_info')
+            self.entries.append(dict(name=pi.name.decode(), shape=tuple(pi.shape[:pi.ndim]), numel=int(pi.numel),
+                                     trainable=bool(pi.trainable), offset=int(pi.offset)))
+        self.by_name = {e['name']: e for e in self.entries}
+
+    def spec(self):
+        return [(e['name'], e['shape'], e['trainable']) for e in self.entries]
+
+
+class LearnerEngine:
+    def __init__(self, B, device: Optional[str] = 'cuda:0', share_with: 'LearnerEngine' = None, **cfg):
+        """device=None -> host-only inspection (parameter tables, workspace size; no HIP calls).
+        share_with -> reuse another engine's parameter arenas (e.g. a B=1 rollout engine)."""
+        self.lib = _lib.load()
+        self.cfg = make_config(B, **cfg)
+        h = C.c_void_p()
+        _lib.check(self.lib.cdrl_learner_create(C.byref(self.cfg), C.byref(h)), 'cdrl_learner_create')
+        self.h = h
+        self.tables = {m: ParamTable(self.lib, h, mid) for m, mid in (('trunk', TRUNK), ('policy', POLICY), ('value', VALUE))}
+        self.params_total = int(self.lib.cdrl_learner_params_total(h))
+        self.grads_total = int(self.lib.cdrl_learner_grads_total(h))
+        self.workspace_bytes = int(self.lib.cdrl_learner_workspace_bytes(h))
+        self.device = device
+        self.hp = dict(policy_lr=3e-4, value_lr=3e-4, dynamics_lr=3e-4, clip_ratio=0.2, entropy_coef=1.0,
+                       clip_norm_policy=1.0, clip_norm_value=1.0, beta1=0.9, beta2=0.999, eps=1e-7)
+        self._keep = []
+        if device is None:
+            return
+        dev = torch.device(device)
+        if share_with is not None:
+            self.params, self.grads = share_with.params, share_with.grads
+            self.adam_m, self.adam_v = share_with.adam_m, share_with.adam_v
+        else:
+            self.params = torch.zeros(self.params_total, dtype=torch.float32, device=dev)
+            self.grads = torch.zeros(self.grads_total, dtype=torch.float32, device=dev)
+            self.adam_m = torch.zeros(self.grads_total, dtype=torch.float32, device=dev)
+            self.adam_v = torch.zeros(self.grads_total, dtype=torch.float32, device=dev)
+        self.workspace = torch.zeros(self.workspace_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(self.lib.cdrl_learner_bind(h, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
+                                              _lib.ptr(self.adam_v), _lib.ptr(self.workspace), self.workspace_bytes),
+                   'cdrl_learner_bind')
+        self.set_hparams()
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self.lib.cdrl_learner_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def region(self, model: str, trainable: bool):
+        mid = MODEL_IDS[model]
+        off = int(self.lib.cdrl_learner_region_offset(self.h, mid, 1 if trainable else 0))
+        n = int(self.lib.cdrl_learner_region_elems(self.h, mid, 1 if trainable else 0))
+        return off, n
+
+    def _view(self, flat, model, e, grad=False):
+        off, _ = self.region(model, e['trainable'])
+        if grad and model == 'old_policy':
+            raise KeyError('old_policy has no gradients')
+        return flat[off + e['offset']: off + e['offset'] + e['numel']].view(e['shape'])
+
+    def param_views(self, model: str) -> Dict[str, torch.Tensor]:
+        table = self.tables['policy' if model == 'old_policy' else model]
+        return {e['name']: self._view(self.params, model, e) for e in table.entries}
+
+    def grad_views(self, model: str) -> Dict[str, torch.Tensor]:
+        return {e['name']: self._view(self.grads, model, e, True) for e in self.tables[model].entries if e['trainable']}
+
+    def adam_views(self, model: str):
+        t = self.tables[model]
+        return ({e['name']: self._view(self.adam_m, model, e) for e in t.entries if e['trainable']},
+                {e['name']: self._view(self.adam_v, model, e) for e in t.entries if e['trainable']})
+
+    def load_params(self, model: str, values: Dict[str, np.ndarray]):
+        views = self.param_views(model)
+        for name, v in views.items():
+            v.copy_(torch.as_tensor(np.asarray(values[name], dtype=np.float32)).reshape(v.shape))
+
+    def export_params(self, model: str) -> Dict[str, np.ndarray]:
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.param_views(model).items()}
+
+    def set_hparams(self, **kw):
+        self.hp.update(kw)
+        hp = _lib.HParams()
+        for k in ('policy_lr', 'value_lr', 'dynamics_lr', 'clip_ratio', 'entropy_coef', 'beta1', 'beta2', 'eps'):
+            setattr(hp, k, float(self.hp[k]))
+        hp.clip_norm_policy = float(self.hp['clip_norm_policy'] or 0.0)
+        hp.clip_norm_value = float(self.hp['clip_norm_value'] or 0.0)
+        _lib.check(self.lib.cdrl_learner_set_hparams(self.h, C.byref(hp), self._stream()), 'set_hparams')
+
+    def reset_optimizer(self):
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        _lib.check(self.lib.cdrl_learner_reset_optimizer_steps(self.h, self._stream()), 'reset_optimizer_steps')
+
+    def buffer(self, which: int, shape=None) -> torch.Tensor:
+        """Zero-copy torch view of an engine-owned workspace buffer."""
+        p = C.c_void_p()
+        n = C.c_int64()
+        _lib.check(self.lib.cdrl_learner_get_buffer(self.h, which, C.byref(p), C.byref(n)), 'get_buffer')
+        base = self.workspace.data_ptr()
+        off = p.value - base
+        t = self.workspace[off: off + 4 * n.value].view(torch.float32)
+        return t.view(shape) if shape is not None else t
+
+    # ------------------------------------------------------------------ steps
+    def _states(self, batch):
+        st = batch['states'] if 'states' in batch else batch
+        return st['state_image'], st['state_road'], st['state_vehicle'], st['state_navigation']
+
+    @staticmethod
+    def _chk(t, shape, name):
+        if t is None:
+            return
+        if tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError(f'{name}: expected contiguous float32 cuda tensor of shape {tuple(shape)}, '
+                             f'got {tuple(t.shape)} {t.dtype} contiguous={t.is_contiguous()} cuda={t.is_cuda}')
+
+    def _check_states(self, img, road, veh, nav):
+        c = self.cfg
+        self._chk(img, (c.B, c.T, c.H, c.W, 3), 'state_image')
+        self._chk(road, (c.B, c.T, c.road), 'state_road')
+        self._chk(veh, (c.B, c.T, c.vehicle), 'state_vehicle')
+        self._chk(nav, (c.B, c.T, c.navigation), 'state_navigation')
+
+    def policy_forward_backward(self, batch, grad_scale=1.0):
+        c = self.cfg
+        img, road, veh, nav = self._states(batch)
+        self._check_states(img, road, veh, nav)
+        self._chk(batch['advantages'], (c.B,), 'advantages')
+        self._chk(batch['old_log_prob'], (c.B, c.A), 'old_log_prob')
+        self._chk(batch['u'], (c.B, c.A), 'u')
+        for k in ('speed', 'similarity'):
+            if batch[k].numel() != c.B:
+                raise ValueError(f'{k}: expected {c.B} elements')
+        pb = _lib.PolicyBatch(image=img.data_ptr(), road=road.data_ptr(), vehicle=veh.data_ptr(),
+                              navigation=nav.data_ptr(), advantages=batch['advantages'].data_ptr(),
+                              old_log_prob=batch['old_log_prob'].data_ptr(), speed=batch['speed'].data_ptr(),
+                              similarity=batch['similarity'].data_ptr(), u=batch['u'].data_ptr(),
+                              du_dalpha=batch['du_da'].data_ptr() if batch.get('du_da') is not None else None,
+                              du_dbeta=batch['du_db'].data_ptr() if batch.get('du_db') is not None else None)
+        _lib.check(self.lib.cdrl_learner_policy_forward_backward(self.h, C.byref(pb), float(grad_scale), self._stream()),
+                   'policy_forward_backward')
+
+    def policy_apply(self):
+        _lib.check(self.lib.cdrl_learner_policy_apply(self.h, self._stream()), 'policy_apply')
+
+    def value_forward_backward(self, batch, grad_scale=1.0):
+        c = self.cfg
+        img, road, veh, nav = self._states(batch)
+        self._check_states(img, road, veh, nav)
+        self._chk(batch['returns'], (c.B, 2), 'returns')
+        vb = _lib.ValueBatch(image=img.data_ptr(), road=road.data_ptr(), vehicle=veh.data_ptr(),
+                             navigation=nav.data_ptr(), returns=batch['returns'].data_ptr(),
+                             speed=batch['speed'].data_ptr(), similarity=batch['similarity'].data_ptr())
+        _lib.check(self.lib.cdrl_learner_value_forward_backward(self.h, C.byref(vb), float(grad_scale), self._stream()),
+                   'value_forward_backward')
+
+    def value_apply(self):
+        _lib.check(self.lib.cdrl_learner_value_apply(self.h, self._stream()), 'value_apply')
+
+    def policy_step(self, batch):
+        self.policy_forward_backward(batch)
+        self.policy_apply()
+
+    def value_step(self, batch):
+        self.value_forward_backward(batch)
+        self.value_apply()
+
+    def update_old_policy(self):
+        _lib.check(self.lib.cdrl_learner_update_old_policy(self.h, self._stream()), 'update_old_policy')
+
+    def trunk_forward_train(self, states):
+        img, road, veh, nav = self._states(states)
+        self._check_states(img, road, veh, nav)
+        _lib.check(self.lib.cdrl_learner_trunk_forward_train(self.h, _lib.ptr(img), _lib.ptr(road), _lib.ptr(veh),
+                                                             _lib.ptr(nav), self._stream()), 'trunk_forward_train')
+        return self.buffer(_lib.BUF_DYNAMICS, (self.cfg.B, self.cfg.dyn))
+
+    def predict(self, states):
+        c = self.cfg
+        img, road, veh, nav = self._states(states)
+        self._check_states(img, road, veh, nav)
+        dist = torch.empty((c.B, 4, c.A), dtype=torch.float32, device=img.device)
+        value = torch.empty((c.B, 4), dtype=torch.float32, device=img.device)
+        dyn = torch.empty((c.B, c.dyn), dtype=torch.float32, device=img.device)
+        _lib.check(self.lib.cdrl_learner_predict(self.h, _lib.ptr(img), _lib.ptr(road), _lib.ptr(veh), _lib.ptr(nav),
+                                                 _lib.ptr(dist), _lib.ptr(value), _lib.ptr(dyn), self._stream()), 'predict')
+        return dict(alpha=dist[:, 0], beta=dist[:, 1], mean=dist[:, 2], std=dist[:, 3], value=value[:, :2],
+                    speed=value[:, 2], similarity=value[:, 3], dynamics=dyn)
+
+    def metrics(self, which='policy'):
+        m = self.buffer(_lib.BUF_METRICS_P if which == 'policy' else _lib.BUF_METRICS_V).cpu().numpy()
+        if which == 'policy':
+            keys = ('loss', 'policy_loss', 'entropy', 'speed_loss', 'similarity_loss', 'ratio', 'log_prob')
+        else:
+            keys = ('loss', 'value_loss', 'speed_loss', 'similarity_loss')
+        return {k: float(m[i]) for i, k in enumerate(keys)}
+
+
+def gae_returns(rewards: torch.Tensor, values_be: torch.Tensor, gamma: float, lambda_: float, scale: float = 2.0):
+    """Device GAE / returns for one env shard (cdrl_gae_returns).  rewards (N+1,), values_be (N+1,2)."""
+    lib = _lib.load()
+    n = rewards.numel() - 1
+    dev = rewards.device
+    returns = torch.empty(n, dtype=torch.float32, device=dev)
+    returns_be = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    adv_raw = torch.empty(n, dtype=torch.float32, device=dev)
+    adv = torch.empty(n, dtype=torch.float32, device=dev)
+    scratch = torch.empty(2 * (n + 1) + 2, dtype=torch.float64, device=dev)
+    _lib.check(lib.cdrl_gae_returns(_lib.ptr(rewards), _lib.ptr(values_be), n, float(gamma), float(lambda_), float(scale),
+                                    _lib.ptr(returns), _lib.ptr(returns_be), _lib.ptr(adv_raw), _lib.ptr(adv),
+                                    _lib.ptr(scratch), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'gae_returns')
+    return returns, returns_be, adv_raw, adv

@@ -1,0 +1,192 @@
+/* libcdrl_hip.so -- C ABI of the MI355X-native PPO learner hot path.
+ *
+ * Drop-in boundary for the learner path of Luca96/carla-driving-rl-agent.  The reference is pure
+ * Python/TensorFlow and has no FFI of its own; each entry point below names the
+ * reference interface (file:line under the reference repo) whose work it replaces.  Python
+ * (ctypes) is the only caller today: carla-driving-rl-agent_amd/_lib.py, see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; cdrl_last_error() gives the message;
+ *   - all pointers are DEVICE pointers to float32 unless stated; `stream` is a hipStream_t;
+ *   - nothing allocates device memory: the caller passes arenas + a workspace sized by
+ *     cdrl_learner_workspace_bytes(); entry points only enqueue work (no host sync);
+ *   - observation tensors use the reference layout (B, T, H, W, 3) / (B, T, D), NHWC dense.
+ */
+#ifndef CDRL_H
+#define CDRL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDRL_VERSION 1
+
+typedef struct cdrl_learner cdrl_learner;
+
+/* Network / batch geometry.  Defaults = CARLAgent.DEFAULT_* (core/carla_agent.py:61-68) on the
+ * real CARLAEnv spaces (core/carla_env.py:18-24,64). */
+typedef struct cdrl_config {
+    int32_t B, T, H, W;                    /* minibatch, time_horizon, image height / width     */
+    int32_t road, vehicle, navigation, A;  /* feature-vector sizes, num_actions                 */
+    int32_t stem;                          /* 24                                                */
+    int32_t stage_c[3];                    /* 116, 232, 464 (g = 1.0)                           */
+    int32_t stage_n[3];                    /* 4, 8, 4                                           */
+    int32_t last;                          /* 768                                               */
+    int32_t feat, rnn_image, rnn_small, dyn, head; /* 16, 256, 32, 512, 320                     */
+    float exp_scale;                       /* 6.0 (core/networks.py:169)                        */
+} cdrl_config;
+
+enum { CDRL_TRUNK = 0, CDRL_POLICY = 1, CDRL_VALUE = 2, CDRL_OLD_POLICY = 3 };
+
+typedef struct cdrl_param_info {
+    char name[64];
+    int32_t shape[4];
+    int32_t ndim;
+    int32_t trainable;
+    int64_t numel;
+    int64_t offset;      /* element offset inside the model's trainable / state region */
+} cdrl_param_info;
+
+/* DynamicParameter values of the step (rl/parameters/parameters.py; rl/agents/ppo.py:42,55,61,
+ * 101-106; core/carla_agent.py:120-124) + Keras Adam constants. */
+typedef struct cdrl_hparams {
+    float policy_lr, value_lr, dynamics_lr;
+    float clip_ratio, entropy_coef;
+    float clip_norm_policy, clip_norm_value;   /* <= 0 disables tf.clip_by_norm */
+    float beta1, beta2, eps;
+} cdrl_hparams;
+
+/* One policy minibatch = what CARLAgent.policy_batch_tensors yields (core/carla_agent.py:323-331)
+ * plus the Beta samples of PolicyNetwork.call (core/networks.py:96-110). */
+typedef struct cdrl_policy_batch {
+    const float *image, *road, *vehicle, *navigation;
+    const float *advantages;      /* (B)    */
+    const float *old_log_prob;    /* (B, A) */
+    const float *speed;           /* (B)  info_buffer['speed'] / 100 */
+    const float *similarity;      /* (B)    */
+    const float *u;               /* (B, A) Beta sample (or stored action) */
+    const float *du_dalpha;       /* (B, A) pathwise Jacobian or NULL */
+    const float *du_dbeta;        /* (B, A) or NULL */
+} cdrl_policy_batch;
+
+/* One value minibatch = CARLAgent.value_batch_tensors (core/carla_agent.py:333-349). */
+typedef struct cdrl_value_batch {
+    const float *image, *road, *vehicle, *navigation;
+    const float *returns;         /* (B, 2) (base, exponent) */
+    const float *speed, *similarity;
+} cdrl_value_batch;
+
+const char* cdrl_last_error(void);
+int cdrl_version(void);
+
+/* ---- learner object ------------------------------------------------------------------------
+ * replaces CARLANetwork.__init__ / dynamics_model / value_network / PolicyNetwork construction
+ * (core/networks.py:150-176,223-253) for one minibatch size. */
+int cdrl_learner_create(const cdrl_config* cfg, cdrl_learner** out);
+void cdrl_learner_destroy(cdrl_learner* l);
+void cdrl_config_default(cdrl_config* cfg);
+
+/* variable inventory: Model.trainable_variables / get_weights ordering (core/networks.py:281-285) */
+int cdrl_learner_param_count(const cdrl_learner* l, int model);
+int cdrl_learner_param_info(const cdrl_learner* l, int model, int index, cdrl_param_info* out);
+int64_t cdrl_learner_region_offset(const cdrl_learner* l, int model, int trainable);
+int64_t cdrl_learner_region_elems(const cdrl_learner* l, int model, int trainable);
+int64_t cdrl_learner_params_total(const cdrl_learner* l);
+int64_t cdrl_learner_grads_total(const cdrl_learner* l);
+size_t cdrl_learner_workspace_bytes(const cdrl_learner* l);
+
+/* params: [policy_tr | trunk_tr | value_tr | policy_state | trunk_state | value_state | old_policy]
+ * grads / adam_m / adam_v: [policy_tr | trunk_tr | value_tr] (one contiguous all-reduce buffer) */
+int cdrl_learner_bind(cdrl_learner* l, float* params, float* grads, float* adam_m, float* adam_v, void* workspace,
+                      size_t workspace_bytes);
+int cdrl_learner_set_hparams(cdrl_learner* l, const cdrl_hparams* hp, void* stream);
+int cdrl_learner_reset_optimizer_steps(cdrl_learner* l, void* stream);
+
+/* CARLAgent.get_policy_gradients (core/carla_agent.py:351-373): train-mode trunk forward,
+ * policy_objective (:394-428), gradients w.r.t. policy and trunk variables.  grad_scale = 1 /
+ * world_size for data-parallel averaging. */
+int cdrl_learner_policy_forward_backward(cdrl_learner* l, const cdrl_policy_batch* b, float grad_scale, void* stream);
+/* CARLAgent.apply_policy_gradients (core/carla_agent.py:375-388) + PPOAgent.apply_policy_gradients
+ * (rl/agents/ppo.py:238-252): trunk Adam, per-tensor clip, old_policy <- policy, policy Adam. */
+int cdrl_learner_policy_apply(cdrl_learner* l, void* stream);
+/* CARLAgent.get_value_gradients / apply_value_gradients (core/carla_agent.py:430-463;
+ * rl/agents/ppo.py:264-275). */
+int cdrl_learner_value_forward_backward(cdrl_learner* l, const cdrl_value_batch* b, float grad_scale, void* stream);
+int cdrl_learner_value_apply(cdrl_learner* l, void* stream);
+/* CARLANetwork.update_old_policy (core/networks.py:281-285). */
+int cdrl_learner_update_old_policy(cdrl_learner* l, void* stream);
+/* CARLANetwork.predict deterministic part (core/networks.py:181-193): inference-mode trunk,
+ * old_policy -> dist (B,4A: alpha, beta, mean, std), value heads -> (B,4: base, exp, speed, sim). */
+int cdrl_learner_predict(cdrl_learner* l, const float* image, const float* road, const float* vehicle,
+                         const float* navigation, float* dist_out, float* value_out, float* dynamics_out, void* stream);
+/* CARLANetwork.dynamics_predict_train (core/networks.py:210-212). */
+int cdrl_learner_trunk_forward_train(cdrl_learner* l, const float* image, const float* road, const float* vehicle,
+                                     const float* navigation, void* stream);
+
+enum {
+    CDRL_BUF_DYNAMICS = 0,   /* (B, dyn)  trunk output                       */
+    CDRL_BUF_IMG_FEAT = 1,   /* (T*B, last) tower output, frame = t*B + b    */
+    CDRL_BUF_METRICS_P = 2,  /* 16 floats: total, policy, entropy, speed, sim, ratio, log_prob */
+    CDRL_BUF_METRICS_V = 3,  /* 16 floats: total, value, speed, sim           */
+    CDRL_BUF_AUX_P = 4,      /* (B, 4A) alpha, beta, log_prob, entropy        */
+    CDRL_BUF_AUX_V = 5,      /* (B, 2) value (base, exp)                      */
+    CDRL_BUF_LIN_P = 6,      /* (B, 2A+2) linear head outputs                 */
+    CDRL_BUF_LIN_V = 7       /* (B, 4)                                        */
+};
+int cdrl_learner_get_buffer(const cdrl_learner* l, int which, float** ptr, int64_t* elems);
+
+/* ---- rollout-buffer post-processing ---------------------------------------------------------
+ * PPOMemory.compute_returns + compute_advantages (rl/agents/ppo.py:699-727), utils.gae /
+ * discount_cumsum / decompose_number / tf_sp_norm (rl/utils.py:57-84,140-151,344-349).
+ * rewards (N+1) and values_be (N+1, 2) already hold the bootstrap entry of end_trajectory
+ * (rl/agents/ppo.py:692-697).  scratch: >= 2*(N+1)+2 doubles. */
+int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double gamma, double lambda, float scale,
+                     float* returns, float* returns_be, float* adv_raw, float* adv, double* scratch, void* stream);
+
+/* ---- op-level entry points (Keras layer call -> one launch; used by the parity tests) -------- */
+/* Conv2D(k=1) / Dense forward: C[M,N] (+)= A[M,K] B[K,N] + bias (core/architectures.py:130,134,140,170) */
+int cdrl_gemm_nn(const float* A, int lda, int a_coff, const float* B, int sbk, int sbn, const float* bias, float* C,
+                 int ldc, int c_coff, int M, int N, int K, int accumulate, void* stream);
+int64_t cdrl_gemm_tn_workspace_elems(int M, int N, int K);
+int cdrl_gemm_tn(const float* A, int lda, int a_coff, const float* D, int ldd, int d_coff, float* out, int M, int N,
+                 int K, float* workspace, int accumulate, void* stream);
+/* Conv2D(24, 3, strides=2) stem (core/architectures.py:159) */
+int cdrl_stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
+                  void* stream);
+int64_t cdrl_stem_bwd_workspace_doubles(int B, int T, int H, int W, int Cout);
+int cdrl_stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,
+                         double* workspace, void* stream);
+/* DepthwiseConv2D(3, strides, 'same') (core/architectures.py:132,138) */
+int cdrl_dwconv_fwd(const float* a, const float* w, const float* bias, float* y, int N, int H, int W, int C, int stride,
+                    void* stream);
+int cdrl_dwconv_bwd_data(const float* dy, const float* w, float* da, int N, int H, int W, int C, int stride, void* stream);
+int64_t cdrl_dwconv_bwd_workspace_doubles(int N, int H, int W, int C, int stride);
+int cdrl_dwconv_bwd_filter(const float* a, const float* dy, float* dw, float* db, int N, int H, int W, int C, int stride,
+                           double* workspace, void* stream);
+/* MaxPooling2D(3, 2, 'same') (core/architectures.py:161) */
+int cdrl_maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, void* stream);
+int cdrl_maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H, int W, int C, void* stream);
+/* BatchNormalization(training=True) per time slice + optional ReLU6 + optional channel_shuffle on
+ * the store (core/architectures.py:44-57,109-118).  stats: 4*G*C floats, workspace: G*128*2*C doubles. */
+int cdrl_bn_train_fwd(const float* y, int G, int Mg, int C, const float* gamma, const float* beta, float* moving_mean,
+                      float* moving_var, int bessel, int relu6, float* out, int out_ld, int out_coff, int shuffle_ctot,
+                      float* stats, double* workspace, void* stream);
+int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, const float* y, int G, int Mg,
+                      int C, const float* stats, int relu6, float* dgamma, float* dbeta, float* dy, float* coef,
+                      double* workspace, void* stream);
+/* CARLAgent.policy_objective / value_objective on linear head outputs (core/carla_agent.py:394-428,
+ * 469-486); writes d(loss)/d(lin) and 16 metric floats. */
+int cdrl_beta_ppo_loss(const float* lin, const float* adv, const float* old_logp, const float* speed,
+                       const float* similarity, const float* u, const float* du_da, const float* du_db, float clip_ratio,
+                       float entropy_coef, int B, int A, float grad_scale, float* dlin, float* metrics, float* aux,
+                       float* hp_scratch16, void* stream);
+int cdrl_value_loss(const float* lin, const float* returns, const float* speed, const float* similarity, int B,
+                    float exp_scale, float grad_scale, float* dlin, float* metrics, float* values, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDRL_H */

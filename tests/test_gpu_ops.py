@@ -1,0 +1,263 @@
+"""Op-level parity: every HIP entry point of include/cdrl.h against a plain PyTorch fp32 / fp64
+CPU reference of the same Keras op (tolerance: 1e-4 relative to the tensor scale, the bar
+BASELINE.json's north_star states for fp32; most ops land at ~1e-6)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from carla_driving_rl_agent_amd import _lib
+from oracle import model as OM
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = 'cuda:0'
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(x):
+    return torch.as_tensor(x).to(DEV).contiguous()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize('M,K,N', [(1000, 58, 58), (777, 116, 116), (300, 24, 58), (513, 232, 232), (130, 464, 768),
+                                   (256, 320, 2), (64, 9, 16), (5, 3, 1)])
+def test_gemm_nn(lib, M, K, N):
+    rng = np.random.default_rng(M + K + N)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = rng.standard_normal((K, N)).astype(np.float32)       # asymmetric operands catch transposes
+    bias = rng.standard_normal(N).astype(np.float32)
+    A, B_, bi = dev(a), dev(b), dev(bias)
+    out = torch.zeros((M, N), device=DEV)
+    _lib.check(lib.cdrl_gemm_nn(P(A), K, 0, P(B_), N, 1, P(bi), P(out), N, 0, M, N, K, 0, S()))
+    ref = a.astype(np.float64) @ b.astype(np.float64) + bias
+    assert rel_err(out.cpu().numpy(), ref) < 1e-5
+    # transposed-B form (backward-data) with accumulate into a channel-slice view
+    big = torch.ones((M, K + 7), device=DEV)
+    _lib.check(lib.cdrl_gemm_nn(P(out), N, 0, P(B_), 1, N, None, P(big), K + 7, 3, M, K, N, 1, S()))
+    ref2 = ref @ b.astype(np.float64).T + 1.0
+    got = big.cpu().numpy()
+    assert rel_err(got[:, 3:3 + K], ref2) < 1e-5
+    assert np.all(got[:, :3] == 1.0) and np.all(got[:, 3 + K:] == 1.0)
+
+
+@pytest.mark.parametrize('M,K,N', [(5000, 58, 58), (3000, 116, 116), (2049, 24, 58), (1500, 232, 232), (700, 464, 768),
+                                   (256, 512, 320), (33, 16, 96)])
+def test_gemm_tn(lib, M, K, N):
+    rng = np.random.default_rng(M + K + N)
+    a = rng.standard_normal((M, K + 5)).astype(np.float32)
+    d = rng.standard_normal((M, N)).astype(np.float32)
+    A, D = dev(a), dev(d)
+    ws = torch.zeros(int(lib.cdrl_gemm_tn_workspace_elems(M, N, K)), device=DEV)
+    out = torch.zeros((K, N), device=DEV)
+    _lib.check(lib.cdrl_gemm_tn(P(A), K + 5, 2, P(D), N, 0, P(out), M, N, K, P(ws), 0, S()))
+    ref = a[:, 2:2 + K].astype(np.float64).T @ d.astype(np.float64)
+    assert rel_err(out.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize('B,T,H,W', [(2, 4, 41, 58), (3, 2, 90, 120)])
+def test_stem(lib, B, T, H, W):
+    rng = np.random.default_rng(1)
+    x = rng.random((B, T, H, W, 3), dtype=np.float32)
+    w = rng.standard_normal((3, 3, 3, 24)).astype(np.float32) * 0.2
+    b = rng.standard_normal(24).astype(np.float32)
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    y = torch.zeros((T * B, Ho, Wo, 24), device=DEV)
+    X, Wd, Bd = dev(x), dev(w), dev(b)
+    _lib.check(lib.cdrl_stem_fwd(P(X), P(Wd), P(Bd), P(y), B, T, H, W, 24, S()))
+    xt = torch.tensor(x, dtype=torch.float64).permute(1, 0, 4, 2, 3).reshape(T * B, 3, H, W).requires_grad_(False)
+    wt = torch.tensor(w, dtype=torch.float64).permute(3, 2, 0, 1).requires_grad_(True)
+    bt = torch.tensor(b, dtype=torch.float64).requires_grad_(True)
+    ref = F.conv2d(xt, wt, bt, stride=2)
+    assert rel_err(y.cpu().numpy(), ref.detach().permute(0, 2, 3, 1).numpy()) < 1e-5
+    dy = rng.standard_normal((T * B, Ho, Wo, 24)).astype(np.float32)
+    ref.backward(torch.tensor(dy, dtype=torch.float64).permute(0, 3, 1, 2))
+    ws = torch.zeros(int(lib.cdrl_stem_bwd_workspace_doubles(B, T, H, W, 24)), dtype=torch.float64, device=DEV)
+    dw = torch.zeros((3, 3, 3, 24), device=DEV)
+    db = torch.zeros(24, device=DEV)
+    DY = dev(dy)
+    _lib.check(lib.cdrl_stem_bwd_filter(P(X), P(DY), P(dw), P(db), B, T, H, W, 24, P(ws), S()))
+    assert rel_err(dw.cpu().numpy(), wt.grad.permute(2, 3, 1, 0).numpy()) < 1e-5
+    assert rel_err(db.cpu().numpy(), bt.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('N,H,W,Cc,stride', [(3, 22, 30, 58, 2), (2, 11, 15, 58, 1), (2, 6, 8, 116, 1), (3, 11, 15, 116, 2),
+                                             (2, 3, 4, 232, 1), (2, 6, 23, 232, 2), (2, 5, 6, 24, 2)])
+def test_dwconv(lib, N, H, W, Cc, stride):
+    rng = np.random.default_rng(N * H + W + Cc)
+    a = rng.standard_normal((N, H, W, Cc)).astype(np.float32)
+    w = rng.standard_normal((3, 3, Cc, 1)).astype(np.float32)
+    b = rng.standard_normal(Cc).astype(np.float32)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    at = torch.tensor(a, dtype=torch.float64).permute(0, 3, 1, 2)[None].requires_grad_(True)
+    p = {'c.w': torch.tensor(w, dtype=torch.float64).requires_grad_(True),
+         'c.b': torch.tensor(b, dtype=torch.float64).requires_grad_(True)}
+    ref = OM.conv_dw(at, p, 'c', stride)[0]
+    Ad, Wd, Bd = dev(a), dev(w), dev(b)
+    y = torch.zeros((N, Ho, Wo, Cc), device=DEV)
+    _lib.check(lib.cdrl_dwconv_fwd(P(Ad), P(Wd), P(Bd), P(y), N, H, W, Cc, stride, S()))
+    assert tuple(ref.shape) == (N, Cc, Ho, Wo)
+    assert rel_err(y.cpu().numpy(), ref.detach().permute(0, 2, 3, 1).numpy()) < 1e-5
+    dy = rng.standard_normal((N, Ho, Wo, Cc)).astype(np.float32)
+    ref.backward(torch.tensor(dy, dtype=torch.float64).permute(0, 3, 1, 2))
+    DY = dev(dy)
+    da = torch.zeros((N, H, W, Cc), device=DEV)
+    _lib.check(lib.cdrl_dwconv_bwd_data(P(DY), P(Wd), P(da), N, H, W, Cc, stride, S()))
+    assert rel_err(da.cpu().numpy(), at.grad[0].permute(0, 2, 3, 1).numpy()) < 1e-5
+    ws = torch.zeros(int(lib.cdrl_dwconv_bwd_workspace_doubles(N, H, W, Cc, stride)), dtype=torch.float64, device=DEV)
+    dw = torch.zeros((3, 3, Cc, 1), device=DEV)
+    db = torch.zeros(Cc, device=DEV)
+    _lib.check(lib.cdrl_dwconv_bwd_filter(P(Ad), P(DY), P(dw), P(db), N, H, W, Cc, stride, P(ws), S()))
+    assert rel_err(dw.cpu().numpy(), p['c.w'].grad.numpy()) < 1e-5
+    assert rel_err(db.cpu().numpy(), p['c.b'].grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('N,H,W', [(3, 44, 59), (2, 19, 27), (2, 20, 28)])
+def test_maxpool(lib, N, H, W):
+    rng = np.random.default_rng(H)
+    a = rng.standard_normal((N, H, W, 24)).astype(np.float32)
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    at = torch.tensor(a, dtype=torch.float64).permute(0, 3, 1, 2).requires_grad_(True)
+    ph, pw = OM.same_pad(H, 3, 2), OM.same_pad(W, 3, 2)
+    ref = F.max_pool2d(F.pad(at, (pw[0], pw[1], ph[0], ph[1]), value=float('-inf')), 3, 2)
+    Ad = dev(a)
+    p = torch.zeros((N, Ho, Wo, 24), device=DEV)
+    am = torch.zeros((N, Ho, Wo, 24), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cdrl_maxpool_fwd(P(Ad), P(p), P(am), N, H, W, 24, S()))
+    assert np.array_equal(p.cpu().numpy(), ref.detach().permute(0, 2, 3, 1).numpy().astype(np.float32))
+    dp = rng.standard_normal((N, Ho, Wo, 24)).astype(np.float32)
+    ref.backward(torch.tensor(dp, dtype=torch.float64).permute(0, 3, 1, 2))
+    da = torch.zeros((N, H, W, 24), device=DEV)
+    DP = dev(dp)
+    _lib.check(lib.cdrl_maxpool_bwd(P(am), P(DP), P(da), N, H, W, 24, S()))
+    assert rel_err(da.cpu().numpy(), at.grad.permute(0, 2, 3, 1).numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('G,Mg,Cc,relu,shuffle', [(4, 330, 58, 1, 0), (4, 96, 116, 0, 0), (4, 50, 92, 1, 1), (1, 64, 352, 0, 0),
+                                                  (4, 24, 768, 1, 0), (4, 1300, 24, 1, 0)])
+def test_bn_train(lib, G, Mg, Cc, relu, shuffle):
+    """Per-time-slice training BatchNorm (+ReLU6, + de-interleave shuffle on the store), fwd + bwd,
+    incl. the T sequential moving-stat EMA updates with Bessel-corrected variance."""
+    rng = np.random.default_rng(G * Mg + Cc)
+    y = (rng.standard_normal((G, Mg, Cc)) * 2.0 + 0.7).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, Cc).astype(np.float32)
+    beta = rng.uniform(-0.5, 0.5, Cc).astype(np.float32)
+    mm0 = rng.uniform(-0.2, 0.2, Cc).astype(np.float32)
+    mv0 = rng.uniform(0.5, 1.5, Cc).astype(np.float32)
+    p = {'b.gamma': torch.tensor(gamma, dtype=torch.float64).requires_grad_(True),
+         'b.beta': torch.tensor(beta, dtype=torch.float64).requires_grad_(True),
+         'b.moving_mean': torch.tensor(mm0, dtype=torch.float64), 'b.moving_var': torch.tensor(mv0, dtype=torch.float64)}
+    yt = torch.tensor(y, dtype=torch.float64).permute(0, 2, 1)[:, None].requires_grad_(True)     # (G,1,C,Mg)
+    ref = OM.bn_slices(yt, p, 'b', True, True)
+    if relu:
+        ref = OM.relu6(ref)
+    ctot = 2 * Cc if shuffle else Cc
+    coff = Cc if shuffle else 0          # main-branch half of a concat buffer
+    out = torch.zeros((G * Mg, ctot), device=DEV)
+    stats = torch.zeros(4 * G * Cc, device=DEV)
+    ws = torch.zeros(G * 128 * 2 * Cc, dtype=torch.float64, device=DEV)
+    Y, Gm, Bt, MM, MV = dev(y), dev(gamma), dev(beta), dev(mm0), dev(mv0)
+    _lib.check(lib.cdrl_bn_train_fwd(P(Y), G, Mg, Cc, P(Gm), P(Bt), P(MM), P(MV), 1, relu, P(out), ctot, coff,
+                                     ctot if shuffle else 0, P(stats), P(ws), S()))
+    refn = ref.detach()[:, 0].permute(0, 2, 1).reshape(G * Mg, Cc).numpy()
+    got = out.cpu().numpy()
+    if shuffle:
+        idx = [((coff + c) & 1) * (ctot // 2) + ((coff + c) >> 1) for c in range(Cc)]
+        got = got[:, idx]
+    assert rel_err(got, refn) < 1e-5
+    assert rel_err(MM.cpu().numpy(), p['b.moving_mean'].numpy()) < 1e-5
+    assert rel_err(MV.cpu().numpy(), p['b.moving_var'].numpy()) < 1e-5
+    # backward
+    dout = rng.standard_normal((G * Mg, ctot)).astype(np.float32)
+    dsel = dout[:, idx] if shuffle else dout
+    ref.backward(torch.tensor(dsel, dtype=torch.float64).reshape(G, Mg, Cc).permute(0, 2, 1)[:, None])
+    DO = dev(dout)
+    dg = torch.zeros(Cc, device=DEV)
+    dbt = torch.zeros(Cc, device=DEV)
+    dy = torch.zeros((G * Mg, Cc), device=DEV)
+    coef = torch.zeros(3 * G * Cc, device=DEV)
+    _lib.check(lib.cdrl_bn_train_bwd(P(DO), ctot, coff, ctot if shuffle else 0, P(Y), G, Mg, Cc, P(stats), relu, P(dg),
+                                     P(dbt), P(dy), P(coef), P(ws), S()))
+    assert rel_err(dg.cpu().numpy(), p['b.gamma'].grad.numpy()) < 1e-5
+    assert rel_err(dbt.cpu().numpy(), p['b.beta'].grad.numpy()) < 1e-5
+    assert rel_err(dy.cpu().numpy(), yt.grad[:, 0].permute(0, 2, 1).reshape(G * Mg, Cc).numpy()) < 2e-5
+
+
+@pytest.mark.parametrize('B,A,faithful', [(256, 2, True), (37, 3, False), (1024, 2, True)])
+def test_policy_loss(lib, B, A, faithful):
+    rng = np.random.default_rng(B + A)
+    L = 2 * A + 2
+    lin = (rng.standard_normal((B, L)) * 1.5).astype(np.float32)
+    adv = rng.standard_normal(B).astype(np.float32)
+    u = np.clip(rng.beta(2, 2, (B, A)), 1e-4, 1 - 1e-4).astype(np.float32)
+    u[0, 0] = 0.0       # exercises _clip_actions (clipped sample -> no pathwise gradient)
+    u[1, 0] = 1.0
+    old = (rng.standard_normal((B, A)) * 0.3).astype(np.float32)
+    spd = rng.uniform(0, 0.3, B).astype(np.float32)
+    sim = rng.uniform(-1, 1, B).astype(np.float32)
+    ja = rng.uniform(-0.3, 0.3, (B, A)).astype(np.float32) if faithful else None
+    jb = rng.uniform(-0.3, 0.3, (B, A)).astype(np.float32) if faithful else None
+    lt = torch.tensor(lin, dtype=torch.float64, requires_grad=True)
+    alpha = OM.softplus101(lt[:, :A])
+    beta = OM.softplus101(lt[:, A:2 * A])
+    tt = lambda x: torch.tensor(x, dtype=torch.float64)
+    z = np.zeros((B, A), np.float32)
+    us = OM._InjectedSample.apply(alpha, beta, tt(u), tt(ja if faithful else z), tt(jb if faithful else z))
+    x = torch.clamp(us, OM.EPSILON, 1.0 - OM.EPSILON)
+    logp = OM.beta_log_prob(x, alpha, beta)
+    ent = OM.beta_entropy(alpha, beta).mean()
+    ratio = torch.exp(logp - tt(old)).mean(dim=1)
+    c = 0.2
+    advt = tt(adv)
+    min_adv = torch.where(advt > 0, (1 + c) * advt, (1 - c) * advt)
+    simp = torch.tanh(lt[:, 2 * A])
+    spdp = 2.0 * torch.sigmoid(lt[:, 2 * A + 1])
+    pl = -torch.minimum(ratio * advt, min_adv).mean()
+    total = pl - 0.7 * ent + 0.5 * ((tt(spd) - spdp) ** 2).mean() + 0.5 * ((tt(sim) - simp) ** 2).mean()
+    total.backward()
+    dlin = torch.zeros((B, L), device=DEV)
+    metrics = torch.zeros(16, device=DEV)
+    aux = torch.zeros((B, 4 * A), device=DEV)
+    hp = torch.zeros(16, device=DEV)
+    args = [dev(lin), dev(adv), dev(old), dev(spd), dev(sim), dev(u), dev(ja) if faithful else None, dev(jb) if faithful else None]
+    _lib.check(lib.cdrl_beta_ppo_loss(*[P(a) for a in args], 0.2, 0.7, B, A, 1.0, P(dlin), P(metrics), P(aux), P(hp), S()))
+    m = metrics.cpu().numpy()
+    assert abs(m[0] - total.item()) < 1e-5 * max(1.0, abs(total.item()))
+    assert abs(m[1] - pl.item()) < 1e-5 * max(1.0, abs(pl.item()))
+    assert abs(m[2] - ent.item()) < 1e-5
+    assert rel_err(dlin.cpu().numpy(), lt.grad.numpy()) < 1e-5
+    ax = aux.cpu().numpy()
+    assert rel_err(ax[:, :A], alpha.detach().numpy()) < 1e-6
+    assert rel_err(ax[:, 2 * A:3 * A], logp.detach().numpy()) < 1e-5
+
+
+def test_value_loss(lib):
+    B = 200
+    rng = np.random.default_rng(3)
+    lin = rng.standard_normal((B, 4)).astype(np.float32)
+    ret = np.stack([rng.uniform(-1, 1, B), rng.integers(0, 6, B)], 1).astype(np.float32)
+    spd = rng.uniform(0, 0.3, B).astype(np.float32)
+    sim = rng.uniform(-1, 1, B).astype(np.float32)
+    lt = torch.tensor(lin, dtype=torch.float64, requires_grad=True)
+    tt = lambda x: torch.tensor(x, dtype=torch.float64)
+    base, ex = torch.tanh(lt[:, 0]), 6.0 * torch.sigmoid(lt[:, 1])
+    sp, si = 2.0 * torch.sigmoid(lt[:, 2]), torch.tanh(lt[:, 3])
+    vl = 0.25 * ((tt(ret[:, 0]) - base) ** 2).mean() + ((tt(ret[:, 1]) - ex) ** 2).mean() / 36.0
+    total = 0.25 * (vl + ((tt(spd) - sp) ** 2).mean() + ((tt(sim) - si) ** 2).mean())
+    total.backward()
+    dlin = torch.zeros((B, 4), device=DEV)
+    metrics = torch.zeros(16, device=DEV)
+    vals = torch.zeros((B, 2), device=DEV)
+    _lib.check(lib.cdrl_value_loss(P(dev(lin)), P(dev(ret)), P(dev(spd)), P(dev(sim)), B, 6.0, 1.0, P(dlin), P(metrics),
+                                   P(vals), S()))
+    assert abs(metrics.cpu().numpy()[0] - total.item()) < 1e-6 * max(1.0, abs(total.item()))
+    assert rel_err(dlin.cpu().numpy(), lt.grad.numpy()) < 1e-5

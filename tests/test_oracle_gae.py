@@ -1,0 +1,64 @@
+"""GAE / returns: (1) the numpy restatement is pinned against scipy.signal.lfilter, the routine the
+reference itself calls (rl/utils.py:59) -- bit-exact; (2) -m gpu: the HIP kernel against the
+restatement -- bit-exact for returns / decomposition / raw advantages."""
+import numpy as np
+import pytest
+import scipy.signal
+
+from oracle import gae as OG
+
+
+def _episode(n, seed, spike=False):
+    rng = np.random.default_rng(seed)
+    rewards = rng.uniform(0, 10, n).astype(np.float32)
+    if spike:
+        rewards[-1] = -1000.0
+    values = np.stack([rng.uniform(-1, 1, n), rng.uniform(0, 6, n)], 1).astype(np.float32)
+    last = np.array([[0.3, 2.0]], np.float32) if not spike else np.zeros((1, 2), np.float32)
+    return OG.end_trajectory(rewards, values, last)
+
+
+@pytest.mark.parametrize('n,disc', [(1, 0.99), (7, 0.9999), (512, 0.9999 * 0.999), (2000, 0.95)])
+def test_discount_cumsum_matches_scipy_bitwise(n, disc):
+    x = np.random.default_rng(n).standard_normal(n).astype(np.float32) * 30
+    ref = scipy.signal.lfilter([1.0], [1.0, float(-disc)], x[::-1], axis=0)[::-1]      # rl/utils.py:59
+    got = OG.discount_cumsum(x, disc)
+    assert ref.dtype == np.float64
+    assert np.array_equal(ref, got)
+
+
+def test_decompose_number():
+    for v, (b, e) in [(2.34, (0.234, 1)), (0.5, (0.5, 0)), (-1234.5, (-0.12345, 4)), (1.0, (1.0, 0)), (0.0, (0.0, 0))]:
+        gb, ge = OG.decompose_number(np.float32(v))
+        assert ge == e and abs(gb - b) < 1e-6
+        assert abs(gb * 10 ** ge - v) < 1e-3 * max(1, abs(v))
+
+
+def test_sp_norm_and_gae_properties():
+    r, v = _episode(256, 1, spike=True)
+    values, adv, advn = OG.compute_advantages(r, v, 0.9999, 0.999, scale=2.0)
+    assert advn.max() <= 2.0 and advn.min() >= -2.0
+    assert np.all(np.sign(advn) == np.sign(adv))
+    # lambda = 0 -> advantages are the TD residuals
+    _, adv0, _ = OG.compute_advantages(r, v, 0.99, 0.0)
+    assert np.allclose(adv0, r[:-1] + np.float32(0.99) * values[1:] - values[:-1])
+    ret, dec = OG.compute_returns(r, 0.9999)
+    assert np.allclose(dec[:, 0] * 10.0 ** dec[:, 1], ret, rtol=1e-5)
+    assert np.all(np.abs(dec[:, 0]) <= 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,spike', [(1, False), (33, False), (256, True), (512, False), (3000, True)])
+def test_gae_kernel_matches_oracle(n, spike):
+    import torch
+    from carla_driving_rl_agent_amd.engine import gae_returns
+    r, v = _episode(n, n, spike)
+    gamma, lam = 0.9999, 0.999
+    ret_ref, dec_ref = OG.compute_returns(r, gamma)
+    _, adv_ref, advn_ref = OG.compute_advantages(r, v, gamma, lam, scale=2.0)
+    ret, dec, adv, advn = gae_returns(torch.tensor(r).cuda(), torch.tensor(v).cuda(), gamma, lam, 2.0)
+    assert np.array_equal(ret.cpu().numpy(), ret_ref)                   # float64 scan, bit-exact
+    assert np.array_equal(dec.cpu().numpy(), dec_ref)                   # float32 repeated /10, bit-exact
+    a = adv.cpu().numpy()
+    assert np.allclose(a, adv_ref, rtol=1e-6, atol=1e-6 * np.abs(adv_ref).max())   # powf(10,x) may differ by 1 ulp
+    assert np.allclose(advn.cpu().numpy(), advn_ref, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,76 @@
+"""Shared helpers for the parity tests (engine vs oracle on identical seeded inputs)."""
+import numpy as np
+import torch
+
+from oracle import model as OM
+from oracle.spec import NetConfig, trunk_spec, policy_spec, value_spec
+from carla_driving_rl_agent_amd import synthetic
+from carla_driving_rl_agent_amd.engine import LearnerEngine
+
+# conv biases directly followed by a train-mode BatchNorm (and dyn.fc.b, followed by the heads'
+# input BN) have an analytically ZERO gradient: what any implementation computes for them is
+# rounding noise, which Adam then normalises to +-lr steps.  They are excluded from the
+# *updated-weight* comparison (they do not influence any output); see DESIGN.md §parity.
+def is_degenerate_bias(name: str) -> bool:
+    if name == 'dyn.fc.b':
+        return True
+    return name.startswith('img.') and name.endswith('.b')
+
+
+def make_pair(B, H, W, seed=0, device='cuda:0', A=2, hp=None, **cfg):
+    ocfg = NetConfig(H=H, W=W, A=A, **cfg)
+    tp = OM.init_params(trunk_spec(ocfg), seed + 1)
+    pp = OM.init_params(policy_spec(ocfg), seed + 2)
+    vp = OM.init_params(value_spec(ocfg), seed + 3)
+    hp = dict(synthetic.DEFAULT_HP if hp is None else hp)
+    oracle = OM.OracleLearner(ocfg, tp, pp, vp, hp)
+    eng = LearnerEngine(B, device=device, H=H, W=W, A=A, **cfg)
+    eng.load_params('trunk', tp)
+    eng.load_params('policy', pp)
+    eng.load_params('value', vp)
+    eng.update_old_policy()
+    eng.set_hparams(policy_lr=hp['policy_lr'], value_lr=hp['value_lr'], dynamics_lr=hp['dynamics_lr'],
+                    clip_ratio=hp['clip_ratio'], entropy_coef=hp['entropy_coef'],
+                    clip_norm_policy=hp['clip_norm_policy'], clip_norm_value=hp['clip_norm_value'])
+    return oracle, eng
+
+
+def make_batches(B, H, W, seed=0, A=2, faithful=True, **dims):
+    r = synthetic.make_rollout(B, H=H, W=W, A=A, seed=seed, **dims)
+    rng = np.random.default_rng(seed + 100)
+    adv = rng.standard_normal(B).astype(np.float32)
+    pol = dict(states=r['states'], advantages=adv, old_log_prob=r['old_log_prob'], speed=(r['speed'][:, 0] / 100.0).astype(np.float32),
+               similarity=r['similarity'][:, 0].copy(), u=r['action'])
+    if faithful:
+        pol['du_da'] = rng.uniform(-0.2, 0.2, size=(B, A)).astype(np.float32)
+        pol['du_db'] = rng.uniform(-0.2, 0.2, size=(B, A)).astype(np.float32)
+    else:
+        pol['du_da'] = np.zeros((B, A), np.float32)
+        pol['du_db'] = np.zeros((B, A), np.float32)
+    val = dict(states=r['states'], returns=r['value'], speed=pol['speed'], similarity=pol['similarity'])
+    return pol, val
+
+
+def oracle_batch(b):
+    """oracle wants speed/similarity as (B,1)."""
+    o = dict(b)
+    o['speed'] = b['speed'].reshape(-1, 1)
+    o['similarity'] = b['similarity'].reshape(-1, 1)
+    return o
+
+
+def to_dev(b, device='cuda:0'):
+    out = {}
+    for k, v in b.items():
+        if isinstance(v, dict):
+            out[k] = {kk: torch.as_tensor(vv).to(device).contiguous() for kk, vv in v.items()}
+        else:
+            out[k] = torch.as_tensor(v).to(device).contiguous()
+    return out
+
+
+def rel_err(a, b):
+    """max |a-b| / (max|b| + tiny): error relative to the tensor's scale."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
