@@ -350,24 +350,39 @@ def clip_by_norm(g: torch.Tensor, c: float) -> torch.Tensor:
 
 class Adam:
     """Keras Adam (beta1 .9, beta2 .999, eps 1e-7, no amsgrad); one instance per optimizer,
-    `t` counts apply_gradients calls (rl/utils.py:29-46)."""
+    `t` counts apply_gradients calls (rl/utils.py:29-46).
+
+    TF keeps lr / beta1 / beta2 / epsilon as float32 tensors and evaluates `1 - beta`,
+    `beta ** t` and the bias-corrected step size in float32 (Keras `_prepare_local` +
+    `ResourceApplyAdam`): 1 - float32(0.999) = 0.000999987..., not 0.001.  The float32 oracle
+    reproduces that float32 scalar arithmetic; the float64 oracle evaluates the same formulas
+    exactly on the float32-rounded constants."""
 
     def __init__(self, names: List[str], params: Dict[str, torch.Tensor], beta1=0.9, beta2=0.999, eps=1e-7):
         self.names = names
-        self.b1, self.b2, self.eps = beta1, beta2, eps
+        self.b1, self.b2, self.eps = np.float32(beta1), np.float32(beta2), np.float32(eps)
         self.t = 0
         self.m = {n: torch.zeros_like(params[n]) for n in names}
         self.v = {n: torch.zeros_like(params[n]) for n in names}
+        self.f32 = params[names[0]].dtype == torch.float32
 
     def step(self, params, grads: Dict[str, torch.Tensor], lr: float):
         self.t += 1
-        alpha = lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        if self.f32:
+            one = np.float32(1.0)
+            t = np.float32(self.t)
+            alpha = float(np.float32(lr) * np.sqrt(one - np.power(self.b2, t)) / (one - np.power(self.b1, t)))
+            omb1, omb2, eps = float(one - self.b1), float(one - self.b2), float(self.eps)
+        else:
+            b1, b2, lr64 = float(self.b1), float(self.b2), float(np.float32(lr))
+            alpha = lr64 * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+            omb1, omb2, eps = 1.0 - b1, 1.0 - b2, float(self.eps)
         with torch.no_grad():
             for n in self.names:
                 g = grads[n]
-                self.m[n].add_((g - self.m[n]) * (1.0 - self.b1))
-                self.v[n].add_((g * g - self.v[n]) * (1.0 - self.b2))
-                params[n].sub_(self.m[n] * alpha / (torch.sqrt(self.v[n]) + self.eps))
+                self.m[n].add_((g - self.m[n]) * omb1)
+                self.v[n].add_((g * g - self.v[n]) * omb2)
+                params[n].sub_(self.m[n] * alpha / (torch.sqrt(self.v[n]) + eps))
 
 
 class OracleLearner:

@@ -8,24 +8,54 @@ import pytest
 import torch
 
 from carla_driving_rl_agent_amd import _lib
-from tests.util import make_pair, make_batches, oracle_batch, to_dev, rel_err, is_degenerate_bias
+from tests.util import make_pair, make_batches, oracle_batch, to_dev, rel_err, is_degenerate_bias, check3
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _compare_grads(eng_views, oracle_grads, tol, scale_floor=0.0):
-    worst = (0.0, None)
-    gmax = max(float(g.abs().max()) for g in oracle_grads.values())
-    for name, g in oracle_grads.items():
-        got = eng_views[name].detach().cpu().numpy().astype(np.float64)
-        ref = g.detach().numpy().astype(np.float64)
-        denom = max(np.abs(ref).max(), scale_floor * gmax, 1e-30)
-        e = float(np.abs(got - ref).max() / denom)
-        if e > worst[0]:
-            worst = (e, name)
-    assert worst[0] < tol, f'gradient mismatch {worst}'
-    return worst
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+REPORT = []
+
+
+def _group(name):
+    return 'tower' if name.startswith('img.') else 'tail'
+
+
+def _compare(eng_views, ref32, ref64, tol, what, floor_frac=0.0, skip=lambda n: False, slack=3.0):
+    """Engine vs the float64 oracle, with the float32 oracle as the noise yardstick.
+
+    Two regimes (measured, see DESIGN.md "Parity methodology"):
+      * tail (heads, trunk tail, GRUs, feature nets): smooth float32 rounding, ~5e-5 -> bound 1e-4;
+      * tower ('img.*'): ReLU6 masks / max-pool argmax are DISCRETE decisions taken on float32
+        pre-activations; an element within rounding distance of a kink flips between any two
+        float32 implementations and moves a channel's gradient by ~1/(rows per BN group).  The
+        float32 oracle itself sits 1e-3..9e-2 from the float64 oracle there.  Flips are sparse
+        random events, so the yardstick is the float32 oracle's WORST tensor of the group, not the
+        same tensor: bound = max(tol, slack * max_group |oracle32 - oracle64|)."""
+    gmax = max(float(np.abs(_np(g)).max()) for g in ref64.values())
+    errs, noise = {}, {'tower': 0.0, 'tail': 0.0}
+    for name, g64 in ref64.items():
+        if skip(name):
+            continue
+        r64 = _np(g64).astype(np.float64)
+        scale = max(np.abs(r64).max(), floor_frac * gmax, 1e-30)
+        errs[name] = float(np.abs(_np(eng_views[name]).astype(np.float64) - r64).max() / scale)
+        n32 = float(np.abs(_np(ref32[name]).astype(np.float64) - r64).max() / scale)
+        noise[_group(name)] = max(noise[_group(name)], n32)
+    for grp in ('tail', 'tower'):
+        names = [n for n in errs if _group(n) == grp]
+        if not names:
+            continue
+        bound = max(tol, slack * noise[grp])
+        worst = max(names, key=lambda n: errs[n])
+        REPORT.append(dict(what=what, group=grp, tensors=len(names), engine_worst_err=errs[worst], tensor=worst,
+                           oracle32_worst_err=noise[grp], bound=bound,
+                           engine_median_err=float(np.median([errs[n] for n in names]))))
+        assert errs[worst] <= bound, f'{what} [{grp}] mismatch on {worst}: err {errs[worst]:.3e} > bound {bound:.3e}'
 
 
 @pytest.mark.parametrize('B,H,W,A', [(6, 48, 64, 2), (4, 41, 58, 3)])
@@ -57,57 +87,154 @@ def test_trunk_forward_and_predict(B, H, W, A):
         assert rel_err(pv[name].cpu().numpy(), oracle.trunk[name].numpy()) < TOL, name
 
 
-@pytest.mark.parametrize('B,H,W,A,faithful', [(6, 48, 64, 2, True), (5, 41, 58, 3, False)])
-def test_policy_and_value_step(B, H, W, A, faithful):
-    oracle, eng = make_pair(B, H, W, seed=3, A=A)
+def _sync_from_o64(oracle, eng):
+    """Put the float32 oracle and the engine on exactly the float64 oracle's state (weights, BN
+    moving statistics, Adam moments).  One Adam step turns float32 rounding noise on ~zero
+    gradients into +-lr parameter kicks (sign flips), and small-batch BatchNorm amplifies those
+    into percent-level output differences between ANY two float32 implementations (the float32
+    oracle itself lands ~8 % from the float64 oracle after one step at B=6) -- so multi-step
+    trajectories are compared step by step from a common state."""
+    o64 = oracle.o64
+    for model, a32, a64, opt32, opt64 in (('trunk', oracle.trunk, o64.trunk, oracle.opt_trunk, o64.opt_trunk),
+                                          ('policy', oracle.policy, o64.policy, oracle.opt_policy, o64.opt_policy),
+                                          ('value', oracle.value, o64.value, oracle.opt_value, o64.opt_value)):
+        views = eng.param_views(model)
+        m_e, v_e = eng.adam_views(model)
+        with torch.no_grad():
+            for name, t64 in a64.items():
+                a32[name].copy_(t64.float())
+                views[name].copy_(t64.float())
+            for name in opt64.names:
+                opt32.m[name].copy_(opt64.m[name].float())
+                opt32.v[name].copy_(opt64.v[name].float())
+                m_e[name].copy_(opt64.m[name].float())
+                v_e[name].copy_(opt64.v[name].float())
+    oracle.old_policy = {k: v.detach().clone().float() for k, v in o64.old_policy.items()}
+    for name, t in eng.param_views('old_policy').items():
+        t.copy_(o64.old_policy[name].float())
+
+
+def _dump_report(tag):
+    import json, os
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open(f'gpurun_out/parity_report_{tag}.json', 'w') as f:
+        json.dump(REPORT, f, indent=1)
+
+
+@pytest.mark.parametrize('B,H,W,A,faithful', [(32, 48, 64, 2, True), (24, 41, 58, 3, False), (16, 90, 120, 2, True)])
+def test_policy_then_value_step(B, H, W, A, faithful):
+    oracle, eng = make_pair(B, H, W, seed=3, A=A, with64=True)
+    o64 = oracle.o64
     pol, val = make_batches(B, H, W, seed=3, A=A, faithful=faithful)
     dpol, dval = to_dev(pol), to_dev(val)
+    del REPORT[:]
 
-    # ---------------- policy minibatch step
-    loss, gp, gt, aux = oracle.policy_grads(oracle_batch(pol))
-    eng.policy_forward_backward(dpol)
-    m = eng.metrics('policy')
-    assert abs(m['loss'] - float(loss)) < TOL * max(1.0, abs(float(loss)))
-    ax = eng.buffer(_lib.BUF_AUX_P, (B, 4, A)).cpu().numpy()
-    assert rel_err(ax[:, 0], aux['alpha'].detach().numpy()) < TOL          # action "logits"
-    assert rel_err(ax[:, 1], aux['beta'].detach().numpy()) < TOL
-    assert rel_err(ax[:, 2], aux['log_prob'].detach().numpy()) < TOL
-    _compare_grads(eng.grad_views('policy'), gp, TOL)
-    # trunk: compare relative to each tensor's own scale, with a floor for the analytically-zero
-    # conv-bias gradients (pure rounding noise in any implementation)
-    _compare_grads(eng.grad_views('trunk'), gt, 2 * TOL, scale_floor=1e-3)
-    oracle.policy_step(None, grads=(loss, gp, gt, aux))
-    eng.policy_apply()
-    for model, ref in (('trunk', oracle.trunk), ('policy', oracle.policy), ('old_policy', oracle.old_policy)):
-        views = eng.param_views(model)
-        for name, r in ref.items():
-            if is_degenerate_bias(name):
-                continue
-            e = rel_err(views[name].cpu().numpy(), r.detach().numpy())
-            assert e < TOL, (model, name, e)
-    m_t, v_t = eng.adam_views('trunk')
-    for name in ('img.s0.u0.pw1.w', 'gru_image.kernel', 'dyn.fc.w'):
-        assert rel_err(m_t[name].cpu().numpy(), oracle.opt_trunk.m[name].numpy()) < 2 * TOL, name
-        assert rel_err(v_t[name].cpu().numpy(), oracle.opt_trunk.v[name].numpy()) < 2 * TOL, name
+    def check_weights(models):
+        # one Adam step moves every element by <= lr whatever the gradient, and elements whose
+        # gradient is at the float32 noise level move by a noise-determined amount: end-to-end
+        # weights are compared noise-aware here; the optimiser itself is pinned to 1e-6 with
+        # injected gradients in test_optimizer_exact_with_injected_gradients.
+        for model, r32, r64 in models:
+            _compare(eng.param_views(model), r32, r64, TOL, f'updated {model} weight', skip=is_degenerate_bias)
 
-    # ---------------- value minibatch step (second trunk Adam step, t = 2)
-    loss, gv, gt, aux = oracle.value_grads(oracle_batch(val))
-    eng.value_forward_backward(dval)
-    m = eng.metrics('value')
-    assert abs(m['loss'] - float(loss)) < TOL * max(1.0, abs(float(loss)))
-    vals = eng.buffer(_lib.BUF_AUX_V, (B, 2)).cpu().numpy()
-    assert rel_err(vals, aux['values'].detach().numpy()) < TOL
-    _compare_grads(eng.grad_views('value'), gv, TOL)
-    _compare_grads(eng.grad_views('trunk'), gt, 2 * TOL, scale_floor=1e-3)
-    oracle.value_step(None, grads=(loss, gv, gt, aux))
-    eng.value_apply()
-    for model, ref in (('trunk', oracle.trunk), ('value', oracle.value)):
-        views = eng.param_views(model)
-        for name, r in ref.items():
-            if is_degenerate_bias(name):
-                continue
-            e = rel_err(views[name].cpu().numpy(), r.detach().numpy())
-            assert e < TOL, (model, name, e)
+    try:
+        # ---------------- policy minibatch step (Adam t = 1)
+        loss, gp, gt, aux = oracle.policy_grads(oracle_batch(pol))
+        loss64, gp64, gt64, aux64 = o64.policy_grads(oracle_batch(pol))
+        eng.policy_forward_backward(dpol)
+        m = eng.metrics('policy')
+        REPORT.append(dict(what='policy loss', engine=m['loss'], oracle32=float(loss.detach()), oracle64=float(loss64.detach())))
+        assert abs(m['loss'] - float(loss64.detach())) < TOL * max(1.0, abs(float(loss64.detach())))
+        ax = eng.buffer(_lib.BUF_AUX_P, (B, 4, A)).cpu().numpy()
+        for i, k in enumerate(('alpha', 'beta', 'log_prob')):           # alpha/beta = the action "logits"
+            err, bound = check3(ax[:, i], _np(aux[k]), _np(aux64[k]), TOL)
+            assert err <= bound, (k, err, bound)
+        _compare(eng.grad_views('policy'), gp, gp64, TOL, 'policy grad', floor_frac=1e-3)
+        # floor: the analytically-zero conv-bias gradients are pure rounding noise in any implementation
+        _compare(eng.grad_views('trunk'), gt, gt64, TOL, 'trunk grad', floor_frac=1e-3)
+        oracle.policy_step(None, grads=(loss, gp, gt, aux))
+        o64.policy_step(None, grads=(loss64, gp64, gt64, aux64))
+        eng.policy_apply()
+        check_weights([('trunk', oracle.trunk, o64.trunk), ('policy', oracle.policy, o64.policy),
+                       ('old_policy', oracle.old_policy, o64.old_policy)])
+        m_t, v_t = eng.adam_views('trunk')
+        _compare(m_t, oracle.opt_trunk.m, o64.opt_trunk.m, TOL, 'adam m', floor_frac=1e-3)
+        _compare(v_t, oracle.opt_trunk.v, o64.opt_trunk.v, 2 * TOL, 'adam v', floor_frac=1e-6, slack=6.0)   # v ~ g^2
+
+        # ---------------- value minibatch step from a common state (second trunk Adam step, t = 2)
+        _sync_from_o64(oracle, eng)
+        loss, gv, gt, aux = oracle.value_grads(oracle_batch(val))
+        loss64, gv64, gt64, aux64 = o64.value_grads(oracle_batch(val))
+        eng.value_forward_backward(dval)
+        m = eng.metrics('value')
+        REPORT.append(dict(what='value loss', engine=m['loss'], oracle32=float(loss.detach()), oracle64=float(loss64.detach())))
+        assert abs(m['loss'] - float(loss64.detach())) < TOL * max(1.0, abs(float(loss64.detach())))
+        vals = eng.buffer(_lib.BUF_AUX_V, (B, 2)).cpu().numpy()
+        err, bound = check3(vals, _np(aux['values']), _np(aux64['values']), TOL)
+        assert err <= bound
+        _compare(eng.grad_views('value'), gv, gv64, TOL, 'value grad', floor_frac=1e-3)
+        _compare(eng.grad_views('trunk'), gt, gt64, TOL, 'trunk grad (value pass)', floor_frac=1e-3)
+        oracle.value_step(None, grads=(loss, gv, gt, aux))
+        o64.value_step(None, grads=(loss64, gv64, gt64, aux64))
+        eng.value_apply()
+        check_weights([('trunk', oracle.trunk, o64.trunk), ('value', oracle.value, o64.value)])
+        m_t, v_t = eng.adam_views('trunk')
+        _compare(m_t, oracle.opt_trunk.m, o64.opt_trunk.m, TOL, 'adam m (t=2)', floor_frac=1e-3)
+    finally:
+        _dump_report(f'B{B}_{H}x{W}')
+
+
+@pytest.mark.parametrize('A', [2, 3])
+def test_optimizer_exact_with_injected_gradients(A):
+    """clip-by-norm per tensor + Keras Adam + old-policy copy + step counters, isolated from gradient
+    rounding noise: the float32 oracle's gradients are injected into the engine's gradient arena,
+    then three consecutive apply steps (policy, value, policy: trunk t = 1, 2, 3) must reproduce the
+    float32 oracle's weights and Adam moments to 1e-6."""
+    B, H, W = 4, 48, 64
+    oracle, eng = make_pair(B, H, W, seed=21, A=A)
+    pol, val = make_batches(B, H, W, seed=21, A=A)
+
+    def inject(model, grads, scale=1.0):
+        views = eng.grad_views(model)
+        for name, g in grads.items():
+            views[name].copy_((g.detach() * scale).float())
+
+    def check(models, tol=1e-6):
+        for model, ref, opt in models:
+            views = eng.param_views(model)
+            for name, r in ref.items():
+                e = rel_err(_np(views[name]), _np(r))
+                assert e < tol, (model, name, e)
+            if opt is not None:
+                m_e, v_e = eng.adam_views(model)
+                for name in opt.names:
+                    assert rel_err(_np(m_e[name]), _np(opt.m[name])) < tol, ('m', name)
+                    assert rel_err(_np(v_e[name]), _np(opt.v[name])) < 10 * tol, ('v', name)
+
+    for step, kind in enumerate(('policy', 'value', 'policy')):
+        if kind == 'policy':
+            loss, gh, gt, aux = oracle.policy_grads(oracle_batch(pol))
+        else:
+            loss, gh, gt, aux = oracle.value_grads(oracle_batch(val))
+        big = 50.0 if step == 2 else 1.0        # make sure the clip is active on some tensors
+        gh = {k: v * big for k, v in gh.items()}
+        # the engine's own forward ran nothing here: sync BN moving stats the oracle forward just updated
+        for model, ref in (('trunk', oracle.trunk), ('policy', oracle.policy), ('value', oracle.value)):
+            views = eng.param_views(model)
+            for name, r in ref.items():
+                if 'moving' in name:
+                    views[name].copy_(r.detach())
+        inject('trunk', gt)
+        inject(kind, gh)
+        if kind == 'policy':
+            oracle.policy_step(None, grads=(loss, gh, gt, aux))
+            eng.policy_apply()
+            check([('trunk', oracle.trunk, oracle.opt_trunk), ('policy', oracle.policy, oracle.opt_policy),
+                   ('old_policy', oracle.old_policy, None)])
+        else:
+            oracle.value_step(None, grads=(loss, gh, gt, aux))
+            eng.value_apply()
+            check([('trunk', oracle.trunk, oracle.opt_trunk), ('value', oracle.value, oracle.opt_value)])
 
 
 def test_determinism():

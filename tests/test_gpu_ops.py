@@ -257,7 +257,7 @@ def test_value_loss(lib):
     dlin = torch.zeros((B, 4), device=DEV)
     metrics = torch.zeros(16, device=DEV)
     vals = torch.zeros((B, 2), device=DEV)
-    _lib.check(lib.cdrl_value_loss(P(dev(lin)), P(dev(ret)), P(dev(spd)), P(dev(sim)), B, 6.0, 1.0, P(dlin), P(metrics),
-                                   P(vals), S()))
+    keep = [dev(lin), dev(ret), dev(spd), dev(sim)]      # keep the device tensors alive across the launch
+    _lib.check(lib.cdrl_value_loss(*[P(k) for k in keep], B, 6.0, 1.0, P(dlin), P(metrics), P(vals), S()))
     assert abs(metrics.cpu().numpy()[0] - total.item()) < 1e-6 * max(1.0, abs(total.item()))
     assert rel_err(dlin.cpu().numpy(), lt.grad.numpy()) < 1e-5
