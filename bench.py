@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""PPO update-steps/sec of the MI355X-native learner hot path (BASELINE.json metric).
+
+One *step* = one PPO update-step = one policy minibatch step + one value minibatch step on a
+per-GPU minibatch of 256 x (4 frames of 90x120x3 + road/vehicle/navigation vectors), fp32:
+2 x (train-mode CARLANetwork trunk fwd+bwd), 2 trunk Adam steps, policy head fwd/bwd + Beta-PPO
+loss + per-tensor clip + old-policy copy + Adam, value head likewise.
+Inputs are resident in HBM when the timed region starts.  N>1: one process per GPU (torchrun),
+rollout buffer sharded by env shard, one RCCL all-reduce of the fused gradient arena per pass.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# per-frame sum over {conv3x3, 1x1 conv, dw3x3, maxpool, GAP} of (in + out) elements
+ALG_ELEMS_PER_FRAME = {(90, 120): 979500, (90, 360): 2902212, (135, 180): 2275248, (135, 540): 6645476}
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes_per_update_step(B, T, H, W):
+    """ALG_BYTES_pass = 3 * 4 B * B * T * sum(in+out); an update-step is 2 passes."""
+    return 2 * 3 * 4 * B * T * ALG_ELEMS_PER_FRAME[(H, W)]
+
+
+def cpu_baseline(B_sample, T, H, W, threads, seed=42):
+    """Oracle (PyTorch-CPU restatement of the reference TF path) timed on the host cores on a bounded
+    sample: update-steps at minibatch B_sample, scaled to 256-sample update-steps/s."""
+    import torch
+    from oracle import model as OM
+    from oracle.spec import NetConfig, trunk_spec, policy_spec, value_spec
+    from carla_driving_rl_agent_amd import synthetic
+    from tests.util import make_batches, oracle_batch
+    torch.set_num_threads(threads)
+    cfg = NetConfig(T=T, H=H, W=W)
+    learner = OM.OracleLearner(cfg, OM.init_params(trunk_spec(cfg), 1, False), OM.init_params(policy_spec(cfg), 2, False),
+                               OM.init_params(value_spec(cfg), 3, False), synthetic.DEFAULT_HP)
+    pol, val = make_batches(B_sample, H, W, seed=seed, faithful=False)
+    pol, val = oracle_batch(pol), oracle_batch(val)
+    learner.policy_step(pol)          # warm-up
+    learner.value_step(val)
+    times = []
+    t_budget = time.time()
+    while len(times) < 3 and (time.time() - t_budget) < 25.0:
+        t0 = time.time()
+        learner.policy_step(pol)
+        learner.value_step(val)
+        times.append(time.time() - t0)
+    best = min(times)
+    return dict(value=(B_sample / 256.0) / best, unit='update-steps/s (256-sample equivalents)', cores=threads, kind='port',
+                sample=f'{len(times)} update-steps of the PyTorch-CPU oracle at minibatch {B_sample} (T={T}, {H}x{W}x3), '
+                       f'best {best:.3f} s/step, scaled by {B_sample}/256; host has {os.cpu_count()} logical cores')
+
+
+def run_cpu_baseline_child(B_sample, T, H, W, threads, timeout=240):
+    """The oracle runs in a CHILD process (plain subprocess, never exec from the GPU-initialised
+    process) with a hard wall-clock limit, so the default bench always finishes within minutes."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='')
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--cpu-sample-batch', str(B_sample),
+           '--cpu-threads', str(threads), '--height', str(H), '--width', str(W)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return dict(value=None, unit='update-steps/s', cores=threads, kind='port', sample=f'failed rc={r.returncode}: {r.stderr[-300:]}')
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit='update-steps/s', cores=threads, kind='port', sample=f'timed out after {timeout}s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--height', type=int, default=90)
+    ap.add_argument('--width', type=int, default=120)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-batch', type=int, default=128)
+    ap.add_argument('--cpu-threads', type=int, default=min(16, os.cpu_count() or 1),
+                    help='oracle intra-op threads; measured on the 2x64-core EPYC GPU host: 16 threads is the '
+                         'fastest setting (32: 2.2x slower, 64: 5.8x slower, 256: does not finish)')
+    ap.add_argument('--cpu-baseline-only', action='store_true')
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.cpu_sample_batch, 4, args.height, args.width, args.cpu_threads)))
+        return
+
+    import torch
+    import torch.distributed as dist
+    from carla_driving_rl_agent_amd import synthetic
+    from carla_driving_rl_agent_amd.engine import LearnerEngine, gae_returns
+    from carla_driving_rl_agent_amd.parallel import DataParallelLearner
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if rank == 0:
+            print(f'[bench] WORLD_SIZE={world} != --gpus {args.gpus}; launch with torchrun for N>1', file=sys.stderr)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = f'cuda:{local_rank}'
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+
+    B, T, H, W = args.batch, 4, args.height, args.width
+    eng = LearnerEngine(B, device=dev, T=T, H=H, W=W)
+    # random-init weights of the reference architecture, identical on every rank
+    from carla_driving_rl_agent_amd.init import init_engine_parameters
+    init_engine_parameters(eng, seed=42)
+    dp = DataParallelLearner(eng)
+    dp.broadcast_parameters()
+
+    # rollout shard of this rank (weak scaling: B timesteps per GPU), already resident in HBM
+    n = B
+    r = synthetic.make_rollout(n, T=T, H=H, W=W, seed=42 + rank)
+    states = {k: torch.as_tensor(v).to(dev) for k, v in r['states'].items()}
+    rewards = torch.as_tensor(r['reward']).to(dev)
+    values = torch.as_tensor(r['value']).to(dev)
+    # end_trajectory: bootstrap with the terminal last_value (0, 0)  (reference core/networks.py:171,214-216)
+    rewards = torch.cat([rewards, torch.zeros(1, device=dev)])
+    values = torch.cat([values, torch.zeros((1, 2), device=dev)])
+    torch.cuda.synchronize()
+    t0 = time.time()
+    returns, returns_be, adv_raw, adv = gae_returns(rewards, values, synthetic.DEFAULT_HP['gamma'],
+                                                    synthetic.DEFAULT_HP['lambda_'], synthetic.DEFAULT_HP['advantage_scale'])
+    torch.cuda.synchronize()
+    gae_ms = (time.time() - t0) * 1e3
+    speed = (torch.as_tensor(r['speed'][:, 0]) / 100.0).to(dev).contiguous()
+    sim = torch.as_tensor(r['similarity'][:, 0]).to(dev).contiguous()
+    pol = dict(states=states, advantages=adv.contiguous(), old_log_prob=torch.as_tensor(r['old_log_prob']).to(dev),
+               speed=speed, similarity=sim, u=torch.as_tensor(r['action']).to(dev), du_da=None, du_db=None)
+    val = dict(states=states, returns=returns_be.contiguous(), speed=speed, similarity=sim)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dp.update_step(pol, val)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.time()
+    ev0.record()
+    for _ in range(args.steps):
+        dp.update_step(pol, val)
+    ev1.record()
+    barrier()
+    elapsed = time.time() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_p = eng.metrics('policy')['loss']
+    loss_v = eng.metrics('value')['loss']
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        alg = alg_bytes_per_update_step(B, T, H, W) if (H, W) in ALG_ELEMS_PER_FRAME else None
+        dev_s_per_step = dev_ms * 1e-3 / args.steps
+        roof = None
+        if alg is not None:
+            achieved = alg / dev_s_per_step / 1e9
+            roof = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        kernel='one PPO update-step (all launches of the step, HIP-event timed on the launch stream)',
+                        algorithmic_bytes_per_launch=alg)
+        out = dict(metric='PPO update-steps/sec (batch=256, 4x90x120x3 obs)', value=round(value, 3), unit='update-steps/s',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload=f'configs[1]: synthetic rollout buffer {B}x{T}-frame {H}x{W}x3 obs per GPU, full '
+                                        f'CARLANetwork fwd/bwd + PPO/value loss + clip + Adam, fp32',
+                               per_gpu_batch=B, global_batch=B * world, time_horizon=T, image=[H, W, 3],
+                               parallelism=f'dp{world}', passes_per_step=2),
+                   roofline=roof, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3),
+                   final_losses=dict(policy=loss_p, value=loss_v))
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = run_cpu_baseline_child(args.cpu_sample_batch, T, H, W, args.cpu_threads)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -44,55 +44,88 @@ int colsum(View x, int rows, int C, double* part, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // forward finalize: stats[0]=mean, [1]=invstd, [2]=scale, [3]=shift, each [G][C]
 // ------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ mov_mean, float* __restrict__ mov_var, int bessel,
-                                   int training, float* __restrict__ stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float gm = gamma[c], bt = beta[c];
+// blockDim = (16 channel lanes, 16 partial lanes): the nb per-block partials of a channel are summed
+// by 16 lanes in parallel (independent, coalesced loads) and combined in a fixed order -> the
+// result is deterministic and the kernel is no longer a serial chain of nb dependent loads.
+#define FIN_CX 16
+#define FIN_PY 16
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ mov_mean, float* __restrict__ mov_var,
+                                                          int bessel, int training, float* __restrict__ stats) {
+    __shared__ double sm[2][FIN_PY][FIN_CX];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c = blockIdx.x * FIN_CX + tx;
+    const bool ok = c < C;
     const int GC = G * C;
     if (!training) {
-        const float mean = mov_mean[c];
-        const float invstd = (float)(1.0 / sqrt((double)mov_var[c] + (double)BN_EPS));
-        for (int g = 0; g < G; ++g) {
-            stats[0 * GC + g * C + c] = mean;
-            stats[1 * GC + g * C + c] = invstd;
-            stats[2 * GC + g * C + c] = gm * invstd;
-            stats[3 * GC + g * C + c] = bt - mean * gm * invstd;
+        if (ok && ty == 0) {
+            const float gm = gamma[c], bt = beta[c];
+            const float mean = mov_mean[c];
+            const float invstd = (float)(1.0 / sqrt((double)mov_var[c] + (double)BN_EPS));
+            for (int g = 0; g < G; ++g) {
+                stats[0 * GC + g * C + c] = mean;
+                stats[1 * GC + g * C + c] = invstd;
+                stats[2 * GC + g * C + c] = gm * invstd;
+                stats[3 * GC + g * C + c] = bt - mean * gm * invstd;
+            }
         }
         return;
     }
-    float mm = mov_mean[c], mv = mov_var[c];
+    float mm = 0.0f, mv = 0.0f, gm = 0.0f, bt = 0.0f;
+    if (ok && ty == 0) {
+        mm = mov_mean[c];
+        mv = mov_var[c];
+        gm = gamma[c];
+        bt = beta[c];
+    }
     const double n = (double)Mg;
     const float corr = (bessel && Mg > 1) ? (float)(n / (n - 1.0)) : 1.0f;
     for (int g = 0; g < G; ++g) {
         double s = 0.0, q = 0.0;
-        for (int b = 0; b < nb; ++b) {
-            s += part[(((int64_t)g * nb + b) * 2 + 0) * C + c];
-            q += part[(((int64_t)g * nb + b) * 2 + 1) * C + c];
+        if (ok) {
+            for (int b = ty; b < nb; b += FIN_PY) {
+                s += part[(((int64_t)g * nb + b) * 2 + 0) * C + c];
+                q += part[(((int64_t)g * nb + b) * 2 + 1) * C + c];
+            }
         }
-        const double mean = s / n;
-        double var = q / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float meanf = (float)mean, varf = (float)var;
-        const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
-        stats[0 * GC + g * C + c] = meanf;
-        stats[1 * GC + g * C + c] = invstd;
-        stats[2 * GC + g * C + c] = gm * invstd;
-        stats[3 * GC + g * C + c] = bt - meanf * gm * invstd;
-        // Keras: moving -= (moving - value) * (1 - momentum), once per time slice (t ascending)
-        mm = mm - (mm - meanf) * 0.01f;
-        mv = mv - (mv - varf * corr) * 0.01f;
+        sm[0][ty][tx] = s;
+        sm[1][ty][tx] = q;
+        __syncthreads();
+        if (ok && ty == 0) {
+            s = 0.0;
+            q = 0.0;
+#pragma unroll
+            for (int y = 0; y < FIN_PY; ++y) {
+                s += sm[0][y][tx];
+                q += sm[1][y][tx];
+            }
+            const double mean = s / n;
+            double var = q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float meanf = (float)mean, varf = (float)var;
+            const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+            stats[0 * GC + g * C + c] = meanf;
+            stats[1 * GC + g * C + c] = invstd;
+            stats[2 * GC + g * C + c] = gm * invstd;
+            stats[3 * GC + g * C + c] = bt - meanf * gm * invstd;
+            // Keras: moving -= (moving - value) * (1 - momentum), once per time slice (t ascending)
+            mm = mm - (mm - meanf) * 0.01f;
+            mv = mv - (mv - varf * corr) * 0.01f;
+        }
+        __syncthreads();
     }
-    mov_mean[c] = mm;
-    mov_var[c] = mv;
+    if (ok && ty == 0) {
+        mov_mean[c] = mm;
+        mov_var[c] = mv;
+    }
 }
 
 int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* gamma, const float* beta,
                 float* mov_mean, float* mov_var, int bessel, int training, float* stats, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, part, nb, G, Mg, C, gamma, beta,
-                       mov_mean, mov_var, bessel, training, stats);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CX)), dim3(FIN_CX, FIN_PY), 0, st, part, nb, G, Mg, C, gamma,
+                       beta, mov_mean, mov_var, bessel, training, stats);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -169,34 +202,54 @@ int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const
     return launch_colreduce<2>(f, G, Mg, C, part, st);
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
-                                       const float* __restrict__ stats, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg,
+                                                              int C, const float* __restrict__ stats,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef) {
+    __shared__ double sm[2][FIN_PY][FIN_CX];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c = blockIdx.x * FIN_CX + tx;
+    const bool ok = c < C;
     const int GC = G * C;
     double dg = 0.0, db = 0.0;
     const double n = (double)Mg;
     for (int g = 0; g < G; ++g) {
         double s = 0.0, q = 0.0;
-        for (int b = 0; b < nb; ++b) {
-            s += part[(((int64_t)g * nb + b) * 2 + 0) * C + c];
-            q += part[(((int64_t)g * nb + b) * 2 + 1) * C + c];
+        if (ok) {
+            for (int b = ty; b < nb; b += FIN_PY) {
+                s += part[(((int64_t)g * nb + b) * 2 + 0) * C + c];
+                q += part[(((int64_t)g * nb + b) * 2 + 1) * C + c];
+            }
         }
-        db += s;
-        dg += q;
-        coef[0 * GC + g * C + c] = stats[2 * GC + g * C + c];   // k1 = gamma * invstd
-        coef[1 * GC + g * C + c] = (float)(s / n);              // k2 = mean(dz)
-        coef[2 * GC + g * C + c] = (float)(q / n);              // k3 = mean(dz * xhat)
+        sm[0][ty][tx] = s;
+        sm[1][ty][tx] = q;
+        __syncthreads();
+        if (ok && ty == 0) {
+            s = 0.0;
+            q = 0.0;
+#pragma unroll
+            for (int y = 0; y < FIN_PY; ++y) {
+                s += sm[0][y][tx];
+                q += sm[1][y][tx];
+            }
+            db += s;
+            dg += q;
+            coef[0 * GC + g * C + c] = stats[2 * GC + g * C + c];   // k1 = gamma * invstd
+            coef[1 * GC + g * C + c] = (float)(s / n);              // k2 = mean(dz)
+            coef[2 * GC + g * C + c] = (float)(q / n);              // k3 = mean(dz * xhat)
+        }
+        __syncthreads();
     }
-    dgamma[c] = (float)dg;      // shared gamma/beta: summed over the T applications (Appendix E)
-    dbeta[c] = (float)db;
+    if (ok && ty == 0) {
+        dgamma[c] = (float)dg;      // shared gamma/beta: summed over the T applications (Appendix E)
+        dbeta[c] = (float)db;
+    }
 }
 
 int bn_bwd_finalize(const double* part, int nb, int G, int Mg, int C, const float* stats, float* dgamma,
                     float* dbeta, float* coef, hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, part, nb, G, Mg, C, stats, dgamma,
-                       dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CX)), dim3(FIN_CX, FIN_PY), 0, st, part, nb, G, Mg, C,
+                       stats, dgamma, dbeta, coef);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -233,19 +286,28 @@ int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const 
     return launch_colreduce<1>(f, G, Mg, C, part2, st);
 }
 
-__global__ void reduce_partials_kernel(const double* __restrict__ part, int nparts, int n, int64_t stride,
-                                       float* __restrict__ out, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __restrict__ part, int nparts, int n,
+                                                              int64_t stride, float* __restrict__ out, int accumulate) {
+    __shared__ double sm[FIN_PY][FIN_CX];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int i = blockIdx.x * FIN_CX + tx;
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * stride + i];
-    out[i] = accumulate ? out[i] + (float)s : (float)s;
+    if (i < n)
+        for (int p = ty; p < nparts; p += FIN_PY) s += part[(int64_t)p * stride + i];
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (i < n && ty == 0) {
+        s = 0.0;
+#pragma unroll
+        for (int y = 0; y < FIN_PY; ++y) s += sm[y][tx];
+        out[i] = accumulate ? out[i] + (float)s : (float)s;
+    }
 }
 
 int reduce_partials(const double* part, int nparts, int n, int64_t stride, float* out, int accumulate,
                     hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, nparts, n, stride, out,
-                       accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, FIN_CX)), dim3(FIN_CX, FIN_PY), 0, st, part, nparts, n, stride,
+                       out, accumulate);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

@@ -65,7 +65,12 @@ struct ColGeom {
     int nb;         // blocks per group
 };
 
-inline ColGeom col_geom(int rows_per_group, int C, int max_blocks_per_group = 128) {
+// blocks per BatchNorm group for the statistics / backward reductions (x G groups), and for the
+// single-group filter-gradient reductions (depthwise / stem): enough workgroups to fill 256 CUs.
+constexpr int NB_STATS = 256;
+constexpr int NB_FILTER = 1024;
+
+inline ColGeom col_geom(int rows_per_group, int C, int max_blocks_per_group = NB_STATS) {
     ColGeom g;
     g.cx = pow2ceil(C);
     if (g.cx < 32) g.cx = 32;

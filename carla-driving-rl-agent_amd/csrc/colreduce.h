@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(256) colreduce_kernel(F f, int Mg, int C, int 
 }
 
 template <int NQ, class F>
-static int launch_colreduce(F f, int G, int Mg, int C, double* part, hipStream_t st) {
-    ColGeom g = col_geom(Mg, C);
+static int launch_colreduce(F f, int G, int Mg, int C, double* part, hipStream_t st, int max_blocks = NB_STATS) {
+    ColGeom g = col_geom(Mg, C, max_blocks);
     dim3 grid(g.nb, G), block(g.cx, g.cy);
     size_t sm = (size_t)g.cy * NQ * g.cx * sizeof(double);
     hipLaunchKernelGGL((colreduce_kernel<NQ, F>), grid, block, sm, st, f, Mg, C, g.rb, part);

@@ -88,7 +88,7 @@ struct StemBwdF {
 
 int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    ColGeom g = col_geom(B * T * Ho * Wo, Cout);
+    ColGeom g = col_geom(B * T * Ho * Wo, Cout, NB_FILTER);
     return (int64_t)g.nb * 28 * Cout;
 }
 
@@ -97,8 +97,8 @@ int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int rows = B * T * Ho * Wo;
     StemBwdF f{x, dy, B, T, H, W, Ho, Wo, Cout};
-    CDRL_TRY(launch_colreduce<28>(f, 1, rows, Cout, part, st));
-    ColGeom g = col_geom(rows, Cout);
+    CDRL_TRY(launch_colreduce<28>(f, 1, rows, Cout, part, st, NB_FILTER));
+    ColGeom g = col_geom(rows, Cout, NB_FILTER);
     CDRL_TRY(reduce_partials(part, g.nb, 27 * Cout, (int64_t)28 * Cout, dw, 0, st));
     CDRL_TRY(reduce_partials(part + 27 * Cout, g.nb, Cout, (int64_t)28 * Cout, db, 0, st));
     return 0;
@@ -230,7 +230,7 @@ struct DwBwdFilterF {
 
 int64_t dw_bwd_part_elems(int N, int H, int W, int C, int stride) {
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
-    ColGeom g = col_geom(N * Ho * Wo, C);
+    ColGeom g = col_geom(N * Ho * Wo, C, NB_FILTER);
     return (int64_t)g.nb * 10 * C;
 }
 
@@ -239,8 +239,8 @@ int dw_bwd_filter(View a, const float* dy, float* dw, float* db, int N, int H, i
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int rows = N * Ho * Wo;
     DwBwdFilterF f{a, dy, H, W, Ho, Wo, C, stride, same_pad_before(H, stride), same_pad_before(W, stride)};
-    CDRL_TRY(launch_colreduce<10>(f, 1, rows, C, part, st));
-    ColGeom g = col_geom(rows, C);
+    CDRL_TRY(launch_colreduce<10>(f, 1, rows, C, part, st, NB_FILTER));
+    ColGeom g = col_geom(rows, C, NB_FILTER);
     CDRL_TRY(reduce_partials(part, g.nb, 9 * C, (int64_t)10 * C, dw, 0, st));
     CDRL_TRY(reduce_partials(part + 9 * C, g.nb, C, (int64_t)10 * C, db, 0, st));
     return 0;

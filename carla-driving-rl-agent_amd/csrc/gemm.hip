@@ -215,13 +215,24 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(View A, View D, float* __r
     }
 }
 
-__global__ void tn_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t n, float* __restrict__ out,
-                                 int accumulate) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// 16 output lanes x 16 split lanes per block: the split partials are summed in parallel with
+// coalesced loads and combined in a fixed order (deterministic).
+__global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t n,
+                                                        float* __restrict__ out, int accumulate) {
+    __shared__ double sm[16][16];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 16 + tx;
     double s = 0.0;
-    for (int p = 0; p < nsplit; ++p) s += (double)part[(int64_t)p * n + i];
-    out[i] = accumulate ? out[i] + (float)s : (float)s;
+    if (i < n)
+        for (int p = ty; p < nsplit; p += 16) s += (double)part[(int64_t)p * n + i];
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (i < n && ty == 0) {
+        s = 0.0;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) s += sm[y][tx];
+        out[i] = accumulate ? out[i] + (float)s : (float)s;
+    }
 }
 
 template <int KT>
@@ -245,7 +256,7 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     }
     CDRL_LAUNCH_CHECK();
     const int64_t n = (int64_t)K * N;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, part, p.nsplit, n, Cout,
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n, 16)), dim3(16, 16), 0, st, part, p.nsplit, n, Cout,
                        accumulate);
     CDRL_LAUNCH_CHECK();
     return 0;

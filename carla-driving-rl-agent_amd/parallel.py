@@ -1,0 +1,68 @@
+"""Data-parallel PPO learner: one process per GPU, rollout buffer sharded by env shard, ONE fused
+RCCL all-reduce per pass over the contiguous gradient arena.
+
+The gradient arena is laid out [policy | trunk | value] so that the policy pass reduces the
+contiguous slice [policy | trunk] and the value pass the slice [trunk | value]; the loss kernels
+already scale gradients by 1/world_size, so a SUM all-reduce yields the average and every rank
+applies the identical clip + Adam update (parameters and Adam state stay replicated).
+BatchNorm statistics are local to a rank's minibatch (N independent reference agents sharing
+weights); the moving statistics are averaged with a second, tiny all-reduce.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallelLearner:
+    def __init__(self, engine, group=None, sync_bn_stats=True):
+        self.engine = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.sync_bn_stats = sync_bn_stats
+        p_off, p_n = engine.region('policy', True)
+        t_off, t_n = engine.region('trunk', True)
+        v_off, v_n = engine.region('value', True)
+        assert p_off == 0 and t_off == p_n and v_off == p_n + t_n, 'gradient arena must be [policy|trunk|value]'
+        self._policy_slice = (0, p_n + t_n)
+        self._value_slice = (t_off, t_off + t_n + v_n)
+        s0, _ = engine.region('policy', False)
+        # [policy_state | trunk_state | value_state | old_policy (weights + state)]: everything that is
+        # not touched by the replicated Adam update; world_size is a power of two, so averaging the
+        # (identical) old-policy weights is exact
+        self._state_slice = (s0, engine.params_total)
+
+    def _allreduce(self, flat, lo, hi, scale=None):
+        if self.world == 1:
+            return
+        view = flat[lo:hi]
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        if scale is not None:
+            view.mul_(scale)
+
+    def broadcast_parameters(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.engine.params, src=src, group=self.group)
+            dist.broadcast(self.engine.adam_m, src=src, group=self.group)
+            dist.broadcast(self.engine.adam_v, src=src, group=self.group)
+
+    def policy_step(self, batch):
+        e = self.engine
+        e.policy_forward_backward(batch, grad_scale=1.0 / self.world)
+        self._allreduce(e.grads, *self._policy_slice)
+        e.policy_apply()
+
+    def value_step(self, batch):
+        e = self.engine
+        e.value_forward_backward(batch, grad_scale=1.0 / self.world)
+        self._allreduce(e.grads, *self._value_slice)
+        e.value_apply()
+
+    def sync_moving_statistics(self):
+        if self.sync_bn_stats and self.world > 1:
+            self._allreduce(self.engine.params, *self._state_slice, scale=1.0 / self.world)
+
+    def update_step(self, policy_batch, value_batch):
+        """One PPO update-step = one policy minibatch step + one value minibatch step
+        (reference rl/agents/ppo.py:199-224)."""
+        self.policy_step(policy_batch)
+        self.value_step(value_batch)
+        self.sync_moving_statistics()

@@ -170,7 +170,7 @@ int cdrl_dwconv_bwd_filter(const float* a, const float* dy, float* dw, float* db
 int cdrl_maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, void* stream);
 int cdrl_maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H, int W, int C, void* stream);
 /* BatchNormalization(training=True) per time slice + optional ReLU6 + optional channel_shuffle on
- * the store (core/architectures.py:44-57,109-118).  stats: 4*G*C floats, workspace: G*128*2*C doubles. */
+ * the store (core/architectures.py:44-57,109-118).  stats: 4*G*C floats, workspace: G*256*2*C doubles. */
 int cdrl_bn_train_fwd(const float* y, int G, int Mg, int C, const float* gamma, const float* beta, float* moving_mean,
                       float* moving_var, int bessel, int relu6, float* out, int out_ld, int out_coff, int shuffle_ctot,
                       float* stats, double* workspace, void* stream);

@@ -164,7 +164,7 @@ def test_bn_train(lib, G, Mg, Cc, relu, shuffle):
     coff = Cc if shuffle else 0          # main-branch half of a concat buffer
     out = torch.zeros((G * Mg, ctot), device=DEV)
     stats = torch.zeros(4 * G * Cc, device=DEV)
-    ws = torch.zeros(G * 128 * 2 * Cc, dtype=torch.float64, device=DEV)
+    ws = torch.zeros(G * 256 * 2 * Cc, dtype=torch.float64, device=DEV)
     Y, Gm, Bt, MM, MV = dev(y), dev(gamma), dev(beta), dev(mm0), dev(mv0)
     _lib.check(lib.cdrl_bn_train_fwd(P(Y), G, Mg, Cc, P(Gm), P(Bt), P(MM), P(MV), 1, relu, P(out), ctot, coff,
                                      ctot if shuffle else 0, P(stats), P(ws), S()))
