@@ -48,9 +48,9 @@ int colsum(View x, int rows, int C, double* part, hipStream_t st) {
 // by 16 lanes in parallel (independent, coalesced loads) and combined in a fixed order -> the
 // result is deterministic and the kernel is no longer a serial chain of nb dependent loads.
 #define FIN_CX 16
-#define FIN_PY 16
+#define FIN_PY 64
 
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ mov_mean, float* __restrict__ mov_var,
                                                           int bessel, int training, float* __restrict__ stats) {
@@ -202,7 +202,7 @@ int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const
     return launch_colreduce<2>(f, G, Mg, C, part, st);
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg,
+__global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg,
                                                               int C, const float* __restrict__ stats,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef) {
@@ -286,7 +286,7 @@ int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const 
     return launch_colreduce<1>(f, G, Mg, C, part2, st);
 }
 
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __restrict__ part, int nparts, int n,
+__global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __restrict__ part, int nparts, int n,
                                                               int64_t stride, float* __restrict__ out, int accumulate) {
     __shared__ double sm[FIN_PY][FIN_CX];
     const int tx = threadIdx.x, ty = threadIdx.y;

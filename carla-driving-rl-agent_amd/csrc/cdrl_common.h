@@ -77,6 +77,9 @@ inline ColGeom col_geom(int rows_per_group, int C, int max_blocks_per_group = NB
     if (g.cx > 256) g.cx = 256;
     g.cy = 256 / g.cx;
     int rb = cdiv(rows_per_group, max_blocks_per_group);
+    // many small workgroups: the streaming kernels need >= 1024 resident workgroups to cover HBM
+    // latency (measured: 64 elements/thread minimum made the late stages 2-3x slower); the finalize
+    // kernels cope with the larger partial counts by summing them with 64 lanes per channel
     int minrb = g.cy * 4;
     if (rb < minrb) rb = minrb;
     rb = cdiv(rb, g.cy) * g.cy;

@@ -50,6 +50,9 @@ int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C
 // Cout[K,N] = sum_m A[m,K]^T * D[m,N]  (split over M; partial buffer `part` >= gemm_tn_part_elems)
 int64_t gemm_tn_part_elems(int M, int N, int K);
 int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st);
+// out[i] (+)= sum_p part[p*stride + i] for float partials (double accumulation, fixed order)
+int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride, float* out, int accumulate,
+                        hipStream_t st);
 
 // ---------------------------------------------------------------- convolutions (conv.hip)
 // x: (B,T,H,W,3) reference layout -> y: [(t*B+b)][Ho][Wo][Cout], 3x3 stride 2 valid.

@@ -86,8 +86,81 @@ struct StemBwdF {
     }
 };
 
+// MFMA form of the stem filter gradient: dW[27][Cout] (+ db as a 28th "ones" patch column) is a
+// TN GEMM  P^T dY  over M = B*T*Ho*Wo pixel rows with the im2col patch tile P (32 rows x 27+1)
+// gathered on the fly into LDS.  Each of the 4 waves owns 32 rows of a 128-row slice and its own
+// 32x32 accumulator; the 4 accumulators are summed through LDS at the end and written as one
+// float partial per workgroup (deterministic two-stage reduction, no atomics).
+typedef float f32x16_c __attribute__((ext_vector_type(16)));
+#define STEM_NBLK 1024
+
+__global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ part, int B, int T, int H, int W, int Ho,
+                                                            int Wo, int Cout, int rows, int rows_per) {
+    __shared__ float P[4][32][33];
+    __shared__ float D[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lcol = lane & 31, lk = lane >> 5;
+    const int r0 = blockIdx.x * rows_per;
+    const int r1 = min(r0 + rows_per, rows);
+    f32x16_c acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int i = lane; i < 32 * 33; i += 64) {       // zero the padding columns once
+        (&P[wave][0][0])[i] = 0.0f;
+        (&D[wave][0][0])[i] = 0.0f;
+    }
+    for (int base = r0; base < r1; base += 128) {
+        const int wrow0 = base + wave * 32;
+        __syncthreads();
+        // patch tile: 32 rows x 28 (27 taps + ones column)
+        for (int idx = lane; idx < 32 * 28; idx += 64) {
+            const int r = idx / 28, j = idx - r * 28;
+            const int row = wrow0 + r;
+            float v = 0.0f;
+            if (row < r1) {
+                if (j == 27) {
+                    v = 1.0f;
+                } else {
+                    const int ox = row % Wo;
+                    const int q = row / Wo;
+                    const int oy = q % Ho;
+                    const int f = q / Ho;
+                    const int t = f / B, b = f - t * B;
+                    const int ky = j / 9, rem = j - ky * 9;
+                    v = x[((((int64_t)b * T + t) * H + 2 * oy + ky) * W + 2 * ox) * 3 + rem];
+                }
+            }
+            P[wave][r][j] = v;
+        }
+        for (int idx = lane; idx < 32 * Cout; idx += 64) {
+            const int r = idx / Cout, c = idx - r * Cout;
+            const int row = wrow0 + r;
+            D[wave][r][c] = row < r1 ? dy[(int64_t)row * Cout + c] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < 32; mm += 2) {
+            const float a = P[wave][mm + lk][lcol];
+            const float bq = D[wave][mm + lk][lcol];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // sum the 4 wave accumulators: reuse P as [4][32][33]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][lcol] = acc[r];
+    __syncthreads();
+    float* out = part + (int64_t)blockIdx.x * 28 * Cout;
+    for (int idx = tid; idx < 28 * Cout; idx += 256) {
+        const int k = idx / Cout, n = idx - k * Cout;
+        out[idx] = (P[0][k][n] + P[1][k][n]) + (P[2][k][n] + P[3][k][n]);
+    }
+}
+
 int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    if (Cout <= 32) return ((int64_t)STEM_NBLK * 28 * Cout + 1) / 2;      // float partials inside a double buffer
     ColGeom g = col_geom(B * T * Ho * Wo, Cout, NB_FILTER);
     return (int64_t)g.nb * 28 * Cout;
 }
@@ -96,6 +169,16 @@ int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B
                     double* part, hipStream_t st) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int rows = B * T * Ho * Wo;
+    if (Cout <= 32) {
+        float* pf = reinterpret_cast<float*>(part);
+        int rows_per = cdiv(cdiv(rows, STEM_NBLK), 128) * 128;
+        const int nblk = cdiv(rows, rows_per);
+        hipLaunchKernelGGL(stem_bwd_mfma_kernel, dim3(nblk), dim3(256), 0, st, x, dy, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                           rows_per);
+        CDRL_LAUNCH_CHECK();
+        CDRL_TRY(reduce_partials_f32(pf, nblk, (int64_t)27 * Cout, (int64_t)28 * Cout, dw, 0, st));
+        return reduce_partials_f32(pf + 27 * Cout, nblk, Cout, (int64_t)28 * Cout, db, 0, st);
+    }
     StemBwdF f{x, dy, B, T, H, W, Ho, Wo, Cout};
     CDRL_TRY(launch_colreduce<28>(f, 1, rows, Cout, part, st, NB_FILTER));
     ColGeom g = col_geom(rows, Cout, NB_FILTER);
@@ -107,9 +190,10 @@ int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B
 // ------------------------------------------------------------------------------------------
 // depthwise 3x3 (reference core/architectures.py:132,138); kernel layout (3,3,C,1) -> [9][C]
 // ------------------------------------------------------------------------------------------
+template <int s>
 __global__ void __launch_bounds__(256) dw_fwd_kernel(View a, const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* __restrict__ y, int rows, int H, int W, int Ho, int Wo, int C,
-                                                     int s, int pt, int pl, int rb) {
+                                                     int pt, int pl, int rb) {
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int CX = blockDim.x, CY = blockDim.y;
     const int r0 = blockIdx.x * rb;
@@ -147,14 +231,19 @@ int dw_fwd(View a, const float* w, const float* bias, float* y, int N, int H, in
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int rows = N * Ho * Wo;
     ColGeom g = col_geom(rows, C, 2048);
-    hipLaunchKernelGGL(dw_fwd_kernel, dim3(g.nb), dim3(g.cx, g.cy), 0, st, a, w, bias, y, rows, H, W, Ho, Wo, C, stride,
-                       same_pad_before(H, stride), same_pad_before(W, stride), g.rb);
+    if (stride == 1)
+        hipLaunchKernelGGL(dw_fwd_kernel<1>, dim3(g.nb), dim3(g.cx, g.cy), 0, st, a, w, bias, y, rows, H, W, Ho, Wo, C,
+                           same_pad_before(H, 1), same_pad_before(W, 1), g.rb);
+    else
+        hipLaunchKernelGGL(dw_fwd_kernel<2>, dim3(g.nb), dim3(g.cx, g.cy), 0, st, a, w, bias, y, rows, H, W, Ho, Wo, C,
+                           same_pad_before(H, 2), same_pad_before(W, 2), g.rb);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
 
+template <int s>
 __global__ void __launch_bounds__(256) dw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                          View da, int rows, int H, int W, int Ho, int Wo, int C, int s,
+                                                          View da, int rows, int H, int W, int Ho, int Wo, int C,
                                                           int pt, int pl, int rb, int accumulate) {
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int CX = blockDim.x, CY = blockDim.y;
@@ -196,8 +285,12 @@ int dw_bwd_data(const float* dy, const float* w, View da, int N, int H, int W, i
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int rows = N * H * W;
     ColGeom g = col_geom(rows, C, 2048);
-    hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(g.nb), dim3(g.cx, g.cy), 0, st, dy, w, da, rows, H, W, Ho, Wo, C, stride,
-                       same_pad_before(H, stride), same_pad_before(W, stride), g.rb, accumulate);
+    if (stride == 1)
+        hipLaunchKernelGGL(dw_bwd_data_kernel<1>, dim3(g.nb), dim3(g.cx, g.cy), 0, st, dy, w, da, rows, H, W, Ho, Wo, C,
+                           same_pad_before(H, 1), same_pad_before(W, 1), g.rb, accumulate);
+    else
+        hipLaunchKernelGGL(dw_bwd_data_kernel<2>, dim3(g.nb), dim3(g.cx, g.cy), 0, st, dy, w, da, rows, H, W, Ho, Wo, C,
+                           same_pad_before(H, 2), same_pad_before(W, 2), g.rb, accumulate);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

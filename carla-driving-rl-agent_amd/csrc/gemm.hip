@@ -22,13 +22,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BM 128
 #define BK 32
 
-template <int NT>
-__global__ void __launch_bounds__(256) gemm_nn_kernel(View A, const float* __restrict__ Bp, int sbk, int sbn,
-                                                      const float* __restrict__ bias, View C, int M, int N, int K,
-                                                      int accumulate) {
+// Software-pipelined K loop: the global loads of slice k+1 are issued into registers before the
+// MFMAs of slice k run out of the other LDS buffer (one barrier per slice).  BT selects the lane
+// order of the B staging so that the global reads stay coalesced for both W (sbn == 1, forward)
+// and W^T (sbk == 1, backward-data); the B tile is padded to BN+1 floats per row so that both
+// store orders are bank-conflict free.
+template <int NT, bool BT, bool VEC>
+__global__ void __launch_bounds__(256, 2) gemm_nn_kernel(View A, const float* __restrict__ Bp, int sbk, int sbn,
+                                                         const float* __restrict__ bias, View C, int M, int N, int K,
+                                                         int accumulate) {
     constexpr int BN = 32 * NT;
-    __shared__ float As[BM][BK + 1];
-    __shared__ float Bs[BK][BN];
+    constexpr int NA = (BM * BK) / 256;          // 16 A elements per thread per slice
+    constexpr int NB = (BK * BN) / 256;          // 4*NT B elements per thread per slice
+    __shared__ float As[2][BM][BK + 1];
+    __shared__ float Bs[2][BK][BN + 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -38,39 +45,82 @@ __global__ void __launch_bounds__(256) gemm_nn_kernel(View A, const float* __res
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-
     const int lrow = lane & 31, lk = lane >> 5;
+    float ra[NA], rb[NB];
+
+    auto load_slice = [&](int k0) {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NA / 2; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx >> 4, kk = (idx & 15) * 2;
+                const int64_t m = m0 + r;
+                float2 v = make_float2(0.0f, 0.0f);
+                if (m < M && (k0 + kk) < K) v = *reinterpret_cast<const float2*>(&A.p[m * A.ld + A.coff + k0 + kk]);
+                ra[2 * i] = v.x;
+                ra[2 * i + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx >> 5, kk = idx & 31;
+                const int64_t m = m0 + r;
+                ra[i] = (m < M && (k0 + kk) < K) ? A.p[m * A.ld + A.coff + k0 + kk] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i;
+            const int kk = BT ? (idx & (BK - 1)) : (idx / BN);
+            const int nn = BT ? (idx / BK) : (idx % BN);
+            rb[i] = ((k0 + kk) < K && (n0 + nn) < N) ? Bp[(int64_t)(k0 + kk) * sbk + (int64_t)(n0 + nn) * sbn] : 0.0f;
+        }
+    };
+    auto store_slice = [&](int buf) {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NA / 2; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx >> 4, kk = (idx & 15) * 2;
+                As[buf][r][kk] = ra[2 * i];
+                As[buf][r][kk + 1] = ra[2 * i + 1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = tid + 256 * i;
+                As[buf][idx >> 5][idx & 31] = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i;
+            const int kk = BT ? (idx & (BK - 1)) : (idx / BN);
+            const int nn = BT ? (idx / BK) : (idx % BN);
+            Bs[buf][kk][nn] = rb[i];
+        }
+    };
+
+    load_slice(0);
+    store_slice(0);
+    __syncthreads();
+    int buf = 0;
     for (int k0 = 0; k0 < K; k0 += BK) {
-        // stage A: 128 x 32
-#pragma unroll
-        for (int i = 0; i < (BM * BK) / 256; ++i) {
-            const int idx = tid + 256 * i;
-            const int r = idx >> 5, kk = idx & 31;
-            const int64_t m = m0 + r;
-            float v = 0.0f;
-            if (m < M && (k0 + kk) < K) v = A.p[m * A.ld + A.coff + k0 + kk];
-            As[r][kk] = v;
-        }
-        // stage B: 32 x BN
-#pragma unroll
-        for (int i = 0; i < (BK * BN) / 256; ++i) {
-            const int idx = tid + 256 * i;
-            const int kk = idx / BN, nn = idx % BN;
-            float v = 0.0f;
-            if ((k0 + kk) < K && (n0 + nn) < N) v = Bp[(int64_t)(k0 + kk) * sbk + (int64_t)(n0 + nn) * sbn];
-            Bs[kk][nn] = v;
-        }
-        __syncthreads();
+        const bool more = (k0 + BK) < K;
+        if (more) load_slice(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a = As[wave * 32 + lrow][kk + lk];
+            const float a = As[buf][wave * 32 + lrow][kk + lk];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const float b = Bs[kk + lk][j * 32 + lrow];
+                const float b = Bs[buf][kk + lk][j * 32 + lrow];
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
             }
         }
+        if (more) store_slice(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
     // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -91,6 +141,18 @@ __global__ void __launch_bounds__(256) gemm_nn_kernel(View A, const float* __res
     }
 }
 
+template <int NT>
+static void launch_nn(bool bt, bool vec, dim3 grid, hipStream_t st, View A, const float* Bp, int sbk, int sbn,
+                      const float* bias, View C, int M, int N, int K, int acc) {
+    if (bt) {
+        if (vec) hipLaunchKernelGGL((gemm_nn_kernel<NT, true, true>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+        else hipLaunchKernelGGL((gemm_nn_kernel<NT, true, false>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_nn_kernel<NT, false, true>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+        else hipLaunchKernelGGL((gemm_nn_kernel<NT, false, false>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+    }
+}
+
 int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C, int M, int N, int K,
             int accumulate, hipStream_t st) {
     if (M <= 0 || N <= 0) return 0;
@@ -99,12 +161,14 @@ int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C
     // balance column blocks: e.g. N=232 -> 2 blocks of 4 tiles; N=92 -> 1 block of 3 tiles
     const int ncb = cdiv(N, 32 * nt);
     nt = cdiv(cdiv(N, ncb), 32);
-    dim3 grid(cdiv(M, BM), cdiv(N, 32 * nt)), block(256);
+    dim3 grid(cdiv(M, BM), cdiv(N, 32 * nt));
+    const bool bt = sbn != 1;
+    const bool vec = (K % 2 == 0) && (A.ld % 2 == 0) && (A.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(A.p) & 7) == 0);
     switch (nt) {
-        case 1: hipLaunchKernelGGL(gemm_nn_kernel<1>, grid, block, 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
-        case 2: hipLaunchKernelGGL(gemm_nn_kernel<2>, grid, block, 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
-        case 3: hipLaunchKernelGGL(gemm_nn_kernel<3>, grid, block, 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
-        default: hipLaunchKernelGGL(gemm_nn_kernel<4>, grid, block, 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+        case 1: launch_nn<1>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+        case 2: launch_nn<2>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+        case 3: launch_nn<3>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+        default: launch_nn<4>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
     }
     CDRL_LAUNCH_CHECK();
     return 0;
@@ -145,14 +209,15 @@ int64_t gemm_tn_part_elems(int M, int N, int K) {
     return (int64_t)p.nsplit * K * N;
 }
 
-template <int KT, int NTL>
-__global__ void __launch_bounds__(256) gemm_tn_kernel(View A, View D, float* __restrict__ part, int M, int N, int K,
-                                                      int rows_per) {
+template <int KT, int NTL, bool VEC>
+__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* __restrict__ part, int M, int N, int K,
+                                                         int rows_per) {
     constexpr int TK = 32 * KT, TNn = 32 * NTL;
     constexpr int NTILES = KT * NTL;
     constexpr int PER_WAVE = (NTILES + 3) / 4;
-    __shared__ float As[TN_BM][TK];
-    __shared__ float Ds[TN_BM][TNn];
+    constexpr int NA = (TN_BM * TK) / 256, ND = (TN_BM * TNn) / 256;     // 4*KT, 4*NTL elements per thread
+    __shared__ float As[2][TN_BM][TK];
+    __shared__ float Ds[2][TN_BM][TNn];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lcol = lane & 31, lk = lane >> 5;
@@ -165,23 +230,82 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(View A, View D, float* __r
     for (int j = 0; j < PER_WAVE; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    float ra[NA], rd[ND];
 
+    auto load_rows = [&](int64_t m0) {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NA / 2; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / (TK / 2), kk = (idx % (TK / 2)) * 2;
+                const int64_t m = m0 + r;
+                float2 v = make_float2(0.0f, 0.0f);
+                if (m < mend && (k0 + kk) < K) v = *reinterpret_cast<const float2*>(&A.p[m * A.ld + A.coff + k0 + kk]);
+                ra[2 * i] = v.x;
+                ra[2 * i + 1] = v.y;
+            }
+#pragma unroll
+            for (int i = 0; i < ND / 2; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / (TNn / 2), nn = (idx % (TNn / 2)) * 2;
+                const int64_t m = m0 + r;
+                float2 v = make_float2(0.0f, 0.0f);
+                if (m < mend && (n0 + nn) < N) v = *reinterpret_cast<const float2*>(&D.p[m * D.ld + D.coff + n0 + nn]);
+                rd[2 * i] = v.x;
+                rd[2 * i + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / TK, kk = idx % TK;
+                const int64_t m = m0 + r;
+                ra[i] = (m < mend && (k0 + kk) < K) ? A.p[m * A.ld + A.coff + k0 + kk] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / TNn, nn = idx % TNn;
+                const int64_t m = m0 + r;
+                rd[i] = (m < mend && (n0 + nn) < N) ? D.p[m * D.ld + D.coff + n0 + nn] : 0.0f;
+            }
+        }
+    };
+    auto store_rows = [&](int buf) {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NA / 2; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / (TK / 2), kk = (idx % (TK / 2)) * 2;
+                *reinterpret_cast<float2*>(&As[buf][r][kk]) = make_float2(ra[2 * i], ra[2 * i + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < ND / 2; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / (TNn / 2), nn = (idx % (TNn / 2)) * 2;
+                *reinterpret_cast<float2*>(&Ds[buf][r][nn]) = make_float2(rd[2 * i], rd[2 * i + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = tid + 256 * i;
+                As[buf][idx / TK][idx % TK] = ra[i];
+            }
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const int idx = tid + 256 * i;
+                Ds[buf][idx / TNn][idx % TNn] = rd[i];
+            }
+        }
+    };
+
+    load_rows(mbeg);
+    store_rows(0);
+    __syncthreads();
+    int buf = 0;
     for (int64_t m0 = mbeg; m0 < mend; m0 += TN_BM) {
-        for (int idx = tid; idx < TN_BM * TK; idx += 256) {
-            const int r = idx / TK, kk = idx % TK;
-            const int64_t m = m0 + r;
-            float v = 0.0f;
-            if (m < mend && (k0 + kk) < K) v = A.p[m * A.ld + A.coff + k0 + kk];
-            As[r][kk] = v;
-        }
-        for (int idx = tid; idx < TN_BM * TNn; idx += 256) {
-            const int r = idx / TNn, nn = idx % TNn;
-            const int64_t m = m0 + r;
-            float v = 0.0f;
-            if (m < mend && (n0 + nn) < N) v = D.p[m * D.ld + D.coff + n0 + nn];
-            Ds[r][nn] = v;
-        }
-        __syncthreads();
+        const bool more = (m0 + TN_BM) < mend;
+        if (more) load_rows(m0 + TN_BM);
 #pragma unroll
         for (int j = 0; j < PER_WAVE; ++j) {
             const int tile = wave + 4 * j;
@@ -189,13 +313,15 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(View A, View D, float* __r
                 const int ki = tile / NTL, nj = tile % NTL;
 #pragma unroll
                 for (int mm = 0; mm < TN_BM; mm += 2) {
-                    const float a = As[mm + lk][ki * 32 + lcol];
-                    const float b = Ds[mm + lk][nj * 32 + lcol];
+                    const float a = As[buf][mm + lk][ki * 32 + lcol];
+                    const float b = Ds[buf][mm + lk][nj * 32 + lcol];
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
                 }
             }
         }
+        if (more) store_rows(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
     float* out = part + (int64_t)blockIdx.x * K * N;
 #pragma unroll
@@ -217,46 +343,62 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(View A, View D, float* __r
 
 // 16 output lanes x 16 split lanes per block: the split partials are summed in parallel with
 // coalesced loads and combined in a fixed order (deterministic).
-__global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t n,
-                                                        float* __restrict__ out, int accumulate) {
-    __shared__ double sm[16][16];
+__global__ void __launch_bounds__(1024) tn_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t n,
+                                                         int64_t stride, float* __restrict__ out, int accumulate) {
+    __shared__ double sm[64][16];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int64_t i = (int64_t)blockIdx.x * 16 + tx;
     double s = 0.0;
     if (i < n)
-        for (int p = ty; p < nsplit; p += 16) s += (double)part[(int64_t)p * n + i];
+        for (int p = ty; p < nsplit; p += 64) s += (double)part[(int64_t)p * stride + i];
     sm[ty][tx] = s;
     __syncthreads();
     if (i < n && ty == 0) {
         s = 0.0;
 #pragma unroll
-        for (int y = 0; y < 16; ++y) s += sm[y][tx];
+        for (int y = 0; y < 64; ++y) s += sm[y][tx];
         out[i] = accumulate ? out[i] + (float)s : (float)s;
     }
 }
 
-template <int KT>
+template <int KT, bool VEC>
 static void launch_tn(int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp) {
     switch (ntl) {
-        case 1: hipLaunchKernelGGL((gemm_tn_kernel<KT, 1>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
-        case 2: hipLaunchKernelGGL((gemm_tn_kernel<KT, 2>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
-        case 3: hipLaunchKernelGGL((gemm_tn_kernel<KT, 3>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
-        default: hipLaunchKernelGGL((gemm_tn_kernel<KT, 4>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
+        case 1: hipLaunchKernelGGL((gemm_tn_kernel<KT, 1, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
+        case 2: hipLaunchKernelGGL((gemm_tn_kernel<KT, 2, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
+        case 3: hipLaunchKernelGGL((gemm_tn_kernel<KT, 3, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
+        default: hipLaunchKernelGGL((gemm_tn_kernel<KT, 4, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
+    }
+}
+
+template <bool VEC>
+static void launch_tn_k(int kt, int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp) {
+    switch (kt) {
+        case 1: launch_tn<1, VEC>(ntl, grid, st, A, D, part, M, N, K, rp); break;
+        case 2: launch_tn<2, VEC>(ntl, grid, st, A, D, part, M, N, K, rp); break;
+        case 3: launch_tn<3, VEC>(ntl, grid, st, A, D, part, M, N, K, rp); break;
+        default: launch_tn<4, VEC>(ntl, grid, st, A, D, part, M, N, K, rp); break;
     }
 }
 
 int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st) {
     TnPlan p = tn_plan(M, N, K);
     dim3 grid(p.nsplit, p.gy, p.gz);
-    switch (p.kt) {
-        case 1: launch_tn<1>(p.ntl, grid, st, A, D, part, M, N, K, p.rows_per); break;
-        case 2: launch_tn<2>(p.ntl, grid, st, A, D, part, M, N, K, p.rows_per); break;
-        case 3: launch_tn<3>(p.ntl, grid, st, A, D, part, M, N, K, p.rows_per); break;
-        default: launch_tn<4>(p.ntl, grid, st, A, D, part, M, N, K, p.rows_per); break;
-    }
+    auto even = [](const View& v) {
+        return (v.ld % 2 == 0) && (v.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 7) == 0);
+    };
+    // float2 path: every row start and every 32-wide tile start is 8-byte aligned
+    const bool vec = even(A) && even(D) && (K % 2 == 0) && (N % 2 == 0);
+    if (vec) launch_tn_k<true>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per);
+    else launch_tn_k<false>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per);
     CDRL_LAUNCH_CHECK();
     const int64_t n = (int64_t)K * N;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n, 16)), dim3(16, 16), 0, st, part, p.nsplit, n, Cout,
+    return reduce_partials_f32(part, p.nsplit, n, n, Cout, accumulate, st);
+}
+
+int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride, float* out, int accumulate,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n, 16)), dim3(16, 64), 0, st, part, nparts, n, stride, out,
                        accumulate);
     CDRL_LAUNCH_CHECK();
     return 0;
