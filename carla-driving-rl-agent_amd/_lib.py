@@ -68,6 +68,8 @@ PROTOTYPES = {
     'cdrl_learner_set_hparams': (_i, [_L, C.POINTER(HParams), _fp]),
     'cdrl_learner_reset_optimizer_steps': (_i, [_L, _fp]),
     'cdrl_learner_policy_forward_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
+    'cdrl_learner_policy_forward': (_i, [_L, _fp, _fp, _fp, _fp, _fp]),
+    'cdrl_learner_policy_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
     'cdrl_learner_policy_apply': (_i, [_L, _fp]),
     'cdrl_learner_value_forward_backward': (_i, [_L, C.POINTER(ValueBatch), _f, _fp]),
     'cdrl_learner_value_apply': (_i, [_L, _fp]),
@@ -76,6 +78,7 @@ PROTOTYPES = {
     'cdrl_learner_trunk_forward_train': (_i, [_L, _fp, _fp, _fp, _fp, _fp]),
     'cdrl_learner_get_buffer': (_i, [_L, _i, C.POINTER(_fp), C.POINTER(_i64)]),
     'cdrl_gae_returns': (_i, [_fp, _fp, _i, _d, _d, _f, _fp, _fp, _fp, _fp, _fp, _fp]),
+    'cdrl_gather_rows': (_i, [_fp, _fp, _fp, _i, _i64, _fp]),
     'cdrl_gemm_nn': (_i, [_fp, _i, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     'cdrl_gemm_tn_workspace_elems': (_i64, [_i, _i, _i]),
     'cdrl_gemm_tn': (_i, [_fp, _i, _i, _fp, _i, _i, _fp, _i, _i, _i, _fp, _i, _fp]),

@@ -1,0 +1,222 @@
+"""CARLAgent / CARLAMemory / FakeCARLAEnvironment on the native learner.
+
+Surface follows the reference core/carla_agent.py: constructor keywords (:70-72), class-level
+DEFAULT_* architectures (:61-68), update() guard (:129-145), policy / value batch tensors
+(:323-349), get_*_gradients / apply_*_gradients (:351-388, :430-463), CARLAMemory (:586-596) and
+the FakeCARLAEnvironment entry point (:26-52).  evaluate() / record() drive a CARLA simulator and
+are outside the learner hot path: they raise instead of pretending.
+"""
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from ..rl import utils, spaces
+from ..rl.agents.ppo import PPOAgent, PPOMemory
+from ..rl.parameters import DynamicParameter
+from .networks import CARLANetwork, relu6
+
+
+class FakeCARLAEnvironment(spaces.Env):
+    """Environment with the state / action spaces of a CARLA environment and no simulator.
+
+    Defaults reproduce the reference's class (three-camera image (90, 360, 3) in [-1, 1], road 9,
+    vehicle 5, past_control 4, command 6, navigation 10, action Box(-1, 1, (3,)), time_horizon 1).
+    Superset for running the learner without CARLA: every size is overridable, step() / reset()
+    return seeded synthetic observations stacked over `time_horizon`, and `info_buffer` /
+    `reset_info()` exist as CARLAgent.update() expects from the real CARLAEnv."""
+
+    def __init__(self, image_shape=(90, 360, 3), time_horizon=1, num_waypoints=10, vehicle_features=5, road_features=9,
+                 num_actions=3, image_range=(-1.0, 1.0), episode_length=None, seed=0):
+        super().__init__()
+        self.num_waypoints = num_waypoints
+        self.NAVIGATION_FEATURES = dict(space=spaces.Box(low=0.0, high=25.0, shape=(num_waypoints,)),
+                                        default=np.zeros(shape=num_waypoints, dtype=np.float32))
+        self.time_horizon = time_horizon
+        self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(num_actions,))
+        self.observation_space = spaces.Dict(
+            road=spaces.Box(low=0.0, high=15.0, shape=(road_features,)),
+            vehicle=spaces.Box(low=-np.inf, high=np.inf, shape=(vehicle_features,)),
+            past_control=spaces.Box(low=-1.0, high=1.0, shape=(4,)), command=spaces.Box(low=0.0, high=1.0, shape=(6,)),
+            image=spaces.Box(low=image_range[0], high=image_range[1], shape=tuple(image_shape)),
+            navigation=self.NAVIGATION_FEATURES['space'])
+        self.image_range = image_range
+        self.episode_length = episode_length
+        self.info_buffer = dict(speed=[], similarity=[])
+        self._rng = np.random.default_rng(seed)
+        self._t = 0
+
+    def seed(self, seed=None):
+        self._rng = np.random.default_rng(seed)
+
+    def reset_info(self):
+        self.info_buffer = dict(speed=[], similarity=[])
+
+    def _observation(self):
+        T, sp = self.time_horizon, self.observation_space.spaces
+        lo, hi = self.image_range
+        obs = dict(image=self._rng.uniform(lo, hi, size=(T,) + sp['image'].shape).astype(np.float32),
+                   road=self._rng.integers(0, 2, size=(T,) + sp['road'].shape).astype(np.float32),
+                   vehicle=self._rng.uniform(0.0, 1.0, size=(T,) + sp['vehicle'].shape).astype(np.float32),
+                   navigation=np.sort(self._rng.uniform(0.0, 25.0, size=(T,) + sp['navigation'].shape), axis=-1).astype(np.float32),
+                   past_control=np.zeros((T, 4), np.float32), command=np.zeros((T, 6), np.float32))
+        return obs
+
+    def reset(self):
+        self._t = 0
+        return self._observation()
+
+    def step(self, action):
+        self._t += 1
+        speed = float(self._rng.uniform(0.0, 30.0))
+        similarity = float(self._rng.uniform(-1.0, 1.0))
+        self.info_buffer['speed'].append(speed)
+        self.info_buffer['similarity'].append(similarity)
+        done = self.episode_length is not None and self._t >= self.episode_length
+        return self._observation(), speed / 3.0 * abs(similarity), done, {}
+
+    def render(self, mode='human'):
+        pass
+
+
+class CARLAgent(PPOAgent):
+    DEFAULT_CONTROL = dict(units=320, num_layers=2, activation=utils.swish6)
+    DEFAULT_CONTROL_VALUE = dict(units=320, num_layers=2, activation=utils.swish6)
+    DEFAULT_DYNAMICS = dict(road=dict(units=16, num_layers=2, activation=relu6),
+                            vehicle=dict(units=16, num_layers=2, activation=relu6),
+                            navigation=dict(units=16, num_layers=2, activation=relu6),
+                            shufflenet=dict(g=1.0, last_channels=768),
+                            rnn=dict(image=256, road=32, vehicle=32, navigation=32),
+                            dynamics=dict(units=512))
+
+    def __init__(self, *args, aug_intensity=1.0, clip_norm=(1.0, 1.0, 1.0), name='carla', load_full=True, eta=0.0,
+                 dynamics_lr=1e-3, update_dynamics=True, delta=0.0, aux=1.0, resample_actions=False, **kwargs):
+        """`resample_actions=True` evaluates the policy loss on a fresh Beta sample of the NEW policy
+        with pathwise gradients, as the reference's PolicyNetwork.call does; the default
+        uses the stored rollout actions (deterministic, same cost)."""
+        assert aug_intensity >= 0.0
+        if not update_dynamics:
+            raise NotImplementedError('update_dynamics=False (frozen trunk) is not implemented natively')
+        network_spec = dict(kwargs.pop('network', {}))
+        network_spec.setdefault('network', CARLANetwork)
+        network_spec.setdefault('control_policy', self.DEFAULT_CONTROL)
+        network_spec.setdefault('control_value', self.DEFAULT_CONTROL_VALUE)
+        network_spec.setdefault('dynamics', self.DEFAULT_DYNAMICS)
+        self.should_update_dynamics = update_dynamics
+        self.dynamics_path = os.path.join(kwargs.get('weights_dir', 'weights'), name, 'dynamics_model')
+        self.load_full = load_full
+        head_clip = clip_norm if isinstance(clip_norm, float) or clip_norm is None else tuple(clip_norm[:2])
+        super().__init__(*args, name=name, network=network_spec, clip_norm=head_clip, **kwargs)
+        self.network: CARLANetwork = self.network
+        self.aug_intensity = aug_intensity
+        self.delta, self.eta, self.aux = delta, eta, aux                  # stored, unused (as in the reference)
+        self.resample_actions = resample_actions
+        # the reference computes should_clip_dynamics_grads but never reads it: trunk grads are unclipped (F9)
+        self.should_clip_dynamics_grads = isinstance(clip_norm, float) or (clip_norm is not None and len(clip_norm) > 2
+                                                                          and isinstance(clip_norm[2], float))
+        self.dynamics_lr = DynamicParameter.create(value=dynamics_lr)
+        self.dynamics_lr.load(config=self.config.get('dynamics_lr', {}))
+        if aug_intensity > 0.0:
+            warnings.warn('rollout-time image augmentation (aug_intensity > 0) is not implemented natively yet; '
+                          'observations are stored un-augmented (SURVEY.md §8(f) item 3)')
+
+    def hyper_parameters(self) -> dict:
+        hp = super().hyper_parameters()
+        hp['dynamics_lr'] = self.dynamics_lr()
+        return hp
+
+    # -- update -----------------------------------------------------------------------------------
+    def update(self):
+        if len(self.memory) < self.batch_size:
+            print('[Not updated] memory too small!')
+            self.env.reset_info()
+            return
+        super().update()
+        self.env.reset_info()
+
+    def _info(self, n):
+        speed = torch.as_tensor(np.asarray(self.env.info_buffer['speed'], dtype=np.float32), device=self.device) / 100.0
+        sim = torch.as_tensor(np.asarray(self.env.info_buffer['similarity'], dtype=np.float32), device=self.device)
+        if speed.shape[0] >= n:
+            return speed[:n].contiguous(), sim[:n].contiguous()
+        pad = torch.zeros(n - speed.shape[0], device=self.device)
+        return torch.cat([speed, pad]), torch.cat([sim, pad])
+
+    def policy_batch_tensors(self):
+        states, advantages, actions, log_probabilities = super().policy_batch_tensors()
+        speed, similarity = self._info(advantages.shape[0])
+        return states, advantages, actions, log_probabilities, speed, similarity
+
+    def value_batch_tensors(self):
+        states, returns = super().value_batch_tensors()
+        speed, similarity = self._info(returns.shape[0])
+        return states, returns, speed, similarity
+
+    def get_policy_gradients(self, batch):
+        states, advantages, actions, log_probabilities, speed, similarity = batch
+        eng = self.network.engine
+        b = dict(states=states, advantages=advantages, old_log_prob=log_probabilities, speed=speed, similarity=similarity,
+                 u=actions, du_da=None, du_db=None)
+        if self.resample_actions:
+            alpha, beta = eng.policy_forward(states)
+            a = alpha.detach().clone().requires_grad_(True)
+            bt = beta.detach().clone().requires_grad_(True)
+            u = torch.distributions.Beta(a, bt).rsample()              # pathwise (reparameterised) sample
+            du_da, du_db = torch.autograd.grad(u.sum(), [a, bt])
+            b.update(u=u.detach().contiguous(), du_da=du_da.contiguous(), du_db=du_db.contiguous())
+            eng.policy_backward(b)
+        else:
+            eng.policy_forward_backward(b)
+        return eng.buffer(2)[0], 'policy'         # device scalar (CDRL_BUF_METRICS_P[0]); gradients stay in the arena
+
+    def apply_policy_gradients(self, gradients):
+        self.network.engine.policy_apply()        # trunk Adam -> clip -> old_policy <- policy -> policy Adam
+        return gradients
+
+    def get_value_gradients(self, batch):
+        states, returns, speed, similarity = batch
+        eng = self.network.engine
+        eng.value_forward_backward(dict(states=states, returns=returns, speed=speed, similarity=similarity))
+        return eng.buffer(3)[0], 'value'
+
+    def apply_value_gradients(self, gradients):
+        self.network.engine.value_apply()
+        return gradients
+
+    # -- rollout helpers ------------------------------------------------------------------------------
+    def get_memory(self):
+        return CARLAMemory(state_spec=self.state_spec, num_actions=self.num_actions, time_horizon=self.env.time_horizon,
+                           device=self.device)
+
+    def preprocess(self):
+        """Stacks a list of T per-step observation dicts (real CARLAEnv) or passes a dict of (T, ...)
+        arrays through, prefixing keys with 'state_' when needed."""
+        def fn(state):
+            if isinstance(state, (list, tuple)):
+                keys = state[0].keys()
+                state = {k: np.stack([np.asarray(s[k], dtype=np.float32) for s in state], axis=0) for k in keys}
+            return {(k if k.startswith('state_') else f'state_{k}'): v for k, v in state.items()}
+        return fn
+
+    def evaluate(self, *args, **kwargs):
+        raise NotImplementedError('CARLAgent.evaluate drives a CARLA simulator (collision / waypoint metrics); '
+                                  'it is outside the learner hot path this package implements')
+
+    def record(self, *args, **kwargs):
+        raise NotImplementedError('CARLAgent.record drives a CARLA simulator; outside the learner hot path')
+
+    def load_weights(self):
+        self.network.load_weights(full=self.load_full)
+
+    def save_config(self):
+        self.update_config(dynamics_lr=self.dynamics_lr.serialize())
+        super().save_config()
+
+
+class CARLAMemory(PPOMemory):
+    """PPOMemory whose state rows carry the `time_horizon` axis: (N, T, ...)."""
+
+    def __init__(self, state_spec: dict, num_actions: int, time_horizon: int, device='cuda:0'):
+        super().__init__(state_spec, num_actions, device=device)
+        self.time_horizon = time_horizon

@@ -174,6 +174,24 @@ int cdrl_learner_policy_forward_backward(cdrl_learner* l, const cdrl_policy_batc
     return l->impl->policy_forward_backward(pb, grad_scale, S(stream));
 }
 
+int cdrl_learner_policy_forward(cdrl_learner* l, const float* image, const float* road, const float* vehicle,
+                                const float* navigation, void* stream) {
+    CHECK_L(l);
+    return l->impl->policy_forward(image, road, vehicle, navigation, S(stream));
+}
+
+int cdrl_learner_policy_backward(cdrl_learner* l, const cdrl_policy_batch* b, float grad_scale, void* stream) {
+    CHECK_L(l);
+    if (!b) return -1;
+    PolicyBatch pb{b->image, b->road, b->vehicle, b->navigation, b->advantages, b->old_log_prob,
+                   b->speed, b->similarity, b->u, b->du_dalpha, b->du_dbeta};
+    if (!pb.adv || !pb.old_logp || !pb.speed || !pb.similarity || !pb.u) {
+        cdrl::set_error("policy batch: null tensor");
+        return -1;
+    }
+    return l->impl->policy_backward(pb, grad_scale, S(stream));
+}
+
 int cdrl_learner_policy_apply(cdrl_learner* l, void* stream) {
     CHECK_L(l);
     return l->impl->policy_apply(S(stream));
@@ -238,6 +256,14 @@ int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double
         return -1;
     }
     return gae_returns(rewards, values_be, N, gamma, lambda, scale, returns, returns_be, adv_raw, adv, scratch, S(stream));
+}
+
+int cdrl_gather_rows(const float* src, const int32_t* idx, float* dst, int nrows, int64_t row_elems, void* stream) {
+    if (!src || !idx || !dst) {
+        cdrl::set_error("cdrl_gather_rows: null argument");
+        return -1;
+    }
+    return gather_rows(src, idx, dst, nrows, row_elems, S(stream));
 }
 
 int cdrl_gemm_nn(const float* A, int lda, int a_coff, const float* B, int sbk, int sbn, const float* bias, float* C,

@@ -41,6 +41,8 @@ int fill(float* p, int64_t n, float v, hipStream_t st);
 // (B,T,D) -> (T*B, D)
 int permute_bt(const float* src, float* dst, int B, int T, int D, hipStream_t st);
 int permute_tb_bwd(const float* src, float* dst, int B, int T, int D, hipStream_t st);
+// dst[i,:] = src[idx[i],:]
+int gather_rows(const float* src, const int* idx, float* dst, int nrows, int64_t row_elems, hipStream_t st);
 
 // ---------------------------------------------------------------- GEMM (gemm.hip)
 // C[M,N] (view) (+)= A[M,K] (view) * B(k,n) + bias[n];  B(k,n) = Bp[k*sbk + n*sbn].

@@ -81,6 +81,10 @@ public:
     int reset_counters(hipStream_t st);
 
     int policy_forward_backward(const PolicyBatch& b, float inv_world, hipStream_t st);
+    // split form for the re-sampling loss (F8): forward -> (host samples u from alpha, beta) -> backward
+    int policy_forward(const float* image, const float* road, const float* vehicle, const float* navigation,
+                       hipStream_t st);
+    int policy_backward(const PolicyBatch& b, float inv_world, hipStream_t st);
     int policy_apply(hipStream_t st);
     int value_forward_backward(const ValueBatch& b, float inv_world, hipStream_t st);
     int value_apply(hipStream_t st);

@@ -601,10 +601,16 @@ int Learner::trunk_forward_train(const float* image, const float* road, const fl
     return run_fwd(trunk_ops_, st, 1);
 }
 
-int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipStream_t st) {
-    CDRL_TRY(set_inputs(b.image, b.road, b.vehicle, b.navigation));
+int Learner::policy_forward(const float* image, const float* road, const float* vehicle, const float* navigation,
+                            hipStream_t st) {
+    CDRL_TRY(set_inputs(image, road, vehicle, navigation));
     CDRL_TRY(run_fwd(trunk_ops_, st, 1));
     CDRL_TRY(run_fwd(policy_ops_, st, 1));
+    // alpha, beta (+ mean, std) of the CURRENT policy for the host-side Beta re-sampling
+    return policy_dist(lin_p_.p, aux_p_, cfg_.B, cfg_.A, st);
+}
+
+int Learner::policy_backward(const PolicyBatch& b, float inv_world, hipStream_t st) {
     PolicyLossArgs a;
     a.lin = lin_p_.p;
     a.adv = b.adv;
@@ -624,6 +630,13 @@ int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipS
     CDRL_TRY(policy_loss(a, st));
     CDRL_TRY(run_bwd(policy_ops_, st));
     return run_bwd(trunk_ops_, st);
+}
+
+int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipStream_t st) {
+    CDRL_TRY(set_inputs(b.image, b.road, b.vehicle, b.navigation));
+    CDRL_TRY(run_fwd(trunk_ops_, st, 1));
+    CDRL_TRY(run_fwd(policy_ops_, st, 1));
+    return policy_backward(b, inv_world, st);
 }
 
 int Learner::value_forward_backward(const ValueBatch& b, float inv_world, hipStream_t st) {

@@ -188,6 +188,38 @@ class LearnerEngine:
         _lib.check(self.lib.cdrl_learner_policy_forward_backward(self.h, C.byref(pb), float(grad_scale), self._stream()),
                    'policy_forward_backward')
 
+    def _policy_batch(self, batch, with_states=True):
+        c = self.cfg
+        img, road, veh, nav = self._states(batch)
+        if with_states:
+            self._check_states(img, road, veh, nav)
+        self._chk(batch['advantages'], (c.B,), 'advantages')
+        self._chk(batch['old_log_prob'], (c.B, c.A), 'old_log_prob')
+        self._chk(batch['u'], (c.B, c.A), 'u')
+        for k in ('du_da', 'du_db'):
+            if batch.get(k) is not None:
+                self._chk(batch[k], (c.B, c.A), k)
+        return _lib.PolicyBatch(image=img.data_ptr(), road=road.data_ptr(), vehicle=veh.data_ptr(),
+                                navigation=nav.data_ptr(), advantages=batch['advantages'].data_ptr(),
+                                old_log_prob=batch['old_log_prob'].data_ptr(), speed=batch['speed'].data_ptr(),
+                                similarity=batch['similarity'].data_ptr(), u=batch['u'].data_ptr(),
+                                du_dalpha=batch['du_da'].data_ptr() if batch.get('du_da') is not None else None,
+                                du_dbeta=batch['du_db'].data_ptr() if batch.get('du_db') is not None else None)
+
+    def policy_forward(self, states):
+        """train-mode forward of trunk + policy head; returns (alpha, beta) views (B, A) of the current policy."""
+        img, road, veh, nav = self._states(states)
+        self._check_states(img, road, veh, nav)
+        _lib.check(self.lib.cdrl_learner_policy_forward(self.h, _lib.ptr(img), _lib.ptr(road), _lib.ptr(veh),
+                                                        _lib.ptr(nav), self._stream()), 'policy_forward')
+        aux = self.buffer(_lib.BUF_AUX_P, (self.cfg.B, 4, self.cfg.A))
+        return aux[:, 0], aux[:, 1]
+
+    def policy_backward(self, batch, grad_scale=1.0):
+        pb = self._policy_batch(batch)
+        _lib.check(self.lib.cdrl_learner_policy_backward(self.h, C.byref(pb), float(grad_scale), self._stream()),
+                   'policy_backward')
+
     def policy_apply(self):
         _lib.check(self.lib.cdrl_learner_policy_apply(self.h, self._stream()), 'policy_apply')
 

@@ -109,6 +109,13 @@ int cdrl_learner_reset_optimizer_steps(cdrl_learner* l, void* stream);
  * policy_objective (:394-428), gradients w.r.t. policy and trunk variables.  grad_scale = 1 /
  * world_size for data-parallel averaging. */
 int cdrl_learner_policy_forward_backward(cdrl_learner* l, const cdrl_policy_batch* b, float grad_scale, void* stream);
+/* The same step split at the Beta sample: PolicyNetwork.call re-samples an action
+ * from the NEW Beta(alpha, beta) (core/networks.py:96-110).  policy_forward runs the train-mode
+ * forward and leaves (alpha, beta, mean, std) in CDRL_BUF_AUX_P; the caller draws u and its
+ * pathwise Jacobians; policy_backward evaluates the loss on them and back-propagates. */
+int cdrl_learner_policy_forward(cdrl_learner* l, const float* image, const float* road, const float* vehicle,
+                                const float* navigation, void* stream);
+int cdrl_learner_policy_backward(cdrl_learner* l, const cdrl_policy_batch* b, float grad_scale, void* stream);
 /* CARLAgent.apply_policy_gradients (core/carla_agent.py:375-388) + PPOAgent.apply_policy_gradients
  * (rl/agents/ppo.py:238-252): trunk Adam, per-tensor clip, old_policy <- policy, policy Adam. */
 int cdrl_learner_policy_apply(cdrl_learner* l, void* stream);
@@ -145,6 +152,10 @@ int cdrl_learner_get_buffer(const cdrl_learner* l, int which, float** ptr, int64
  * (rl/agents/ppo.py:692-697).  scratch: >= 2*(N+1)+2 doubles. */
 int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double gamma, double lambda, float scale,
                      float* returns, float* returns_be, float* adv_raw, float* adv, double* scratch, void* stream);
+
+/* Minibatch assembly: utils.data_to_batches' tf.data gather of the shuffled rollout rows
+ * (rl/utils.py:365-393); dst[i, :] = src[idx[i], :], idx = int32 device array of row numbers. */
+int cdrl_gather_rows(const float* src, const int32_t* idx, float* dst, int nrows, int64_t row_elems, void* stream);
 
 /* ---- op-level entry points (Keras layer call -> one launch; used by the parity tests) -------- */
 /* Conv2D(k=1) / Dense forward: C[M,N] (+)= A[M,K] B[K,N] + bias (core/architectures.py:130,134,140,170) */

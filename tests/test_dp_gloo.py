@@ -1,0 +1,131 @@
+"""Data-parallel path on CPU: world_size-2 gloo processes drive the product's DataParallelLearner
+(slices, all-reduce, step order) over an oracle-backed stand-in for the GPU engine; the result must
+equal ONE oracle learner fed the average of the two shards' gradients."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H, W, B = 48, 64, 4
+
+
+class OracleBackedEngine:
+    """Implements the engine surface DataParallelLearner touches (region / grads / params /
+    *_forward_backward / *_apply) with the CPU oracle, using the real engine's arena layout."""
+
+    def __init__(self, seed):
+        from oracle import model as OM
+        from oracle.spec import NetConfig, trunk_spec, policy_spec, value_spec
+        from carla_driving_rl_agent_amd import synthetic
+        from carla_driving_rl_agent_amd.engine import LearnerEngine
+        self.layout = LearnerEngine(B, device=None, H=H, W=W)          # host-only: parameter tables + offsets
+        cfg = NetConfig(H=H, W=W)
+        self.oracle = OM.OracleLearner(cfg, OM.init_params(trunk_spec(cfg), seed + 1), OM.init_params(policy_spec(cfg), seed + 2),
+                                       OM.init_params(value_spec(cfg), seed + 3), synthetic.DEFAULT_HP)
+        self.params_total = self.layout.params_total
+        self.grads = torch.zeros(self.layout.grads_total)
+        self.params = torch.zeros(self.layout.params_total)
+        self.adam_m = torch.zeros(self.layout.grads_total)
+        self.adam_v = torch.zeros(self.layout.grads_total)
+        self._pending = None
+
+    def region(self, model, trainable):
+        return self.layout.region(model, trainable)
+
+    def _scatter(self, model, grads, scale):
+        off, _ = self.region(model, True)
+        for e in self.layout.tables[model].entries:
+            if e['trainable']:
+                self.grads[off + e['offset']: off + e['offset'] + e['numel']] = grads[e['name']].detach().reshape(-1) * scale
+
+    def _gather(self, model):
+        off, _ = self.region(model, True)
+        return {e['name']: self.grads[off + e['offset']: off + e['offset'] + e['numel']].view(e['shape']).clone()
+                for e in self.layout.tables[model].entries if e['trainable']}
+
+    def policy_forward_backward(self, batch, grad_scale=1.0):
+        loss, gp, gt, aux = self.oracle.policy_grads(batch)
+        self._scatter('policy', gp, grad_scale)
+        self._scatter('trunk', gt, grad_scale)
+        self._pending = (loss, aux)
+
+    def policy_apply(self):
+        loss, aux = self._pending
+        self.oracle.policy_step(None, grads=(loss, self._gather('policy'), self._gather('trunk'), aux))
+
+    def value_forward_backward(self, batch, grad_scale=1.0):
+        loss, gv, gt, aux = self.oracle.value_grads(batch)
+        self._scatter('value', gv, grad_scale)
+        self._scatter('trunk', gt, grad_scale)
+        self._pending = (loss, aux)
+
+    def value_apply(self):
+        loss, aux = self._pending
+        self.oracle.value_step(None, grads=(loss, self._gather('value'), self._gather('trunk'), aux))
+
+
+def _batches(rank):
+    from tests.util import make_batches, oracle_batch
+    pol, val = make_batches(B, H, W, seed=50 + rank)
+    return oracle_batch(pol), oracle_batch(val)
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from carla_driving_rl_agent_amd.parallel import DataParallelLearner
+    eng = OracleBackedEngine(seed=7)
+    dp = DataParallelLearner(eng, sync_bn_stats=False)
+    assert dp.world == world
+    pol, val = _batches(rank)
+    dp.policy_step(pol)
+    torch.save(eng.grads.clone(), os.path.join(out, f'grads_after_policy{rank}.pt'))     # all-reduced arena
+    dp.value_step(val)
+    torch.save({k: v.detach().clone() for k, v in eng.oracle.trunk.items() if 'moving' not in k}, os.path.join(out, f'trunk{rank}.pt'))
+    torch.save({k: v.detach().clone() for k, v in eng.oracle.policy.items() if 'moving' not in k}, os.path.join(out, f'policy{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_equals_averaged_gradients(tmp_path):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    t0, t1 = torch.load(tmp_path / 'trunk0.pt'), torch.load(tmp_path / 'trunk1.pt')
+    p0, p1 = torch.load(tmp_path / 'policy0.pt'), torch.load(tmp_path / 'policy1.pt')
+    for k in t0:       # replicas stay identical: same averaged gradients, same Adam update on every rank
+        assert torch.equal(t0[k], t1[k]), k
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    # reference semantics: one learner, gradients averaged over the two env shards.  Compared on the
+    # all-reduced GRADIENT arena (linear in the shard gradients -> exact to rounding); comparing weights
+    # after Adam would only measure sign flips of noise-level gradients.
+    sys.path.insert(0, ROOT)
+    g0 = torch.load(tmp_path / 'grads_after_policy0.pt')
+    g1 = torch.load(tmp_path / 'grads_after_policy1.pt')
+    assert torch.equal(g0, g1)
+    lay = OracleBackedEngine(seed=7)
+    shards = [OracleBackedEngine(seed=7).oracle for _ in range(2)]
+    grads = [sh.policy_grads(_batches(r)[0]) for r, sh in enumerate(shards)]
+    for model, idx in (('policy', 1), ('trunk', 2)):
+        off, _ = lay.region(model, True)
+        gmax = max(float(v.abs().max()) for v in grads[0][idx].values())
+        for e in lay.layout.tables[model].entries:
+            if not e['trainable']:
+                continue
+            avg = (grads[0][idx][e['name']] + grads[1][idx][e['name']]).detach() * 0.5
+            got = g0[off + e['offset']: off + e['offset'] + e['numel']].view(e['shape'])
+            assert float((got - avg).abs().max()) <= 1e-5 * gmax, (model, e['name'])   # oracle run-to-run thread noise ~1e-6
+    # the value-head region was not part of the policy all-reduce slice and must be untouched (zeros)
+    voff, vn = lay.region('value', True)
+    assert float(g0[voff:voff + vn].abs().max()) == 0.0

@@ -1,0 +1,58 @@
+"""CARLAgent on FakeCARLAEnvironment: the reference's README entry point and a full
+learn() -> rollout -> GAE -> minibatch update cycle, all through the HIP library."""
+import numpy as np
+import pytest
+import torch
+
+from carla_driving_rl_agent_amd.core import CARLAgent, FakeCARLAEnvironment
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(**kw):
+    cfg = dict(image_shape=(48, 64, 3), time_horizon=4, num_waypoints=5, vehicle_features=4, num_actions=2)
+    cfg.update(kw)
+    return FakeCARLAEnvironment(**cfg)
+
+
+def test_readme_summary_snippet(capsys):
+    # README.md:58-61 of the reference: CARLAgent(FakeCARLAEnvironment(), batch_size=1, log_mode=None).summary()
+    agent = CARLAgent(FakeCARLAEnvironment(image_shape=(90, 120, 3)), batch_size=1, log_mode=None)
+    agent.summary()
+    out = capsys.readouterr().out
+    assert 'Policy Network' in out and 'Value Network' in out and 'Dynamics Model' in out
+    assert 'Total params: 2,' in out      # trunk ~2.1 M parameters
+
+
+@pytest.mark.parametrize('resample', [False, True])
+def test_learn_cycle(tmp_path, resample):
+    env = _env()
+    agent = CARLAgent(env, batch_size=8, log_mode=None, seed=3, skip_data=1, drop_batch_remainder=True, shuffle=True,
+                      policy_lr=3e-4, value_lr=3e-4, dynamics_lr=3e-4, gamma=0.9999, lambda_=0.999, clip_ratio=0.2,
+                      entropy_regularization=1.0, aug_intensity=0.0, weights_dir=str(tmp_path), name='t',
+                      resample_actions=resample, optimization_steps=(1, 1))
+    before = agent.network.engine.params.clone()
+    agent.learn(episodes=1, timesteps=17, save_every='end', close=False)
+    after = agent.network.engine.params
+    assert torch.isfinite(after).all()
+    assert not torch.equal(before, after)
+    m = agent.network.engine.metrics('policy')
+    assert np.isfinite(m['loss'])
+    assert float(agent.network.engine.adam_v.abs().sum()) > 0
+    # checkpoint round trip (three files + config.json, optimizer state not saved)
+    saved = agent.network.get_weights()
+    agent2 = CARLAgent(_env(), batch_size=8, log_mode=None, seed=9, weights_dir=str(tmp_path), name='t', load=True,
+                       aug_intensity=0.0)
+    for model, w in agent2.network.get_weights().items():
+        for k, v in w.items():
+            assert np.array_equal(v, saved[model][k]), (model, k)
+    # old_policy == policy after load (reference core/networks.py:305)
+    eng = agent2.network.engine
+    assert torch.equal(eng.param_views('old_policy')['pi.fc0.w'], eng.param_views('policy')['pi.fc0.w'])
+
+
+def test_update_guard_small_memory(capsys):
+    agent = CARLAgent(_env(), batch_size=32, log_mode=None, aug_intensity=0.0)
+    agent.learn(episodes=1, timesteps=5, close=False)       # 5 < 32: update() must refuse and reset the info buffer
+    assert '[Not updated] memory too small!' in capsys.readouterr().out
+    assert agent.env.info_buffer == dict(speed=[], similarity=[])
