@@ -15,30 +15,40 @@ namespace cdrl {
 
 #define BN_EPS 1e-3f
 
+template <int VEC>
 struct StatsF {
     View y;
-    __device__ void operator()(int, int64_t row, int c, double* acc) const {
-        double v = (double)y.p[row * y.ld + y.coff + c];
-        acc[0] += v;
-        acc[1] += v * v;
+    bool al;
+    __device__ void operator()(int, int64_t row, int c0, double (*acc)[VEC]) const {
+        const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const double d = (double)v.v[i];
+            acc[0][i] += d;
+            acc[1][i] += d * d;
+        }
     }
 };
 
 int colstats(View y, int G, int Mg, int C, double* part, hipStream_t st) {
-    StatsF f{y};
-    return launch_colreduce<2>(f, G, Mg, C, part, st);
+    const bool al = view_aligned(y, vcol_geom(Mg, C).vec);
+    return launch_vcolreduce<2, StatsF>(G, Mg, C, part, st, NB_STATS, y, al);
 }
 
+template <int VEC>
 struct SumF {
     View x;
-    __device__ void operator()(int, int64_t row, int c, double* acc) const {
-        acc[0] += (double)x.p[row * x.ld + x.coff + c];
+    bool al;
+    __device__ void operator()(int, int64_t row, int c0, double (*acc)[VEC]) const {
+        const VecF<VEC> v = vload_view<VEC>(x, row, c0, 0, al);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[0][i] += (double)v.v[i];
     }
 };
 
 int colsum(View x, int rows, int C, double* part, hipStream_t st) {
-    SumF f{x};
-    return launch_colreduce<1>(f, 1, rows, C, part, st);
+    const bool al = view_aligned(x, vcol_geom(rows, C).vec);
+    return launch_vcolreduce<1, SumF>(1, rows, C, part, st, NB_STATS, x, al);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -138,35 +148,49 @@ __device__ __forceinline__ float apply_act(float z, int act) {
     return z;
 }
 
-__global__ void __launch_bounds__(256) bn_apply_kernel(View y, int Mg, int C, int rb, int GC,
+template <int VEC>
+__global__ void __launch_bounds__(256) bn_apply_kernel(View y, int Mg, int C, int rb, int nloop, int GC,
                                                        const float* __restrict__ stats, int act, View dst,
-                                                       int shuffle_ctot) {
+                                                       int shuffle_ctot, bool al_in, bool al_out) {
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int CX = blockDim.x, CY = blockDim.y;
     const int g = blockIdx.y;
     const int r0 = blockIdx.x * rb;
     const int r1 = min(r0 + rb, Mg);
-    for (int c = tx; c < C; c += CX) {
-        float sc = 1.0f, sh = 0.0f;
-        if (stats) {
-            sc = stats[2 * GC + g * C + c];
-            sh = stats[3 * GC + g * C + c];
+    for (int l = 0; l < nloop; ++l) {
+        const int c0 = (l * CX + tx) * VEC;
+        if (c0 >= C) continue;
+        VecF<VEC> sc, sh;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            sc.v[i] = 1.0f;
+            sh.v[i] = 0.0f;
         }
-        int dc = dst.coff + c;
-        if (shuffle_ctot) dc = shuffle_dst(dc, shuffle_ctot);
+        if (stats) {
+            sc = vload<VEC>(stats + 2 * GC + g * C + c0);
+            sh = vload<VEC>(stats + 3 * GC + g * C + c0);
+        }
         for (int r = r0 + ty; r < r1; r += CY) {
             const int64_t row = (int64_t)g * Mg + r;
-            const float v = y.p[row * y.ld + y.coff + c];
-            dst.p[row * dst.ld + dc] = apply_act(fmaf(sc, v, sh), act);
+            VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_in);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v.v[i] = apply_act(fmaf(sc.v[i], v.v[i], sh.v[i]), act);
+            vstore_view<VEC>(dst, row, c0, shuffle_ctot, al_out, v);
         }
     }
 }
 
 int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
              hipStream_t st) {
-    ColGeom g = col_geom(Mg, C, 1024);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(g.nb, G), dim3(g.cx, g.cy), 0, st, y, Mg, C, g.rb, G * C, stats, act,
-                       dst, shuffle_ctot);
+    VColGeom g = vcol_geom(Mg, C, 2048);
+    const bool ai = view_aligned(y, g.vec), ao = view_aligned(dst, g.vec);
+    dim3 grid(g.nb, G), block(g.cx, g.cy);
+    if (g.vec == 4)
+        hipLaunchKernelGGL(bn_apply_kernel<4>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao);
+    else if (g.vec == 2)
+        hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -174,32 +198,40 @@ int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
+template <int VEC>
 struct BnBwdReduceF {
     View da;
     int shuffle_ctot;
     View y;
     const float* stats;
     int GC, C, act;
-    __device__ void operator()(int g, int64_t row, int c, double* acc) const {
-        int dc = da.coff + c;
-        if (shuffle_ctot) dc = shuffle_dst(dc, shuffle_ctot);
-        float d = da.p[row * da.ld + dc];
-        const float v = y.p[row * y.ld + y.coff + c];
-        const float mean = stats[0 * GC + g * C + c], invstd = stats[1 * GC + g * C + c];
+    bool al_da, al_y;
+    __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
+        VecF<VEC> d = vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
+        const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_y);
+        const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
         if (act == ACT_RELU6) {
-            const float z = fmaf(stats[2 * GC + g * C + c], v, stats[3 * GC + g * C + c]);
-            if (!(z > 0.0f && z < 6.0f)) d = 0.0f;
+            const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float z = fmaf(sc.v[i], v.v[i], sh.v[i]);
+                if (!(z > 0.0f && z < 6.0f)) d.v[i] = 0.0f;
+            }
         }
-        const float xh = (v - mean) * invstd;
-        acc[0] += (double)d;
-        acc[1] += (double)d * (double)xh;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float xh = (v.v[i] - mean.v[i]) * invstd.v[i];
+            acc[0][i] += (double)d.v[i];
+            acc[1][i] += (double)d.v[i] * (double)xh;
+        }
     }
 };
 
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
                   double* part, hipStream_t st) {
-    BnBwdReduceF f{da, shuffle_ctot, y, stats, G * C, C, act};
-    return launch_colreduce<2>(f, G, Mg, C, part, st);
+    const int vec = vcol_geom(Mg, C).vec;
+    return launch_vcolreduce<2, BnBwdReduceF>(G, Mg, C, part, st, NB_STATS, da, shuffle_ctot, y, stats, G * C, C, act,
+                                              view_aligned(da, vec), view_aligned(y, vec));
 }
 
 __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg,
@@ -254,6 +286,7 @@ int bn_bwd_finalize(const double* part, int nb, int G, int Mg, int C, const floa
     return 0;
 }
 
+template <int VEC>
 struct BnBwdApplyF {
     View da;
     int shuffle_ctot;
@@ -262,28 +295,41 @@ struct BnBwdApplyF {
     const float* coef;
     int GC, C, act;
     float* dy;
-    __device__ void operator()(int g, int64_t row, int c, double* acc) const {
-        int dc = da.coff + c;
-        if (shuffle_ctot) dc = shuffle_dst(dc, shuffle_ctot);
-        float d = da.p[row * da.ld + dc];
-        const float v = y.p[row * y.ld + y.coff + c];
-        const float mean = stats[0 * GC + g * C + c], invstd = stats[1 * GC + g * C + c];
+    bool al_da, al_y;
+    __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
+        VecF<VEC> d = vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
+        const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_y);
+        const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
         if (act == ACT_RELU6) {
-            const float z = fmaf(stats[2 * GC + g * C + c], v, stats[3 * GC + g * C + c]);
-            if (!(z > 0.0f && z < 6.0f)) d = 0.0f;
+            const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float z = fmaf(sc.v[i], v.v[i], sh.v[i]);
+                if (!(z > 0.0f && z < 6.0f)) d.v[i] = 0.0f;
+            }
         }
-        const float xh = (v - mean) * invstd;
-        const float k1 = coef[0 * GC + g * C + c], k2 = coef[1 * GC + g * C + c], k3 = coef[2 * GC + g * C + c];
-        const float o = k1 * (d - k2 - xh * k3);
-        dy[row * C + c] = o;
-        acc[0] += (double)o;
+        const VecF<VEC> k1 = vload<VEC>(coef + 0 * GC + g * C + c0), k2 = vload<VEC>(coef + 1 * GC + g * C + c0),
+                        k3 = vload<VEC>(coef + 2 * GC + g * C + c0);
+        VecF<VEC> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float xh = (v.v[i] - mean.v[i]) * invstd.v[i];
+            o.v[i] = k1.v[i] * (d.v[i] - k2.v[i] - xh * k3.v[i]);
+            acc[0][i] += (double)o.v[i];
+        }
+        vstore<VEC>(dy + row * C + c0, o);
     }
 };
 
 int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, const float* coef,
                  int act, float* dy, double* part2, hipStream_t st) {
-    BnBwdApplyF f{da, shuffle_ctot, y, stats, coef, G * C, C, act, dy};
-    return launch_colreduce<1>(f, G, Mg, C, part2, st);
+    const int vec = vcol_geom(Mg, C).vec;
+    if ((reinterpret_cast<uintptr_t>(dy) % (4 * vec)) != 0) {
+        set_error("bn_bwd_apply: dy must be %d-byte aligned", 4 * vec);
+        return -1;
+    }
+    return launch_vcolreduce<1, BnBwdApplyF>(G, Mg, C, part2, st, NB_STATS, da, shuffle_ctot, y, stats, coef, G * C, C, act,
+                                             dy, view_aligned(da, vec), view_aligned(y, vec));
 }
 
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __restrict__ part, int nparts, int n,

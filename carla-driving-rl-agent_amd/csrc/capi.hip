@@ -324,7 +324,7 @@ int cdrl_bn_train_fwd(const float* y, int G, int Mg, int C, const float* gamma, 
                       float* moving_var, int bessel, int relu6, float* out, int out_ld, int out_coff, int shuffle_ctot,
                       float* stats, double* workspace, void* stream) {
     View yv = make_view(const_cast<float*>(y), C);
-    const int nb = col_geom(Mg, C).nb;
+    const int nb = vcol_geom(Mg, C).nb;
     CDRL_TRY(colstats(yv, G, Mg, C, workspace, S(stream)));
     CDRL_TRY(bn_finalize(workspace, nb, G, Mg, C, gamma, beta, moving_mean, moving_var, bessel, 1, stats, S(stream)));
     return bn_apply(yv, G, Mg, C, stats, relu6 ? ACT_RELU6 : ACT_NONE, make_view(out, out_ld, out_coff), shuffle_ctot,
@@ -336,7 +336,7 @@ int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle
                       double* workspace, void* stream) {
     View yv = make_view(const_cast<float*>(y), C);
     View dv = make_view(const_cast<float*>(dout), dout_ld, dout_coff);
-    const int nb = col_geom(Mg, C).nb;
+    const int nb = vcol_geom(Mg, C).nb;
     const int act = relu6 ? ACT_RELU6 : ACT_NONE;
     CDRL_TRY(bn_bwd_reduce(dv, shuffle_ctot, yv, G, Mg, C, stats, act, workspace, S(stream)));
     CDRL_TRY(bn_bwd_finalize(workspace, nb, G, Mg, C, stats, dgamma, dbeta, coef, S(stream)));

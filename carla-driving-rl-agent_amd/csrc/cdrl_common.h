@@ -88,4 +88,31 @@ inline ColGeom col_geom(int rows_per_group, int C, int max_blocks_per_group = NB
     return g;
 }
 
+// Geometry of the VECTORISED column-mapped kernels (BatchNorm family, column sums): every thread
+// owns `vec` consecutive channels (16-byte accesses when C % 4 == 0, 8-byte when C is even), the
+// block is (cx = C/vec channel lanes) x (cy row lanes) -- not a power of two in general (C = 116:
+// 29 x 8 = 232 threads).  A function of (rows, C) only, so producers and consumers of the partial
+// sums agree on `nb` without talking to each other.
+struct VColGeom {
+    int vec, cx, cy, nloop;   // nloop: channel-lane passes when C/vec > 256
+    int rb, nb;
+};
+
+inline VColGeom vcol_geom(int rows_per_group, int C, int max_blocks_per_group = NB_STATS) {
+    VColGeom g;
+    g.vec = (C % 4 == 0) ? 4 : ((C % 2 == 0) ? 2 : 1);
+    const int lanes = C / g.vec;
+    g.cx = lanes > 256 ? 256 : lanes;
+    g.nloop = cdiv(lanes, g.cx);
+    g.cy = 256 / g.cx;
+    if (g.cy < 1) g.cy = 1;
+    int rb = cdiv(rows_per_group, max_blocks_per_group);
+    int minrb = g.cy * 2;
+    if (rb < minrb) rb = minrb;
+    rb = cdiv(rb, g.cy) * g.cy;
+    g.rb = rb;
+    g.nb = cdiv(rows_per_group, rb);
+    return g;
+}
+
 }  // namespace cdrl

@@ -55,4 +55,136 @@ static int launch_colreduce(F f, int G, int Mg, int C, double* part, hipStream_t
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// vectorised skeleton: F::operator()(g, row, c0, acc) handles VEC consecutive channels c0..c0+VEC-1
+// of one row and accumulates into acc[NQ][VEC].
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+struct VecF {
+    float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ VecF<VEC> vload(const float* p) {
+    VecF<VEC> r;
+    if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2 % VEC] = t.z; r.v[3 % VEC] = t.w;
+    } else if (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        r.v[0] = t.x; r.v[1 % VEC] = t.y;
+    } else {
+        r.v[0] = *p;
+    }
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void vstore(float* p, const VecF<VEC>& r) {
+    if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]);
+    else if (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1 % VEC]);
+    else *p = r.v[0];
+}
+
+// loads VEC channels of a view; `shuffle_ctot` != 0 -> element-wise through the de-interleave map
+template <int VEC>
+__device__ __forceinline__ VecF<VEC> vload_view(const View& v, int64_t row, int c0, int shuffle_ctot, bool aligned) {
+    VecF<VEC> r;
+    if (!shuffle_ctot && aligned) return vload<VEC>(v.p + row * v.ld + v.coff + c0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        int cc = v.coff + c0 + i;
+        if (shuffle_ctot) cc = shuffle_dst(cc, shuffle_ctot);
+        r.v[i] = v.p[row * v.ld + cc];
+    }
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void vstore_view(const View& v, int64_t row, int c0, int shuffle_ctot, bool aligned,
+                                            const VecF<VEC>& r) {
+    if (!shuffle_ctot && aligned) {
+        vstore<VEC>(v.p + row * v.ld + v.coff + c0, r);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        int cc = v.coff + c0 + i;
+        if (shuffle_ctot) cc = shuffle_dst(cc, shuffle_ctot);
+        v.p[row * v.ld + cc] = r.v[i];
+    }
+}
+
+__host__ inline bool view_aligned(const View& v, int vec) {
+    return (v.ld % vec == 0) && (v.coff % vec == 0) && ((reinterpret_cast<uintptr_t>(v.p) % (4 * vec)) == 0);
+}
+
+template <int NQ, int VEC, class F>
+__global__ void __launch_bounds__(256) vcolreduce_kernel(F f, int Mg, int C, int rb, int nloop,
+                                                         double* __restrict__ part) {
+    extern __shared__ double sm[];   // [CY][NQ*VEC][CX]
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int g = blockIdx.y;
+    const int nb = gridDim.x;
+    const int r0 = blockIdx.x * rb;
+    const int r1 = min(r0 + rb, Mg);
+    for (int l = 0; l < nloop; ++l) {
+        const int c0 = (l * CX + tx) * VEC;
+        double acc[NQ][VEC];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[q][i] = 0.0;
+        if (c0 < C) {
+            for (int r = r0 + ty; r < r1; r += CY) f(g, (int64_t)g * Mg + r, c0, acc);
+        }
+        if (CY > 1) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) sm[(ty * NQ * VEC + q * VEC + i) * CX + tx] = acc[q][i];
+            __syncthreads();
+            if (ty == 0) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        double s = acc[q][i];
+                        for (int y = 1; y < CY; ++y) s += sm[(y * NQ * VEC + q * VEC + i) * CX + tx];
+                        acc[q][i] = s;
+                    }
+            }
+            __syncthreads();
+        }
+        if (ty == 0 && c0 < C) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    part[(((int64_t)g * nb + blockIdx.x) * NQ + q) * C + c0 + i] = acc[q][i];
+        }
+    }
+}
+
+// F<VEC> must be a class template; launches the variant matching vcol_geom(Mg, C).vec
+template <int NQ, template <int> class F, class... Args>
+static int launch_vcolreduce(int G, int Mg, int C, double* part, hipStream_t st, int max_blocks, Args... args) {
+    VColGeom g = vcol_geom(Mg, C, max_blocks);
+    dim3 grid(g.nb, G), block(g.cx, g.cy);
+    const size_t sm = (size_t)g.cy * NQ * g.vec * g.cx * sizeof(double);
+    if (g.vec == 4) {
+        F<4> f{args...};
+        hipLaunchKernelGGL((vcolreduce_kernel<NQ, 4, F<4>>), grid, block, sm, st, f, Mg, C, g.rb, g.nloop, part);
+    } else if (g.vec == 2) {
+        F<2> f{args...};
+        hipLaunchKernelGGL((vcolreduce_kernel<NQ, 2, F<2>>), grid, block, sm, st, f, Mg, C, g.rb, g.nloop, part);
+    } else {
+        F<1> f{args...};
+        hipLaunchKernelGGL((vcolreduce_kernel<NQ, 1, F<1>>), grid, block, sm, st, f, Mg, C, g.rb, g.nloop, part);
+    }
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace cdrl

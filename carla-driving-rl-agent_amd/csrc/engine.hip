@@ -147,7 +147,7 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     PRef mv = param(model, prefix + ".moving_var", {C}, false);
     float* stats = alloc((size_t)4 * G * C);
     float* coef = alloc((size_t)3 * G * C);
-    const int nb = col_geom(Mg, C).nb;
+    const int nb = vcol_geom(Mg, C).nb;
     note_scratch((size_t)G * nb * 2 * C, (size_t)G * nb * C, 0, 0);
     BnRec rec{G, Mg, C, nb};
     const int bes = bessel ? 1 : 0;
@@ -208,8 +208,8 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
         z = alloc((size_t)M * N);
         dz = alloc((size_t)M * N);
     }
-    note_scratch((size_t)col_geom(M, N).nb * N, 0, 0, (size_t)gemm_tn_part_elems(M, N, K));
-    const int nb = col_geom(M, N).nb;
+    note_scratch((size_t)vcol_geom(M, N).nb * N, 0, 0, (size_t)gemm_tn_part_elems(M, N, K));
+    const int nb = vcol_geom(M, N).nb;
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
         if (act == ACT_NONE) return gemm_nn(in, w.p, N, 1, b.p, out, M, N, K, 0, st);
@@ -246,9 +246,9 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
     float* dHP = alloc((size_t)T * B * U3);
     float* dHa = alloc((size_t)B * u);
     float* dHb = alloc((size_t)B * u);
-    note_scratch((size_t)col_geom(T * B, U3).nb * U3, 0, 0,
+    note_scratch((size_t)vcol_geom(T * B, U3).nb * U3, 0, 0,
                  (size_t)std::max(gemm_tn_part_elems(T * B, U3, In), gemm_tn_part_elems(T * B, U3, u)));
-    const int nbc = col_geom(T * B, U3).nb;
+    const int nbc = vcol_geom(T * B, U3).nb;
     View xv = x.v();
     View xg = x.gv();
     Op op;
@@ -297,7 +297,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
     const Config& c = cfg_;
     const int B = c.B, T = c.T, N = B * T;
     const int Hs = (c.H - 3) / 2 + 1, Ws = (c.W - 3) / 2 + 1;
-    auto bnrec = [](int G, int Mg, int C) { return BnRec{G, Mg, C, col_geom(Mg, C).nb}; };
+    auto bnrec = [](int G, int Mg, int C) { return BnRec{G, Mg, C, vcol_geom(Mg, C).nb}; };
 
     // ---- stem (core/architectures.py:159-161)
     {

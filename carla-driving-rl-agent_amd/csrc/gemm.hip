@@ -13,13 +13,14 @@
 // padded to 33 floats per row -> conflict-free ds_read_b32 for the MFMA A fragment, B fragment
 // reads are lane-consecutive).  Awkward channel counts (24/58/92/116/232/464) are zero-padded in
 // LDS only; HBM tensors stay dense NHWC.
+#include <stdlib.h>
+
 #include "cdrl_kernels.h"
 
 namespace cdrl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define BM 128
 #define BK 32
 
 // Software-pipelined K loop: the global loads of slice k+1 are issued into registers before the
@@ -27,22 +28,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // order of the B staging so that the global reads stay coalesced for both W (sbn == 1, forward)
 // and W^T (sbk == 1, backward-data); the B tile is padded to BN+1 floats per row so that both
 // store orders are bank-conflict free.
-template <int NT, bool BT, bool VEC>
+// WR = wave rows: 4 -> 128-row tile, every wave owns 32 rows x all NT column tiles;
+//                 2 -> 64-row tile, 2x2 wave grid, every wave owns 32 rows x NT/2 column tiles (more,
+//                      smaller workgroups: balances the late, small-M layers over 256 CUs).
+template <int NT, bool BT, bool VEC, int WR>
 __global__ void __launch_bounds__(256, 2) gemm_nn_kernel(View A, const float* __restrict__ Bp, int sbk, int sbn,
                                                          const float* __restrict__ bias, View C, int M, int N, int K,
                                                          int accumulate) {
+    constexpr int BM = 32 * WR;
+    constexpr int WC = 4 / WR;                   // wave columns
+    constexpr int NTW = NT / WC;                 // column tiles per wave
     constexpr int BN = 32 * NT;
-    constexpr int NA = (BM * BK) / 256;          // 16 A elements per thread per slice
+    constexpr int NA = (BM * BK) / 256;          // A elements per thread per slice
     constexpr int NB = (BK * BN) / 256;          // 4*NT B elements per thread per slice
     __shared__ float As[2][BM][BK + 1];
     __shared__ float Bs[2][BK][BN + 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WR, wc = wave / WR;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    f32x16 acc[NT];
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     const int lrow = lane & 31, lk = lane >> 5;
@@ -111,10 +119,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nn_kernel(View A, const float* __
         if (more) load_slice(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a = As[buf][wave * 32 + lrow][kk + lk];
+            const float a = As[buf][wr * 32 + lrow][kk + lk];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float b = Bs[buf][kk + lk][j * 32 + lrow];
+            for (int j = 0; j < NTW; ++j) {
+                const float b = Bs[buf][kk + lk][(wc + j * WC) * 32 + lrow];
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
             }
         }
@@ -124,13 +132,13 @@ __global__ void __launch_bounds__(256, 2) gemm_nn_kernel(View A, const float* __
     }
     // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * 32 + lrow;
+    for (int j = 0; j < NTW; ++j) {
+        const int n = n0 + (wc + j * WC) * 32 + lrow;
         if (n >= N) continue;
         const float bv = bias ? bias[n] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int64_t m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             if (m < M) {
                 float* c = &C.p[m * C.ld + C.coff + n];
                 float v = acc[j][r] + bv;
@@ -141,34 +149,48 @@ __global__ void __launch_bounds__(256, 2) gemm_nn_kernel(View A, const float* __
     }
 }
 
-template <int NT>
+template <int NT, int WR>
 static void launch_nn(bool bt, bool vec, dim3 grid, hipStream_t st, View A, const float* Bp, int sbk, int sbn,
                       const float* bias, View C, int M, int N, int K, int acc) {
     if (bt) {
-        if (vec) hipLaunchKernelGGL((gemm_nn_kernel<NT, true, true>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
-        else hipLaunchKernelGGL((gemm_nn_kernel<NT, true, false>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+        if (vec) hipLaunchKernelGGL((gemm_nn_kernel<NT, true, true, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+        else hipLaunchKernelGGL((gemm_nn_kernel<NT, true, false, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
     } else {
-        if (vec) hipLaunchKernelGGL((gemm_nn_kernel<NT, false, true>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
-        else hipLaunchKernelGGL((gemm_nn_kernel<NT, false, false>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+        if (vec) hipLaunchKernelGGL((gemm_nn_kernel<NT, false, true, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+        else hipLaunchKernelGGL((gemm_nn_kernel<NT, false, false, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
     }
 }
+
+static int g_nn_bm64_threshold = -1;
 
 int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C, int M, int N, int K,
             int accumulate, hipStream_t st) {
     if (M <= 0 || N <= 0) return 0;
+    if (g_nn_bm64_threshold < 0) {
+        const char* e = getenv("CDRL_NN_BM64_BLOCKS");      // tuning knob: use 64-row tiles below this many 128-row blocks
+        g_nn_bm64_threshold = e ? atoi(e) : (1 << 30);   // measured: 64-row tiles win at every learner shape
+    }
     int nt = cdiv(N, 32);
     if (nt > 4) nt = 4;
     // balance column blocks: e.g. N=232 -> 2 blocks of 4 tiles; N=92 -> 1 block of 3 tiles
     const int ncb = cdiv(N, 32 * nt);
     nt = cdiv(cdiv(N, ncb), 32);
-    dim3 grid(cdiv(M, BM), cdiv(N, 32 * nt));
+    const int gy = cdiv(N, 32 * nt);
     const bool bt = sbn != 1;
     const bool vec = (K % 2 == 0) && (A.ld % 2 == 0) && (A.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(A.p) & 7) == 0);
-    switch (nt) {
-        case 1: launch_nn<1>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
-        case 2: launch_nn<2>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
-        case 3: launch_nn<3>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
-        default: launch_nn<4>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+    const bool small = (nt % 2 == 0) && (cdiv(M, 128) * gy < g_nn_bm64_threshold);
+    if (small) {
+        dim3 grid(cdiv(M, 64), gy);
+        if (nt == 2) launch_nn<2, 2>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate);
+        else launch_nn<4, 2>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate);
+    } else {
+        dim3 grid(cdiv(M, 128), gy);
+        switch (nt) {
+            case 1: launch_nn<1, 4>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+            case 2: launch_nn<2, 4>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+            case 3: launch_nn<3, 4>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+            default: launch_nn<4, 4>(bt, vec, grid, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate); break;
+        }
     }
     CDRL_LAUNCH_CHECK();
     return 0;
