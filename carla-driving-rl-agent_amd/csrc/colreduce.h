@@ -122,7 +122,7 @@ __host__ inline bool view_aligned(const View& v, int vec) {
 template <int NQ, int VEC, class F>
 __global__ void __launch_bounds__(256) vcolreduce_kernel(F f, int Mg, int C, int rb, int nloop,
                                                          double* __restrict__ part) {
-    extern __shared__ double sm[];   // [CY][NQ*VEC][CX]
+    extern __shared__ double sm[];   // [CY][VEC][CX]
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int CX = blockDim.x, CY = blockDim.y;
     const int g = blockIdx.y;
@@ -140,22 +140,22 @@ __global__ void __launch_bounds__(256) vcolreduce_kernel(F f, int Mg, int C, int
             for (int r = r0 + ty; r < r1; r += CY) f(g, (int64_t)g * Mg + r, c0, acc);
         }
         if (CY > 1) {
+            // one quantity at a time through a [CY][VEC][CX] LDS slab (keeps LDS at a few KB for NQ = 10)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
+            for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) sm[(ty * NQ * VEC + q * VEC + i) * CX + tx] = acc[q][i];
-            __syncthreads();
-            if (ty == 0) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
+                for (int i = 0; i < VEC; ++i) sm[(ty * VEC + i) * CX + tx] = acc[q][i];
+                __syncthreads();
+                if (ty == 0) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
                         double s = acc[q][i];
-                        for (int y = 1; y < CY; ++y) s += sm[(y * NQ * VEC + q * VEC + i) * CX + tx];
+                        for (int y = 1; y < CY; ++y) s += sm[(y * VEC + i) * CX + tx];
                         acc[q][i] = s;
                     }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         if (ty == 0 && c0 < C) {
 #pragma unroll
@@ -172,7 +172,7 @@ template <int NQ, template <int> class F, class... Args>
 static int launch_vcolreduce(int G, int Mg, int C, double* part, hipStream_t st, int max_blocks, Args... args) {
     VColGeom g = vcol_geom(Mg, C, max_blocks);
     dim3 grid(g.nb, G), block(g.cx, g.cy);
-    const size_t sm = (size_t)g.cy * NQ * g.vec * g.cx * sizeof(double);
+    const size_t sm = (size_t)g.cy * g.vec * g.cx * sizeof(double);
     if (g.vec == 4) {
         F<4> f{args...};
         hipLaunchKernelGGL((vcolreduce_kernel<NQ, 4, F<4>>), grid, block, sm, st, f, Mg, C, g.rb, g.nloop, part);

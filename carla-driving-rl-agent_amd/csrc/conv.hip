@@ -190,25 +190,27 @@ int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B
 // ------------------------------------------------------------------------------------------
 // depthwise 3x3 (reference core/architectures.py:132,138); kernel layout (3,3,C,1) -> [9][C]
 // ------------------------------------------------------------------------------------------
-template <int s>
+template <int s, int VEC>
 __global__ void __launch_bounds__(256) dw_fwd_kernel(View a, const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* __restrict__ y, int rows, int H, int W, int Ho, int Wo, int C,
-                                                     int pt, int pl, int rb) {
+                                                     int pt, int pl, int rb, int nloop, bool al) {
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int CX = blockDim.x, CY = blockDim.y;
     const int r0 = blockIdx.x * rb;
     const int r1 = min(r0 + rb, rows);
-    for (int c = tx; c < C; c += CX) {
-        float wk[9];
+    for (int l = 0; l < nloop; ++l) {
+        const int c0 = (l * CX + tx) * VEC;
+        if (c0 >= C) continue;
+        VecF<VEC> wk[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k] = w[k * C + c];
-        const float bv = bias[c];
+        for (int k = 0; k < 9; ++k) wk[k] = vload<VEC>(w + k * C + c0);
+        const VecF<VEC> bv = vload<VEC>(bias + c0);
         for (int r = r0 + ty; r < r1; r += CY) {
             const int ox = r % Wo;
             const int q = r / Wo;
             const int oy = q % Ho;
             const int n = q / Ho;
-            float acc = bv;
+            VecF<VEC> acc = bv;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = oy * s + ky - pt;
@@ -218,47 +220,60 @@ __global__ void __launch_bounds__(256) dw_fwd_kernel(View a, const float* __rest
                     const int ix = ox * s + kx - pl;
                     if (ix < 0 || ix >= W) continue;
                     const int64_t irow = ((int64_t)n * H + iy) * W + ix;
-                    acc = fmaf(a.p[irow * a.ld + a.coff + c], wk[ky * 3 + kx], acc);
+                    const VecF<VEC> x = vload_view<VEC>(a, irow, c0, 0, al);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(x.v[i], wk[ky * 3 + kx].v[i], acc.v[i]);
                 }
             }
-            y[(int64_t)r * C + c] = acc;
+            vstore<VEC>(y + (int64_t)r * C + c0, acc);
         }
     }
+}
+
+template <int s>
+static void launch_dw_fwd(const VColGeom& g, hipStream_t st, View a, const float* w, const float* bias, float* y, int rows,
+                          int H, int W, int Ho, int Wo, int C) {
+    dim3 grid(g.nb), block(g.cx, g.cy);
+    const bool al = view_aligned(a, g.vec);
+    const int pt = same_pad_before(H, s), pl = same_pad_before(W, s);
+    if (g.vec == 4) hipLaunchKernelGGL((dw_fwd_kernel<s, 4>), grid, block, 0, st, a, w, bias, y, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop, al);
+    else if (g.vec == 2) hipLaunchKernelGGL((dw_fwd_kernel<s, 2>), grid, block, 0, st, a, w, bias, y, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop, al);
+    else hipLaunchKernelGGL((dw_fwd_kernel<s, 1>), grid, block, 0, st, a, w, bias, y, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop, al);
 }
 
 int dw_fwd(View a, const float* w, const float* bias, float* y, int N, int H, int W, int C, int stride,
            hipStream_t st) {
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int rows = N * Ho * Wo;
-    ColGeom g = col_geom(rows, C, 2048);
-    if (stride == 1)
-        hipLaunchKernelGGL(dw_fwd_kernel<1>, dim3(g.nb), dim3(g.cx, g.cy), 0, st, a, w, bias, y, rows, H, W, Ho, Wo, C,
-                           same_pad_before(H, 1), same_pad_before(W, 1), g.rb);
-    else
-        hipLaunchKernelGGL(dw_fwd_kernel<2>, dim3(g.nb), dim3(g.cx, g.cy), 0, st, a, w, bias, y, rows, H, W, Ho, Wo, C,
-                           same_pad_before(H, 2), same_pad_before(W, 2), g.rb);
+    VColGeom g = vcol_geom(rows, C, 4096);
+    if (stride == 1) launch_dw_fwd<1>(g, st, a, w, bias, y, rows, H, W, Ho, Wo, C);
+    else launch_dw_fwd<2>(g, st, a, w, bias, y, rows, H, W, Ho, Wo, C);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
 
-template <int s>
+template <int s, int VEC>
 __global__ void __launch_bounds__(256) dw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                           View da, int rows, int H, int W, int Ho, int Wo, int C,
-                                                          int pt, int pl, int rb, int accumulate) {
+                                                          int pt, int pl, int rb, int nloop, int accumulate, bool al) {
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int CX = blockDim.x, CY = blockDim.y;
     const int r0 = blockIdx.x * rb;
     const int r1 = min(r0 + rb, rows);
-    for (int c = tx; c < C; c += CX) {
-        float wk[9];
+    for (int l = 0; l < nloop; ++l) {
+        const int c0 = (l * CX + tx) * VEC;
+        if (c0 >= C) continue;
+        VecF<VEC> wk[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k] = w[k * C + c];
+        for (int k = 0; k < 9; ++k) wk[k] = vload<VEC>(w + k * C + c0);
         for (int r = r0 + ty; r < r1; r += CY) {
             const int ix = r % W;
             const int q = r / W;
             const int iy = q % H;
             const int n = q / H;
-            float acc = 0.0f;
+            VecF<VEC> acc;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc.v[i] = 0.0f;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int ny = iy + pt - ky;
@@ -271,40 +286,55 @@ __global__ void __launch_bounds__(256) dw_bwd_data_kernel(const float* __restric
                     if (nx < 0 || (nx % s) != 0) continue;
                     const int ox = nx / s;
                     if (ox >= Wo) continue;
-                    acc = fmaf(dy[(((int64_t)n * Ho + oy) * Wo + ox) * C + c], wk[ky * 3 + kx], acc);
+                    const VecF<VEC> d = vload<VEC>(dy + (((int64_t)n * Ho + oy) * Wo + ox) * C + c0);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(d.v[i], wk[ky * 3 + kx].v[i], acc.v[i]);
                 }
             }
-            float* d = &da.p[(int64_t)r * da.ld + da.coff + c];
-            *d = accumulate ? *d + acc : acc;
+            if (accumulate) {
+                const VecF<VEC> old = vload_view<VEC>(da, r, c0, 0, al);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc.v[i] += old.v[i];
+            }
+            vstore_view<VEC>(da, r, c0, 0, al, acc);
         }
     }
+}
+
+template <int s>
+static void launch_dw_bwd_data(const VColGeom& g, hipStream_t st, const float* dy, const float* w, View da, int rows, int H,
+                               int W, int Ho, int Wo, int C, int accumulate) {
+    dim3 grid(g.nb), block(g.cx, g.cy);
+    const bool al = view_aligned(da, g.vec);
+    const int pt = same_pad_before(H, s), pl = same_pad_before(W, s);
+    if (g.vec == 4) hipLaunchKernelGGL((dw_bwd_data_kernel<s, 4>), grid, block, 0, st, dy, w, da, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop, accumulate, al);
+    else if (g.vec == 2) hipLaunchKernelGGL((dw_bwd_data_kernel<s, 2>), grid, block, 0, st, dy, w, da, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop, accumulate, al);
+    else hipLaunchKernelGGL((dw_bwd_data_kernel<s, 1>), grid, block, 0, st, dy, w, da, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop, accumulate, al);
 }
 
 int dw_bwd_data(const float* dy, const float* w, View da, int N, int H, int W, int C, int stride, int accumulate,
                 hipStream_t st) {
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int rows = N * H * W;
-    ColGeom g = col_geom(rows, C, 2048);
-    if (stride == 1)
-        hipLaunchKernelGGL(dw_bwd_data_kernel<1>, dim3(g.nb), dim3(g.cx, g.cy), 0, st, dy, w, da, rows, H, W, Ho, Wo, C,
-                           same_pad_before(H, 1), same_pad_before(W, 1), g.rb, accumulate);
-    else
-        hipLaunchKernelGGL(dw_bwd_data_kernel<2>, dim3(g.nb), dim3(g.cx, g.cy), 0, st, dy, w, da, rows, H, W, Ho, Wo, C,
-                           same_pad_before(H, 2), same_pad_before(W, 2), g.rb, accumulate);
+    VColGeom g = vcol_geom(rows, C, 4096);
+    if (stride == 1) launch_dw_bwd_data<1>(g, st, dy, w, da, rows, H, W, Ho, Wo, C, accumulate);
+    else launch_dw_bwd_data<2>(g, st, dy, w, da, rows, H, W, Ho, Wo, C, accumulate);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
 
+template <int VEC>
 struct DwBwdFilterF {
     View a;
     const float* dy;
     int H, W, Ho, Wo, C, s, pt, pl;
-    __device__ void operator()(int, int64_t row, int c, double* acc) const {
+    bool al;
+    __device__ void operator()(int, int64_t row, int c0, double (*acc)[VEC]) const {
         const int ox = (int)(row % Wo);
         const int64_t q = row / Wo;
         const int oy = (int)(q % Ho);
         const int n = (int)(q / Ho);
-        const float d = dy[row * C + c];
+        const VecF<VEC> d = vload<VEC>(dy + row * C + c0);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * s + ky - pt;
@@ -314,16 +344,19 @@ struct DwBwdFilterF {
                 const int ix = ox * s + kx - pl;
                 if (ix < 0 || ix >= W) continue;
                 const int64_t irow = ((int64_t)n * H + iy) * W + ix;
-                acc[ky * 3 + kx] += (double)(a.p[irow * a.ld + a.coff + c] * d);
+                const VecF<VEC> x = vload_view<VEC>(a, irow, c0, 0, al);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[ky * 3 + kx][i] += (double)(x.v[i] * d.v[i]);
             }
         }
-        acc[9] += (double)d;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[9][i] += (double)d.v[i];
     }
 };
 
 int64_t dw_bwd_part_elems(int N, int H, int W, int C, int stride) {
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
-    ColGeom g = col_geom(N * Ho * Wo, C, NB_FILTER);
+    VColGeom g = vcol_geom(N * Ho * Wo, C, NB_FILTER);
     return (int64_t)g.nb * 10 * C;
 }
 
@@ -331,9 +364,10 @@ int dw_bwd_filter(View a, const float* dy, float* dw, float* db, int N, int H, i
                   double* part, hipStream_t st) {
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int rows = N * Ho * Wo;
-    DwBwdFilterF f{a, dy, H, W, Ho, Wo, C, stride, same_pad_before(H, stride), same_pad_before(W, stride)};
-    CDRL_TRY(launch_colreduce<10>(f, 1, rows, C, part, st, NB_FILTER));
-    ColGeom g = col_geom(rows, C, NB_FILTER);
+    VColGeom g = vcol_geom(rows, C, NB_FILTER);
+    CDRL_TRY((launch_vcolreduce<10, DwBwdFilterF>(1, rows, C, part, st, NB_FILTER, a, dy, H, W, Ho, Wo, C, stride,
+                                                  same_pad_before(H, stride), same_pad_before(W, stride),
+                                                  view_aligned(a, g.vec))));
     CDRL_TRY(reduce_partials(part, g.nb, 9 * C, (int64_t)10 * C, dw, 0, st));
     CDRL_TRY(reduce_partials(part + 9 * C, g.nb, C, (int64_t)10 * C, db, 0, st));
     return 0;
