@@ -29,6 +29,22 @@ def alg_bytes_per_update_step(B, T, H, W):
     return 2 * 3 * 4 * B * T * ALG_ELEMS_PER_FRAME[(H, W)]
 
 
+def pmc_traffic(B, T, H, W):
+    """HBM bytes per update-step from the committed PMC run (profiles/*_pmc_traffic.json; collected and
+    corrected as MI355X_MICROARCH.md prescribes, see the file's `method`), or None if no run matches."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
+        try:
+            d = json.load(open(f))
+            w = d['workload']
+            if (w['B'], w['T'], w['H'], w['W']) == (B, T, H, W):
+                best = d['bytes_per_update_step']
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(B_sample, T, H, W, threads, seed=42):
     """Oracle (PyTorch-CPU restatement of the reference TF path) timed on the host cores on a bounded
     sample: update-steps at minibatch B_sample, scaled to 256-sample update-steps/s."""
@@ -109,8 +125,10 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = f'cuda:{local_rank}'
-    if world > 1:
+    use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('CDRL_FORCE_COLLECTIVES') == '1')
+    if use_dist:      # launched by torchrun: RCCL over xGMI (CDRL_FORCE_COLLECTIVES=1 exercises it on 1 GPU too)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
 
     B, T, H, W = args.batch, 4, args.height, args.width
@@ -118,7 +136,7 @@ def main():
     # random-init weights of the reference architecture, identical on every rank
     from carla_driving_rl_agent_amd.init import init_engine_parameters
     init_engine_parameters(eng, seed=42)
-    dp = DataParallelLearner(eng)
+    dp = DataParallelLearner(eng, force_collectives=use_dist and world == 1)
     dp.broadcast_parameters()
 
     # rollout shard of this rank (weak scaling: B timesteps per GPU), already resident in HBM
@@ -143,7 +161,7 @@ def main():
     val = dict(states=states, returns=returns_be.contiguous(), speed=speed, similarity=sim)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,7 +177,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -175,7 +193,7 @@ def main():
         if alg is not None:
             achieved = alg / dev_s_per_step / 1e9
             roof = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(B, T, H, W),
                         kernel='one PPO update-step (all launches of the step, HIP-event timed on the launch stream)',
                         algorithmic_bytes_per_launch=alg)
         out = dict(metric='PPO update-steps/sec (batch=256, 4x90x120x3 obs)', value=round(value, 3), unit='update-steps/s',
@@ -190,7 +208,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = run_cpu_baseline_child(args.cpu_sample_batch, T, H, W, args.cpu_threads)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

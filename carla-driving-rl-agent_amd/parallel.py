@@ -13,11 +13,12 @@ import torch.distributed as dist
 
 
 class DataParallelLearner:
-    def __init__(self, engine, group=None, sync_bn_stats=True):
+    def __init__(self, engine, group=None, sync_bn_stats=True, force_collectives=False):
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.sync_bn_stats = sync_bn_stats
+        self.force = force_collectives and dist.is_initialized()     # run the collectives even at world 1 (smoke tests)
         p_off, p_n = engine.region('policy', True)
         t_off, t_n = engine.region('trunk', True)
         v_off, v_n = engine.region('value', True)
@@ -31,7 +32,7 @@ class DataParallelLearner:
         self._state_slice = (s0, engine.params_total)
 
     def _allreduce(self, flat, lo, hi, scale=None):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         view = flat[lo:hi]
         dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
@@ -39,7 +40,7 @@ class DataParallelLearner:
             view.mul_(scale)
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.broadcast(self.engine.params, src=src, group=self.group)
             dist.broadcast(self.engine.adam_m, src=src, group=self.group)
             dist.broadcast(self.engine.adam_v, src=src, group=self.group)
@@ -57,7 +58,7 @@ class DataParallelLearner:
         e.value_apply()
 
     def sync_moving_statistics(self):
-        if self.sync_bn_stats and self.world > 1:
+        if self.sync_bn_stats and (self.world > 1 or self.force):
             self._allreduce(self.engine.params, *self._state_slice, scale=1.0 / self.world)
 
     def update_step(self, policy_batch, value_batch):
