@@ -93,6 +93,8 @@ PROTOTYPES = {
     'cdrl_maxpool_bwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp]),
     'cdrl_bn_train_fwd': (_i, [_fp, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _fp, _i, _i, _i, _fp, _fp, _fp]),
     'cdrl_bn_train_bwd': (_i, [_fp, _i, _i, _i, _fp, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
+    'cdrl_maxpool_bn_fwd': (_i, [_fp, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _fp]),
+    'cdrl_bn_train_bwd_pooled': (_i, [_fp, _fp, _i, _i, _fp, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     'cdrl_beta_ppo_loss': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _i, _i, _f, _fp, _fp, _fp, _fp, _fp]),
     'cdrl_value_loss': (_i, [_fp, _fp, _fp, _fp, _i, _f, _f, _fp, _fp, _fp, _fp]),
 }

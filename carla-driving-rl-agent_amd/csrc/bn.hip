@@ -206,8 +206,10 @@ struct BnBwdReduceF {
     const float* stats;
     int GC, C, act;
     bool al_da, al_y;
+    bool use_pool;
+    PoolSrc pool;
     __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
-        VecF<VEC> d = vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
+        VecF<VEC> d = use_pool ? pool_gather<VEC>(pool, row, c0, C) : vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
         const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_y);
         const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
         if (act == ACT_RELU6) {
@@ -228,10 +230,12 @@ struct BnBwdReduceF {
 };
 
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
-                  double* part, hipStream_t st) {
+                  double* part, hipStream_t st, const PoolSrc* pool) {
     const int vec = vcol_geom(Mg, C).vec;
+    PoolSrc ps{};
+    if (pool) ps = *pool;
     return launch_vcolreduce<2, BnBwdReduceF>(G, Mg, C, part, st, NB_STATS, da, shuffle_ctot, y, stats, G * C, C, act,
-                                              view_aligned(da, vec), view_aligned(y, vec));
+                                              pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps);
 }
 
 __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg,
@@ -296,8 +300,10 @@ struct BnBwdApplyF {
     int GC, C, act;
     float* dy;
     bool al_da, al_y;
+    bool use_pool;
+    PoolSrc pool;
     __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
-        VecF<VEC> d = vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
+        VecF<VEC> d = use_pool ? pool_gather<VEC>(pool, row, c0, C) : vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
         const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_y);
         const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
         if (act == ACT_RELU6) {
@@ -322,14 +328,16 @@ struct BnBwdApplyF {
 };
 
 int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, const float* coef,
-                 int act, float* dy, double* part2, hipStream_t st) {
+                 int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool) {
     const int vec = vcol_geom(Mg, C).vec;
+    PoolSrc ps{};
+    if (pool) ps = *pool;
     if ((reinterpret_cast<uintptr_t>(dy) % (4 * vec)) != 0) {
         set_error("bn_bwd_apply: dy must be %d-byte aligned", 4 * vec);
         return -1;
     }
     return launch_vcolreduce<1, BnBwdApplyF>(G, Mg, C, part2, st, NB_STATS, da, shuffle_ctot, y, stats, coef, G * C, C, act,
-                                             dy, view_aligned(da, vec), view_aligned(y, vec));
+                                             dy, pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps);
 }
 
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __restrict__ part, int nparts, int n,

@@ -343,6 +343,23 @@ int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle
     return bn_bwd_apply(dv, shuffle_ctot, yv, G, Mg, C, stats, coef, act, dy, workspace, S(stream));
 }
 
+int cdrl_maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax,
+                        int N, int H, int W, int C, void* stream) {
+    return maxpool_bn_fwd(y, stats, G, frames_per_group, p, argmax, N, H, W, C, S(stream));
+}
+
+int cdrl_bn_train_bwd_pooled(const uint8_t* argmax, const float* dp, int H, int W, const float* y, int G, int Mg, int C,
+                             const float* stats, float* dgamma, float* dbeta, float* dy, float* coef, double* workspace,
+                             void* stream) {
+    View yv = make_view(const_cast<float*>(y), C);
+    View none = make_view(nullptr, 0);
+    PoolSrc ps = make_pool_src(argmax, dp, H, W);
+    const int nb = vcol_geom(Mg, C).nb;
+    CDRL_TRY(bn_bwd_reduce(none, 0, yv, G, Mg, C, stats, ACT_RELU6, workspace, S(stream), &ps));
+    CDRL_TRY(bn_bwd_finalize(workspace, nb, G, Mg, C, stats, dgamma, dbeta, coef, S(stream)));
+    return bn_bwd_apply(none, 0, yv, G, Mg, C, stats, coef, ACT_RELU6, dy, workspace, S(stream), &ps);
+}
+
 int cdrl_beta_ppo_loss(const float* lin, const float* adv, const float* old_logp, const float* speed,
                        const float* similarity, const float* u, const float* du_da, const float* du_db, float clip_ratio,
                        float entropy_coef, int B, int A, float grad_scale, float* dlin, float* metrics, float* aux,

@@ -18,15 +18,23 @@ int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* g
 // stats == nullptr -> plain copy.
 int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
              hipStream_t st);
+// Gradient source "through a 3x3/s2 SAME max-pool": d(a)[n,iy,ix,c] = sum of dp over the windows whose
+// saved argmax points at (iy,ix).  Lets the stem BatchNorm backward read the pooled gradient directly
+// (the 255 MB pre-pool gradient tensor is never written or re-read).
+struct PoolSrc {
+    const uint8_t* argmax;   // [N][Ho][Wo][C]
+    const float* dp;         // [N][Ho][Wo][C]
+    int H, W, Ho, Wo, pt, pl;
+};
 // Backward: reduce (sum dz, sum dz*xhat) -> part [G][nb][2][C]
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
-                  double* part, hipStream_t st);
+                  double* part, hipStream_t st, const PoolSrc* pool = nullptr);
 // dgamma/dbeta (+= over groups; `accumulate` keeps previous content) and coefficients coef[3][G][C]
 int bn_bwd_finalize(const double* part, int nb, int G, int Mg, int C, const float* stats, float* dgamma,
                     float* dbeta, float* coef, hipStream_t st);
 // dy = k1*(dz - k2 - xhat*k3) (dense [G*Mg][C]); also column sums of dy -> part2 [G][nb][C]
 int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats,
-                 const float* coef, int act, float* dy, double* part2, hipStream_t st);
+                 const float* coef, int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool = nullptr);
 // out[i] (+)= sum_p part[p*stride + i], i < n
 int reduce_partials(const double* part, int nparts, int n, int64_t stride, float* out, int accumulate,
                     hipStream_t st);
@@ -73,6 +81,10 @@ int dw_bwd_filter(View a, const float* dy, float* dw, float* db, int N, int H, i
                   double* part, hipStream_t st);
 int maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, hipStream_t st);
 int maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H, int W, int C, hipStream_t st);
+// fused BN-apply + ReLU6 + max-pool on the raw conv output y (frames of group g = [g*frames_per_group, ...))
+int maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax, int N,
+                   int H, int W, int C, hipStream_t st);
+PoolSrc make_pool_src(const uint8_t* argmax, const float* dp, int H, int W);
 // mean over the P pixels of each frame: a [N][P][C] -> out [N][C]
 int gap_fwd(const float* a, float* out, int N, int P, int C, hipStream_t st);
 int gap_bwd(const float* dout, float* da, int N, int P, int C, hipStream_t st);

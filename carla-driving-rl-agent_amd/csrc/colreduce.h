@@ -115,6 +115,45 @@ __device__ __forceinline__ void vstore_view(const View& v, int64_t row, int c0, 
     }
 }
 
+// gradient w.r.t. the pre-pool activation, gathered from the pooled gradient through the saved argmax
+template <int VEC>
+__device__ __forceinline__ VecF<VEC> pool_gather(const PoolSrc& ps, int64_t row, int c0, int C) {
+    const int ix = (int)(row % ps.W);
+    const int64_t q = row / ps.W;
+    const int iy = (int)(q % ps.H);
+    const int64_t n = q / ps.H;
+    VecF<VEC> acc;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc.v[i] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ny = iy + ps.pt - ky;
+        if (ny < 0 || (ny & 1)) continue;
+        const int oy = ny >> 1;
+        if (oy >= ps.Ho) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int nx = ix + ps.pl - kx;
+            if (nx < 0 || (nx & 1)) continue;
+            const int ox = nx >> 1;
+            if (ox >= ps.Wo) continue;
+            const int64_t o = ((n * ps.Ho + oy) * ps.Wo + ox) * C + c0;
+            const VecF<VEC> d = vload<VEC>(ps.dp + o);
+            if (VEC == 4) {       // the 4 argmax bytes of this lane in one 32-bit load
+                const uint32_t am = *reinterpret_cast<const uint32_t*>(ps.argmax + o);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (((am >> (8 * i)) & 0xffu) == (uint32_t)(ky * 3 + kx)) acc.v[i] += d.v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (ps.argmax[o + i] == (uint8_t)(ky * 3 + kx)) acc.v[i] += d.v[i];
+            }
+        }
+    }
+    return acc;
+}
+
 __host__ inline bool view_aligned(const View& v, int vec) {
     return (v.ld % vec == 0) && (v.coff % vec == 0) && ((reinterpret_cast<uintptr_t>(v.p) % (4 * vec)) == 0);
 }

@@ -468,6 +468,92 @@ int maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H,
     return 0;
 }
 
+// fused BN-apply + ReLU6 + max-pool: reads the RAW stem conv output, so the 255 MB activated tensor
+// is never materialised (the backward needs only y, the statistics and the argmax).
+template <int VEC>
+__global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                             int GC, int fpg, float* __restrict__ p,
+                                                             uint8_t* __restrict__ argmax, int rows, int H, int W, int Ho,
+                                                             int Wo, int C, int pt, int pl, int rb, int nloop) {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int r0 = blockIdx.x * rb;
+    const int r1 = min(r0 + rb, rows);
+    for (int l = 0; l < nloop; ++l) {
+        const int c0 = (l * CX + tx) * VEC;
+        if (c0 >= C) continue;
+        for (int r = r0 + ty; r < r1; r += CY) {
+            const int ox = r % Wo;
+            const int q = r / Wo;
+            const int oy = q % Ho;
+            const int n = q / Ho;
+            const int g = n / fpg;
+            const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
+            VecF<VEC> best;
+            int bi[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                best.v[i] = -INFINITY;
+                bi[i] = 0;
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * 2 + ky - pt;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * 2 + kx - pl;
+                    if (ix < 0 || ix >= W) continue;
+                    const VecF<VEC> x = vload<VEC>(y + (((int64_t)n * H + iy) * W + ix) * C + c0);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float a = fminf(fmaxf(fmaf(sc.v[i], x.v[i], sh.v[i]), 0.0f), 6.0f);
+                        if (a > best.v[i]) {
+                            best.v[i] = a;
+                            bi[i] = ky * 3 + kx;
+                        }
+                    }
+                }
+            }
+            vstore<VEC>(p + (int64_t)r * C + c0, best);
+            if (VEC == 4) {
+                *reinterpret_cast<uint32_t*>(argmax + (int64_t)r * C + c0) =
+                    (uint32_t)bi[0] | ((uint32_t)bi[1 % VEC] << 8) | ((uint32_t)bi[2 % VEC] << 16) | ((uint32_t)bi[3 % VEC] << 24);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) argmax[(int64_t)r * C + c0 + i] = (uint8_t)bi[i];
+            }
+        }
+    }
+}
+
+int maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax, int N,
+                   int H, int W, int C, hipStream_t st) {
+    const int Ho = same_out(H, 2), Wo = same_out(W, 2);
+    const int rows = N * Ho * Wo;
+    VColGeom g = vcol_geom(rows, C, 4096);
+    dim3 grid(g.nb), block(g.cx, g.cy);
+    const int pt = same_pad_before(H, 2), pl = same_pad_before(W, 2);
+    if (g.vec == 4) hipLaunchKernelGGL(maxpool_bn_fwd_kernel<4>, grid, block, 0, st, y, stats, G * C, frames_per_group, p, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
+    else if (g.vec == 2) hipLaunchKernelGGL(maxpool_bn_fwd_kernel<2>, grid, block, 0, st, y, stats, G * C, frames_per_group, p, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
+    else hipLaunchKernelGGL(maxpool_bn_fwd_kernel<1>, grid, block, 0, st, y, stats, G * C, frames_per_group, p, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+PoolSrc make_pool_src(const uint8_t* argmax, const float* dp, int H, int W) {
+    PoolSrc ps;
+    ps.argmax = argmax;
+    ps.dp = dp;
+    ps.H = H;
+    ps.W = W;
+    ps.Ho = same_out(H, 2);
+    ps.Wo = same_out(W, 2);
+    ps.pt = same_pad_before(H, 2);
+    ps.pl = same_pad_before(W, 2);
+    return ps;
+}
+
 // ------------------------------------------------------------------------------------------
 // GlobalAveragePooling2D (reference core/architectures.py:172)
 // ------------------------------------------------------------------------------------------

@@ -302,7 +302,6 @@ void Learner::build_trunk(std::vector<Op>& ops) {
     // ---- stem (core/architectures.py:159-161)
     {
         Tens y = tens(N * Hs * Ws, c.stem, false);
-        Tens a = tens(N * Hs * Ws, c.stem);
         PRef w = param(M_TRUNK, "img.stem.conv.w", {3, 3, 3, c.stem}, true);
         PRef b = param(M_TRUNK, "img.stem.conv.b", {c.stem}, true);
         note_scratch((size_t)stem_bwd_part_elems(B, T, c.H, c.W, c.stem), 0, (size_t)N * Hs * Ws * c.stem, 0);
@@ -311,14 +310,38 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         op.fwd = [=](hipStream_t st, int) -> int { return stem_fwd(in_image_, w.p, b.p, y.p, B, T, H, W, Cs, st); };
         op.bwd = [=](hipStream_t st) -> int { return stem_bwd_filter(in_image_, dy_, w.g, b.g, B, T, H, W, Cs, part_, st); };
         ops.push_back(op);
-        add_bn(ops, M_TRUNK, "img.stem.bn", y.v(), T, B * Hs * Ws, c.stem, true, ACT_RELU6, a.v(), 0, a.gv(), 0, dy_);
+        // stem BN + ReLU6 + max-pool as one fused block: the BN op only produces statistics in the forward
+        // (no apply), the pool kernel applies scale/shift/ReLU6 on the raw conv output while pooling, and the
+        // BN backward gathers its incoming gradient straight from the pooled gradient through the argmax.
         const int Hp = same_out_h(Hs, 2), Wp = same_out_h(Ws, 2);
         Tens pool = tens(N * Hp * Wp, c.stem);
         uint8_t* argmax = reinterpret_cast<uint8_t*>(alloc(((size_t)N * Hp * Wp * c.stem + 3) / 4));
-        Op mp;
-        mp.fwd = [=](hipStream_t st, int) -> int { return maxpool_fwd(a.p, pool.p, argmax, N, Hs, Ws, Cs, st); };
-        mp.bwd = [=](hipStream_t st) -> int { return maxpool_bwd(argmax, pool.g, a.g, N, Hs, Ws, Cs, st); };
-        ops.push_back(mp);
+        {
+            const int G = T, Mg = B * Hs * Ws, C = c.stem;
+            PRef gamma = param(M_TRUNK, "img.stem.bn.gamma", {C}, true);
+            PRef beta = param(M_TRUNK, "img.stem.bn.beta", {C}, true);
+            PRef mm = param(M_TRUNK, "img.stem.bn.moving_mean", {C}, false);
+            PRef mv = param(M_TRUNK, "img.stem.bn.moving_var", {C}, false);
+            float* stats = alloc((size_t)4 * G * C);
+            float* coef = alloc((size_t)3 * G * C);
+            const int nb = vcol_geom(Mg, C).nb;
+            note_scratch((size_t)G * nb * 2 * C, (size_t)G * nb * C, 0, 0);
+            View yv = y.v();
+            Op bn;
+            bn.fwd = [=](hipStream_t st, int training) -> int {
+                if (training) CDRL_TRY(colstats(yv, G, Mg, C, part_, st));
+                CDRL_TRY(bn_finalize(part_, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, 1, training, stats, st));
+                return maxpool_bn_fwd(y.p, stats, G, B, pool.p, argmax, N, Hs, Ws, C, st);
+            };
+            bn.bwd = [=](hipStream_t st) -> int {
+                PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
+                View none{nullptr, 0, 0};
+                CDRL_TRY(bn_bwd_reduce(none, 0, yv, G, Mg, C, stats, ACT_RELU6, part_, st, &ps));
+                CDRL_TRY(bn_bwd_finalize(part_, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
+                return bn_bwd_apply(none, 0, yv, G, Mg, C, stats, coef, ACT_RELU6, dy_, part2_, st, &ps);
+            };
+            ops.push_back(bn);
+        }
 
         // ---- stages (core/architectures.py:120-151,164-167)
         Tens X = pool;

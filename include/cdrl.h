@@ -188,6 +188,14 @@ int cdrl_bn_train_fwd(const float* y, int G, int Mg, int C, const float* gamma, 
 int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, const float* y, int G, int Mg,
                       int C, const float* stats, int relu6, float* dgamma, float* dbeta, float* dy, float* coef,
                       double* workspace, void* stream);
+/* Fused stem block (core/architectures.py:160-161): BatchNorm-apply + ReLU6 + MaxPooling2D(3,2,'same') on the
+ * raw conv output (stats from cdrl_bn_train_fwd), and the BatchNorm backward that gathers its incoming
+ * gradient from the pooled gradient `dp` through the saved argmax. */
+int cdrl_maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax,
+                        int N, int H, int W, int C, void* stream);
+int cdrl_bn_train_bwd_pooled(const uint8_t* argmax, const float* dp, int H, int W, const float* y, int G, int Mg, int C,
+                             const float* stats, float* dgamma, float* dbeta, float* dy, float* coef, double* workspace,
+                             void* stream);
 /* CARLAgent.policy_objective / value_objective on linear head outputs (core/carla_agent.py:394-428,
  * 469-486); writes d(loss)/d(lin) and 16 metric floats. */
 int cdrl_beta_ppo_loss(const float* lin, const float* adv, const float* old_logp, const float* speed,

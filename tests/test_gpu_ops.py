@@ -192,6 +192,47 @@ def test_bn_train(lib, G, Mg, Cc, relu, shuffle):
     assert rel_err(dy.cpu().numpy(), yt.grad[:, 0].permute(0, 2, 1).reshape(G * Mg, Cc).numpy()) < 2e-5
 
 
+@pytest.mark.parametrize('B,T,H,W', [(3, 4, 21, 28), (2, 2, 44, 59)])
+def test_fused_stem_block(lib, B, T, H, W):
+    """BN(train, per time slice) + ReLU6 + max-pool fused forward, and the BN backward that pulls its
+    gradient through the pool argmax: against torch autograd of the unfused composition."""
+    Cc, N = 24, B * T
+    rng = np.random.default_rng(H * W)
+    y = (rng.standard_normal((T, B, H, W, Cc)) * 1.5 + 0.3).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, Cc).astype(np.float32)
+    gamma[::5] *= -1.0                                    # negative scale: max must be taken AFTER the affine
+    beta = rng.uniform(-0.5, 0.5, Cc).astype(np.float32)
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    p = {'b.gamma': torch.tensor(gamma, dtype=torch.float64).requires_grad_(True),
+         'b.beta': torch.tensor(beta, dtype=torch.float64).requires_grad_(True),
+         'b.moving_mean': torch.zeros(Cc, dtype=torch.float64), 'b.moving_var': torch.ones(Cc, dtype=torch.float64)}
+    yt = torch.tensor(y, dtype=torch.float64).permute(0, 1, 4, 2, 3).requires_grad_(True)     # (T,B,C,H,W)
+    a = OM.relu6(OM.bn_slices(yt, p, 'b', True, True))
+    ph, pw = OM.same_pad(H, 3, 2), OM.same_pad(W, 3, 2)
+    ref = F.max_pool2d(F.pad(a.reshape(N, Cc, H, W), (pw[0], pw[1], ph[0], ph[1]), value=float('-inf')), 3, 2)
+    G, Mg = T, B * H * W
+    Y, Gm, Bt = dev(y.reshape(N, H, W, Cc)), dev(gamma), dev(beta)
+    MM, MV = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    stats = torch.zeros(4 * G * Cc, device=DEV)
+    ws = torch.zeros(G * 256 * 2 * Cc, dtype=torch.float64, device=DEV)
+    scratch = torch.zeros((N * H * W, Cc), device=DEV)
+    _lib.check(lib.cdrl_bn_train_fwd(P(Y), G, Mg, Cc, P(Gm), P(Bt), P(MM), P(MV), 1, 1, P(scratch), Cc, 0, 0, P(stats), P(ws), S()))
+    pool = torch.zeros((N, Ho, Wo, Cc), device=DEV)
+    am = torch.zeros((N, Ho, Wo, Cc), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cdrl_maxpool_bn_fwd(P(Y), P(stats), G, B, P(pool), P(am), N, H, W, Cc, S()))
+    assert rel_err(pool.cpu().numpy(), ref.detach().permute(0, 2, 3, 1).numpy()) < 1e-5
+    dp = rng.standard_normal((N, Ho, Wo, Cc)).astype(np.float32)
+    ref.backward(torch.tensor(dp, dtype=torch.float64).permute(0, 3, 1, 2))
+    DP = dev(dp)
+    dg, dbt = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    dy = torch.zeros((N * H * W, Cc), device=DEV)
+    coef = torch.zeros(3 * G * Cc, device=DEV)
+    _lib.check(lib.cdrl_bn_train_bwd_pooled(P(am), P(DP), H, W, P(Y), G, Mg, Cc, P(stats), P(dg), P(dbt), P(dy), P(coef), P(ws), S()))
+    assert rel_err(dg.cpu().numpy(), p['b.gamma'].grad.numpy()) < 1e-5
+    assert rel_err(dbt.cpu().numpy(), p['b.beta'].grad.numpy()) < 1e-5
+    assert rel_err(dy.cpu().numpy(), yt.grad.permute(0, 1, 3, 4, 2).reshape(N * H * W, Cc).numpy()) < 2e-5
+
+
 @pytest.mark.parametrize('B,A,faithful', [(256, 2, True), (37, 3, False), (1024, 2, True)])
 def test_policy_loss(lib, B, A, faithful):
     rng = np.random.default_rng(B + A)
