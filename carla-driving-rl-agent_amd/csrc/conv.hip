@@ -21,10 +21,46 @@ __host__ __device__ inline int same_pad_before(int n, int s) {
 // stem: Conv2D(24, 3, strides=2, 'valid') on the (B,T,H,W,3) observation tensor
 // (reference core/architectures.py:159).  Output frame index = t*B + b.
 // ------------------------------------------------------------------------------------------
+// each thread computes 4 consecutive output channels of one pixel: the 27 input taps are loaded once
+// per 4 outputs, weights come from LDS as float4, the store is one 16-byte access.
 __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y, int B,
                                                        int T, int H, int W, int Ho, int Wo, int Cout) {
     extern __shared__ float ws[];      // [27][Cout] + [Cout]
+    for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) ws[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) ws[27 * Cout + i] = bias[i];
+    __syncthreads();
+    const int C4 = Cout >> 2;
+    const int64_t total = (int64_t)B * T * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % C4) * 4;
+        int64_t pix = i / C4;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int f = (int)(pix / Ho);
+        const int t = f / B, b = f % B;
+        const float* xp = x + ((((int64_t)b * T + t) * H + 2 * oy) * W + 2 * ox) * 3;
+        float4 acc = *reinterpret_cast<const float4*>(&ws[27 * Cout + co]);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {          // 3 pixels x 3 channels are contiguous in the input row
+                const float xv = xp[(int64_t)ky * W * 3 + j];
+                const float4 wv = *reinterpret_cast<const float4*>(&ws[(ky * 9 + j) * Cout + co]);
+                acc.x = fmaf(xv, wv.x, acc.x);
+                acc.y = fmaf(xv, wv.y, acc.y);
+                acc.z = fmaf(xv, wv.z, acc.z);
+                acc.w = fmaf(xv, wv.w, acc.w);
+            }
+        *reinterpret_cast<float4*>(&y[(i / C4) * Cout + co]) = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) stem_fwd_scalar_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int B, int T, int H, int W, int Ho, int Wo, int Cout) {
+    extern __shared__ float ws[];
     for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) ws[i] = w[i];
     for (int i = threadIdx.x; i < Cout; i += blockDim.x) ws[27 * Cout + i] = bias[i];
     __syncthreads();
@@ -42,10 +78,7 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int ci = 0; ci < 3; ++ci)
-                    acc = fmaf(xp[((int64_t)ky * W + kx) * 3 + ci], ws[((ky * 3 + kx) * 3 + ci) * Cout + co], acc);
+            for (int j = 0; j < 9; ++j) acc = fmaf(xp[(int64_t)ky * W * 3 + j], ws[(ky * 9 + j) * Cout + co], acc);
         y[i] = acc;
     }
 }
@@ -53,12 +86,17 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
 int stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
              hipStream_t st) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    const int64_t total = (int64_t)B * T * Ho * Wo * Cout;
-    int64_t nb = cdiv64(total, 256 * 4);
-    if (nb > 8192) nb = 8192;
+    const bool v4 = (Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    const int64_t total = (int64_t)B * T * Ho * Wo * (v4 ? Cout / 4 : Cout);
+    int64_t nb = cdiv64(total, 256 * 2);
+    if (nb > 16384) nb = 16384;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)nb), dim3(256), (27 * Cout + Cout) * sizeof(float), st, x, w, bias,
-                       y, B, T, H, W, Ho, Wo, Cout);
+    const size_t lds = (27 * Cout + Cout) * sizeof(float);
+    if (v4)
+        hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)nb), dim3(256), lds, st, x, w, bias, y, B, T, H, W, Ho, Wo, Cout);
+    else
+        hipLaunchKernelGGL(stem_fwd_scalar_kernel, dim3((unsigned)nb), dim3(256), lds, st, x, w, bias, y, B, T, H, W, Ho, Wo,
+                           Cout);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -113,25 +151,29 @@ __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restr
     for (int base = r0; base < r1; base += 128) {
         const int wrow0 = base + wave * 32;
         __syncthreads();
-        // patch tile: 32 rows x 28 (27 taps + ones column)
-        for (int idx = lane; idx < 32 * 28; idx += 64) {
-            const int r = idx / 28, j = idx - r * 28;
+        // patch tile: 32 rows x 28 (27 taps + ones column).  Lane l owns row (l & 31) and the 14 columns
+        // [14*(l>>5), 14*(l>>5)+14): ONE row decode per lane per slice, tap offsets are compile-time constants.
+        {
+            const int r = lane & 31, half = lane >> 5;
             const int row = wrow0 + r;
-            float v = 0.0f;
-            if (row < r1) {
-                if (j == 27) {
-                    v = 1.0f;
-                } else {
-                    const int ox = row % Wo;
-                    const int q = row / Wo;
-                    const int oy = q % Ho;
-                    const int f = q / Ho;
-                    const int t = f / B, b = f - t * B;
-                    const int ky = j / 9, rem = j - ky * 9;
-                    v = x[((((int64_t)b * T + t) * H + 2 * oy + ky) * W + 2 * ox) * 3 + rem];
-                }
+            const bool ok = row < r1;
+            const float* xp = x;
+            if (ok) {
+                const int ox = row % Wo;
+                const int q = row / Wo;
+                const int oy = q % Ho;
+                const int f = q / Ho;
+                const int t = f / B, b = f - t * B;
+                xp = x + ((((int64_t)b * T + t) * H + 2 * oy) * W + 2 * ox) * 3;
             }
-            P[wave][r][j] = v;
+#pragma unroll
+            for (int jj = 0; jj < 14; ++jj) {
+                const int64_t o0 = (int64_t)(jj / 9) * W * 3 + (jj % 9);
+                const int64_t o1 = (int64_t)((14 + jj) / 9) * W * 3 + ((14 + jj) % 9);
+                float val = 0.0f;
+                if (ok) val = (half && jj == 13) ? 1.0f : xp[half ? o1 : o0];
+                P[wave][r][half * 14 + jj] = val;
+            }
         }
         for (int idx = lane; idx < 32 * Cout; idx += 64) {
             const int r = idx / Cout, c = idx - r * Cout;
