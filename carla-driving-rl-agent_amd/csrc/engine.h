@@ -131,17 +131,18 @@ private:
     void build_trunk(std::vector<Op>& ops);
     void build_head(std::vector<Op>& ops, int model, const std::string& prefix, Tens& lin, int nheads,
                     const int* head_dims, const char* const* head_names);
+    // dx == nullptr: tower mode, the gradient w.r.t. the BN input goes to the current scratch slot
     BnRec add_bn(std::vector<Op>& ops, int model, const std::string& prefix, View x, int G, int Mg, int C, bool bessel,
                  int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx);
     void add_pw(std::vector<Op>& ops, const std::string& prefix, View in, int rows, int Cin, int Cout, float* y,
-                float* dy, View din, int din_acc, BnRec bn_after);
+                View din, int din_acc, BnRec bn_after);
     void add_dw(std::vector<Op>& ops, const std::string& prefix, View in, int N, int H, int W, int C, int stride,
-                float* y, float* dy, View din, int din_acc);
+                float* y, View din, int din_acc);
     void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
                    View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);
     void add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,
                  bool need_dx);
-    void note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn_f);
+    void note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn_f, size_t fpart_d = 0);
 
     int run_fwd(std::vector<Op>& ops, hipStream_t st, int training);
     int run_bwd(std::vector<Op>& ops, hipStream_t st);
@@ -158,9 +159,29 @@ private:
     char* ws_base_ = nullptr;
     size_t ws_off_ = 0, ws_bytes_ = 0;
     // scratch maxima (from the dry build) and pointers
-    size_t max_part_ = 0, max_part2_ = 0, max_dy_ = 0, max_tn_ = 0;
+    size_t max_part_ = 0, max_part2_ = 0, max_dy_ = 0, max_tn_ = 0, max_fpart_ = 0;
     double *part_ = nullptr, *part2_ = nullptr;
     float *dy_ = nullptr, *tn_part_ = nullptr;
+    // Backward-pass side stream: the filter / bias gradients of the tower (gemm_tn, depthwise and stem
+    // filter reductions, db) are off the critical path dy -> bwd-data -> next layer, so they run on a
+    // second HIP stream and overlap the latency-bound main chain.  NSLOT rotating scratch sets
+    // (dy, db partials, split-M partials, filter partials) + events make the hand-off race-free.
+    static constexpr int NSLOT = 4;
+    float* dys_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    double* part2s_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    float* tns_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    double* fparts_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side_ = nullptr;
+    hipEvent_t ev_main_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_side_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_join_ = nullptr;
+    bool side_enabled_ = true;
+    bool slot_used_[NSLOT] = {false, false, false, false};
+    int slot_ = 0;
+    int next_slot(hipStream_t st);                       // main: claim a scratch slot (waits for its last side job)
+    hipStream_t fork_side(hipStream_t st);               // main -> side dependency for the current slot
+    int done_side(hipStream_t side);                     // side job of the current slot finished
+    int join_side(hipStream_t st);
 
     std::vector<Op> trunk_ops_, policy_ops_, value_ops_, old_policy_ops_;
     // live input pointers (read by the first ops through these slots)

@@ -12,7 +12,10 @@
 // (ld, channel offset) plus a destination-index permutation in the BN-apply store (F7).
 #include "engine.h"
 
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 namespace cdrl {
 
@@ -38,6 +41,40 @@ Learner::Learner(const Config& cfg) : cfg_(cfg) {
 
 Learner::~Learner() {
     if (hp_stage_) (void)hipHostFree(hp_stage_);
+    for (int i = 0; i < NSLOT; ++i) {
+        if (ev_main_[i]) (void)hipEventDestroy(ev_main_[i]);
+        if (ev_side_[i]) (void)hipEventDestroy(ev_side_[i]);
+    }
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (side_) (void)hipStreamDestroy(side_);
+}
+
+int Learner::next_slot(hipStream_t st) {
+    slot_ = (slot_ + 1) % NSLOT;
+    if (side_enabled_ && slot_used_[slot_]) CDRL_HIP(hipStreamWaitEvent(st, ev_side_[slot_], 0));
+    return 0;
+}
+
+hipStream_t Learner::fork_side(hipStream_t st) {
+    if (!side_enabled_) return st;
+    if (hipEventRecord(ev_main_[slot_], st) != hipSuccess) return st;
+    if (hipStreamWaitEvent(side_, ev_main_[slot_], 0) != hipSuccess) return st;
+    return side_;
+}
+
+int Learner::done_side(hipStream_t side) {
+    if (!side_enabled_ || side != side_) return 0;
+    CDRL_HIP(hipEventRecord(ev_side_[slot_], side_));
+    slot_used_[slot_] = true;
+    return 0;
+}
+
+int Learner::join_side(hipStream_t st) {
+    if (!side_enabled_) return 0;
+    CDRL_HIP(hipEventRecord(ev_join_, side_));
+    CDRL_HIP(hipStreamWaitEvent(st, ev_join_, 0));
+    for (int i = 0; i < NSLOT; ++i) slot_used_[i] = false;
+    return 0;
 }
 
 int64_t Learner::tr_offset(int model) const {
@@ -129,11 +166,12 @@ Learner::PRef Learner::param(int model, const std::string& name, std::initialize
     return r;
 }
 
-void Learner::note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn_f) {
+void Learner::note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn_f, size_t fpart_d) {
     if (part_d > max_part_) max_part_ = part_d;
     if (part2_d > max_part2_) max_part2_ = part2_d;
     if (dy_f > max_dy_) max_dy_ = dy_f;
     if (tn_f > max_tn_) max_tn_ = tn_f;
+    if (fpart_d > max_fpart_) max_fpart_ = fpart_d;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -160,14 +198,16 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     op.bwd = [=](hipStream_t st) -> int {
         CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, part_, st));
         CDRL_TRY(bn_bwd_finalize(part_, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
-        return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, part2_, st);
+        if (dx) return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, part2_, st);
+        CDRL_TRY(next_slot(st));       // tower: dy + db partials go to a rotating scratch slot
+        return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dys_[slot_], part2s_[slot_], st);
     };
     ops.push_back(op);
     return rec;
 }
 
 void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, int rows, int Cin, int Cout, float* y,
-                     float* dy, View din, int din_acc, BnRec bn_after) {
+                     View din, int din_acc, BnRec bn_after) {
     PRef w = param(M_TRUNK, prefix + ".w", {1, 1, Cin, Cout}, true);
     PRef b = param(M_TRUNK, prefix + ".b", {Cout}, true);
     note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin));
@@ -176,25 +216,33 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         return gemm_nn(in, w.p, Cout, 1, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
     };
     op.bwd = [=](hipStream_t st) -> int {
-        // bias gradient = column sums of dy, already reduced per block by bn_bwd_apply
-        CDRL_TRY(reduce_partials(part2_, bn_after.G * bn_after.nb, Cout, Cout, b.g, 0, st));
+        float* dy = dys_[slot_];
+        // side stream: bias gradient (column sums of dy, reduced per block by bn_bwd_apply) + filter gradient
+        hipStream_t side = fork_side(st);
+        CDRL_TRY(reduce_partials(part2s_[slot_], bn_after.G * bn_after.nb, Cout, Cout, b.g, 0, side));
+        CDRL_TRY(gemm_tn(in, make_view(dy, Cout), w.g, rows, Cout, Cin, tns_[slot_], 0, side));
+        CDRL_TRY(done_side(side));
+        // main stream: the critical path to the previous layer
         if (din.p) CDRL_TRY(gemm_nn(make_view(dy, Cout), w.p, 1, Cout, nullptr, din, rows, Cin, Cout, din_acc, st));
-        return gemm_tn(in, make_view(dy, Cout), w.g, rows, Cout, Cin, tn_part_, 0, st);
+        return 0;
     };
     ops.push_back(op);
 }
 
 void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, int N, int H, int W, int C, int stride,
-                     float* y, float* dy, View din, int din_acc) {
+                     float* y, View din, int din_acc) {
     PRef w = param(M_TRUNK, prefix + ".w", {3, 3, C, 1}, true);
     PRef b = param(M_TRUNK, prefix + ".b", {C}, true);
     const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
-    note_scratch((size_t)dw_bwd_part_elems(N, H, W, C, stride), 0, (size_t)N * Ho * Wo * C, 0);
+    note_scratch(0, 0, (size_t)N * Ho * Wo * C, 0, (size_t)dw_bwd_part_elems(N, H, W, C, stride));
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int { return dw_fwd(in, w.p, b.p, y, N, H, W, C, stride, st); };
     op.bwd = [=](hipStream_t st) -> int {
-        CDRL_TRY(dw_bwd_data(dy, w.p, din, N, H, W, C, stride, din_acc, st));
-        return dw_bwd_filter(in, dy, w.g, b.g, N, H, W, C, stride, part_, st);
+        float* dy = dys_[slot_];
+        hipStream_t side = fork_side(st);
+        CDRL_TRY(dw_bwd_filter(in, dy, w.g, b.g, N, H, W, C, stride, fparts_[slot_], side));
+        CDRL_TRY(done_side(side));
+        return dw_bwd_data(dy, w.p, din, N, H, W, C, stride, din_acc, st);
     };
     ops.push_back(op);
 }
@@ -304,11 +352,15 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         Tens y = tens(N * Hs * Ws, c.stem, false);
         PRef w = param(M_TRUNK, "img.stem.conv.w", {3, 3, 3, c.stem}, true);
         PRef b = param(M_TRUNK, "img.stem.conv.b", {c.stem}, true);
-        note_scratch((size_t)stem_bwd_part_elems(B, T, c.H, c.W, c.stem), 0, (size_t)N * Hs * Ws * c.stem, 0);
+        note_scratch(0, 0, (size_t)N * Hs * Ws * c.stem, 0, (size_t)stem_bwd_part_elems(B, T, c.H, c.W, c.stem));
         Op op;
         const int H = c.H, W = c.W, Cs = c.stem;
         op.fwd = [=](hipStream_t st, int) -> int { return stem_fwd(in_image_, w.p, b.p, y.p, B, T, H, W, Cs, st); };
-        op.bwd = [=](hipStream_t st) -> int { return stem_bwd_filter(in_image_, dy_, w.g, b.g, B, T, H, W, Cs, part_, st); };
+        op.bwd = [=](hipStream_t st) -> int {
+            hipStream_t side = fork_side(st);
+            CDRL_TRY(stem_bwd_filter(in_image_, dys_[slot_], w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side));
+            return done_side(side);
+        };
         ops.push_back(op);
         // stem BN + ReLU6 + max-pool as one fused block: the BN op only produces statistics in the forward
         // (no apply), the pool kernel applies scale/shift/ReLU6 on the raw conv output while pooling, and the
@@ -338,7 +390,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 View none{nullptr, 0, 0};
                 CDRL_TRY(bn_bwd_reduce(none, 0, yv, G, Mg, C, stats, ACT_RELU6, part_, st, &ps));
                 CDRL_TRY(bn_bwd_finalize(part_, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
-                return bn_bwd_apply(none, 0, yv, G, Mg, C, stats, coef, ACT_RELU6, dy_, part2_, st, &ps);
+                CDRL_TRY(next_slot(st));
+                return bn_bwd_apply(none, 0, yv, G, Mg, C, stats, coef, ACT_RELU6, dys_[slot_], part2s_[slot_], st, &ps);
             };
             ops.push_back(bn);
         }
@@ -369,25 +422,25 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     ops.push_back(cp);
                 }
                 Tens y1 = tens(rows_in, mid, false), a1 = tens(rows_in, mid);
-                add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, dy_, X.gv(main_off),
+                add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off),
                        stride == 2 ? 1 : 0, bnrec(T, Mg_in, mid));
-                add_bn(ops, M_TRUNK, pre + ".bn1", y1.v(), T, Mg_in, mid, true, ACT_RELU6, a1.v(), 0, a1.gv(), 0, dy_);
+                add_bn(ops, M_TRUNK, pre + ".bn1", y1.v(), T, Mg_in, mid, true, ACT_RELU6, a1.v(), 0, a1.gv(), 0, nullptr);
                 Tens y2 = tens(rows_out, mid, false), a2 = tens(rows_out, mid);
-                add_dw(ops, pre + ".dw", a1.v(), N, curH, curW, mid, stride, y2.p, dy_, a1.gv(), 0);
-                add_bn(ops, M_TRUNK, pre + ".bn2", y2.v(), T, Mg_out, mid, true, ACT_NONE, a2.v(), 0, a2.gv(), 0, dy_);
+                add_dw(ops, pre + ".dw", a1.v(), N, curH, curW, mid, stride, y2.p, a1.gv(), 0);
+                add_bn(ops, M_TRUNK, pre + ".bn2", y2.v(), T, Mg_out, mid, true, ACT_NONE, a2.v(), 0, a2.gv(), 0, nullptr);
                 Tens y3 = tens(rows_out, main_out, false);
-                add_pw(ops, pre + ".pw2", a2.v(), rows_out, mid, main_out, y3.p, dy_, a2.gv(), 0, bnrec(T, Mg_out, main_out));
+                add_pw(ops, pre + ".pw2", a2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out));
                 add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C,
-                       out.gv(sc_c), C, dy_);
+                       out.gv(sc_c), C, nullptr);
                 if (stride == 2) {
                     Tens ys1 = tens(rows_out, sc_c, false), b1 = tens(rows_out, sc_c);
-                    add_dw(ops, pre + ".sc_dw", X.v(0), N, curH, curW, sc_c, 2, ys1.p, dy_, X.gv(0), 0);
+                    add_dw(ops, pre + ".sc_dw", X.v(0), N, curH, curW, sc_c, 2, ys1.p, X.gv(0), 0);
                     add_bn(ops, M_TRUNK, pre + ".sc_bn1", ys1.v(), T, Mg_out, sc_c, true, ACT_NONE, b1.v(), 0, b1.gv(), 0,
-                           dy_);
+                           nullptr);
                     Tens ys2 = tens(rows_out, sc_c, false);
-                    add_pw(ops, pre + ".sc_pw", b1.v(), rows_out, sc_c, sc_c, ys2.p, dy_, b1.gv(), 0, bnrec(T, Mg_out, sc_c));
+                    add_pw(ops, pre + ".sc_pw", b1.v(), rows_out, sc_c, sc_c, ys2.p, b1.gv(), 0, bnrec(T, Mg_out, sc_c));
                     add_bn(ops, M_TRUNK, pre + ".sc_bn2", ys2.v(), T, Mg_out, sc_c, true, ACT_RELU6, out.v(0), C, out.gv(0),
-                           C, dy_);
+                           C, nullptr);
                 }
                 X = out;
                 curH = Ho;
@@ -398,8 +451,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         // ---- head conv + GAP (core/architectures.py:170-172)
         const int P = curH * curW, rows = N * P;
         Tens yh = tens(rows, c.last, false), ah = tens(rows, c.last);
-        add_pw(ops, "img.head.conv", X.v(), rows, curC, c.last, yh.p, dy_, X.gv(), 0, bnrec(T, B * P, c.last));
-        add_bn(ops, M_TRUNK, "img.head.bn", yh.v(), T, B * P, c.last, true, ACT_RELU6, ah.v(), 0, ah.gv(), 0, dy_);
+        add_pw(ops, "img.head.conv", X.v(), rows, curC, c.last, yh.p, X.gv(), 0, bnrec(T, B * P, c.last));
+        add_bn(ops, M_TRUNK, "img.head.bn", yh.v(), T, B * P, c.last, true, ACT_RELU6, ah.v(), 0, ah.gv(), 0, nullptr);
         feat_ = tens(N, c.last);
         Tens feat = feat_;
         const int Cl = c.last;
@@ -478,8 +531,14 @@ void Learner::build(bool dry) {
     if (!dry) {
         part_ = alloc_d(max_part_);
         part2_ = alloc_d(max_part2_);
-        dy_ = alloc(max_dy_);
+        dy_ = nullptr;
         tn_part_ = alloc(max_tn_);
+        for (int i = 0; i < NSLOT; ++i) {
+            dys_[i] = alloc(max_dy_);
+            part2s_[i] = alloc_d(max_part2_);
+            tns_[i] = alloc(max_tn_);
+            fparts_[i] = alloc_d(max_fpart_);
+        }
     }
     build_trunk(trunk_ops_);
     const int A = cfg_.A;
@@ -514,7 +573,9 @@ void Learner::build(bool dry) {
     if (dry) {
         // scratch goes first in the real layout; account for it here
         ws_off_ += align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
-                   align_up(max_dy_ * sizeof(float), 256) + align_up(max_tn_ * sizeof(float), 256);
+                   align_up(max_tn_ * sizeof(float), 256) +
+                   NSLOT * (align_up(max_dy_ * sizeof(float), 256) + align_up(max_part2_ * sizeof(double), 256) +
+                            align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256));
         ws_bytes_ = ws_off_ + 4096;
     }
 }
@@ -572,6 +633,16 @@ int Learner::bind(const Buffers& b) {
         return -1;
     }
     CDRL_TRY(upload_seg_tables());
+    if (!side_) {
+        const char* env = getenv("CDRL_SIDE_STREAM");
+        side_enabled_ = !(env && atoi(env) == 0);
+        CDRL_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+        for (int i = 0; i < NSLOT; ++i) {
+            CDRL_HIP(hipEventCreateWithFlags(&ev_main_[i], hipEventDisableTiming));
+            CDRL_HIP(hipEventCreateWithFlags(&ev_side_[i], hipEventDisableTiming));
+        }
+        CDRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
     if (!hp_stage_) CDRL_HIP(hipHostMalloc(reinterpret_cast<void**>(&hp_stage_), sizeof(DevHP), 0));
     CDRL_HIP(hipMemcpy(hp_dev_, &hp_host_, sizeof(DevHP), hipMemcpyHostToDevice));
     return 0;
@@ -652,7 +723,8 @@ int Learner::policy_backward(const PolicyBatch& b, float inv_world, hipStream_t 
     a.inv_world = inv_world;
     CDRL_TRY(policy_loss(a, st));
     CDRL_TRY(run_bwd(policy_ops_, st));
-    return run_bwd(trunk_ops_, st);
+    CDRL_TRY(run_bwd(trunk_ops_, st));
+    return join_side(st);
 }
 
 int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipStream_t st) {
@@ -679,7 +751,8 @@ int Learner::value_forward_backward(const ValueBatch& b, float inv_world, hipStr
     a.inv_world = inv_world;
     CDRL_TRY(value_loss(a, st));
     CDRL_TRY(run_bwd(value_ops_, st));
-    return run_bwd(trunk_ops_, st);
+    CDRL_TRY(run_bwd(trunk_ops_, st));
+    return join_side(st);
 }
 
 int Learner::update_old_policy(hipStream_t st) {
