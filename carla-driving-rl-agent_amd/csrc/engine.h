@@ -160,8 +160,19 @@ private:
     size_t ws_off_ = 0, ws_bytes_ = 0;
     // scratch maxima (from the dry build) and pointers
     size_t max_part_ = 0, max_part2_ = 0, max_dy_ = 0, max_tn_ = 0, max_fpart_ = 0;
-    double *part_ = nullptr, *part2_ = nullptr;
-    float *dy_ = nullptr, *tn_part_ = nullptr;
+    // reduction scratch of the ops on the main stream / of the auxiliary ops (feature nets + small GRUs),
+    // which run concurrently on the side stream and therefore need their own
+    struct Scratch {
+        double* part = nullptr;
+        double* part2 = nullptr;
+        float* tn = nullptr;
+    };
+    Scratch scr_main_, scr_aux_;
+    Scratch* build_scr_ = &scr_main_;
+    std::vector<Op> aux_ops_;
+    hipEvent_t ev_aux_fork_ = nullptr, ev_aux_done_ = nullptr;
+    void add_aux_fork(std::vector<Op>& ops);
+    void add_aux_join(std::vector<Op>& ops);
     // Backward-pass side stream: the filter / bias gradients of the tower (gemm_tn, depthwise and stem
     // filter reductions, db) are off the critical path dy -> bwd-data -> next layer, so they run on a
     // second HIP stream and overlap the latency-bound main chain.  NSLOT rotating scratch sets

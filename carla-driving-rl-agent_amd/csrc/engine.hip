@@ -46,6 +46,8 @@ Learner::~Learner() {
         if (ev_side_[i]) (void)hipEventDestroy(ev_side_[i]);
     }
     if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (ev_aux_fork_) (void)hipEventDestroy(ev_aux_fork_);
+    if (ev_aux_done_) (void)hipEventDestroy(ev_aux_done_);
     if (side_) (void)hipStreamDestroy(side_);
 }
 
@@ -189,16 +191,17 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     note_scratch((size_t)G * nb * 2 * C, (size_t)G * nb * C, 0, 0);
     BnRec rec{G, Mg, C, nb};
     const int bes = bessel ? 1 : 0;
+    Scratch* sc = build_scr_;
     Op op;
     op.fwd = [=](hipStream_t st, int training) -> int {
-        if (training) CDRL_TRY(colstats(x, G, Mg, C, part_, st));
-        CDRL_TRY(bn_finalize(part_, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
+        if (training) CDRL_TRY(colstats(x, G, Mg, C, sc->part, st));
+        CDRL_TRY(bn_finalize(sc->part, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
         return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st);
     };
     op.bwd = [=](hipStream_t st) -> int {
-        CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, part_, st));
-        CDRL_TRY(bn_bwd_finalize(part_, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
-        if (dx) return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, part2_, st);
+        CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st));
+        CDRL_TRY(bn_bwd_finalize(sc->part, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
+        if (dx) return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, sc->part2, st);
         CDRL_TRY(next_slot(st));       // tower: dy + db partials go to a rotating scratch slot
         return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dys_[slot_], part2s_[slot_], st);
     };
@@ -258,6 +261,7 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
     }
     note_scratch((size_t)vcol_geom(M, N).nb * N, 0, 0, (size_t)gemm_tn_part_elems(M, N, K));
     const int nb = vcol_geom(M, N).nb;
+    Scratch* sc = build_scr_;
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
         if (act == ACT_NONE) return gemm_nn(in, w.p, N, 1, b.p, out, M, N, K, 0, st);
@@ -270,10 +274,10 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
             CDRL_TRY(act_bwd(z, dout.p, dz, (int64_t)M * N, act, st));
             dzv = make_view(dz, N);
         }
-        CDRL_TRY(colsum(dzv, M, N, part_, st));
-        CDRL_TRY(reduce_partials(part_, nb, N, N, b.g, 0, st));
+        CDRL_TRY(colsum(dzv, M, N, sc->part, st));
+        CDRL_TRY(reduce_partials(sc->part, nb, N, N, b.g, 0, st));
         if (need_din) CDRL_TRY(gemm_nn(dzv, w.p, 1, N, nullptr, din, M, K, N, din_acc, st));
-        return gemm_tn(in, dzv, w.g, M, N, K, tn_part_, 0, st);
+        return gemm_tn(in, dzv, w.g, M, N, K, sc->tn, 0, st);
     };
     ops.push_back(op);
 }
@@ -299,6 +303,7 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
     const int nbc = vcol_geom(T * B, U3).nb;
     View xv = x.v();
     View xg = x.gv();
+    Scratch* sc = build_scr_;
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
         CDRL_TRY(fill(Hs, (int64_t)B * u, 0.0f, st));
@@ -326,14 +331,47 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
             cur = nxt;
             nxt = tmp;
         }
-        CDRL_TRY(gemm_tn(xv, make_view(dXP, U3), Kp.g, T * B, U3, In, tn_part_, 0, st));
-        CDRL_TRY(colsum(make_view(dXP, U3), T * B, U3, part_, st));
-        CDRL_TRY(reduce_partials(part_, nbc, U3, U3, bp.g, 0, st));
-        CDRL_TRY(gemm_tn(make_view(Hs, u), make_view(dHP, U3), Rp.g, T * B, U3, u, tn_part_, 0, st));
-        CDRL_TRY(colsum(make_view(dHP, U3), T * B, U3, part_, st));
-        CDRL_TRY(reduce_partials(part_, nbc, U3, U3, bp.g + U3, 0, st));
+        CDRL_TRY(gemm_tn(xv, make_view(dXP, U3), Kp.g, T * B, U3, In, sc->tn, 0, st));
+        CDRL_TRY(colsum(make_view(dXP, U3), T * B, U3, sc->part, st));
+        CDRL_TRY(reduce_partials(sc->part, nbc, U3, U3, bp.g, 0, st));
+        CDRL_TRY(gemm_tn(make_view(Hs, u), make_view(dHP, U3), Rp.g, T * B, U3, u, sc->tn, 0, st));
+        CDRL_TRY(colsum(make_view(dHP, U3), T * B, U3, sc->part, st));
+        CDRL_TRY(reduce_partials(sc->part, nbc, U3, U3, bp.g + U3, 0, st));
         if (need_dx) CDRL_TRY(gemm_nn(make_view(dXP, U3), Kp.p, 1, U3, nullptr, xg, T * B, In, U3, 0, st));
         return 0;
+    };
+    ops.push_back(op);
+}
+
+// The road / vehicle / navigation feature nets and their GRUs are ~150 latency-bound launches that
+// do not depend on the image tower: they are enqueued on the side stream at the start of the forward
+// (fork) and joined right before the concat BatchNorm; in the backward they are forked as soon as the
+// gradient of the concat exists and run under the tower's backward.
+void Learner::add_aux_fork(std::vector<Op>& ops) {
+    Op op;
+    op.fwd = [=](hipStream_t st, int training) -> int {
+        if (!side_enabled_) return run_fwd(aux_ops_, st, training);
+        CDRL_HIP(hipEventRecord(ev_aux_fork_, st));           // parameters / inputs produced on the main stream
+        CDRL_HIP(hipStreamWaitEvent(side_, ev_aux_fork_, 0));
+        CDRL_TRY(run_fwd(aux_ops_, side_, training));
+        CDRL_HIP(hipEventRecord(ev_aux_done_, side_));
+        return 0;
+    };
+    op.bwd = [](hipStream_t) -> int { return 0; };
+    ops.push_back(op);
+}
+
+void Learner::add_aux_join(std::vector<Op>& ops) {
+    Op op;
+    op.fwd = [=](hipStream_t st, int) -> int {
+        if (side_enabled_) CDRL_HIP(hipStreamWaitEvent(st, ev_aux_done_, 0));
+        return 0;
+    };
+    op.bwd = [=](hipStream_t st) -> int {
+        if (!side_enabled_) return run_bwd(aux_ops_, st);
+        CDRL_HIP(hipEventRecord(ev_aux_fork_, st));           // gradient of the concat is ready
+        CDRL_HIP(hipStreamWaitEvent(side_, ev_aux_fork_, 0));
+        return run_bwd(aux_ops_, side_);                      // joined by join_side() at the end of the backward
     };
     ops.push_back(op);
 }
@@ -346,6 +384,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
     const int B = c.B, T = c.T, N = B * T;
     const int Hs = (c.H - 3) / 2 + 1, Ws = (c.W - 3) / 2 + 1;
     auto bnrec = [](int G, int Mg, int C) { return BnRec{G, Mg, C, vcol_geom(Mg, C).nb}; };
+    aux_ops_.clear();
+    add_aux_fork(ops);
 
     // ---- stem (core/architectures.py:159-161)
     {
@@ -381,15 +421,15 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             View yv = y.v();
             Op bn;
             bn.fwd = [=](hipStream_t st, int training) -> int {
-                if (training) CDRL_TRY(colstats(yv, G, Mg, C, part_, st));
-                CDRL_TRY(bn_finalize(part_, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, 1, training, stats, st));
+                if (training) CDRL_TRY(colstats(yv, G, Mg, C, scr_main_.part, st));
+                CDRL_TRY(bn_finalize(scr_main_.part, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, 1, training, stats, st));
                 return maxpool_bn_fwd(y.p, stats, G, B, pool.p, argmax, N, Hs, Ws, C, st);
             };
             bn.bwd = [=](hipStream_t st) -> int {
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
                 View none{nullptr, 0, 0};
-                CDRL_TRY(bn_bwd_reduce(none, 0, yv, G, Mg, C, stats, ACT_RELU6, part_, st, &ps));
-                CDRL_TRY(bn_bwd_finalize(part_, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
+                CDRL_TRY(bn_bwd_reduce(none, 0, yv, G, Mg, C, stats, ACT_RELU6, scr_main_.part, st, &ps));
+                CDRL_TRY(bn_bwd_finalize(scr_main_.part, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
                 CDRL_TRY(next_slot(st));
                 return bn_bwd_apply(none, 0, yv, G, Mg, C, stats, coef, ACT_RELU6, dys_[slot_], part2s_[slot_], st, &ps);
             };
@@ -477,14 +517,16 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             return permute_bt(src, xin.p, B, T, D, st);
         };
         pin.bwd = [](hipStream_t) -> int { return 0; };
-        ops.push_back(pin);
+        build_scr_ = &scr_aux_;
+        aux_ops_.push_back(pin);
         Tens a0 = tens(N, c.feat), n0 = tens(N, c.feat), a1 = tens(N, c.feat), n1 = tens(N, c.feat);
-        add_dense(ops, M_TRUNK, nm + ".fc0", xin.v(), N, D, c.feat, ACT_RELU6, a0.v(), a0.gv(), View{nullptr, 0, 0}, 0,
+        add_dense(aux_ops_, M_TRUNK, nm + ".fc0", xin.v(), N, D, c.feat, ACT_RELU6, a0.v(), a0.gv(), View{nullptr, 0, 0}, 0,
                   false, "glorot");
-        add_bn(ops, M_TRUNK, nm + ".bn0", a0.v(), T, B, c.feat, false, ACT_NONE, n0.v(), 0, n0.gv(), 0, a0.g);
-        add_dense(ops, M_TRUNK, nm + ".fc1", n0.v(), N, c.feat, c.feat, ACT_RELU6, a1.v(), a1.gv(), n0.gv(), 0, true,
+        add_bn(aux_ops_, M_TRUNK, nm + ".bn0", a0.v(), T, B, c.feat, false, ACT_NONE, n0.v(), 0, n0.gv(), 0, a0.g);
+        add_dense(aux_ops_, M_TRUNK, nm + ".fc1", n0.v(), N, c.feat, c.feat, ACT_RELU6, a1.v(), a1.gv(), n0.gv(), 0, true,
                   "glorot");
-        add_bn(ops, M_TRUNK, nm + ".bn1", a1.v(), T, B, c.feat, false, ACT_NONE, n1.v(), 0, n1.gv(), 0, a1.g);
+        add_bn(aux_ops_, M_TRUNK, nm + ".bn1", a1.v(), T, B, c.feat, false, ACT_NONE, n1.v(), 0, n1.gv(), 0, a1.g);
+        build_scr_ = &scr_main_;
         fout[i] = n1;
     }
 
@@ -492,9 +534,12 @@ void Learner::build_trunk(std::vector<Op>& ops) {
     const int catC = c.rnn_image + 3 * c.rnn_small;
     Tens cat = tens(B, catC);
     add_gru(ops, "gru_image", feat_, c.last, c.rnn_image, cat.v(0), cat.gv(0), true);
+    build_scr_ = &scr_aux_;
     for (int i = 0; i < 3; ++i)
-        add_gru(ops, std::string("gru_") + fnames[i], fout[i], c.feat, c.rnn_small, cat.v(c.rnn_image + i * c.rnn_small),
+        add_gru(aux_ops_, std::string("gru_") + fnames[i], fout[i], c.feat, c.rnn_small, cat.v(c.rnn_image + i * c.rnn_small),
                 cat.gv(c.rnn_image + i * c.rnn_small), true);
+    build_scr_ = &scr_main_;
+    add_aux_join(ops);
     Tens ncat = tens(B, catC);
     add_bn(ops, M_TRUNK, "dyn.bn", cat.v(), 1, B, catC, false, ACT_NONE, ncat.v(), 0, ncat.gv(), 0, cat.g);
     dyn_ = tens(B, c.dyn);
@@ -529,10 +574,12 @@ void Learner::build(bool dry) {
     value_ops_.clear();
     old_policy_ops_.clear();
     if (!dry) {
-        part_ = alloc_d(max_part_);
-        part2_ = alloc_d(max_part2_);
-        dy_ = nullptr;
-        tn_part_ = alloc(max_tn_);
+        scr_main_.part = alloc_d(max_part_);
+        scr_main_.part2 = alloc_d(max_part2_);
+        scr_main_.tn = alloc(max_tn_);
+        scr_aux_.part = alloc_d(max_part_);
+        scr_aux_.part2 = alloc_d(max_part2_);
+        scr_aux_.tn = alloc(max_tn_);
         for (int i = 0; i < NSLOT; ++i) {
             dys_[i] = alloc(max_dy_);
             part2s_[i] = alloc_d(max_part2_);
@@ -572,8 +619,8 @@ void Learner::build(bool dry) {
     }
     if (dry) {
         // scratch goes first in the real layout; account for it here
-        ws_off_ += align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
-                   align_up(max_tn_ * sizeof(float), 256) +
+        ws_off_ += 2 * (align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
+                        align_up(max_tn_ * sizeof(float), 256)) +
                    NSLOT * (align_up(max_dy_ * sizeof(float), 256) + align_up(max_part2_ * sizeof(double), 256) +
                             align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256));
         ws_bytes_ = ws_off_ + 4096;
@@ -642,6 +689,8 @@ int Learner::bind(const Buffers& b) {
             CDRL_HIP(hipEventCreateWithFlags(&ev_side_[i], hipEventDisableTiming));
         }
         CDRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_aux_fork_, hipEventDisableTiming));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_aux_done_, hipEventDisableTiming));
     }
     if (!hp_stage_) CDRL_HIP(hipHostMalloc(reinterpret_cast<void**>(&hp_stage_), sizeof(DevHP), 0));
     CDRL_HIP(hipMemcpy(hp_dev_, &hp_host_, sizeof(DevHP), hipMemcpyHostToDevice));
