@@ -45,7 +45,7 @@ class ValueBatch(C.Structure):
 
 
 TRUNK, POLICY, VALUE, OLD_POLICY = 0, 1, 2, 3
-BUF_DYNAMICS, BUF_IMG_FEAT, BUF_METRICS_P, BUF_METRICS_V, BUF_AUX_P, BUF_AUX_V, BUF_LIN_P, BUF_LIN_V = range(8)
+BUF_DYNAMICS, BUF_IMG_FEAT, BUF_METRICS_P, BUF_METRICS_V, BUF_AUX_P, BUF_AUX_V, BUF_LIN_P, BUF_LIN_V, BUF_SAMPLE = range(9)
 
 _i, _i64, _f, _d, _sz = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 _L = C.c_void_p
@@ -70,6 +70,9 @@ PROTOTYPES = {
     'cdrl_learner_policy_forward_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
     'cdrl_learner_policy_forward': (_i, [_L, _fp, _fp, _fp, _fp, _fp]),
     'cdrl_learner_policy_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
+    'cdrl_learner_policy_forward_backward_resample': (_i, [_L, C.POINTER(PolicyBatch), C.c_uint64, C.c_uint64, _f, _fp]),
+    'cdrl_beta_sample': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp, _fp]),
+    'cdrl_gamma_implicit_grad': (_i, [_fp, _fp, _i, _fp, _fp]),
     'cdrl_learner_policy_apply': (_i, [_L, _fp]),
     'cdrl_learner_value_forward_backward': (_i, [_L, C.POINTER(ValueBatch), _f, _fp]),
     'cdrl_learner_value_apply': (_i, [_L, _fp]),

@@ -112,6 +112,7 @@ class CARLAgent(PPOAgent):
         self.aug_intensity = aug_intensity
         self.delta, self.eta, self.aux = delta, eta, aux                  # stored, unused (as in the reference)
         self.resample_actions = resample_actions
+        self._sample_offset = 0
         # the reference computes should_clip_dynamics_grads but never reads it: trunk grads are unclipped (F9)
         self.should_clip_dynamics_grads = isinstance(clip_norm, float) or (clip_norm is not None and len(clip_norm) > 2
                                                                           and isinstance(clip_norm[2], float))
@@ -159,13 +160,10 @@ class CARLAgent(PPOAgent):
         b = dict(states=states, advantages=advantages, old_log_prob=log_probabilities, speed=speed, similarity=similarity,
                  u=actions, du_da=None, du_db=None)
         if self.resample_actions:
-            alpha, beta = eng.policy_forward(states)
-            a = alpha.detach().clone().requires_grad_(True)
-            bt = beta.detach().clone().requires_grad_(True)
-            u = torch.distributions.Beta(a, bt).rsample()              # pathwise (reparameterised) sample
-            du_da, du_db = torch.autograd.grad(u.sum(), [a, bt])
-            b.update(u=u.detach().contiguous(), du_da=du_da.contiguous(), du_db=du_db.contiguous())
-            eng.policy_backward(b)
+            # Beta(alpha, beta) of the NEW policy is sampled on the device with pathwise Jacobians
+            self._sample_offset += 1
+            eng.policy_forward_backward_resample(b, seed=self.seed if self.seed is not None else 0,
+                                                 offset=self._sample_offset)
         else:
             eng.policy_forward_backward(b)
         return eng.buffer(2)[0], 'policy'         # device scalar (CDRL_BUF_METRICS_P[0]); gradients stay in the arena

@@ -192,6 +192,32 @@ int cdrl_learner_policy_backward(cdrl_learner* l, const cdrl_policy_batch* b, fl
     return l->impl->policy_backward(pb, grad_scale, S(stream));
 }
 
+int cdrl_learner_policy_forward_backward_resample(cdrl_learner* l, const cdrl_policy_batch* b, uint64_t seed,
+                                                 uint64_t offset, float grad_scale, void* stream) {
+    CHECK_L(l);
+    if (!b) return -1;
+    PolicyBatch pb{b->image, b->road, b->vehicle, b->navigation, b->advantages, b->old_log_prob,
+                   b->speed, b->similarity, nullptr, nullptr, nullptr};
+    if (!pb.adv || !pb.old_logp || !pb.speed || !pb.similarity) {
+        cdrl::set_error("policy batch: null tensor");
+        return -1;
+    }
+    return l->impl->policy_forward_backward_resample(pb, seed, offset, grad_scale, S(stream));
+}
+
+int cdrl_beta_sample(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,
+                     float* u, float* du_dalpha, float* du_dbeta, void* stream) {
+    if (!alpha || !beta || !u) {
+        cdrl::set_error("cdrl_beta_sample: null argument");
+        return -1;
+    }
+    return beta_sample(alpha, beta, rows, A, ld, seed, offset, u, du_dalpha, du_dbeta, S(stream));
+}
+
+int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* out, void* stream) {
+    return gamma_implicit_grad(a, g, n, out, S(stream));
+}
+
 int cdrl_learner_policy_apply(cdrl_learner* l, void* stream) {
     CHECK_L(l);
     return l->impl->policy_apply(S(stream));
@@ -244,6 +270,7 @@ int cdrl_learner_get_buffer(const cdrl_learner* l, int which, float** ptr, int64
         case CDRL_BUF_AUX_V: *ptr = l->impl->value_aux(); *elems = (int64_t)c.B * 2; break;
         case CDRL_BUF_LIN_P: *ptr = l->impl->policy_lin(); *elems = (int64_t)c.B * (2 * c.A + 2); break;
         case CDRL_BUF_LIN_V: *ptr = l->impl->value_lin(); *elems = (int64_t)c.B * 4; break;
+        case CDRL_BUF_SAMPLE: *ptr = l->impl->sample_buffer(); *elems = (int64_t)c.B * c.A; break;
         default: cdrl::set_error("unknown buffer id %d", which); return -1;
     }
     return 0;

@@ -131,6 +131,13 @@ int value_loss(const ValueLossArgs& a, hipStream_t st);
 int policy_dist(const float* lin, float* out /*[B][4A]: alpha,beta,mean,std*/, int B, int A, hipStream_t st);
 int value_act(const float* lin, float* out /*[B][4] base,exp,speed,sim*/, int B, float exp_scale, hipStream_t st);
 
+// ---------------------------------------------------------------- Beta sampling (sample.hip)
+// u ~ Beta(alpha, beta) (as a Gamma ratio) with pathwise derivatives du/dalpha, du/dbeta (implicit
+// reparameterisation of the two Gamma samples).  Element (row, col): alpha[row*ld + col].
+int beta_sample(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset, float* u,
+                float* du_da, float* du_db, hipStream_t st);
+int gamma_implicit_grad(const double* a, const double* g, int n, double* out, hipStream_t st);
+
 // ---------------------------------------------------------------- optimiser (optim.hip)
 // Device hyper-parameter block, refreshed by the host before each step (graph-replay safe).
 struct DevHP {

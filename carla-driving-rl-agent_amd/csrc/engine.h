@@ -85,6 +85,10 @@ public:
     int policy_forward(const float* image, const float* road, const float* vehicle, const float* navigation,
                        hipStream_t st);
     int policy_backward(const PolicyBatch& b, float inv_world, hipStream_t st);
+    // forward -> on-device Beta re-sampling (u, du/dalpha, du/dbeta) -> backward; batch.u / du_* are ignored
+    int policy_forward_backward_resample(const PolicyBatch& b, uint64_t seed, uint64_t offset, float inv_world,
+                                         hipStream_t st);
+    float* sample_buffer() const { return sample_u_; }
     int policy_apply(hipStream_t st);
     int value_forward_backward(const ValueBatch& b, float inv_world, hipStream_t st);
     int value_apply(hipStream_t st);
@@ -203,6 +207,7 @@ private:
 
     Tens dyn_, feat_, lin_p_, lin_v_, lin_old_;
     float *metrics_p_ = nullptr, *metrics_v_ = nullptr, *aux_p_ = nullptr, *aux_v_ = nullptr;
+    float *sample_u_ = nullptr, *sample_da_ = nullptr, *sample_db_ = nullptr;
     DevHP hp_host_;
     DevHP* hp_dev_ = nullptr;
     DevHP* hp_stage_ = nullptr;     // pinned host staging

@@ -600,6 +600,9 @@ void Learner::build(bool dry) {
     metrics_v_ = alloc(16);
     aux_p_ = alloc((size_t)cfg_.B * 4 * A);
     aux_v_ = alloc((size_t)cfg_.B * 2);
+    sample_u_ = alloc((size_t)cfg_.B * A);
+    sample_da_ = alloc((size_t)cfg_.B * A);
+    sample_db_ = alloc((size_t)cfg_.B * A);
     hp_dev_ = reinterpret_cast<DevHP*>(alloc(sizeof(DevHP) / sizeof(float) + 4));
     // optimiser tables
     for (int m = 1; m <= 2; ++m) {
@@ -774,6 +777,18 @@ int Learner::policy_backward(const PolicyBatch& b, float inv_world, hipStream_t 
     CDRL_TRY(run_bwd(policy_ops_, st));
     CDRL_TRY(run_bwd(trunk_ops_, st));
     return join_side(st);
+}
+
+int Learner::policy_forward_backward_resample(const PolicyBatch& b, uint64_t seed, uint64_t offset, float inv_world,
+                                              hipStream_t st) {
+    CDRL_TRY(policy_forward(b.image, b.road, b.vehicle, b.navigation, st));
+    const int A = cfg_.A;
+    CDRL_TRY(beta_sample(aux_p_, aux_p_ + A, cfg_.B, A, 4 * A, seed, offset, sample_u_, sample_da_, sample_db_, st));
+    PolicyBatch r = b;
+    r.u = sample_u_;
+    r.du_da = sample_da_;
+    r.du_db = sample_db_;
+    return policy_backward(r, inv_world, st);
 }
 
 int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipStream_t st) {

@@ -220,6 +220,15 @@ class LearnerEngine:
         _lib.check(self.lib.cdrl_learner_policy_backward(self.h, C.byref(pb), float(grad_scale), self._stream()),
                    'policy_backward')
 
+    def policy_forward_backward_resample(self, batch, seed: int, offset: int, grad_scale=1.0):
+        """F8-faithful step with the Beta re-sampling done on the device (no torch.distributions)."""
+        b = dict(batch)
+        b.setdefault('u', batch['old_log_prob'])       # placeholder; ignored by the entry point
+        pb = self._policy_batch(b)
+        _lib.check(self.lib.cdrl_learner_policy_forward_backward_resample(self.h, C.byref(pb), int(seed), int(offset),
+                                                                         float(grad_scale), self._stream()),
+                   'policy_forward_backward_resample')
+
     def policy_apply(self):
         _lib.check(self.lib.cdrl_learner_policy_apply(self.h, self._stream()), 'policy_apply')
 

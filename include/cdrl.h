@@ -116,6 +116,12 @@ int cdrl_learner_policy_forward_backward(cdrl_learner* l, const cdrl_policy_batc
 int cdrl_learner_policy_forward(cdrl_learner* l, const float* image, const float* road, const float* vehicle,
                                 const float* navigation, void* stream);
 int cdrl_learner_policy_backward(cdrl_learner* l, const cdrl_policy_batch* b, float grad_scale, void* stream);
+/* Fully on-device form of the re-sampling step: forward, u ~ Beta(alpha, beta) of the new policy drawn
+ * by cdrl_beta_sample with pathwise Jacobians (what TFP's reparameterised Beta provides to
+ * PolicyNetwork.call, core/networks.py:96-110,136-137), backward.  b->u / du_* are ignored.
+ * (seed, offset) select the Philox stream; the drawn sample is left in CDRL_BUF_SAMPLE. */
+int cdrl_learner_policy_forward_backward_resample(cdrl_learner* l, const cdrl_policy_batch* b, uint64_t seed,
+                                                 uint64_t offset, float grad_scale, void* stream);
 /* CARLAgent.apply_policy_gradients (core/carla_agent.py:375-388) + PPOAgent.apply_policy_gradients
  * (rl/agents/ppo.py:238-252): trunk Adam, per-tensor clip, old_policy <- policy, policy Adam. */
 int cdrl_learner_policy_apply(cdrl_learner* l, void* stream);
@@ -141,7 +147,8 @@ enum {
     CDRL_BUF_AUX_P = 4,      /* (B, 4A) alpha, beta, log_prob, entropy        */
     CDRL_BUF_AUX_V = 5,      /* (B, 2) value (base, exp)                      */
     CDRL_BUF_LIN_P = 6,      /* (B, 2A+2) linear head outputs                 */
-    CDRL_BUF_LIN_V = 7       /* (B, 4)                                        */
+    CDRL_BUF_LIN_V = 7,      /* (B, 4)                                        */
+    CDRL_BUF_SAMPLE = 8      /* (B, A) Beta sample drawn by ..._resample       */
 };
 int cdrl_learner_get_buffer(const cdrl_learner* l, int which, float** ptr, int64_t* elems);
 
@@ -152,6 +159,13 @@ int cdrl_learner_get_buffer(const cdrl_learner* l, int which, float** ptr, int64
  * (rl/agents/ppo.py:692-697).  scratch: >= 2*(N+1)+2 doubles. */
 int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double gamma, double lambda, float scale,
                      float* returns, float* returns_be, float* adv_raw, float* adv, double* scratch, void* stream);
+
+/* tfp.distributions.Beta(alpha, beta).sample() with reparameterisation gradients (core/networks.py:
+ * 136-137): u = g1/(g1+g2), g ~ Gamma via Marsaglia-Tsang on a Philox-4x32-10 stream, du/dalpha and
+ * du/dbeta by implicit differentiation of the Gamma CDF.  Element (row, col) reads alpha[row*ld + col]. */
+int cdrl_beta_sample(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,
+                     float* u, float* du_dalpha, float* du_dbeta, void* stream);
+int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* out, void* stream);
 
 /* Minibatch assembly: utils.data_to_batches' tf.data gather of the shuffled rollout rows
  * (rl/utils.py:365-393); dst[i, :] = src[idx[i], :], idx = int32 device array of row numbers. */
