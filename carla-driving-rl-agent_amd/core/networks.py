@@ -159,8 +159,19 @@ class CARLANetwork(Network):
             np.savez(path, **self.engine.export_params(model))
 
     def load_weights(self, full=True):
+        """Loads this package's .npz checkpoints, or -- when `<name>.index` exists -- the reference's own
+        TensorFlow checkpoint-V2 files (tf_checkpoint.py; tensors whose data shard is absent are skipped
+        with a warning, e.g. the trunk shards the reference repository does not ship)."""
+        from .. import tf_checkpoint
         paths = self._paths()
         for model in (('policy', 'value', 'trunk') if full else ('trunk',)):
+            prefix = paths[model][:-4]
+            if not os.path.exists(paths[model]) and os.path.exists(prefix + '.index'):
+                loaded = tf_checkpoint.load_into_engine(self.engine, model, prefix, strict=False)
+                n = len(self.engine.tables[model].entries)
+                if len(loaded) < n:
+                    print(f'[load_weights] {prefix}: {len(loaded)}/{n} tensors present in the TF checkpoint')
+                continue
             with np.load(paths[model]) as f:
                 self.engine.load_params(model, {k: f[k] for k in f.files})
         if full:
