@@ -157,8 +157,10 @@ class CARLAgent(PPOAgent):
     def get_policy_gradients(self, batch):
         states, advantages, actions, log_probabilities, speed, similarity = batch
         eng = self.network.engine
-        b = dict(states=states, advantages=advantages, old_log_prob=log_probabilities, speed=speed, similarity=similarity,
-                 u=actions, du_da=None, du_db=None)
+        b = dict(states={k: states[k] for k in ('state_image', 'state_road', 'state_vehicle', 'state_navigation')},
+                 advantages=advantages, old_log_prob=log_probabilities, speed=speed, similarity=similarity, u=actions)
+        b = eng.stage(b, 'policy')           # fixed addresses -> the captured hipGraph of the step is replayed
+        b.update(du_da=None, du_db=None)
         if self.resample_actions:
             # Beta(alpha, beta) of the NEW policy is sampled on the device with pathwise Jacobians
             self._sample_offset += 1
@@ -175,7 +177,9 @@ class CARLAgent(PPOAgent):
     def get_value_gradients(self, batch):
         states, returns, speed, similarity = batch
         eng = self.network.engine
-        eng.value_forward_backward(dict(states=states, returns=returns, speed=speed, similarity=similarity))
+        b = dict(states={k: states[k] for k in ('state_image', 'state_road', 'state_vehicle', 'state_navigation')},
+                 returns=returns, speed=speed, similarity=similarity)
+        eng.value_forward_backward(eng.stage(b, 'value'))
         return eng.buffer(3)[0], 'value'
 
     def apply_value_gradients(self, gradients):

@@ -2,6 +2,7 @@
 // heads), the flat parameter-arena layout and the workspace plan for one batch size.
 #pragma once
 #include <functional>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -148,6 +149,26 @@ private:
                  bool need_dx);
     void note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn_f, size_t fpart_d = 0);
 
+    // Every public step runs on the engine's own stream `main_` (bridged to the caller's stream with
+    // events) and, when `graphable`, is captured once into a hipGraph (main + side stream, ~1000
+    // kernel nodes per pass) and replayed afterwards: the update-step is launch-bound on the host
+    // otherwise (measured: 22 ms of CPU enqueue time per 30 ms update-step).  The cache key is the
+    // step kind + every pointer / scalar argument baked into the captured kernel arguments.
+    int launch(hipStream_t caller, std::vector<uint64_t> key, bool graphable, const std::function<int(hipStream_t)>& body);
+    void drop_graphs();
+    hipStream_t main_ = nullptr;
+    hipEvent_t ev_in_ = nullptr, ev_out_ = nullptr;
+    bool graphs_enabled_ = true;
+    std::map<std::vector<uint64_t>, hipGraphExec_t> graphs_;
+    int policy_backward_impl(const PolicyBatch& b, float inv_world, hipStream_t st);
+    int policy_forward_impl(const float* image, const float* road, const float* vehicle, const float* navigation,
+                            hipStream_t st);
+    int value_forward_backward_impl(const ValueBatch& b, float inv_world, hipStream_t st);
+    int update_old_policy_impl(hipStream_t st);
+    int policy_apply_impl(hipStream_t st);
+    int value_apply_impl(hipStream_t st);
+    int predict_impl(const float* image, const float* road, const float* vehicle, const float* navigation, float* dist_out,
+                     float* value_out, float* dyn_out, hipStream_t st);
     int run_fwd(std::vector<Op>& ops, hipStream_t st, int training);
     int run_bwd(std::vector<Op>& ops, hipStream_t st);
     int set_inputs(const float* image, const float* road, const float* vehicle, const float* navigation);

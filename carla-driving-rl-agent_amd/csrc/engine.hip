@@ -45,10 +45,63 @@ Learner::~Learner() {
         if (ev_main_[i]) (void)hipEventDestroy(ev_main_[i]);
         if (ev_side_[i]) (void)hipEventDestroy(ev_side_[i]);
     }
+    drop_graphs();
+    if (ev_in_) (void)hipEventDestroy(ev_in_);
+    if (ev_out_) (void)hipEventDestroy(ev_out_);
+    if (main_) (void)hipStreamDestroy(main_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (ev_aux_fork_) (void)hipEventDestroy(ev_aux_fork_);
     if (ev_aux_done_) (void)hipEventDestroy(ev_aux_done_);
     if (side_) (void)hipStreamDestroy(side_);
+}
+
+void Learner::drop_graphs() {
+    for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
+    graphs_.clear();
+}
+
+int Learner::launch(hipStream_t caller, std::vector<uint64_t> key, bool graphable,
+                    const std::function<int(hipStream_t)>& body) {
+    if (!main_) {
+        set_error("learner not bound");
+        return -1;
+    }
+    CDRL_HIP(hipEventRecord(ev_in_, caller));
+    CDRL_HIP(hipStreamWaitEvent(main_, ev_in_, 0));
+    int rc = 0;
+    if (!graphs_enabled_ || !graphable) {
+        rc = body(main_);
+    } else {
+        auto it = graphs_.find(key);
+        if (it == graphs_.end()) {
+            if (graphs_.size() >= 32) drop_graphs();
+            hipGraph_t graph = nullptr;
+            CDRL_HIP(hipStreamBeginCapture(main_, hipStreamCaptureModeRelaxed));
+            rc = body(main_);
+            hipError_t ce = hipStreamEndCapture(main_, &graph);
+            if (rc != 0 || ce != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                if (rc == 0) {
+                    set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+                    rc = -2;
+                }
+                return rc;
+            }
+            hipGraphExec_t exec = nullptr;
+            hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) {
+                set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+                return -2;
+            }
+            it = graphs_.emplace(std::move(key), exec).first;
+        }
+        CDRL_HIP(hipGraphLaunch(it->second, main_));
+    }
+    if (rc != 0) return rc;
+    CDRL_HIP(hipEventRecord(ev_out_, main_));
+    CDRL_HIP(hipStreamWaitEvent(caller, ev_out_, 0));
+    return 0;
 }
 
 int Learner::next_slot(hipStream_t st) {
@@ -675,6 +728,7 @@ int Learner::bind(const Buffers& b) {
         set_error("bind: workspace too small (%zu < %zu)", b.workspace_bytes, ws_bytes_);
         return -1;
     }
+    drop_graphs();
     buf_ = b;
     ws_base_ = reinterpret_cast<char*>(b.workspace);
     build(false);
@@ -686,6 +740,15 @@ int Learner::bind(const Buffers& b) {
     if (!side_) {
         const char* env = getenv("CDRL_SIDE_STREAM");
         side_enabled_ = !(env && atoi(env) == 0);
+        // hipGraph replay is OFF by default: measured on MI355X / ROCm 7.2 at B=256 the captured update-step
+        // (4 graphs of ~500-1000 kernel nodes over two streams) replays in 32.7 ms vs 31.0 ms eager, and the
+        // host still spends 15 ms per step inside hipGraphLaunch (22 ms for eager launches): neither mode is
+        // host-bound.  CDRL_GRAPH=1 enables it (parity suite passes in both modes).
+        const char* genv = getenv("CDRL_GRAPH");
+        graphs_enabled_ = genv && atoi(genv) != 0;
+        CDRL_HIP(hipStreamCreateWithFlags(&main_, hipStreamNonBlocking));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_in_, hipEventDisableTiming));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_out_, hipEventDisableTiming));
         CDRL_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
         for (int i = 0; i < NSLOT; ++i) {
             CDRL_HIP(hipEventCreateWithFlags(&ev_main_[i], hipEventDisableTiming));
@@ -742,21 +805,32 @@ int Learner::set_inputs(const float* image, const float* road, const float* vehi
 }
 
 int Learner::trunk_forward_train(const float* image, const float* road, const float* vehicle, const float* navigation,
-                                 hipStream_t st) {
-    CDRL_TRY(set_inputs(image, road, vehicle, navigation));
-    return run_fwd(trunk_ops_, st, 1);
+                                 hipStream_t caller) {
+    return launch(caller, {}, false, [&](hipStream_t st) -> int {
+        CDRL_TRY(set_inputs(image, road, vehicle, navigation));
+        return run_fwd(trunk_ops_, st, 1);
+    });
 }
 
 int Learner::policy_forward(const float* image, const float* road, const float* vehicle, const float* navigation,
-                            hipStream_t st) {
+                            hipStream_t caller) {
+    return launch(caller, {}, false, [&](hipStream_t st) -> int { return policy_forward_impl(image, road, vehicle, navigation, st); });
+}
+
+int Learner::policy_forward_impl(const float* image, const float* road, const float* vehicle, const float* navigation,
+                                 hipStream_t st) {
     CDRL_TRY(set_inputs(image, road, vehicle, navigation));
     CDRL_TRY(run_fwd(trunk_ops_, st, 1));
     CDRL_TRY(run_fwd(policy_ops_, st, 1));
-    // alpha, beta (+ mean, std) of the CURRENT policy for the host-side Beta re-sampling
+    // alpha, beta (+ mean, std) of the CURRENT policy for the Beta re-sampling
     return policy_dist(lin_p_.p, aux_p_, cfg_.B, cfg_.A, st);
 }
 
-int Learner::policy_backward(const PolicyBatch& b, float inv_world, hipStream_t st) {
+int Learner::policy_backward(const PolicyBatch& b, float inv_world, hipStream_t caller) {
+    return launch(caller, {}, false, [&](hipStream_t st) -> int { return policy_backward_impl(b, inv_world, st); });
+}
+
+int Learner::policy_backward_impl(const PolicyBatch& b, float inv_world, hipStream_t st) {
     PolicyLossArgs a;
     a.lin = lin_p_.p;
     a.adv = b.adv;
@@ -780,25 +854,45 @@ int Learner::policy_backward(const PolicyBatch& b, float inv_world, hipStream_t 
 }
 
 int Learner::policy_forward_backward_resample(const PolicyBatch& b, uint64_t seed, uint64_t offset, float inv_world,
-                                              hipStream_t st) {
-    CDRL_TRY(policy_forward(b.image, b.road, b.vehicle, b.navigation, st));
-    const int A = cfg_.A;
-    CDRL_TRY(beta_sample(aux_p_, aux_p_ + A, cfg_.B, A, 4 * A, seed, offset, sample_u_, sample_da_, sample_db_, st));
-    PolicyBatch r = b;
-    r.u = sample_u_;
-    r.du_da = sample_da_;
-    r.du_db = sample_db_;
-    return policy_backward(r, inv_world, st);
+                                              hipStream_t caller) {
+    // (seed, offset) are kernel arguments that change every call -> eager, not graph-replayed
+    return launch(caller, {}, false, [&](hipStream_t st) -> int {
+        CDRL_TRY(policy_forward_impl(b.image, b.road, b.vehicle, b.navigation, st));
+        const int A = cfg_.A;
+        CDRL_TRY(beta_sample(aux_p_, aux_p_ + A, cfg_.B, A, 4 * A, seed, offset, sample_u_, sample_da_, sample_db_, st));
+        PolicyBatch r = b;
+        r.u = sample_u_;
+        r.du_da = sample_da_;
+        r.du_db = sample_db_;
+        return policy_backward_impl(r, inv_world, st);
+    });
 }
 
-int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipStream_t st) {
-    CDRL_TRY(set_inputs(b.image, b.road, b.vehicle, b.navigation));
-    CDRL_TRY(run_fwd(trunk_ops_, st, 1));
-    CDRL_TRY(run_fwd(policy_ops_, st, 1));
-    return policy_backward(b, inv_world, st);
+static inline uint64_t K(const void* p) { return (uint64_t)reinterpret_cast<uintptr_t>(p); }
+static inline uint64_t Kf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
 }
 
-int Learner::value_forward_backward(const ValueBatch& b, float inv_world, hipStream_t st) {
+int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipStream_t caller) {
+    std::vector<uint64_t> key = {1, K(b.image), K(b.road), K(b.vehicle), K(b.navigation), K(b.adv), K(b.old_logp), K(b.speed),
+                                 K(b.similarity), K(b.u), K(b.du_da), K(b.du_db), Kf(inv_world)};
+    return launch(caller, key, true, [&](hipStream_t st) -> int {
+        CDRL_TRY(set_inputs(b.image, b.road, b.vehicle, b.navigation));
+        CDRL_TRY(run_fwd(trunk_ops_, st, 1));
+        CDRL_TRY(run_fwd(policy_ops_, st, 1));
+        return policy_backward_impl(b, inv_world, st);
+    });
+}
+
+int Learner::value_forward_backward(const ValueBatch& b, float inv_world, hipStream_t caller) {
+    std::vector<uint64_t> key = {2, K(b.image), K(b.road), K(b.vehicle), K(b.navigation), K(b.returns), K(b.speed),
+                                 K(b.similarity), Kf(inv_world)};
+    return launch(caller, key, true, [&](hipStream_t st) -> int { return value_forward_backward_impl(b, inv_world, st); });
+}
+
+int Learner::value_forward_backward_impl(const ValueBatch& b, float inv_world, hipStream_t st) {
     CDRL_TRY(set_inputs(b.image, b.road, b.vehicle, b.navigation));
     CDRL_TRY(run_fwd(trunk_ops_, st, 1));
     CDRL_TRY(run_fwd(value_ops_, st, 1));
@@ -819,7 +913,11 @@ int Learner::value_forward_backward(const ValueBatch& b, float inv_world, hipStr
     return join_side(st);
 }
 
-int Learner::update_old_policy(hipStream_t st) {
+int Learner::update_old_policy(hipStream_t caller) {
+    return launch(caller, {}, false, [&](hipStream_t st) -> int { return update_old_policy_impl(st); });
+}
+
+int Learner::update_old_policy_impl(hipStream_t st) {
     // old_policy.set_weights(policy.get_weights()): all weights incl. BN moving statistics
     // (reference core/networks.py:281-285)
     CDRL_HIP(hipMemcpyAsync(buf_.params + tr_offset(M_OLD_POLICY), buf_.params + tr_offset(M_POLICY),
@@ -829,7 +927,11 @@ int Learner::update_old_policy(hipStream_t st) {
     return 0;
 }
 
-int Learner::policy_apply(hipStream_t st) {
+int Learner::policy_apply(hipStream_t caller) {
+    return launch(caller, {3}, true, [&](hipStream_t st) -> int { return policy_apply_impl(st); });
+}
+
+int Learner::policy_apply_impl(hipStream_t st) {
     // order: trunk Adam (unclipped, F9) -> clip -> old_policy <- policy -> policy Adam
     const int64_t to = tr_offset(M_TRUNK), po = tr_offset(M_POLICY);
     CDRL_TRY(clip_adam(buf_.params + to, buf_.grads + to, buf_.adam_m + to, buf_.adam_v + to, tr_size_[M_TRUNK], nullptr,
@@ -838,13 +940,17 @@ int Learner::policy_apply(hipStream_t st) {
     SegTable& s = seg_[M_POLICY];
     CDRL_TRY(tensor_sqnorms(buf_.grads + po, s.segs, s.ntensors, s.chunk_tensor, s.chunk_off, s.nchunks, s.chunk_part,
                             s.sqnorms, st));
-    CDRL_TRY(update_old_policy(st));
+    CDRL_TRY(update_old_policy_impl(st));
     CDRL_TRY(clip_adam(buf_.params + po, buf_.grads + po, buf_.adam_m + po, buf_.adam_v + po, tr_size_[M_POLICY],
                        s.chunk_tensor, s.chunk_off, s.nchunks, s.segs, s.sqnorms, hp_dev_, 0, st));
     return adam_tick(hp_dev_, 0, st);
 }
 
-int Learner::value_apply(hipStream_t st) {
+int Learner::value_apply(hipStream_t caller) {
+    return launch(caller, {4}, true, [&](hipStream_t st) -> int { return value_apply_impl(st); });
+}
+
+int Learner::value_apply_impl(hipStream_t st) {
     const int64_t to = tr_offset(M_TRUNK), vo = tr_offset(M_VALUE);
     CDRL_TRY(clip_adam(buf_.params + to, buf_.grads + to, buf_.adam_m + to, buf_.adam_v + to, tr_size_[M_TRUNK], nullptr,
                        nullptr, 0, nullptr, nullptr, hp_dev_, 2, st));
@@ -858,7 +964,15 @@ int Learner::value_apply(hipStream_t st) {
 }
 
 int Learner::predict(const float* image, const float* road, const float* vehicle, const float* navigation,
-                     float* dist_out, float* value_out, float* dyn_out, hipStream_t st) {
+                     float* dist_out, float* value_out, float* dyn_out, hipStream_t caller) {
+    std::vector<uint64_t> key = {5, K(image), K(road), K(vehicle), K(navigation), K(dist_out), K(value_out), K(dyn_out)};
+    return launch(caller, key, true, [&](hipStream_t st) -> int {
+        return predict_impl(image, road, vehicle, navigation, dist_out, value_out, dyn_out, st);
+    });
+}
+
+int Learner::predict_impl(const float* image, const float* road, const float* vehicle, const float* navigation,
+                          float* dist_out, float* value_out, float* dyn_out, hipStream_t st) {
     CDRL_TRY(set_inputs(image, road, vehicle, navigation));
     CDRL_TRY(run_fwd(trunk_ops_, st, 0));
     CDRL_TRY(run_fwd(old_policy_ops_, st, 0));

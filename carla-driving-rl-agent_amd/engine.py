@@ -64,6 +64,8 @@ class LearnerEngine:
         self.hp = dict(policy_lr=3e-4, value_lr=3e-4, dynamics_lr=3e-4, clip_ratio=0.2, entropy_coef=1.0,
                        clip_norm_policy=1.0, clip_norm_value=1.0, beta1=0.9, beta2=0.999, eps=1e-7)
         self._keep = []
+        self._keep_stage = {}
+        self._pred_out = None
         if device is None:
             return
         dev = torch.device(device)
@@ -148,6 +150,28 @@ class LearnerEngine:
         off = p.value - base
         t = self.workspace[off: off + 4 * n.value].view(torch.float32)
         return t.view(shape) if shape is not None else t
+
+    # ------------------------------------------------------------------ staging
+    def stage(self, batch: dict, slot: str) -> dict:
+        """Copies a (nested) batch into persistent device buffers owned by the engine and returns those.
+        The step entry points are replayed from captured hipGraphs keyed on their pointer arguments, so
+        minibatches that live in fresh tensors every time (tf.data-style gathers) go through fixed
+        staging buffers (one D2D copy, ~0.05 ms for a 256x4x90x120x3 minibatch)."""
+        store = self._keep_stage.setdefault(slot, {})
+
+        def put(key, t):
+            if t is None:
+                return None
+            buf = store.get(key)
+            if buf is None or buf.shape != t.shape:
+                buf = torch.empty_like(t, memory_format=torch.contiguous_format)
+                store[key] = buf
+            buf.copy_(t)
+            return buf
+        out = {}
+        for k, v in batch.items():
+            out[k] = {kk: put(f'{k}/{kk}', vv) for kk, vv in v.items()} if isinstance(v, dict) else put(k, v)
+        return out
 
     # ------------------------------------------------------------------ steps
     def _states(self, batch):
@@ -266,11 +290,15 @@ class LearnerEngine:
 
     def predict(self, states):
         c = self.cfg
-        img, road, veh, nav = self._states(states)
+        st = states['states'] if 'states' in states else states
+        staged = self.stage({k: st[k] for k in ('state_image', 'state_road', 'state_vehicle', 'state_navigation')}, 'predict')
+        img, road, veh, nav = self._states(staged)
         self._check_states(img, road, veh, nav)
-        dist = torch.empty((c.B, 4, c.A), dtype=torch.float32, device=img.device)
-        value = torch.empty((c.B, 4), dtype=torch.float32, device=img.device)
-        dyn = torch.empty((c.B, c.dyn), dtype=torch.float32, device=img.device)
+        if self._pred_out is None:       # persistent outputs: the captured graph writes to fixed addresses
+            self._pred_out = (torch.empty((c.B, 4, c.A), dtype=torch.float32, device=img.device),
+                              torch.empty((c.B, 4), dtype=torch.float32, device=img.device),
+                              torch.empty((c.B, c.dyn), dtype=torch.float32, device=img.device))
+        dist, value, dyn = self._pred_out
         _lib.check(self.lib.cdrl_learner_predict(self.h, _lib.ptr(img), _lib.ptr(road), _lib.ptr(veh), _lib.ptr(nav),
                                                  _lib.ptr(dist), _lib.ptr(value), _lib.ptr(dyn), self._stream()), 'predict')
         return dict(alpha=dist[:, 0], beta=dist[:, 1], mean=dist[:, 2], std=dist[:, 3], value=value[:, :2],
