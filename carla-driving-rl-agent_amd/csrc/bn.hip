@@ -58,13 +58,15 @@ int colsum(View x, int rows, int C, double* part, hipStream_t st) {
 // by 16 lanes in parallel (independent, coalesced loads) and combined in a fixed order -> the
 // result is deterministic and the kernel is no longer a serial chain of nb dependent loads.
 #define FIN_CX 16
-#define FIN_PY 64
+#define FIN_PY 32
+#define FIN_G 4       // groups folded per barrier round (T = 4 time slices)
 
 __global__ void __launch_bounds__(1024) bn_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ mov_mean, float* __restrict__ mov_var,
                                                           int bessel, int training, float* __restrict__ stats) {
-    __shared__ double sm[2][FIN_PY][FIN_CX];
+    __shared__ double sm[FIN_G][2][FIN_PY][FIN_CX];
+    __shared__ double red[FIN_G][2][FIN_CX];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c = blockIdx.x * FIN_CX + tx;
     const bool ok = c < C;
@@ -92,37 +94,47 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const double* __restr
     }
     const double n = (double)Mg;
     const float corr = (bessel && Mg > 1) ? (float)(n / (n - 1.0)) : 1.0f;
-    for (int g = 0; g < G; ++g) {
-        double s = 0.0, q = 0.0;
-        if (ok) {
-            for (int b = ty; b < nb; b += FIN_PY) {
-                s += part[(((int64_t)g * nb + b) * 2 + 0) * C + c];
-                q += part[(((int64_t)g * nb + b) * 2 + 1) * C + c];
+    // phase 1: every (channel, partial-lane) thread sums its share of the partials of ALL groups -- the
+    // loads of the G groups are independent, one barrier instead of 2 per group
+    for (int g0 = 0; g0 < G; g0 += FIN_G) {
+        const int ng = min(FIN_G, G - g0);
+        for (int gg = 0; gg < ng; ++gg) {
+            double s = 0.0, q = 0.0;
+            if (ok) {
+                for (int b = ty; b < nb; b += FIN_PY) {
+                    s += part[(((int64_t)(g0 + gg) * nb + b) * 2 + 0) * C + c];
+                    q += part[(((int64_t)(g0 + gg) * nb + b) * 2 + 1) * C + c];
+                }
             }
+            sm[gg][0][ty][tx] = s;
+            sm[gg][1][ty][tx] = q;
         }
-        sm[0][ty][tx] = s;
-        sm[1][ty][tx] = q;
+        __syncthreads();
+        // phase 2: thread (tx, ty < 2*ng) folds the FIN_PY lane sums of one (group, quantity) pair
+        if (ok && ty < 2 * ng) {
+            const int gg = ty >> 1, qq = ty & 1;
+            double s = 0.0;
+#pragma unroll 8
+            for (int y = 0; y < FIN_PY; ++y) s += sm[gg][qq][y][tx];
+            red[gg][qq][tx] = s;
+        }
         __syncthreads();
         if (ok && ty == 0) {
-            s = 0.0;
-            q = 0.0;
-#pragma unroll
-            for (int y = 0; y < FIN_PY; ++y) {
-                s += sm[0][y][tx];
-                q += sm[1][y][tx];
+            for (int gg = 0; gg < ng; ++gg) {
+                const int g = g0 + gg;
+                const double mean = red[gg][0][tx] / n;
+                double var = red[gg][1][tx] / n - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float meanf = (float)mean, varf = (float)var;
+                const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+                stats[0 * GC + g * C + c] = meanf;
+                stats[1 * GC + g * C + c] = invstd;
+                stats[2 * GC + g * C + c] = gm * invstd;
+                stats[3 * GC + g * C + c] = bt - meanf * gm * invstd;
+                // Keras: moving -= (moving - value) * (1 - momentum), once per time slice (t ascending)
+                mm = mm - (mm - meanf) * 0.01f;
+                mv = mv - (mv - varf * corr) * 0.01f;
             }
-            const double mean = s / n;
-            double var = q / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float meanf = (float)mean, varf = (float)var;
-            const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
-            stats[0 * GC + g * C + c] = meanf;
-            stats[1 * GC + g * C + c] = invstd;
-            stats[2 * GC + g * C + c] = gm * invstd;
-            stats[3 * GC + g * C + c] = bt - meanf * gm * invstd;
-            // Keras: moving -= (moving - value) * (1 - momentum), once per time slice (t ascending)
-            mm = mm - (mm - meanf) * 0.01f;
-            mv = mv - (mv - varf * corr) * 0.01f;
         }
         __syncthreads();
     }
@@ -242,37 +254,46 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const double* __r
                                                               int C, const float* __restrict__ stats,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef) {
-    __shared__ double sm[2][FIN_PY][FIN_CX];
+    __shared__ double sm[FIN_G][2][FIN_PY][FIN_CX];
+    __shared__ double red[FIN_G][2][FIN_CX];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c = blockIdx.x * FIN_CX + tx;
     const bool ok = c < C;
     const int GC = G * C;
     double dg = 0.0, db = 0.0;
     const double n = (double)Mg;
-    for (int g = 0; g < G; ++g) {
-        double s = 0.0, q = 0.0;
-        if (ok) {
-            for (int b = ty; b < nb; b += FIN_PY) {
-                s += part[(((int64_t)g * nb + b) * 2 + 0) * C + c];
-                q += part[(((int64_t)g * nb + b) * 2 + 1) * C + c];
+    for (int g0 = 0; g0 < G; g0 += FIN_G) {
+        const int ng = min(FIN_G, G - g0);
+        for (int gg = 0; gg < ng; ++gg) {
+            double s = 0.0, q = 0.0;
+            if (ok) {
+                for (int b = ty; b < nb; b += FIN_PY) {
+                    s += part[(((int64_t)(g0 + gg) * nb + b) * 2 + 0) * C + c];
+                    q += part[(((int64_t)(g0 + gg) * nb + b) * 2 + 1) * C + c];
+                }
             }
+            sm[gg][0][ty][tx] = s;
+            sm[gg][1][ty][tx] = q;
         }
-        sm[0][ty][tx] = s;
-        sm[1][ty][tx] = q;
+        __syncthreads();
+        if (ok && ty < 2 * ng) {
+            const int gg = ty >> 1, qq = ty & 1;
+            double s = 0.0;
+#pragma unroll 8
+            for (int y = 0; y < FIN_PY; ++y) s += sm[gg][qq][y][tx];
+            red[gg][qq][tx] = s;
+        }
         __syncthreads();
         if (ok && ty == 0) {
-            s = 0.0;
-            q = 0.0;
-#pragma unroll
-            for (int y = 0; y < FIN_PY; ++y) {
-                s += sm[0][y][tx];
-                q += sm[1][y][tx];
+            for (int gg = 0; gg < ng; ++gg) {
+                const int g = g0 + gg;
+                const double s = red[gg][0][tx], q = red[gg][1][tx];
+                db += s;
+                dg += q;
+                coef[0 * GC + g * C + c] = stats[2 * GC + g * C + c];   // k1 = gamma * invstd
+                coef[1 * GC + g * C + c] = (float)(s / n);              // k2 = mean(dz)
+                coef[2 * GC + g * C + c] = (float)(q / n);              // k3 = mean(dz * xhat)
             }
-            db += s;
-            dg += q;
-            coef[0 * GC + g * C + c] = stats[2 * GC + g * C + c];   // k1 = gamma * invstd
-            coef[1 * GC + g * C + c] = (float)(s / n);              // k2 = mean(dz)
-            coef[2 * GC + g * C + c] = (float)(q / n);              // k3 = mean(dz * xhat)
         }
         __syncthreads();
     }

@@ -76,6 +76,10 @@ int dw_fwd(View a, const float* w, const float* bias, float* y, int N, int H, in
            hipStream_t st);
 int dw_bwd_data(const float* dy, const float* w, View da, int N, int H, int W, int C, int stride, int accumulate,
                 hipStream_t st);
+// dw_bwd_data fused with the BatchNorm-backward reduction of the layer that produced the depthwise input
+// (a = act(bn(y_pre))): writes da AND the per-group partial sums (sum dz, sum dz*xhat) of that BN.
+int dw_bwd_data_bnreduce(const float* dy, const float* w, View da, int N, int H, int W, int C, int stride, int G,
+                         const float* y_pre, const float* stats_pre, int act_pre, double* part, hipStream_t st);
 int64_t dw_bwd_part_elems(int N, int H, int W, int C, int stride);
 int dw_bwd_filter(View a, const float* dy, float* dw, float* db, int N, int H, int W, int C, int stride,
                   double* part, hipStream_t st);

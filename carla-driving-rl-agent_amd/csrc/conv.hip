@@ -366,6 +366,73 @@ int dw_bwd_data(const float* dy, const float* w, View da, int N, int H, int W, i
 }
 
 template <int VEC>
+struct DwBwdDataBnF {
+    const float* dy;
+    const float* w;
+    View da;
+    int H, W, Ho, Wo, C, s, pt, pl;
+    const float* ypre;
+    const float* stats;
+    int GC, act;
+    bool al;
+    __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
+        const int ix = (int)(row % W);
+        const int64_t q = row / W;
+        const int iy = (int)(q % H);
+        const int64_t n = q / H;
+        VecF<VEC> d;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d.v[i] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ny = iy + pt - ky;
+            if (ny < 0 || (ny % s) != 0) continue;
+            const int oy = ny / s;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int nx = ix + pl - kx;
+                if (nx < 0 || (nx % s) != 0) continue;
+                const int ox = nx / s;
+                if (ox >= Wo) continue;
+                const VecF<VEC> g2 = vload<VEC>(dy + ((n * Ho + oy) * Wo + ox) * C + c0);
+                const VecF<VEC> wk = vload<VEC>(w + (ky * 3 + kx) * C + c0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) d.v[i] = fmaf(g2.v[i], wk.v[i], d.v[i]);
+            }
+        }
+        vstore_view<VEC>(da, row, c0, 0, al, d);
+        // BatchNorm-backward sums of the producing layer
+        const VecF<VEC> v = vload<VEC>(ypre + row * C + c0);
+        const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
+        if (act == ACT_RELU6) {
+            const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float z = fmaf(sc.v[i], v.v[i], sh.v[i]);
+                if (!(z > 0.0f && z < 6.0f)) d.v[i] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float xh = (v.v[i] - mean.v[i]) * invstd.v[i];
+            acc[0][i] += (double)d.v[i];
+            acc[1][i] += (double)d.v[i] * (double)xh;
+        }
+    }
+};
+
+int dw_bwd_data_bnreduce(const float* dy, const float* w, View da, int N, int H, int W, int C, int stride, int G,
+                         const float* y_pre, const float* stats_pre, int act_pre, double* part, hipStream_t st) {
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    const int Mg = (N / G) * H * W;
+    const int vec = vcol_geom(Mg, C).vec;
+    return launch_vcolreduce<2, DwBwdDataBnF>(G, Mg, C, part, st, NB_STATS, dy, w, da, H, W, Ho, Wo, C, stride,
+                                              same_pad_before(H, stride), same_pad_before(W, stride), y_pre, stats_pre, G * C,
+                                              act_pre, view_aligned(da, vec));
+}
+
+template <int VEC>
 struct DwBwdFilterF {
     View a;
     const float* dy;

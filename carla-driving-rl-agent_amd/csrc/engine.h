@@ -3,6 +3,7 @@
 #pragma once
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -125,6 +126,12 @@ private:
     };
     struct BnRec {
         int G, Mg, C, nb;
+        float* stats = nullptr;            // [4][G][C] of this BatchNorm
+        float* y = nullptr;                // its (dense) input
+        int act = 0;
+        // set by the op that produces this BN's incoming gradient when it also accumulates the BN-backward
+        // sums (sum dz, sum dz*xhat) in its own pass: the BN backward then skips its reduce kernel
+        std::shared_ptr<bool> reduce_fused;
     };
 
     // --- building
@@ -142,7 +149,7 @@ private:
     void add_pw(std::vector<Op>& ops, const std::string& prefix, View in, int rows, int Cin, int Cout, float* y,
                 View din, int din_acc, BnRec bn_after);
     void add_dw(std::vector<Op>& ops, const std::string& prefix, View in, int N, int H, int W, int C, int stride,
-                float* y, View din, int din_acc);
+                float* y, View din, int din_acc, const BnRec* pre_bn = nullptr);
     void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
                    View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);
     void add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,

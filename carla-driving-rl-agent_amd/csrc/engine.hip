@@ -242,7 +242,16 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     float* coef = alloc((size_t)3 * G * C);
     const int nb = vcol_geom(Mg, C).nb;
     note_scratch((size_t)G * nb * 2 * C, (size_t)G * nb * C, 0, 0);
-    BnRec rec{G, Mg, C, nb};
+    BnRec rec;
+    rec.G = G;
+    rec.Mg = Mg;
+    rec.C = C;
+    rec.nb = nb;
+    rec.stats = stats;
+    rec.y = (x.ld == C && x.coff == 0) ? x.p : nullptr;
+    rec.act = act;
+    rec.reduce_fused = std::make_shared<bool>(false);
+    std::shared_ptr<bool> fused = rec.reduce_fused;
     const int bes = bessel ? 1 : 0;
     Scratch* sc = build_scr_;
     Op op;
@@ -252,7 +261,7 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
         return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st);
     };
     op.bwd = [=](hipStream_t st) -> int {
-        CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st));
+        if (!*fused) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st));
         CDRL_TRY(bn_bwd_finalize(sc->part, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
         if (dx) return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, sc->part2, st);
         CDRL_TRY(next_slot(st));       // tower: dy + db partials go to a rotating scratch slot
@@ -286,11 +295,18 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
 }
 
 void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, int N, int H, int W, int C, int stride,
-                     float* y, View din, int din_acc) {
+                     float* y, View din, int din_acc, const BnRec* pre_bn) {
     PRef w = param(M_TRUNK, prefix + ".w", {3, 3, C, 1}, true);
     PRef b = param(M_TRUNK, prefix + ".b", {C}, true);
     const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
     note_scratch(0, 0, (size_t)N * Ho * Wo * C, 0, (size_t)dw_bwd_part_elems(N, H, W, C, stride));
+    static const bool fuse_env = !(getenv("CDRL_FUSE_BNRED") && atoi(getenv("CDRL_FUSE_BNRED")) == 0);
+    const bool fuse = fuse_env && pre_bn && pre_bn->y && din_acc == 0 && pre_bn->C == C && pre_bn->Mg * pre_bn->G == N * H * W;
+    BnRec pre;
+    if (fuse) {
+        pre = *pre_bn;
+        *pre.reduce_fused = true;
+    }
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int { return dw_fwd(in, w.p, b.p, y, N, H, W, C, stride, st); };
     op.bwd = [=](hipStream_t st) -> int {
@@ -298,6 +314,8 @@ void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, i
         hipStream_t side = fork_side(st);
         CDRL_TRY(dw_bwd_filter(in, dy, w.g, b.g, N, H, W, C, stride, fparts_[slot_], side));
         CDRL_TRY(done_side(side));
+        if (fuse)      // bwd-data + BN-backward sums of the layer that produced `in` in one pass over da
+            return dw_bwd_data_bnreduce(dy, w.p, din, N, H, W, C, stride, pre.G, pre.y, pre.stats, pre.act, scr_main_.part, st);
         return dw_bwd_data(dy, w.p, din, N, H, W, C, stride, din_acc, st);
     };
     ops.push_back(op);
@@ -436,7 +454,14 @@ void Learner::build_trunk(std::vector<Op>& ops) {
     const Config& c = cfg_;
     const int B = c.B, T = c.T, N = B * T;
     const int Hs = (c.H - 3) / 2 + 1, Ws = (c.W - 3) / 2 + 1;
-    auto bnrec = [](int G, int Mg, int C) { return BnRec{G, Mg, C, vcol_geom(Mg, C).nb}; };
+    auto bnrec = [](int G, int Mg, int C) {
+        BnRec r;
+        r.G = G;
+        r.Mg = Mg;
+        r.C = C;
+        r.nb = vcol_geom(Mg, C).nb;
+        return r;
+    };
     aux_ops_.clear();
     add_aux_fork(ops);
 
@@ -517,9 +542,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 Tens y1 = tens(rows_in, mid, false), a1 = tens(rows_in, mid);
                 add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off),
                        stride == 2 ? 1 : 0, bnrec(T, Mg_in, mid));
-                add_bn(ops, M_TRUNK, pre + ".bn1", y1.v(), T, Mg_in, mid, true, ACT_RELU6, a1.v(), 0, a1.gv(), 0, nullptr);
+                BnRec r1 = add_bn(ops, M_TRUNK, pre + ".bn1", y1.v(), T, Mg_in, mid, true, ACT_RELU6, a1.v(), 0, a1.gv(), 0, nullptr);
                 Tens y2 = tens(rows_out, mid, false), a2 = tens(rows_out, mid);
-                add_dw(ops, pre + ".dw", a1.v(), N, curH, curW, mid, stride, y2.p, a1.gv(), 0);
+                add_dw(ops, pre + ".dw", a1.v(), N, curH, curW, mid, stride, y2.p, a1.gv(), 0, &r1);
                 add_bn(ops, M_TRUNK, pre + ".bn2", y2.v(), T, Mg_out, mid, true, ACT_NONE, a2.v(), 0, a2.gv(), 0, nullptr);
                 Tens y3 = tens(rows_out, main_out, false);
                 add_pw(ops, pre + ".pw2", a2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out));
