@@ -339,6 +339,47 @@ int cdrl_dwconv_bwd_filter(const float* a, const float* dy, float* dw, float* db
     return dw_bwd_filter(make_view(const_cast<float*>(a), C), dy, dw, db, N, H, W, C, stride, workspace, S(stream));
 }
 
+int64_t cdrl_dwconv_bn_workspace_doubles(int G, int B, int H, int W, int C, int stride) {
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    const int64_t nb_out = vcol_geom(B * Ho * Wo, C).nb, nb_in = vcol_geom(B * H * W, C).nb;
+    const int64_t nbm = nb_out > nb_in ? nb_out : nb_in;
+    return dwf_stats_part_elems(B, G, H, W, C, stride) + dwf_filter_part_elems(B, G, H, W, C, stride) + (int64_t)G * nbm * 3 * C;
+}
+
+int cdrl_dwconv_bn_fwd(const float* x, const float* pre_stats, const float* w, const float* bias, float* y, int G, int B,
+                       int H, int W, int C, int stride, const float* gamma, const float* beta, float* moving_mean,
+                       float* moving_var, int bessel, float* post_stats, double* workspace, void* stream) {
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    CDRL_TRY(dwf_fwd(x, pre_stats, w, bias, y, workspace, G, B, H, W, C, stride, S(stream)));
+    return bn_finalize(workspace, dwf_geom(B, G, H, W, C, stride).nb, G, B * Ho * Wo, C, gamma, beta, moving_mean, moving_var,
+                       bessel, 1, post_stats, S(stream));
+}
+
+int cdrl_dwconv_bn_bwd(const float* x, const float* pre_stats, const float* dout, const float* y, const float* post_stats,
+                       const float* w, int G, int B, int H, int W, int C, int stride, float* dx, float* dw, float* db,
+                       float* dgamma_post, float* dbeta_post, float* coef_post, float* dgamma_pre, float* dbeta_pre,
+                       float* coef_pre, double* workspace, void* stream) {
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    const int Mo = B * Ho * Wo, Mi = B * H * W;
+    const DwfGeom g = dwf_geom(B, G, H, W, C, stride);
+    double* part_bn = workspace;
+    double* part_w = part_bn + dwf_stats_part_elems(B, G, H, W, C, stride);
+    double* part_r = part_w + dwf_filter_part_elems(B, G, H, W, C, stride);
+    hipStream_t st = S(stream);
+    View vd = make_view(const_cast<float*>(dout), C), vy = make_view(const_cast<float*>(y), C);
+    CDRL_TRY(bn_bwd_reduce(vd, 0, vy, G, Mo, C, post_stats, ACT_NONE, part_r, st, nullptr));
+    CDRL_TRY(bn_bwd_finalize(part_r, vcol_geom(Mo, C).nb, G, Mo, C, post_stats, dgamma_post, dbeta_post, coef_post, st));
+    CDRL_TRY(dwf_bwd(x, pre_stats, dout, y, post_stats, coef_post, w, make_view(dx, C), part_bn, part_w, G, B, H, W, C, stride, st));
+    CDRL_TRY(reduce_partials(part_w, G * g.nb, 9 * C, (int64_t)10 * C, dw, 0, st));
+    CDRL_TRY(reduce_partials(part_w + 9 * C, G * g.nb, C, (int64_t)10 * C, db, 0, st));
+    if (pre_stats) {
+        CDRL_TRY(bn_bwd_finalize(part_bn, g.nb, G, Mi, C, pre_stats, dgamma_pre, dbeta_pre, coef_pre, st));
+        View vx = make_view(const_cast<float*>(x), C);
+        CDRL_TRY(bn_bwd_apply(make_view(dx, C), 0, vx, G, Mi, C, pre_stats, coef_pre, ACT_NONE, dx, part_r, st, nullptr));
+    }
+    return 0;
+}
+
 int cdrl_maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, void* stream) {
     return maxpool_fwd(a, p, argmax, N, H, W, C, S(stream));
 }

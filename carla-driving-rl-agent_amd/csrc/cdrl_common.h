@@ -93,6 +93,15 @@ inline ColGeom col_geom(int rows_per_group, int C, int max_blocks_per_group = NB
 // block is (cx = C/vec channel lanes) x (cy row lanes) -- not a power of two in general (C = 116:
 // 29 x 8 = 232 threads).  A function of (rows, C) only, so producers and consumers of the partial
 // sums agree on `nb` without talking to each other.
+// TF 'SAME' geometry of a 3x3 window (asymmetric padding for stride 2 on even sizes)
+__host__ __device__ inline int same_out(int n, int s) { return (n + s - 1) / s; }
+__host__ __device__ inline int same_pad_before(int n, int s) {
+    const int out = (n + s - 1) / s;
+    int tot = (out - 1) * s + 3 - n;
+    if (tot < 0) tot = 0;
+    return tot / 2;
+}
+
 struct VColGeom {
     int vec, cx, cy, nloop;   // nloop: channel-lane passes when C/vec > 256
     int rb, nb;

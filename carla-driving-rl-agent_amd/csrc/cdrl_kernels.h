@@ -83,6 +83,26 @@ int dw_bwd_data_bnreduce(const float* dy, const float* w, View da, int N, int H,
 int64_t dw_bwd_part_elems(int N, int H, int W, int C, int stride);
 int dw_bwd_filter(View a, const float* dy, float* dw, float* db, int N, int H, int W, int C, int stride,
                   double* part, hipStream_t st);
+// ---- fused depthwise block (dwfused.hip): whole frames staged in LDS.  G groups x B frames per group.
+struct DwfGeom {
+    int vec, nch, cchunk, cx, cy, fpb, nb;     // nb: partial blocks per group (B / frames-per-block)
+    size_t lds_fwd, lds_bwd;
+};
+DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride);
+int64_t dwf_stats_part_elems(int B, int G, int H, int W, int C, int stride);      // doubles: [G][nb][2][C]
+int64_t dwf_filter_part_elems(int B, int G, int H, int W, int C, int stride);     // doubles: [G*nb][10][C]
+// y = dw3x3(pre_stats ? relu6(scale*x+shift) : x) + bias and the per-block (sum y, sum y^2) partials of the
+// BatchNorm that follows (layout of bn_finalize with nb = dwf_geom().nb).
+int dwf_fwd(const float* x, const float* pre_stats, const float* w, const float* bias, float* y, double* part, int G,
+            int B, int H, int W, int C, int stride, hipStream_t st);
+// dout: gradient w.r.t. the output of the BatchNorm (no activation) that follows the depthwise conv; y2: the raw
+// depthwise output; post_stats / post_coef: that BN's statistics and backward coefficients (k1,k2,k3).
+// Writes the filter / bias partials (part_w: reduce with reduce_partials over G*nb parts, row stride 10*C) and
+//   pre_stats != null: dx = ReLU6-masked gradient at the pre-BN's output + its (sum dz, sum dz*xhat) partials
+//   pre_stats == null: dx = gradient w.r.t. x.
+int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const float* y2, const float* post_stats,
+            const float* post_coef, const float* w, View dx, double* part_bn, double* part_w, int G, int B, int H, int W,
+            int C, int stride, hipStream_t st);
 int maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, hipStream_t st);
 int maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H, int W, int C, hipStream_t st);
 // fused BN-apply + ReLU6 + max-pool on the raw conv output y (frames of group g = [g*frames_per_group, ...))

@@ -9,14 +9,6 @@
 
 namespace cdrl {
 
-__host__ __device__ inline int same_out(int n, int s) { return (n + s - 1) / s; }
-__host__ __device__ inline int same_pad_before(int n, int s) {
-    const int out = (n + s - 1) / s;
-    int tot = (out - 1) * s + 3 - n;
-    if (tot < 0) tot = 0;
-    return tot / 2;
-}
-
 // ------------------------------------------------------------------------------------------
 // stem: Conv2D(24, 3, strides=2, 'valid') on the (B,T,H,W,3) observation tensor
 // (reference core/architectures.py:159).  Output frame index = t*B + b.

@@ -1,0 +1,429 @@
+// Fused depthwise-3x3 block of the ShuffleNet unit (gfx950): one workgroup owns whole frames.
+//
+// Reference: core/architectures.py:120-145 -- the unit's  pw -> BN+ReLU6 -> dw3x3 -> BN -> pw  chain.
+// A depthwise conv is local to one frame and one channel, and at the tower's resolutions a frame
+// (22x30 ... 3x4 pixels x <= 232 channels) fits in LDS.  So instead of streaming every tensor through
+// HBM once per elementary op, a workgroup stages the frame(s) in LDS once and does everything that
+// is local to the frame on it:
+//
+//   forward   tile <- relu6(scale1 * y1 + shift1)      (BN1 apply: a1 is never written to HBM)
+//             y2   <- dw3x3(tile) + bias               (9 LDS reads per output)
+//             (sum y2, sum y2^2) per channel           -> BN2 statistics partials (no second pass over y2)
+//
+//   backward  D    <- k1 * (da2 - k2 - xhat2 * k3)     (BN2 backward apply: dy2 is never written to HBM)
+//             A    <- relu6(scale1 * y1 + shift1)      (recomputed, not stored)
+//             dW   += A (x) D per tap, db += D         -> filter / bias gradient partials
+//             dz1  <- mask1 * dw3x3^T(D)               (ReLU6 mask of BN1's output)
+//             (sum dz1, sum dz1 * xhat1)               -> BN1 backward partials
+//
+// HBM traffic per element: forward 1 read + 1 write (was 3 reads + 2 writes over apply / dw / stats),
+// backward 3 reads + 1 write + an L2-resident re-read of y1 (was 9 reads + 2 writes over bn-apply /
+// dw-data / dw-filter / bn-reduce).  Launches per unit: forward 3 -> 1, backward 4 -> 1.
+//
+// Grid = (groups * frame-blocks, channel chunks); block = (channel lanes, pixel lanes); channel chunks
+// only when a full-width frame does not fit the LDS budget (the 22x30 stride-2 inputs).  Partial sums
+// are double, written per block, combined in fixed order by the finalize kernels (deterministic).
+// The `pre` prologue is optional (shortcut branch: the depthwise reads an activation tensor directly).
+#include "colreduce.h"
+
+namespace cdrl {
+
+static constexpr size_t DWF_LDS_BUDGET = 76 * 1024;      // 2 workgroups per CU (160 KB LDS)
+
+DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
+    DwfGeom g;
+    const int Ho = same_out(H, stride), Wo = same_out(W, stride);
+    g.vec = (C % 4 == 0) ? 4 : ((C % 2 == 0) ? 2 : 1);
+    const size_t per_c = (size_t)(H * W + Ho * Wo) * sizeof(float);
+    int maxc = (int)(DWF_LDS_BUDGET / per_c) / g.vec * g.vec;
+    if (maxc < g.vec) maxc = g.vec;
+    if (maxc > 256 * g.vec) maxc = 256 * g.vec;
+    const int lanes = C / g.vec;
+    if (maxc >= C) {
+        g.nch = 1;
+        g.cchunk = C;
+    } else {
+        int nch = cdiv(C, maxc);
+        g.cchunk = cdiv(lanes, nch) * g.vec;
+        g.nch = cdiv(C, g.cchunk);
+    }
+    g.cx = g.cchunk / g.vec;
+    g.cy = 256 / g.cx;
+    if (g.cy < 1) g.cy = 1;
+    // small frames: several frames per workgroup (fewer partials, less per-block overhead), keeping >= 512 blocks
+    int fpb = 1;
+    const int work = Ho * Wo * g.cx;
+    while (fpb < 8 && work * fpb * 2 <= 4096 && B % (fpb * 2) == 0 && (int64_t)G * (B / (fpb * 2)) * g.nch >= 512) fpb *= 2;
+    g.fpb = fpb;
+    g.nb = B / fpb;
+    const size_t red = (size_t)g.cy * g.vec * g.cx * sizeof(double);
+    g.lds_fwd = (size_t)H * W * g.cchunk * sizeof(float);
+    g.lds_bwd = (size_t)(H * W + Ho * Wo) * g.cchunk * sizeof(float);
+    if (g.lds_fwd < red) g.lds_fwd = red;
+    if (g.lds_bwd < red) g.lds_bwd = red;
+    return g;
+}
+
+int64_t dwf_stats_part_elems(int B, int G, int H, int W, int C, int stride) {
+    return (int64_t)G * dwf_geom(B, G, H, W, C, stride).nb * 2 * C;
+}
+int64_t dwf_filter_part_elems(int B, int G, int H, int W, int C, int stride) {
+    return (int64_t)G * dwf_geom(B, G, H, W, C, stride).nb * 10 * C;
+}
+
+// reduce one double per (channel lane, vec) over the pixel lanes through LDS; result valid on ty == 0
+template <int VEC>
+__device__ __forceinline__ void block_colsum(double* sm, double (&a)[VEC], int tx, int ty, int CX, int CY) {
+    if (CY == 1) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sm[(ty * VEC + i) * CX + tx] = a[i];
+    __syncthreads();
+    if (ty == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            double s = a[i];
+            for (int y = 1; y < CY; ++y) s += sm[(y * VEC + i) * CX + tx];
+            a[i] = s;
+        }
+    }
+}
+
+template <int S, int VEC, bool PRE>
+__global__ void __launch_bounds__(256) dwf_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pre_stats,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ y, double* __restrict__ part, int Bf, int H, int W,
+                                                      int Ho, int Wo, int C, int GC, int pt, int pl, int fpb, int nb,
+                                                      int cchunk) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // [H*W][cc]
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int g = blockIdx.x / nb, b = blockIdx.x % nb;
+    const int cbase = blockIdx.y * cchunk;
+    const int cc = min(cchunk, C - cbase);
+    const bool on = tx * VEC < cc;
+    const int c = cbase + tx * VEC;
+    VecF<VEC> wk[9], bv, sc, sh;
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = vload<VEC>(w + k * C + c);
+        bv = vload<VEC>(bias + c);
+        if (PRE) {
+            sc = vload<VEC>(pre_stats + 2 * GC + g * C + c);
+            sh = vload<VEC>(pre_stats + 3 * GC + g * C + c);
+        }
+    }
+    double s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.0;
+    const int P = H * W, Po = Ho * Wo;
+    for (int f = 0; f < fpb; ++f) {
+        const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f;
+        if (f) __syncthreads();
+        if (on) {
+            const float* xp = x + n * P * C + c;
+            for (int p = ty; p < P; p += CY) {
+                VecF<VEC> v = vload<VEC>(xp + (int64_t)p * C);
+                if (PRE) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v.v[i] = fminf(fmaxf(fmaf(sc.v[i], v.v[i], sh.v[i]), 0.0f), 6.0f);
+                }
+                vstore<VEC>(&tile[p * cchunk + tx * VEC], v);
+            }
+        }
+        __syncthreads();
+        if (on) {
+            float* yp = y + n * Po * C + c;
+            for (int p = ty; p < Po; p += CY) {
+                const int oy = p / Wo, ox = p - oy * Wo;
+                VecF<VEC> acc = bv;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int iy = oy * S + ky - pt;
+                    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ix = ox * S + kx - pl;
+                        if (ix < 0 || ix >= W) continue;
+                        const VecF<VEC> a = vload<VEC>(&tile[(iy * W + ix) * cchunk + tx * VEC]);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(a.v[i], wk[ky * 3 + kx].v[i], acc.v[i]);
+                    }
+                }
+                vstore<VEC>(yp + (int64_t)p * C, acc);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const double d = (double)acc.v[i];
+                    s1[i] += d;
+                    s2[i] += d * d;
+                }
+            }
+        }
+    }
+    double* sm = reinterpret_cast<double*>(tile);
+    block_colsum<VEC>(sm, s1, tx, ty, CX, CY);
+    block_colsum<VEC>(sm, s2, tx, ty, CX, CY);
+    if (ty == 0 && on) {
+        double* pp = part + ((int64_t)g * nb + b) * 2 * C + c;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            pp[i] = s1[i];
+            pp[C + i] = s2[i];
+        }
+    }
+}
+
+template <int S, int VEC, bool PRE>
+__global__ void __launch_bounds__(256) dwf_bwd_kernel(const float* __restrict__ x, const float* __restrict__ pre_stats,
+                                                      const float* __restrict__ dout, const float* __restrict__ y2,
+                                                      const float* __restrict__ post_stats,
+                                                      const float* __restrict__ post_coef, const float* __restrict__ w,
+                                                      View dx, double* __restrict__ part_bn, double* __restrict__ part_w,
+                                                      int Bf, int H, int W, int Ho, int Wo, int C, int GC, int pt, int pl,
+                                                      int fpb, int nb, int cchunk, bool dx_al) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // A [H*W][cc] | D [Ho*Wo][cc]
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int g = blockIdx.x / nb, b = blockIdx.x % nb;
+    const int cbase = blockIdx.y * cchunk;
+    const int cc = min(cchunk, C - cbase);
+    const bool on = tx * VEC < cc;
+    const int c = cbase + tx * VEC;
+    const int P = H * W, Po = Ho * Wo;
+    float* tA = tile;
+    float* tD = tile + (size_t)P * cchunk;
+    VecF<VEC> wk[9], sc, sh, mean1, inv1, mean2, inv2, k1, k2, k3;
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = vload<VEC>(w + k * C + c);
+        if (PRE) {
+            mean1 = vload<VEC>(pre_stats + 0 * GC + g * C + c);
+            inv1 = vload<VEC>(pre_stats + 1 * GC + g * C + c);
+            sc = vload<VEC>(pre_stats + 2 * GC + g * C + c);
+            sh = vload<VEC>(pre_stats + 3 * GC + g * C + c);
+        }
+        mean2 = vload<VEC>(post_stats + 0 * GC + g * C + c);
+        inv2 = vload<VEC>(post_stats + 1 * GC + g * C + c);
+        k1 = vload<VEC>(post_coef + 0 * GC + g * C + c);
+        k2 = vload<VEC>(post_coef + 1 * GC + g * C + c);
+        k3 = vload<VEC>(post_coef + 2 * GC + g * C + c);
+    }
+    double gw[10][VEC], gb1[VEC], gb2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        gb1[i] = gb2[i] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) gw[k][i] = 0.0;
+    }
+    for (int f = 0; f < fpb; ++f) {
+        const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f;
+        if (f) __syncthreads();
+        if (on) {
+            const float* xp = x + n * P * C + c;
+            for (int p = ty; p < P; p += CY) {
+                VecF<VEC> v = vload<VEC>(xp + (int64_t)p * C);
+                if (PRE) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v.v[i] = fminf(fmaxf(fmaf(sc.v[i], v.v[i], sh.v[i]), 0.0f), 6.0f);
+                }
+                vstore<VEC>(&tA[p * cchunk + tx * VEC], v);
+            }
+            const float* dp = dout + n * Po * C + c;
+            const float* yp = y2 + n * Po * C + c;
+            for (int p = ty; p < Po; p += CY) {
+                const VecF<VEC> d = vload<VEC>(dp + (int64_t)p * C);
+                const VecF<VEC> v = vload<VEC>(yp + (int64_t)p * C);
+                VecF<VEC> o;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float xh = (v.v[i] - mean2.v[i]) * inv2.v[i];
+                    o.v[i] = k1.v[i] * (d.v[i] - k2.v[i] - xh * k3.v[i]);
+                }
+                vstore<VEC>(&tD[p * cchunk + tx * VEC], o);
+            }
+        }
+        __syncthreads();
+        if (on) {
+            // filter / bias gradient: every output pixel contributes D * A(window)
+            for (int p = ty; p < Po; p += CY) {
+                const int oy = p / Wo, ox = p - oy * Wo;
+                const VecF<VEC> d = vload<VEC>(&tD[p * cchunk + tx * VEC]);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int iy = oy * S + ky - pt;
+                    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ix = ox * S + kx - pl;
+                        if (ix < 0 || ix >= W) continue;
+                        const VecF<VEC> a = vload<VEC>(&tA[(iy * W + ix) * cchunk + tx * VEC]);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) gw[ky * 3 + kx][i] += (double)(a.v[i] * d.v[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) gw[9][i] += (double)d.v[i];
+            }
+            // gradient w.r.t. the depthwise input (transposed conv), masked by ReLU6 of the pre BN
+            const float* xp = x + n * P * C + c;
+            for (int p = ty; p < P; p += CY) {
+                const int iy = p / W, ix = p - iy * W;
+                VecF<VEC> acc;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc.v[i] = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int ny = iy + pt - ky;
+                    if (ny < 0 || (ny % S) != 0) continue;
+                    const int oy = ny / S;
+                    if (oy >= Ho) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int nx = ix + pl - kx;
+                        if (nx < 0 || (nx % S) != 0) continue;
+                        const int ox = nx / S;
+                        if (ox >= Wo) continue;
+                        const VecF<VEC> d = vload<VEC>(&tD[(oy * Wo + ox) * cchunk + tx * VEC]);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(d.v[i], wk[ky * 3 + kx].v[i], acc.v[i]);
+                    }
+                }
+                const int64_t row = n * P + p;
+                if (PRE) {
+                    const VecF<VEC> a = vload<VEC>(&tA[p * cchunk + tx * VEC]);
+                    const VecF<VEC> v = vload<VEC>(xp + (int64_t)p * C);      // L2-resident re-read of y1 for xhat1
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        if (!(a.v[i] > 0.0f && a.v[i] < 6.0f)) acc.v[i] = 0.0f;
+                        const float xh = (v.v[i] - mean1.v[i]) * inv1.v[i];
+                        gb1[i] += (double)acc.v[i];
+                        gb2[i] += (double)acc.v[i] * (double)xh;
+                    }
+                }
+                vstore_view<VEC>(dx, row, c, 0, dx_al, acc);
+            }
+        }
+    }
+    double* sm = reinterpret_cast<double*>(tile);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) block_colsum<VEC>(sm, gw[k], tx, ty, CX, CY);
+    if (PRE) {
+        block_colsum<VEC>(sm, gb1, tx, ty, CX, CY);
+        block_colsum<VEC>(sm, gb2, tx, ty, CX, CY);
+    }
+    if (ty == 0 && on) {
+        double* pw = part_w + ((int64_t)g * nb + b) * 10 * C + c;
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) pw[k * C + i] = gw[k][i];
+        if (PRE) {
+            double* pp = part_bn + ((int64_t)g * nb + b) * 2 * C + c;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                pp[i] = gb1[i];
+                pp[C + i] = gb2[i];
+            }
+        }
+    }
+}
+
+template <class K>
+static int allow_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+template <int S, int VEC, bool PRE>
+static int launch_dwf_fwd(const DwfGeom& g, hipStream_t st, const float* x, const float* pre_stats, const float* w,
+                          const float* bias, float* y, double* part, int G, int B, int H, int W, int C) {
+    const int Ho = same_out(H, S), Wo = same_out(W, S);
+    CDRL_TRY(allow_lds(dwf_fwd_kernel<S, VEC, PRE>, g.lds_fwd));
+    hipLaunchKernelGGL((dwf_fwd_kernel<S, VEC, PRE>), dim3(G * g.nb, g.nch), dim3(g.cx, g.cy), g.lds_fwd, st, x, pre_stats, w, bias,
+                       y, part, B, H, W, Ho, Wo, C, G * C, same_pad_before(H, S), same_pad_before(W, S), g.fpb, g.nb, g.cchunk);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int S, int VEC>
+static int launch_dwf_fwd_pre(const DwfGeom& g, hipStream_t st, const float* x, const float* pre_stats, const float* w,
+                              const float* bias, float* y, double* part, int G, int B, int H, int W, int C) {
+    if (pre_stats) return launch_dwf_fwd<S, VEC, true>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C);
+    return launch_dwf_fwd<S, VEC, false>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C);
+}
+
+int dwf_fwd(const float* x, const float* pre_stats, const float* w, const float* bias, float* y, double* part, int G,
+            int B, int H, int W, int C, int stride, hipStream_t st) {
+    if (stride != 1 && stride != 2) {
+        set_error("dwf_fwd: stride must be 1 or 2");
+        return -1;
+    }
+    const DwfGeom g = dwf_geom(B, G, H, W, C, stride);
+    if (g.lds_fwd > 150 * 1024) {
+        set_error("dwf_fwd: frame %dx%d does not fit LDS even at %d channels", H, W, g.cchunk);
+        return -1;
+    }
+#define CDRL_DWF_FWD(S, V) return launch_dwf_fwd_pre<S, V>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C)
+    if (stride == 1) {
+        if (g.vec == 4) CDRL_DWF_FWD(1, 4);
+        if (g.vec == 2) CDRL_DWF_FWD(1, 2);
+        CDRL_DWF_FWD(1, 1);
+    }
+    if (g.vec == 4) CDRL_DWF_FWD(2, 4);
+    if (g.vec == 2) CDRL_DWF_FWD(2, 2);
+    CDRL_DWF_FWD(2, 1);
+#undef CDRL_DWF_FWD
+}
+
+template <int S, int VEC, bool PRE>
+static int launch_dwf_bwd(const DwfGeom& g, hipStream_t st, const float* x, const float* pre_stats, const float* dout,
+                          const float* y2, const float* post_stats, const float* post_coef, const float* w, View dx,
+                          double* part_bn, double* part_w, int G, int B, int H, int W, int C) {
+    const int Ho = same_out(H, S), Wo = same_out(W, S);
+    CDRL_TRY(allow_lds(dwf_bwd_kernel<S, VEC, PRE>, g.lds_bwd));
+    hipLaunchKernelGGL((dwf_bwd_kernel<S, VEC, PRE>), dim3(G * g.nb, g.nch), dim3(g.cx, g.cy), g.lds_bwd, st, x, pre_stats, dout, y2,
+                       post_stats, post_coef, w, dx, part_bn, part_w, B, H, W, Ho, Wo, C, G * C, same_pad_before(H, S),
+                       same_pad_before(W, S), g.fpb, g.nb, g.cchunk, view_aligned(dx, g.vec));
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int S, int VEC>
+static int launch_dwf_bwd_pre(const DwfGeom& g, hipStream_t st, const float* x, const float* pre_stats, const float* dout,
+                              const float* y2, const float* post_stats, const float* post_coef, const float* w, View dx,
+                              double* part_bn, double* part_w, int G, int B, int H, int W, int C) {
+    if (pre_stats)
+        return launch_dwf_bwd<S, VEC, true>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C);
+    return launch_dwf_bwd<S, VEC, false>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C);
+}
+
+int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const float* y2, const float* post_stats,
+            const float* post_coef, const float* w, View dx, double* part_bn, double* part_w, int G, int B, int H, int W,
+            int C, int stride, hipStream_t st) {
+    if (stride != 1 && stride != 2) {
+        set_error("dwf_bwd: stride must be 1 or 2");
+        return -1;
+    }
+    if (pre_stats && !part_bn) {
+        set_error("dwf_bwd: part_bn is required with a pre-BN prologue");
+        return -1;
+    }
+    const DwfGeom g = dwf_geom(B, G, H, W, C, stride);
+    if (g.lds_bwd > 150 * 1024) {
+        set_error("dwf_bwd: frame %dx%d does not fit LDS even at %d channels", H, W, g.cchunk);
+        return -1;
+    }
+#define CDRL_DWF_BWD(S, V) \
+    return launch_dwf_bwd_pre<S, V>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C)
+    if (stride == 1) {
+        if (g.vec == 4) CDRL_DWF_BWD(1, 4);
+        if (g.vec == 2) CDRL_DWF_BWD(1, 2);
+        CDRL_DWF_BWD(1, 1);
+    }
+    if (g.vec == 4) CDRL_DWF_BWD(2, 4);
+    if (g.vec == 2) CDRL_DWF_BWD(2, 2);
+    CDRL_DWF_BWD(2, 1);
+#undef CDRL_DWF_BWD
+}
+
+}  // namespace cdrl

@@ -150,6 +150,12 @@ private:
                 View din, int din_acc, BnRec bn_after);
     void add_dw(std::vector<Op>& ops, const std::string& prefix, View in, int N, int H, int W, int C, int stride,
                 float* y, View din, int din_acc, const BnRec* pre_bn = nullptr);
+    // Fused depthwise block (dwfused.hip): [BN `bn_pre` (+ReLU6) of the raw 1x1-conv output x, or none] -> dw3x3 ->
+    // BN `bn_post` (no activation) -> out.  Emits three ops (pre-BN, depthwise, post-BN); the normalised depthwise
+    // input and the post-BN input gradient never touch HBM.  din: gradient target when there is no pre-BN.
+    void add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw, const char* bn_post,
+                      float* x, int H, int W, int C, int stride, float* y2, View out, View dout, View din);
+    bool fused_dw_ = true;
     void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
                    View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);
     void add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,

@@ -321,6 +321,86 @@ void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, i
     ops.push_back(op);
 }
 
+void Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw,
+                           const char* bn_post, float* x, int H, int W, int C, int stride, float* y2, View out, View dout,
+                           View din) {
+    const int B = cfg_.B, G = cfg_.T, N = B * G;
+    const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
+    const int Mi = B * H * W, Mo = B * Ho * Wo;
+    const bool pre = bn_pre != nullptr;
+    PRef g1, b1, mm1, mv1;
+    float *stats1 = nullptr, *coef1 = nullptr;
+    if (pre) {
+        const std::string n1 = unit + "." + bn_pre;
+        g1 = param(M_TRUNK, n1 + ".gamma", {C}, true);
+        b1 = param(M_TRUNK, n1 + ".beta", {C}, true);
+        mm1 = param(M_TRUNK, n1 + ".moving_mean", {C}, false);
+        mv1 = param(M_TRUNK, n1 + ".moving_var", {C}, false);
+        stats1 = alloc((size_t)4 * G * C);
+        coef1 = alloc((size_t)3 * G * C);
+    }
+    PRef w = param(M_TRUNK, unit + "." + dw + ".w", {3, 3, C, 1}, true);
+    PRef b = param(M_TRUNK, unit + "." + dw + ".b", {C}, true);
+    const std::string n2 = unit + "." + bn_post;
+    PRef g2 = param(M_TRUNK, n2 + ".gamma", {C}, true);
+    PRef b2 = param(M_TRUNK, n2 + ".beta", {C}, true);
+    PRef mm2 = param(M_TRUNK, n2 + ".moving_mean", {C}, false);
+    PRef mv2 = param(M_TRUNK, n2 + ".moving_var", {C}, false);
+    float* stats2 = alloc((size_t)4 * G * C);
+    float* coef2 = alloc((size_t)3 * G * C);
+    const int nb_in = vcol_geom(Mi, C).nb, nb_out = vcol_geom(Mo, C).nb;
+    const int nbf = dwf_geom(B, G, H, W, C, stride).nb;
+    const size_t nbmax = (size_t)std::max(std::max(nb_in, nb_out), nbf);
+    note_scratch((size_t)G * nbmax * 2 * C, (size_t)G * nbmax * C, (size_t)N * H * W * C, 0,
+                 (size_t)dwf_filter_part_elems(B, G, H, W, C, stride));
+    const View xv = make_view(x, C), y2v = make_view(y2, C);
+
+    if (pre) {      // BN1: statistics only in the forward; backward = finalize of the sums the depthwise op produced
+        Op op;
+        op.fwd = [=](hipStream_t st, int training) -> int {
+            if (training) CDRL_TRY(colstats(xv, G, Mi, C, scr_main_.part, st));
+            return bn_finalize(scr_main_.part, nb_in, G, Mi, C, g1.p, b1.p, mm1.p, mv1.p, 1, training, stats1, st);
+        };
+        op.bwd = [=](hipStream_t st) -> int {
+            CDRL_TRY(bn_bwd_finalize(scr_main_.part, nbf, G, Mi, C, stats1, g1.g, b1.g, coef1, st));
+            const float* dz = dys_[slot_];                 // masked gradient left there by the depthwise op
+            CDRL_TRY(next_slot(st));
+            return bn_bwd_apply(make_view(const_cast<float*>(dz), C), 0, xv, G, Mi, C, stats1, coef1, ACT_NONE, dys_[slot_],
+                                part2s_[slot_], st);
+        };
+        ops.push_back(op);
+    }
+    {
+        Op op;
+        op.fwd = [=](hipStream_t st, int) -> int {
+            return dwf_fwd(x, stats1, w.p, b.p, y2, scr_main_.part, G, B, H, W, C, stride, st);
+        };
+        op.bwd = [=](hipStream_t st) -> int {
+            CDRL_TRY(next_slot(st));
+            double* pw = fparts_[slot_];
+            const View dx = pre ? make_view(dys_[slot_], C) : din;
+            CDRL_TRY(dwf_bwd(x, stats1, dout.p, y2, stats2, coef2, w.p, dx, scr_main_.part, pw, G, B, H, W, C, stride, st));
+            hipStream_t side = fork_side(st);
+            CDRL_TRY(reduce_partials(pw, G * nbf, 9 * C, (int64_t)10 * C, w.g, 0, side));
+            CDRL_TRY(reduce_partials(pw + 9 * C, G * nbf, C, (int64_t)10 * C, b.g, 0, side));
+            return done_side(side);
+        };
+        ops.push_back(op);
+    }
+    {               // BN2: finalize + apply in the forward; backward = sums + coefficients only (applied by the dw op)
+        Op op;
+        op.fwd = [=](hipStream_t st, int training) -> int {
+            CDRL_TRY(bn_finalize(scr_main_.part, nbf, G, Mo, C, g2.p, b2.p, mm2.p, mv2.p, 1, training, stats2, st));
+            return bn_apply(y2v, G, Mo, C, stats2, ACT_NONE, out, 0, st);
+        };
+        op.bwd = [=](hipStream_t st) -> int {
+            CDRL_TRY(bn_bwd_reduce(dout, 0, y2v, G, Mo, C, stats2, ACT_NONE, scr_main_.part, st));
+            return bn_bwd_finalize(scr_main_.part, nb_out, G, Mo, C, stats2, g2.g, b2.g, coef2, st);
+        };
+        ops.push_back(op);
+    }
+}
+
 void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N,
                         int act, View out, View dout, View din, int din_acc, bool need_din, const char*) {
     PRef w = param(model, prefix + ".w", {K, N}, true);
@@ -464,6 +544,10 @@ void Learner::build_trunk(std::vector<Op>& ops) {
     };
     aux_ops_.clear();
     add_aux_fork(ops);
+    {
+        const char* e = getenv("CDRL_FUSED_DW");        // 0 -> unfused bn-apply / depthwise / stats kernels
+        fused_dw_ = !(e && atoi(e) == 0);
+    }
 
     // ---- stem (core/architectures.py:159-161)
     {
@@ -539,22 +623,34 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     cp.bwd = [=](hipStream_t st) -> int { return gather_view(gsrc, C, rows_in, sc_c, gdst, 0, st); };
                     ops.push_back(cp);
                 }
-                Tens y1 = tens(rows_in, mid, false), a1 = tens(rows_in, mid);
+                Tens y1 = tens(rows_in, mid, false);
                 add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off),
                        stride == 2 ? 1 : 0, bnrec(T, Mg_in, mid));
-                BnRec r1 = add_bn(ops, M_TRUNK, pre + ".bn1", y1.v(), T, Mg_in, mid, true, ACT_RELU6, a1.v(), 0, a1.gv(), 0, nullptr);
                 Tens y2 = tens(rows_out, mid, false), a2 = tens(rows_out, mid);
-                add_dw(ops, pre + ".dw", a1.v(), N, curH, curW, mid, stride, y2.p, a1.gv(), 0, &r1);
-                add_bn(ops, M_TRUNK, pre + ".bn2", y2.v(), T, Mg_out, mid, true, ACT_NONE, a2.v(), 0, a2.gv(), 0, nullptr);
+                if (fused_dw_) {
+                    add_dw_block(ops, pre, "bn1", "dw", "bn2", y1.p, curH, curW, mid, stride, y2.p, a2.v(), a2.gv(),
+                                 View{nullptr, 0, 0});
+                } else {
+                    Tens a1 = tens(rows_in, mid);
+                    BnRec r1 = add_bn(ops, M_TRUNK, pre + ".bn1", y1.v(), T, Mg_in, mid, true, ACT_RELU6, a1.v(), 0, a1.gv(), 0,
+                                      nullptr);
+                    add_dw(ops, pre + ".dw", a1.v(), N, curH, curW, mid, stride, y2.p, a1.gv(), 0, &r1);
+                    add_bn(ops, M_TRUNK, pre + ".bn2", y2.v(), T, Mg_out, mid, true, ACT_NONE, a2.v(), 0, a2.gv(), 0, nullptr);
+                }
                 Tens y3 = tens(rows_out, main_out, false);
                 add_pw(ops, pre + ".pw2", a2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out));
                 add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C,
                        out.gv(sc_c), C, nullptr);
                 if (stride == 2) {
                     Tens ys1 = tens(rows_out, sc_c, false), b1 = tens(rows_out, sc_c);
-                    add_dw(ops, pre + ".sc_dw", X.v(0), N, curH, curW, sc_c, 2, ys1.p, X.gv(0), 0);
-                    add_bn(ops, M_TRUNK, pre + ".sc_bn1", ys1.v(), T, Mg_out, sc_c, true, ACT_NONE, b1.v(), 0, b1.gv(), 0,
-                           nullptr);
+                    if (fused_dw_) {
+                        add_dw_block(ops, pre, nullptr, "sc_dw", "sc_bn1", X.p, curH, curW, sc_c, 2, ys1.p, b1.v(), b1.gv(),
+                                     X.gv(0));
+                    } else {
+                        add_dw(ops, pre + ".sc_dw", X.v(0), N, curH, curW, sc_c, 2, ys1.p, X.gv(0), 0);
+                        add_bn(ops, M_TRUNK, pre + ".sc_bn1", ys1.v(), T, Mg_out, sc_c, true, ACT_NONE, b1.v(), 0, b1.gv(), 0,
+                               nullptr);
+                    }
                     Tens ys2 = tens(rows_out, sc_c, false);
                     add_pw(ops, pre + ".sc_pw", b1.v(), rows_out, sc_c, sc_c, ys2.p, b1.gv(), 0, bnrec(T, Mg_out, sc_c));
                     add_bn(ops, M_TRUNK, pre + ".sc_bn2", ys2.v(), T, Mg_out, sc_c, true, ACT_RELU6, out.v(0), C, out.gv(0),
@@ -771,10 +867,16 @@ int Learner::bind(const Buffers& b) {
         // host-bound.  CDRL_GRAPH=1 enables it (parity suite passes in both modes).
         const char* genv = getenv("CDRL_GRAPH");
         graphs_enabled_ = genv && atoi(genv) != 0;
-        CDRL_HIP(hipStreamCreateWithFlags(&main_, hipStreamNonBlocking));
+        // the main stream carries the dependent chain (critical path): highest priority; the side stream
+        // (filter / bias gradients, small-modality nets) fills idle CUs at the lowest priority so that its wide
+        // reductions do not delay the short main-stream kernels.  CDRL_STREAM_PRIO=0 -> equal priorities.
+        int prio_lo = 0, prio_hi = 0;
+        const char* penv = getenv("CDRL_STREAM_PRIO");
+        if (!(penv && atoi(penv) == 0)) CDRL_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        CDRL_HIP(hipStreamCreateWithPriority(&main_, hipStreamNonBlocking, prio_hi));
         CDRL_HIP(hipEventCreateWithFlags(&ev_in_, hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_out_, hipEventDisableTiming));
-        CDRL_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+        CDRL_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, prio_lo));
         for (int i = 0; i < NSLOT; ++i) {
             CDRL_HIP(hipEventCreateWithFlags(&ev_main_[i], hipEventDisableTiming));
             CDRL_HIP(hipEventCreateWithFlags(&ev_side_[i], hipEventDisableTiming));

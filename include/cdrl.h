@@ -191,6 +191,25 @@ int cdrl_dwconv_bwd_data(const float* dy, const float* w, float* da, int N, int 
 int64_t cdrl_dwconv_bwd_workspace_doubles(int N, int H, int W, int C, int stride);
 int cdrl_dwconv_bwd_filter(const float* a, const float* dy, float* dw, float* db, int N, int H, int W, int C, int stride,
                            double* workspace, void* stream);
+/* Fused depthwise block of the ShuffleNet unit: [BatchNormalization + ReLU6 of the previous 1x1 conv, applied on
+ * load] -> DepthwiseConv2D(3, stride, 'same') -> statistics of the BatchNormalization that follows
+ * (core/architectures.py:130-139; per-time-slice BN :44-57).  Whole frames are staged in LDS; the normalised
+ * depthwise input is never written to memory.  x: [G*B frames][H][W][C] raw output of the previous conv
+ * (pre_stats = that BN's 4*G*C statistics block from cdrl_bn_train_fwd / this function) or, with pre_stats = NULL,
+ * an activation tensor used as is.  Outputs: y (raw depthwise output), post_stats (4*G*C) of the following BN
+ * (moving statistics updated as in cdrl_bn_train_fwd). */
+int64_t cdrl_dwconv_bn_workspace_doubles(int G, int B, int H, int W, int C, int stride);
+int cdrl_dwconv_bn_fwd(const float* x, const float* pre_stats, const float* w, const float* bias, float* y, int G, int B,
+                       int H, int W, int C, int stride, const float* gamma, const float* beta, float* moving_mean,
+                       float* moving_var, int bessel, float* post_stats, double* workspace, void* stream);
+/* Backward of the same block.  dout: gradient w.r.t. the OUTPUT of the following BatchNormalization (no activation);
+ * y: raw depthwise output.  Produces dw (3,3,C,1), db, the following BN's dgamma/dbeta (+ coef_post, 3*G*C scratch)
+ * and dx = gradient w.r.t. x; with pre_stats != NULL the previous BN(+ReLU6) is back-propagated too
+ * (dgamma_pre, dbeta_pre, coef_pre 3*G*C scratch) so that dx is the gradient w.r.t. the raw conv output x. */
+int cdrl_dwconv_bn_bwd(const float* x, const float* pre_stats, const float* dout, const float* y, const float* post_stats,
+                       const float* w, int G, int B, int H, int W, int C, int stride, float* dx, float* dw, float* db,
+                       float* dgamma_post, float* dbeta_post, float* coef_post, float* dgamma_pre, float* dbeta_pre,
+                       float* coef_pre, double* workspace, void* stream);
 /* MaxPooling2D(3, 2, 'same') (core/architectures.py:161) */
 int cdrl_maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, void* stream);
 int cdrl_maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H, int W, int C, void* stream);

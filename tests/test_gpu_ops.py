@@ -122,6 +122,79 @@ def test_dwconv(lib, N, H, W, Cc, stride):
     assert rel_err(db.cpu().numpy(), p['c.b'].grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('T,B,H,W,Cc,stride,pre', [(4, 2, 11, 15, 58, 1, 1), (2, 4, 22, 30, 58, 2, 1), (4, 8, 3, 4, 232, 1, 1),
+                                                  (2, 3, 6, 8, 116, 1, 1), (2, 2, 22, 30, 24, 2, 0), (4, 2, 11, 15, 116, 2, 0),
+                                                  (2, 2, 6, 23, 232, 2, 1), (1, 2, 22, 90, 58, 2, 1)])
+def test_dwconv_bn_fused(lib, T, B, H, W, Cc, stride, pre):
+    """Fused depthwise block (frames in LDS): [BN+ReLU6 prologue] -> dw3x3 -> following BN statistics, and its
+    backward (BN-backward prologue, filter/bias gradients, input gradient, ReLU6 mask, previous BN backward):
+    against torch autograd of the unfused composition."""
+    rng = np.random.default_rng(T * B + H * W + Cc + stride)
+    N = T * B
+    x = (rng.standard_normal((T, B, H, W, Cc)) * 1.5 + 0.4).astype(np.float32)
+    w = rng.standard_normal((3, 3, Cc, 1)).astype(np.float32)
+    b = rng.standard_normal(Cc).astype(np.float32)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+
+    def bnp(name):
+        return {f'{name}.gamma': torch.tensor(rng.uniform(0.5, 1.5, Cc), dtype=torch.float64).requires_grad_(True),
+                f'{name}.beta': torch.tensor(rng.uniform(1.0, 3.0, Cc), dtype=torch.float64).requires_grad_(True),
+                f'{name}.moving_mean': torch.tensor(rng.uniform(-0.2, 0.2, Cc), dtype=torch.float64),
+                f'{name}.moving_var': torch.tensor(rng.uniform(0.5, 1.5, Cc), dtype=torch.float64)}
+    p = {'c.w': torch.tensor(w, dtype=torch.float64).requires_grad_(True),
+         'c.b': torch.tensor(b, dtype=torch.float64).requires_grad_(True), **bnp('pre'), **bnp('post')}
+    f32 = {k: v.detach().clone().float() for k, v in p.items()}
+    xt = torch.tensor(x, dtype=torch.float64).permute(0, 1, 4, 2, 3).requires_grad_(True)        # (T,B,C,H,W)
+    a = OM.relu6(OM.bn_slices(xt, p, 'pre', True, True)) if pre else xt
+    y2 = OM.conv_dw(a, p, 'c', stride)
+    out = OM.bn_slices(y2, p, 'post', True, True)
+    dout = rng.standard_normal((T, B, Ho, Wo, Cc)).astype(np.float32)
+    out.backward(torch.tensor(dout, dtype=torch.float64).permute(0, 1, 4, 2, 3))
+
+    X, Wd, Bd, DO = dev(x), dev(w), dev(b), dev(dout)
+    pre_stats = None
+    if pre:
+        pre_stats = torch.zeros(4 * T * Cc, device=DEV)
+        tmp = torch.zeros((N * H * W, Cc), device=DEV)
+        ws0 = torch.zeros(T * 256 * 2 * Cc, dtype=torch.float64, device=DEV)
+        mm, mv = dev(f32['pre.moving_mean']), dev(f32['pre.moving_var'])
+        g1, b1 = dev(f32['pre.gamma']), dev(f32['pre.beta'])          # keep alive: P() only passes the address
+        _lib.check(lib.cdrl_bn_train_fwd(P(X), T, B * H * W, Cc, P(g1), P(b1), P(mm), P(mv),
+                                         1, 1, P(tmp), Cc, 0, 0, P(pre_stats), P(ws0), S()))
+    ws = torch.zeros(int(lib.cdrl_dwconv_bn_workspace_doubles(T, B, H, W, Cc, stride)), dtype=torch.float64, device=DEV)
+    y = torch.zeros((N, Ho, Wo, Cc), device=DEV)
+    post_stats = torch.zeros(4 * T * Cc, device=DEV)
+    g2, b2 = dev(f32['post.gamma']), dev(f32['post.beta'])
+    mm2, mv2 = dev(f32['post.moving_mean']), dev(f32['post.moving_var'])
+    _lib.check(lib.cdrl_dwconv_bn_fwd(P(X), P(pre_stats), P(Wd), P(Bd), P(y), T, B, H, W, Cc, stride, P(g2), P(b2), P(mm2), P(mv2),
+                                      1, P(post_stats), P(ws), S()))
+    y2n = y2.detach().permute(0, 1, 3, 4, 2).reshape(N, Ho, Wo, Cc).numpy()
+    assert rel_err(y.cpu().numpy(), y2n) < 1e-5
+    st = post_stats.cpu().numpy().reshape(4, T, Cc)
+    y2g = y2n.reshape(T, -1, Cc)
+    assert rel_err(st[0], y2g.mean(axis=1)) < 1e-5
+    assert rel_err(st[1], 1.0 / np.sqrt(y2g.var(axis=1) + 1e-3)) < 1e-5
+    assert rel_err(mm2.cpu().numpy(), p['post.moving_mean'].numpy()) < 1e-5
+    assert rel_err(mv2.cpu().numpy(), p['post.moving_var'].numpy()) < 1e-5
+    # backward
+    dx = torch.zeros((N, H, W, Cc), device=DEV)
+    dw = torch.zeros((3, 3, Cc, 1), device=DEV)
+    db = torch.zeros(Cc, device=DEV)
+    vecs = [torch.zeros(Cc, device=DEV) for _ in range(4)]
+    coefs = [torch.zeros(3 * T * Cc, device=DEV) for _ in range(2)]
+    _lib.check(lib.cdrl_dwconv_bn_bwd(P(X), P(pre_stats), P(DO), P(y), P(post_stats), P(Wd), T, B, H, W, Cc, stride, P(dx), P(dw),
+                                      P(db), P(vecs[0]), P(vecs[1]), P(coefs[0]), P(vecs[2]), P(vecs[3]), P(coefs[1]), P(ws), S()))
+    assert rel_err(dx.cpu().numpy(), xt.grad.permute(0, 1, 3, 4, 2).reshape(N, H, W, Cc).numpy()) < 2e-5
+    assert rel_err(dw.cpu().numpy(), p['c.w'].grad.numpy()) < 2e-5
+    # the bias feeds a train-mode BN: its true gradient is 0, the computed one is rounding noise of the sums
+    assert np.abs(db.cpu().numpy()).max() < 1e-4 * np.abs(dw.cpu().numpy()).max()
+    assert rel_err(vecs[0].cpu().numpy(), p['post.gamma'].grad.numpy()) < 2e-5
+    assert rel_err(vecs[1].cpu().numpy(), p['post.beta'].grad.numpy()) < 2e-5
+    if pre:
+        assert rel_err(vecs[2].cpu().numpy(), p['pre.gamma'].grad.numpy()) < 2e-5
+        assert rel_err(vecs[3].cpu().numpy(), p['pre.beta'].grad.numpy()) < 2e-5
+
+
 @pytest.mark.parametrize('N,H,W', [(3, 44, 59), (2, 19, 27), (2, 20, 28)])
 def test_maxpool(lib, N, H, W):
     rng = np.random.default_rng(H)

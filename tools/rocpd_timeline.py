@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Dumps the last N kernel dispatches of a rocprofv3 (rocpd sqlite) trace in start order:
+start_us (relative), dur_us, gap to previous end on the same queue, queue, grid, workgroup, kernel.
+Usage: tools/rocpd_timeline.py <results.db> [last_n]   -> tsv on stdout."""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r'\(.*$', '', name)
+    return name.replace('void ', '').replace('cdrl::', '')[:70]
+
+
+def main():
+    db = sys.argv[1]
+    last = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute('pragma table_info(kernels)')]
+    print('# columns:', cols, file=sys.stderr)
+    name_col = 'name' if 'name' in cols else 'kernel_name'
+    q_col = next((x for x in ('queue_id', 'queue', 'stream_id', 'stream') if x in cols), None)
+    g_col = next((x for x in ('grid_x', 'grid_size_x', 'grid_size') if x in cols), None)
+    w_col = next((x for x in ('workgroup_x', 'workgroup_size_x', 'workgroup_size') if x in cols), None)
+    sel = ', '.join([name_col, 'start', 'end'] + [x or '0' for x in (q_col, g_col, w_col)])
+    rows = c.execute(f'select {sel} from kernels order by start').fetchall()[-last:]
+    t0 = rows[0][1]
+    last_end = {}
+    print('start_us\tdur_us\tgap_us\tqueue\tgrid\twg\tkernel')
+    for n, s, e, q, g, w in rows:
+        gap = (s - last_end[q]) / 1e3 if q in last_end else 0.0
+        last_end[q] = e
+        print(f'{(s - t0) / 1e3:.1f}\t{(e - s) / 1e3:.1f}\t{gap:.1f}\t{q}\t{g}\t{w}\t{short(n)}')
+
+
+if __name__ == '__main__':
+    main()
