@@ -54,19 +54,66 @@ int colsum(View x, int rows, int C, double* part, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // forward finalize: stats[0]=mean, [1]=invstd, [2]=scale, [3]=shift, each [G][C]
 // ------------------------------------------------------------------------------------------
-// blockDim = (16 channel lanes, 16 partial lanes): the nb per-block partials of a channel are summed
-// by 16 lanes in parallel (independent, coalesced loads) and combined in a fixed order -> the
-// result is deterministic and the kernel is no longer a serial chain of nb dependent loads.
+// blockDim = (16 channel lanes, 64 partial lanes).  The 64 lanes are split over the G groups (time slices) and, inside
+// a group, over the nb per-block partials; every thread issues its loads in batches of FIN_U independent requests
+// (a serial chain of nb dependent L2 round trips was 10 us of a 13 us kernel) and the lanes are combined through LDS
+// in a fixed order -> deterministic.
 #define FIN_CX 16
-#define FIN_PY 32
-#define FIN_G 4       // groups folded per barrier round (T = 4 time slices)
+#define FIN_PY 64
+#define FIN_U 8
+
+// (sum_b p0[b*step], sum_b p1[b*step]) over b = first, first+stride, ... < count; 2*FIN_U loads in flight
+__device__ __forceinline__ void strided_sum2(const double* __restrict__ p0, const double* __restrict__ p1, int64_t step,
+                                             int first, int stride, int count, double& s0, double& s1) {
+    s0 = 0.0;
+    s1 = 0.0;
+    for (int b0 = first; b0 < count; b0 += stride * FIN_U) {
+        double v0[FIN_U], v1[FIN_U];
+#pragma unroll
+        for (int u = 0; u < FIN_U; ++u) {
+            const int b = b0 + u * stride;
+            v0[u] = b < count ? p0[(int64_t)b * step] : 0.0;
+            v1[u] = b < count ? p1[(int64_t)b * step] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < FIN_U; ++u) {
+            s0 += v0[u];
+            s1 += v1[u];
+        }
+    }
+}
+
+__device__ __forceinline__ int fin_group_slots(int G) { return G <= 1 ? 1 : (G <= 2 ? 2 : (G <= 4 ? 4 : 8)); }
+
+// sums the [G][nb][2][C] partials of channel c for the groups g0 .. g0+Gp-1 into red[group slot][2][FIN_CX]
+__device__ __forceinline__ void fin_reduce(const double* __restrict__ part, int nb, int G, int C, int c, bool ok, int g0, int Gp,
+                                           double (*sm)[FIN_PY][FIN_CX], double (*red)[2][FIN_CX]) {
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int L = FIN_PY / Gp;
+    const int gi = g0 + ty / L, bl = ty % L;
+    double s = 0.0, q = 0.0;
+    if (ok && gi < G) {
+        const double* base = part + ((int64_t)gi * nb * 2) * C + c;
+        strided_sum2(base, base + C, (int64_t)2 * C, bl, L, nb, s, q);
+    }
+    sm[0][ty][tx] = s;
+    sm[1][ty][tx] = q;
+    __syncthreads();
+    if (ok && ty < 2 * Gp) {
+        const int gg = ty >> 1, qq = ty & 1;
+        double a = 0.0;
+        for (int y = 0; y < L; ++y) a += sm[qq][gg * L + y][tx];
+        red[gg][qq][tx] = a;
+    }
+    __syncthreads();
+}
 
 __global__ void __launch_bounds__(1024) bn_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ mov_mean, float* __restrict__ mov_var,
                                                           int bessel, int training, float* __restrict__ stats) {
-    __shared__ double sm[FIN_G][2][FIN_PY][FIN_CX];
-    __shared__ double red[FIN_G][2][FIN_CX];
+    __shared__ double sm[2][FIN_PY][FIN_CX];
+    __shared__ double red[8][2][FIN_CX];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c = blockIdx.x * FIN_CX + tx;
     const bool ok = c < C;
@@ -94,32 +141,11 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const double* __restr
     }
     const double n = (double)Mg;
     const float corr = (bessel && Mg > 1) ? (float)(n / (n - 1.0)) : 1.0f;
-    // phase 1: every (channel, partial-lane) thread sums its share of the partials of ALL groups -- the
-    // loads of the G groups are independent, one barrier instead of 2 per group
-    for (int g0 = 0; g0 < G; g0 += FIN_G) {
-        const int ng = min(FIN_G, G - g0);
-        for (int gg = 0; gg < ng; ++gg) {
-            double s = 0.0, q = 0.0;
-            if (ok) {
-                for (int b = ty; b < nb; b += FIN_PY) {
-                    s += part[(((int64_t)(g0 + gg) * nb + b) * 2 + 0) * C + c];
-                    q += part[(((int64_t)(g0 + gg) * nb + b) * 2 + 1) * C + c];
-                }
-            }
-            sm[gg][0][ty][tx] = s;
-            sm[gg][1][ty][tx] = q;
-        }
-        __syncthreads();
-        // phase 2: thread (tx, ty < 2*ng) folds the FIN_PY lane sums of one (group, quantity) pair
-        if (ok && ty < 2 * ng) {
-            const int gg = ty >> 1, qq = ty & 1;
-            double s = 0.0;
-#pragma unroll 8
-            for (int y = 0; y < FIN_PY; ++y) s += sm[gg][qq][y][tx];
-            red[gg][qq][tx] = s;
-        }
-        __syncthreads();
+    const int Gp = fin_group_slots(G);
+    for (int g0 = 0; g0 < G; g0 += Gp) {
+        fin_reduce(part, nb, G, C, c, ok, g0, Gp, sm, red);
         if (ok && ty == 0) {
+            const int ng = min(Gp, G - g0);
             for (int gg = 0; gg < ng; ++gg) {
                 const int g = g0 + gg;
                 const double mean = red[gg][0][tx] / n;
@@ -254,37 +280,19 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const double* __r
                                                               int C, const float* __restrict__ stats,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef) {
-    __shared__ double sm[FIN_G][2][FIN_PY][FIN_CX];
-    __shared__ double red[FIN_G][2][FIN_CX];
+    __shared__ double sm[2][FIN_PY][FIN_CX];
+    __shared__ double red[8][2][FIN_CX];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c = blockIdx.x * FIN_CX + tx;
     const bool ok = c < C;
     const int GC = G * C;
     double dg = 0.0, db = 0.0;
     const double n = (double)Mg;
-    for (int g0 = 0; g0 < G; g0 += FIN_G) {
-        const int ng = min(FIN_G, G - g0);
-        for (int gg = 0; gg < ng; ++gg) {
-            double s = 0.0, q = 0.0;
-            if (ok) {
-                for (int b = ty; b < nb; b += FIN_PY) {
-                    s += part[(((int64_t)(g0 + gg) * nb + b) * 2 + 0) * C + c];
-                    q += part[(((int64_t)(g0 + gg) * nb + b) * 2 + 1) * C + c];
-                }
-            }
-            sm[gg][0][ty][tx] = s;
-            sm[gg][1][ty][tx] = q;
-        }
-        __syncthreads();
-        if (ok && ty < 2 * ng) {
-            const int gg = ty >> 1, qq = ty & 1;
-            double s = 0.0;
-#pragma unroll 8
-            for (int y = 0; y < FIN_PY; ++y) s += sm[gg][qq][y][tx];
-            red[gg][qq][tx] = s;
-        }
-        __syncthreads();
+    const int Gp = fin_group_slots(G);
+    for (int g0 = 0; g0 < G; g0 += Gp) {
+        fin_reduce(part, nb, G, C, c, ok, g0, Gp, sm, red);
         if (ok && ty == 0) {
+            const int ng = min(Gp, G - g0);
             for (int gg = 0; gg < ng; ++gg) {
                 const int g = g0 + gg;
                 const double s = red[gg][0][tx], q = red[gg][1][tx];
@@ -367,8 +375,18 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __r
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int i = blockIdx.x * FIN_CX + tx;
     double s = 0.0;
-    if (i < n)
-        for (int p = ty; p < nparts; p += FIN_PY) s += part[(int64_t)p * stride + i];
+    if (i < n) {
+        for (int p0 = ty; p0 < nparts; p0 += FIN_PY * FIN_U) {      // FIN_U independent loads in flight
+            double v[FIN_U];
+#pragma unroll
+            for (int u = 0; u < FIN_U; ++u) {
+                const int p = p0 + u * FIN_PY;
+                v[u] = p < nparts ? part[(int64_t)p * stride + i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < FIN_U; ++u) s += v[u];
+        }
+    }
     sm[ty][tx] = s;
     __syncthreads();
     if (i < n && ty == 0) {

@@ -550,8 +550,18 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float* __restrict
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int64_t i = (int64_t)blockIdx.x * 16 + tx;
     double s = 0.0;
-    if (i < n)
-        for (int p = ty; p < nsplit; p += 64) s += (double)part[(int64_t)p * stride + i];
+    if (i < n) {
+        for (int p0 = ty; p0 < nsplit; p0 += 64 * 8) {       // 8 independent loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = p0 + u * 64;
+                v[u] = p < nsplit ? part[(int64_t)p * stride + i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+    }
     sm[ty][tx] = s;
     __syncthreads();
     if (i < n && ty == 0) {
