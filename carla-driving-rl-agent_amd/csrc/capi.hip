@@ -339,6 +339,15 @@ int cdrl_dwconv_bwd_filter(const float* a, const float* dy, float* dw, float* db
     return dw_bwd_filter(make_view(const_cast<float*>(a), C), dy, dw, db, N, H, W, C, stride, workspace, S(stream));
 }
 
+int cdrl_pwconv_fused_partial_rows(int G, int Mg, int N, int K) { return pw_nn_plan(G, Mg, N, K).nbpg; }
+
+int cdrl_pwconv_fused(const float* a, int lda, int a_coff, const float* pro_stats, const float* w, int sbk, int sbn,
+                      const float* bias, float* c, int ldc, int c_coff, int accumulate, int G, int Mg, int N, int K,
+                      int epilogue, const float* epi_y, const float* epi_stats, double* part, void* stream) {
+    return pw_nn(make_view(const_cast<float*>(a), lda, a_coff), pro_stats, w, sbk, sbn, bias, make_view(c, ldc, c_coff),
+                 accumulate, G, Mg, N, K, epilogue, epi_y, epi_stats, part, S(stream));
+}
+
 int64_t cdrl_dwconv_bn_workspace_doubles(int G, int B, int H, int W, int C, int stride) {
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int64_t nb_out = vcol_geom(B * Ho * Wo, C).nb, nb_in = vcol_geom(B * H * W, C).nb;

@@ -58,8 +58,23 @@ int gather_rows(const float* src, const int* idx, float* dst, int nrows, int64_t
 int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C, int M, int N, int K,
             int accumulate, hipStream_t st);
 // Cout[K,N] = sum_m A[m,K]^T * D[m,N]  (split over M; partial buffer `part` >= gemm_tn_part_elems)
-int64_t gemm_tn_part_elems(int M, int N, int K);
-int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st);
+// G > 1: rows are G equal BatchNorm groups; pro_stats ([4][G][K]) != null applies A <- scale[g][k]*A + shift[g][k] on load.
+int64_t gemm_tn_part_elems(int M, int N, int K, int G = 1);
+int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G = 1,
+            const float* pro_stats = nullptr);
+
+// ---------------------------------------------------------------- fused pointwise conv (gemm_pw.hip)
+// Persistent skinny GEMM for K, N <= 128: C[m,n] (+)= sum_k pro(A[m,k]) W(k,n) + bias[n] over G groups of Mg rows.
+//   pro_stats != null : A <- scale[g][k]*A + shift[g][k]  (BatchNorm apply of the previous layer)
+//   epilogue 1        : part[g][b][2][N] = (sum c, sum c^2)            -> bn_finalize(part, nb = pw_nn_plan().nbpg)
+//   epilogue 2        : part[g][b][2][N] = (sum c, sum c*xhat(ey))     -> bn_bwd_finalize(part, nb = ...nbpg)
+struct PwPlan {
+    int bm, tpb, nbpg;     // rows per tile, tiles per workgroup, workgroups (= partial rows) per group
+};
+bool pw_nn_supported(View A, int N, int K);
+PwPlan pw_nn_plan(int G, int Mg, int N, int K);
+int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, const float* bias, View C, int accumulate, int G,
+          int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st);
 // out[i] (+)= sum_p part[p*stride + i] for float partials (double accumulation, fixed order)
 int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride, float* out, int accumulate,
                         hipStream_t st);
@@ -86,6 +101,7 @@ int dw_bwd_filter(View a, const float* dy, float* dw, float* db, int N, int H, i
 // ---- fused depthwise block (dwfused.hip): whole frames staged in LDS.  G groups x B frames per group.
 struct DwfGeom {
     int vec, nch, cchunk, cx, cy, fpb, nb;     // nb: partial blocks per group (B / frames-per-block)
+    int vec_bwd, cx_bwd, cy_bwd;               // backward lane shape (fewer channels per thread: register budget)
     size_t lds_fwd, lds_bwd;
 };
 DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride);

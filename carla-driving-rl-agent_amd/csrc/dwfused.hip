@@ -11,24 +11,31 @@
 //             (sum y2, sum y2^2) per channel           -> BN2 statistics partials (no second pass over y2)
 //
 //   backward  D    <- k1 * (da2 - k2 - xhat2 * k3)     (BN2 backward apply: dy2 is never written to HBM)
-//             A    <- relu6(scale1 * y1 + shift1)      (recomputed, not stored)
+//             A    <- y1 (raw; relu6(scale1 * y1 + shift1) is re-applied on each LDS read, nothing is stored)
 //             dW   += A (x) D per tap, db += D         -> filter / bias gradient partials
 //             dz1  <- mask1 * dw3x3^T(D)               (ReLU6 mask of BN1's output)
 //             (sum dz1, sum dz1 * xhat1)               -> BN1 backward partials
 //
 // HBM traffic per element: forward 1 read + 1 write (was 3 reads + 2 writes over apply / dw / stats),
-// backward 3 reads + 1 write + an L2-resident re-read of y1 (was 9 reads + 2 writes over bn-apply /
+// backward 3 reads + 1 write (was 9 reads + 2 writes over bn-apply /
 // dw-data / dw-filter / bn-reduce).  Launches per unit: forward 3 -> 1, backward 4 -> 1.
 //
 // Grid = (groups * frame-blocks, channel chunks); block = (channel lanes, pixel lanes); channel chunks
 // only when a full-width frame does not fit the LDS budget (the 22x30 stride-2 inputs).  Partial sums
 // are double, written per block, combined in fixed order by the finalize kernels (deterministic).
 // The `pre` prologue is optional (shortcut branch: the depthwise reads an activation tensor directly).
+#include <stdlib.h>
+
 #include "colreduce.h"
 
 namespace cdrl {
 
 static constexpr size_t DWF_LDS_BUDGET = 76 * 1024;      // 2 workgroups per CU (160 KB LDS)
+#define DWF_T_FWD 1024                                   // threads per workgroup, forward / backward
+#define DWF_T_BWD 512
+#define DWF_T_FWD_DEFAULT 512                            // (tunable: CDRL_DWF_TF / CDRL_DWF_TB, <= the maxima above)
+#define DWF_T_BWD_DEFAULT 256
+#define DWF_U 4                                          // global loads in flight per thread in the tile loads
 
 DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     DwfGeom g;
@@ -37,7 +44,7 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     const size_t per_c = (size_t)(H * W + Ho * Wo) * sizeof(float);
     int maxc = (int)(DWF_LDS_BUDGET / per_c) / g.vec * g.vec;
     if (maxc < g.vec) maxc = g.vec;
-    if (maxc > 256 * g.vec) maxc = 256 * g.vec;
+    if (maxc > 256) maxc = 256;
     const int lanes = C / g.vec;
     if (maxc >= C) {
         g.nch = 1;
@@ -47,8 +54,14 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
         g.cchunk = cdiv(lanes, nch) * g.vec;
         g.nch = cdiv(C, g.cchunk);
     }
+    // wide workgroups: the tile loads are a latency chain of (pixels / cy) rounds that every thread sits through before
+    // the first barrier, so the pixel lanes are made as many as the frame has output pixels (<= 1024 threads forward)
+    const int Po_ = Ho * Wo;
+    static const int t_fwd = getenv("CDRL_DWF_TF") ? atoi(getenv("CDRL_DWF_TF")) : DWF_T_FWD_DEFAULT;
+    static const int t_bwd = getenv("CDRL_DWF_TB") ? atoi(getenv("CDRL_DWF_TB")) : DWF_T_BWD_DEFAULT;
     g.cx = g.cchunk / g.vec;
-    g.cy = 256 / g.cx;
+    g.cy = t_fwd / g.cx;
+    if (g.cy > Po_) g.cy = Po_;
     if (g.cy < 1) g.cy = 1;
     // small frames: several frames per workgroup (fewer partials, less per-block overhead), keeping >= 512 blocks
     int fpb = 1;
@@ -56,11 +69,19 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     while (fpb < 8 && work * fpb * 2 <= 4096 && B % (fpb * 2) == 0 && (int64_t)G * (B / (fpb * 2)) * g.nch >= 512) fpb *= 2;
     g.fpb = fpb;
     g.nb = B / fpb;
-    const size_t red = (size_t)g.cy * g.vec * g.cx * sizeof(double);
+    // backward: 12 double accumulators per channel lane -> at 4 channels per thread the kernel needs > 256 VGPRs (one
+    // workgroup per CU); 2 channels per thread keep it at ~150 (3 waves / SIMD)
+    g.vec_bwd = g.vec > 2 ? 2 : g.vec;
+    g.cx_bwd = g.cchunk / g.vec_bwd;
+    g.cy_bwd = t_bwd / g.cx_bwd;
+    if (g.cy_bwd > Po_) g.cy_bwd = Po_;
+    if (g.cy_bwd < 1) g.cy_bwd = 1;
+    const size_t red_f = (size_t)2 * g.cy * g.vec * g.cx * sizeof(double);
+    const size_t red_b = (size_t)10 * g.cy_bwd * g.vec_bwd * g.cx_bwd * sizeof(double);
     g.lds_fwd = (size_t)H * W * g.cchunk * sizeof(float);
     g.lds_bwd = (size_t)(H * W + Ho * Wo) * g.cchunk * sizeof(float);
-    if (g.lds_fwd < red) g.lds_fwd = red;
-    if (g.lds_bwd < red) g.lds_bwd = red;
+    if (g.lds_fwd < red_f) g.lds_fwd = red_f;
+    if (g.lds_bwd < red_b) g.lds_bwd = red_b;
     return g;
 }
 
@@ -89,8 +110,29 @@ __device__ __forceinline__ void block_colsum(double* sm, double (&a)[VEC], int t
     }
 }
 
+// All NQ per-thread quantities go to LDS at once ([q][ty][VEC][CX] doubles) and every (q, i, tx) column is summed
+// over the pixel lanes by a different thread: one barrier pair for the whole tail instead of one per quantity
+// (12 quantities x (2 barriers + a serial loop on ty == 0) was several microseconds per workgroup).
+template <int NQ, int VEC>
+__device__ __forceinline__ void block_colsum_all(double* sm, double (&a)[NQ][VEC], int tx, int ty, int CX, int CY, bool on,
+                                                 double* out /* &part[row][0][c0] */, int qstride) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) sm[((q * CY + ty) * VEC + i) * CX + tx] = a[q][i];
+    __syncthreads();
+    const int ncol = NQ * VEC;           // columns per channel lane
+    for (int j = ty; j < ncol; j += CY) {
+        const int q = j / VEC, i = j - q * VEC;
+        double s = 0.0;
+        for (int y = 0; y < CY; ++y) s += sm[((q * CY + y) * VEC + i) * CX + tx];
+        if (on) out[(int64_t)q * qstride + i] = s;
+    }
+}
+
 template <int S, int VEC, bool PRE>
-__global__ void __launch_bounds__(256) dwf_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pre_stats,
+__global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pre_stats,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       float* __restrict__ y, double* __restrict__ part, int Bf, int H, int W,
                                                       int Ho, int Wo, int C, int GC, int pt, int pl, int fpb, int nb,
@@ -122,13 +164,24 @@ __global__ void __launch_bounds__(256) dwf_fwd_kernel(const float* __restrict__ 
         if (f) __syncthreads();
         if (on) {
             const float* xp = x + n * P * C + c;
-            for (int p = ty; p < P; p += CY) {
-                VecF<VEC> v = vload<VEC>(xp + (int64_t)p * C);
-                if (PRE) {
+            for (int p0 = ty; p0 < P; p0 += CY * DWF_U) {        // DWF_U independent loads in flight per thread
+                VecF<VEC> v[DWF_U];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) v.v[i] = fminf(fmaxf(fmaf(sc.v[i], v.v[i], sh.v[i]), 0.0f), 6.0f);
+                for (int u = 0; u < DWF_U; ++u) {
+                    const int p = p0 + u * CY;
+                    if (p < P) v[u] = vload<VEC>(xp + (int64_t)p * C);
                 }
-                vstore<VEC>(&tile[p * cchunk + tx * VEC], v);
+#pragma unroll
+                for (int u = 0; u < DWF_U; ++u) {
+                    const int p = p0 + u * CY;
+                    if (p < P) {
+                        if (PRE) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) v[u].v[i] = fminf(fmaxf(fmaf(sc.v[i], v[u].v[i], sh.v[i]), 0.0f), 6.0f);
+                        }
+                        vstore<VEC>(&tile[p * cchunk + tx * VEC], v[u]);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -161,20 +214,17 @@ __global__ void __launch_bounds__(256) dwf_fwd_kernel(const float* __restrict__ 
         }
     }
     double* sm = reinterpret_cast<double*>(tile);
-    block_colsum<VEC>(sm, s1, tx, ty, CX, CY);
-    block_colsum<VEC>(sm, s2, tx, ty, CX, CY);
-    if (ty == 0 && on) {
-        double* pp = part + ((int64_t)g * nb + b) * 2 * C + c;
+    double sq[2][VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            pp[i] = s1[i];
-            pp[C + i] = s2[i];
-        }
+    for (int i = 0; i < VEC; ++i) {
+        sq[0][i] = s1[i];
+        sq[1][i] = s2[i];
     }
+    block_colsum_all<2, VEC>(sm, sq, tx, ty, CX, CY, on, part + ((int64_t)g * nb + b) * 2 * C + c, C);
 }
 
 template <int S, int VEC, bool PRE>
-__global__ void __launch_bounds__(256) dwf_bwd_kernel(const float* __restrict__ x, const float* __restrict__ pre_stats,
+__global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restrict__ x, const float* __restrict__ pre_stats,
                                                       const float* __restrict__ dout, const float* __restrict__ y2,
                                                       const float* __restrict__ post_stats,
                                                       const float* __restrict__ post_coef, const float* __restrict__ w,
@@ -219,27 +269,47 @@ __global__ void __launch_bounds__(256) dwf_bwd_kernel(const float* __restrict__ 
         const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f;
         if (f) __syncthreads();
         if (on) {
+            // tile A holds the RAW input (y1 when PRE): the BN1 + ReLU6 affine is re-applied on every LDS read (3 VALU
+            // ops) so that xhat1 for the BN1 sums also comes from LDS instead of a second global read
             const float* xp = x + n * P * C + c;
-            for (int p = ty; p < P; p += CY) {
-                VecF<VEC> v = vload<VEC>(xp + (int64_t)p * C);
-                if (PRE) {
+            for (int p0 = ty; p0 < P; p0 += CY * DWF_U) {
+                VecF<VEC> v[DWF_U];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) v.v[i] = fminf(fmaxf(fmaf(sc.v[i], v.v[i], sh.v[i]), 0.0f), 6.0f);
+                for (int u = 0; u < DWF_U; ++u) {
+                    const int p = p0 + u * CY;
+                    if (p < P) v[u] = vload<VEC>(xp + (int64_t)p * C);
                 }
-                vstore<VEC>(&tA[p * cchunk + tx * VEC], v);
+#pragma unroll
+                for (int u = 0; u < DWF_U; ++u) {
+                    const int p = p0 + u * CY;
+                    if (p < P) vstore<VEC>(&tA[p * cchunk + tx * VEC], v[u]);
+                }
             }
             const float* dp = dout + n * Po * C + c;
             const float* yp = y2 + n * Po * C + c;
-            for (int p = ty; p < Po; p += CY) {
-                const VecF<VEC> d = vload<VEC>(dp + (int64_t)p * C);
-                const VecF<VEC> v = vload<VEC>(yp + (int64_t)p * C);
-                VecF<VEC> o;
+            for (int p0 = ty; p0 < Po; p0 += CY * DWF_U) {
+                VecF<VEC> d[DWF_U], v[DWF_U];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    const float xh = (v.v[i] - mean2.v[i]) * inv2.v[i];
-                    o.v[i] = k1.v[i] * (d.v[i] - k2.v[i] - xh * k3.v[i]);
+                for (int u = 0; u < DWF_U; ++u) {
+                    const int p = p0 + u * CY;
+                    if (p < Po) {
+                        d[u] = vload<VEC>(dp + (int64_t)p * C);
+                        v[u] = vload<VEC>(yp + (int64_t)p * C);
+                    }
                 }
-                vstore<VEC>(&tD[p * cchunk + tx * VEC], o);
+#pragma unroll
+                for (int u = 0; u < DWF_U; ++u) {
+                    const int p = p0 + u * CY;
+                    if (p < Po) {
+                        VecF<VEC> o;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            const float xh = (v[u].v[i] - mean2.v[i]) * inv2.v[i];
+                            o.v[i] = k1.v[i] * (d[u].v[i] - k2.v[i] - xh * k3.v[i]);
+                        }
+                        vstore<VEC>(&tD[p * cchunk + tx * VEC], o);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -256,7 +326,11 @@ __global__ void __launch_bounds__(256) dwf_bwd_kernel(const float* __restrict__ 
                     for (int kx = 0; kx < 3; ++kx) {
                         const int ix = ox * S + kx - pl;
                         if (ix < 0 || ix >= W) continue;
-                        const VecF<VEC> a = vload<VEC>(&tA[(iy * W + ix) * cchunk + tx * VEC]);
+                        VecF<VEC> a = vload<VEC>(&tA[(iy * W + ix) * cchunk + tx * VEC]);
+                        if (PRE) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) a.v[i] = fminf(fmaxf(fmaf(sc.v[i], a.v[i], sh.v[i]), 0.0f), 6.0f);
+                        }
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) gw[ky * 3 + kx][i] += (double)(a.v[i] * d.v[i]);
                     }
@@ -265,7 +339,6 @@ __global__ void __launch_bounds__(256) dwf_bwd_kernel(const float* __restrict__ 
                 for (int i = 0; i < VEC; ++i) gw[9][i] += (double)d.v[i];
             }
             // gradient w.r.t. the depthwise input (transposed conv), masked by ReLU6 of the pre BN
-            const float* xp = x + n * P * C + c;
             for (int p = ty; p < P; p += CY) {
                 const int iy = p / W, ix = p - iy * W;
                 VecF<VEC> acc;
@@ -290,11 +363,11 @@ __global__ void __launch_bounds__(256) dwf_bwd_kernel(const float* __restrict__ 
                 }
                 const int64_t row = n * P + p;
                 if (PRE) {
-                    const VecF<VEC> a = vload<VEC>(&tA[p * cchunk + tx * VEC]);
-                    const VecF<VEC> v = vload<VEC>(xp + (int64_t)p * C);      // L2-resident re-read of y1 for xhat1
+                    const VecF<VEC> v = vload<VEC>(&tA[p * cchunk + tx * VEC]);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
-                        if (!(a.v[i] > 0.0f && a.v[i] < 6.0f)) acc.v[i] = 0.0f;
+                        const float z = fmaf(sc.v[i], v.v[i], sh.v[i]);
+                        if (!(z > 0.0f && z < 6.0f)) acc.v[i] = 0.0f;
                         const float xh = (v.v[i] - mean1.v[i]) * inv1.v[i];
                         gb1[i] += (double)acc.v[i];
                         gb2[i] += (double)acc.v[i] * (double)xh;
@@ -305,26 +378,15 @@ __global__ void __launch_bounds__(256) dwf_bwd_kernel(const float* __restrict__ 
         }
     }
     double* sm = reinterpret_cast<double*>(tile);
-#pragma unroll
-    for (int k = 0; k < 10; ++k) block_colsum<VEC>(sm, gw[k], tx, ty, CX, CY);
+    block_colsum_all<10, VEC>(sm, gw, tx, ty, CX, CY, on, part_w + ((int64_t)g * nb + b) * 10 * C + c, C);
     if (PRE) {
-        block_colsum<VEC>(sm, gb1, tx, ty, CX, CY);
-        block_colsum<VEC>(sm, gb2, tx, ty, CX, CY);
-    }
-    if (ty == 0 && on) {
-        double* pw = part_w + ((int64_t)g * nb + b) * 10 * C + c;
+        double gq[2][VEC];
 #pragma unroll
-        for (int k = 0; k < 10; ++k)
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) pw[k * C + i] = gw[k][i];
-        if (PRE) {
-            double* pp = part_bn + ((int64_t)g * nb + b) * 2 * C + c;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                pp[i] = gb1[i];
-                pp[C + i] = gb2[i];
-            }
+        for (int i = 0; i < VEC; ++i) {
+            gq[0][i] = gb1[i];
+            gq[1][i] = gb2[i];
         }
+        block_colsum_all<2, VEC>(sm, gq, tx, ty, CX, CY, on, part_bn + ((int64_t)g * nb + b) * 2 * C + c, C);
     }
 }
 
@@ -381,9 +443,9 @@ static int launch_dwf_bwd(const DwfGeom& g, hipStream_t st, const float* x, cons
                           double* part_bn, double* part_w, int G, int B, int H, int W, int C) {
     const int Ho = same_out(H, S), Wo = same_out(W, S);
     CDRL_TRY(allow_lds(dwf_bwd_kernel<S, VEC, PRE>, g.lds_bwd));
-    hipLaunchKernelGGL((dwf_bwd_kernel<S, VEC, PRE>), dim3(G * g.nb, g.nch), dim3(g.cx, g.cy), g.lds_bwd, st, x, pre_stats, dout, y2,
+    hipLaunchKernelGGL((dwf_bwd_kernel<S, VEC, PRE>), dim3(G * g.nb, g.nch), dim3(g.cx_bwd, g.cy_bwd), g.lds_bwd, st, x, pre_stats, dout, y2,
                        post_stats, post_coef, w, dx, part_bn, part_w, B, H, W, Ho, Wo, C, G * C, same_pad_before(H, S),
-                       same_pad_before(W, S), g.fpb, g.nb, g.cchunk, view_aligned(dx, g.vec));
+                       same_pad_before(W, S), g.fpb, g.nb, g.cchunk, view_aligned(dx, g.vec_bwd));
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -416,12 +478,10 @@ int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const flo
 #define CDRL_DWF_BWD(S, V) \
     return launch_dwf_bwd_pre<S, V>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C)
     if (stride == 1) {
-        if (g.vec == 4) CDRL_DWF_BWD(1, 4);
-        if (g.vec == 2) CDRL_DWF_BWD(1, 2);
+        if (g.vec_bwd == 2) CDRL_DWF_BWD(1, 2);
         CDRL_DWF_BWD(1, 1);
     }
-    if (g.vec == 4) CDRL_DWF_BWD(2, 4);
-    if (g.vec == 2) CDRL_DWF_BWD(2, 2);
+    if (g.vec_bwd == 2) CDRL_DWF_BWD(2, 2);
     CDRL_DWF_BWD(2, 1);
 #undef CDRL_DWF_BWD
 }

@@ -61,6 +61,16 @@ struct Op {
     std::function<int(hipStream_t)> bwd;
 };
 
+// BatchNorm work folded into a pointwise conv (gemm_pw.hip); all optional
+struct PwFuse {
+    bool fwd_pw = false;                 // forward through the persistent skinny GEMM
+    const float* pro_stats = nullptr;    // input = BN-apply(in) with these statistics (in = raw previous conv output)
+    bool epi_stats = false;              // forward epilogue: statistics partials of the following BN -> scr_main_.part
+    bool bwd_pw = false;                 // backward-data through the persistent skinny GEMM
+    const float* bwd_ey = nullptr;       // backward epilogue: BN-backward sums of the BN whose raw input is bwd_ey
+    const float* bwd_epi_stats = nullptr;
+};
+
 class Learner {
 public:
     explicit Learner(const Config& cfg);
@@ -144,18 +154,24 @@ private:
     void build_head(std::vector<Op>& ops, int model, const std::string& prefix, Tens& lin, int nheads,
                     const int* head_dims, const char* const* head_names);
     // dx == nullptr: tower mode, the gradient w.r.t. the BN input goes to the current scratch slot
+    // stats_nb > 0: the statistics partials were already written by the producing op (that many rows per group)
     BnRec add_bn(std::vector<Op>& ops, int model, const std::string& prefix, View x, int G, int Mg, int C, bool bessel,
-                 int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx);
+                 int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx, int stats_nb = 0);
     void add_pw(std::vector<Op>& ops, const std::string& prefix, View in, int rows, int Cin, int Cout, float* y,
-                View din, int din_acc, BnRec bn_after);
+                View din, int din_acc, BnRec bn_after, PwFuse fuse = PwFuse());
     void add_dw(std::vector<Op>& ops, const std::string& prefix, View in, int N, int H, int W, int C, int stride,
                 float* y, View din, int din_acc, const BnRec* pre_bn = nullptr);
     // Fused depthwise block (dwfused.hip): [BN `bn_pre` (+ReLU6) of the raw 1x1-conv output x, or none] -> dw3x3 ->
     // BN `bn_post` (no activation) -> out.  Emits three ops (pre-BN, depthwise, post-BN); the normalised depthwise
     // input and the post-BN input gradient never touch HBM.  din: gradient target when there is no pre-BN.
-    void add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw, const char* bn_post,
-                      float* x, int H, int W, int C, int stride, float* y2, View out, View dout, View din);
-    bool fused_dw_ = true;
+    // pre_stats_nb > 0: the pre-BN statistics partials were already written (by the producing GEMM's epilogue) with
+    // that many partial rows per group; post_apply = false: the post-BN output is not materialised (its consumer
+    // applies it on load); post_bwd_nb > 0: the post-BN backward sums were written by the GEMM that produced dout.
+    // Returns the post-BN statistics block.
+    float* add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw, const char* bn_post,
+                        float* x, int H, int W, int C, int stride, float* y2, View out, View dout, View din,
+                        int pre_stats_nb = 0, bool post_apply = true, int post_bwd_nb = 0);
+    bool fused_dw_ = true, fused_pw_ = true;
     void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
                    View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);
     void add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,

@@ -233,7 +233,8 @@ void Learner::note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn
 // op builders
 // ------------------------------------------------------------------------------------------
 Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::string& prefix, View x, int G, int Mg, int C,
-                               bool bessel, int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx) {
+                               bool bessel, int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx,
+                               int stats_nb) {
     PRef gamma = param(model, prefix + ".gamma", {C}, true);
     PRef beta = param(model, prefix + ".beta", {C}, true);
     PRef mm = param(model, prefix + ".moving_mean", {C}, false);
@@ -241,7 +242,7 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     float* stats = alloc((size_t)4 * G * C);
     float* coef = alloc((size_t)3 * G * C);
     const int nb = vcol_geom(Mg, C).nb;
-    note_scratch((size_t)G * nb * 2 * C, (size_t)G * nb * C, 0, 0);
+    note_scratch((size_t)G * std::max(nb, stats_nb) * 2 * C, (size_t)G * nb * C, 0, 0);
     BnRec rec;
     rec.G = G;
     rec.Mg = Mg;
@@ -256,8 +257,8 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     Scratch* sc = build_scr_;
     Op op;
     op.fwd = [=](hipStream_t st, int training) -> int {
-        if (training) CDRL_TRY(colstats(x, G, Mg, C, sc->part, st));
-        CDRL_TRY(bn_finalize(sc->part, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
+        if (training && !stats_nb) CDRL_TRY(colstats(x, G, Mg, C, sc->part, st));
+        CDRL_TRY(bn_finalize(sc->part, stats_nb ? stats_nb : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
         return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st);
     };
     op.bwd = [=](hipStream_t st) -> int {
@@ -272,12 +273,19 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
 }
 
 void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, int rows, int Cin, int Cout, float* y,
-                     View din, int din_acc, BnRec bn_after) {
+                     View din, int din_acc, BnRec bn_after, PwFuse fuse) {
     PRef w = param(M_TRUNK, prefix + ".w", {1, 1, Cin, Cout}, true);
     PRef b = param(M_TRUNK, prefix + ".b", {Cout}, true);
-    note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin));
+    const int G = cfg_.T, Mg = rows / G;
+    const int tn_groups = fuse.pro_stats ? G : 1;
+    note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin, tn_groups));
+    if (fuse.epi_stats) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cout, Cin).nbpg * 2 * Cout, 0, 0, 0);
+    if (fuse.bwd_ey) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cin, Cout).nbpg * 2 * Cin, 0, 0, 0);
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
+        if (fuse.fwd_pw)
+            return pw_nn(in, fuse.pro_stats, w.p, Cout, 1, b.p, make_view(y, Cout), 0, G, Mg, Cout, Cin, fuse.epi_stats ? 1 : 0,
+                         nullptr, nullptr, scr_main_.part, st);
         return gemm_nn(in, w.p, Cout, 1, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
     };
     op.bwd = [=](hipStream_t st) -> int {
@@ -285,10 +293,15 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         // side stream: bias gradient (column sums of dy, reduced per block by bn_bwd_apply) + filter gradient
         hipStream_t side = fork_side(st);
         CDRL_TRY(reduce_partials(part2s_[slot_], bn_after.G * bn_after.nb, Cout, Cout, b.g, 0, side));
-        CDRL_TRY(gemm_tn(in, make_view(dy, Cout), w.g, rows, Cout, Cin, tns_[slot_], 0, side));
+        CDRL_TRY(gemm_tn(in, make_view(dy, Cout), w.g, rows, Cout, Cin, tns_[slot_], 0, side, tn_groups, fuse.pro_stats));
         CDRL_TRY(done_side(side));
         // main stream: the critical path to the previous layer
-        if (din.p) CDRL_TRY(gemm_nn(make_view(dy, Cout), w.p, 1, Cout, nullptr, din, rows, Cin, Cout, din_acc, st));
+        if (din.p) {
+            if (fuse.bwd_pw)
+                return pw_nn(make_view(dy, Cout), nullptr, w.p, 1, Cout, nullptr, din, din_acc, G, Mg, Cin, Cout,
+                             fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, scr_main_.part, st);
+            CDRL_TRY(gemm_nn(make_view(dy, Cout), w.p, 1, Cout, nullptr, din, rows, Cin, Cout, din_acc, st));
+        }
         return 0;
     };
     ops.push_back(op);
@@ -321,9 +334,9 @@ void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, i
     ops.push_back(op);
 }
 
-void Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw,
-                           const char* bn_post, float* x, int H, int W, int C, int stride, float* y2, View out, View dout,
-                           View din) {
+float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw,
+                             const char* bn_post, float* x, int H, int W, int C, int stride, float* y2, View out, View dout,
+                             View din, int pre_stats_nb, bool post_apply, int post_bwd_nb) {
     const int B = cfg_.B, G = cfg_.T, N = B * G;
     const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
     const int Mi = B * H * W, Mo = B * Ho * Wo;
@@ -350,7 +363,7 @@ void Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, const 
     float* coef2 = alloc((size_t)3 * G * C);
     const int nb_in = vcol_geom(Mi, C).nb, nb_out = vcol_geom(Mo, C).nb;
     const int nbf = dwf_geom(B, G, H, W, C, stride).nb;
-    const size_t nbmax = (size_t)std::max(std::max(nb_in, nb_out), nbf);
+    const size_t nbmax = (size_t)std::max(std::max(std::max(nb_in, nb_out), nbf), std::max(pre_stats_nb, post_bwd_nb));
     note_scratch((size_t)G * nbmax * 2 * C, (size_t)G * nbmax * C, (size_t)N * H * W * C, 0,
                  (size_t)dwf_filter_part_elems(B, G, H, W, C, stride));
     const View xv = make_view(x, C), y2v = make_view(y2, C);
@@ -358,8 +371,9 @@ void Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, const 
     if (pre) {      // BN1: statistics only in the forward; backward = finalize of the sums the depthwise op produced
         Op op;
         op.fwd = [=](hipStream_t st, int training) -> int {
-            if (training) CDRL_TRY(colstats(xv, G, Mi, C, scr_main_.part, st));
-            return bn_finalize(scr_main_.part, nb_in, G, Mi, C, g1.p, b1.p, mm1.p, mv1.p, 1, training, stats1, st);
+            if (training && !pre_stats_nb) CDRL_TRY(colstats(xv, G, Mi, C, scr_main_.part, st));
+            return bn_finalize(scr_main_.part, pre_stats_nb ? pre_stats_nb : nb_in, G, Mi, C, g1.p, b1.p, mm1.p, mv1.p, 1, training,
+                               stats1, st);
         };
         op.bwd = [=](hipStream_t st) -> int {
             CDRL_TRY(bn_bwd_finalize(scr_main_.part, nbf, G, Mi, C, stats1, g1.g, b1.g, coef1, st));
@@ -391,14 +405,16 @@ void Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, const 
         Op op;
         op.fwd = [=](hipStream_t st, int training) -> int {
             CDRL_TRY(bn_finalize(scr_main_.part, nbf, G, Mo, C, g2.p, b2.p, mm2.p, mv2.p, 1, training, stats2, st));
+            if (!post_apply) return 0;
             return bn_apply(y2v, G, Mo, C, stats2, ACT_NONE, out, 0, st);
         };
         op.bwd = [=](hipStream_t st) -> int {
-            CDRL_TRY(bn_bwd_reduce(dout, 0, y2v, G, Mo, C, stats2, ACT_NONE, scr_main_.part, st));
-            return bn_bwd_finalize(scr_main_.part, nb_out, G, Mo, C, stats2, g2.g, b2.g, coef2, st);
+            if (!post_bwd_nb) CDRL_TRY(bn_bwd_reduce(dout, 0, y2v, G, Mo, C, stats2, ACT_NONE, scr_main_.part, st));
+            return bn_bwd_finalize(scr_main_.part, post_bwd_nb ? post_bwd_nb : nb_out, G, Mo, C, stats2, g2.g, b2.g, coef2, st);
         };
         ops.push_back(op);
     }
+    return stats2;
 }
 
 void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N,
@@ -547,6 +563,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
     {
         const char* e = getenv("CDRL_FUSED_DW");        // 0 -> unfused bn-apply / depthwise / stats kernels
         fused_dw_ = !(e && atoi(e) == 0);
+        const char* e2 = getenv("CDRL_FUSED_PW");       // 0 -> generic tiled GEMM + separate BN passes around the 1x1 convs
+        fused_pw_ = !(e2 && atoi(e2) == 0);
     }
 
     // ---- stem (core/architectures.py:159-161)
@@ -624,23 +642,50 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     ops.push_back(cp);
                 }
                 Tens y1 = tens(rows_in, mid, false);
-                add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off),
-                       stride == 2 ? 1 : 0, bnrec(T, Mg_in, mid));
                 Tens y2 = tens(rows_out, mid, false), a2 = tens(rows_out, mid);
-                if (fused_dw_) {
-                    add_dw_block(ops, pre, "bn1", "dw", "bn2", y1.p, curH, curW, mid, stride, y2.p, a2.v(), a2.gv(),
-                                 View{nullptr, 0, 0});
-                } else {
-                    Tens a1 = tens(rows_in, mid);
-                    BnRec r1 = add_bn(ops, M_TRUNK, pre + ".bn1", y1.v(), T, Mg_in, mid, true, ACT_RELU6, a1.v(), 0, a1.gv(), 0,
-                                      nullptr);
-                    add_dw(ops, pre + ".dw", a1.v(), N, curH, curW, mid, stride, y2.p, a1.gv(), 0, &r1);
-                    add_bn(ops, M_TRUNK, pre + ".bn2", y2.v(), T, Mg_out, mid, true, ACT_NONE, a2.v(), 0, a2.gv(), 0, nullptr);
-                }
                 Tens y3 = tens(rows_out, main_out, false);
-                add_pw(ops, pre + ".pw2", a2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out));
-                add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C,
-                       out.gv(sc_c), C, nullptr);
+                // BatchNorm work folded into the 1x1-conv GEMMs (K, N <= 128: stages 0 and 1)
+                const bool fpw = fused_dw_ && fused_pw_ && pw_nn_supported(X.v(main_off), mid, main_in) &&
+                                 pw_nn_supported(y2.v(), main_out, mid) && pw_nn_supported(y3.v(), mid, main_out) &&
+                                 pw_nn_supported(y1.v(), main_in, mid);
+                if (fpw) {
+                    PwFuse f1;
+                    f1.fwd_pw = true;
+                    f1.epi_stats = true;
+                    f1.bwd_pw = true;
+                    add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off), stride == 2 ? 1 : 0,
+                           bnrec(T, Mg_in, mid), f1);
+                    const int nb1 = pw_nn_plan(T, Mg_in, mid, main_in).nbpg;
+                    const int nbb = pw_nn_plan(T, Mg_out, mid, main_out).nbpg;        // pw2 backward-data epilogue rows
+                    float* stats2 = add_dw_block(ops, pre, "bn1", "dw", "bn2", y1.p, curH, curW, mid, stride, y2.p, a2.v(), a2.gv(),
+                                                 View{nullptr, 0, 0}, nb1, false, nbb);
+                    PwFuse f2;
+                    f2.fwd_pw = true;
+                    f2.pro_stats = stats2;
+                    f2.epi_stats = true;
+                    f2.bwd_pw = true;
+                    f2.bwd_ey = y2.p;
+                    f2.bwd_epi_stats = stats2;
+                    add_pw(ops, pre + ".pw2", y2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out), f2);
+                    add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C, out.gv(sc_c), C,
+                           nullptr, pw_nn_plan(T, Mg_out, main_out, mid).nbpg);
+                } else {
+                    add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off), stride == 2 ? 1 : 0,
+                           bnrec(T, Mg_in, mid));
+                    if (fused_dw_) {
+                        add_dw_block(ops, pre, "bn1", "dw", "bn2", y1.p, curH, curW, mid, stride, y2.p, a2.v(), a2.gv(),
+                                     View{nullptr, 0, 0});
+                    } else {
+                        Tens a1 = tens(rows_in, mid);
+                        BnRec r1 = add_bn(ops, M_TRUNK, pre + ".bn1", y1.v(), T, Mg_in, mid, true, ACT_RELU6, a1.v(), 0, a1.gv(), 0,
+                                          nullptr);
+                        add_dw(ops, pre + ".dw", a1.v(), N, curH, curW, mid, stride, y2.p, a1.gv(), 0, &r1);
+                        add_bn(ops, M_TRUNK, pre + ".bn2", y2.v(), T, Mg_out, mid, true, ACT_NONE, a2.v(), 0, a2.gv(), 0, nullptr);
+                    }
+                    add_pw(ops, pre + ".pw2", a2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out));
+                    add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C, out.gv(sc_c), C,
+                           nullptr);
+                }
                 if (stride == 2) {
                     Tens ys1 = tens(rows_out, sc_c, false), b1 = tens(rows_out, sc_c);
                     if (fused_dw_) {

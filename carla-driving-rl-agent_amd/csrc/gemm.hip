@@ -386,33 +386,39 @@ struct TnPlan {
     int kt, ntl;        // 32-wide tiles per block along K and N
     int gy, gz;         // blocks along K and N
     int nsplit;         // blocks along M
+    int nspg;           // ... per group
     int rows_per;       // rows per split (multiple of TN_BM)
 };
 
-static TnPlan tn_plan(int M, int N, int K) {
+// G > 1: the M rows are G equal groups (BatchNorm time slices) and no split straddles a group boundary, so that a
+// per-(group, k) affine prologue on A needs one group index per workgroup.
+static TnPlan tn_plan(int M, int N, int K, int G = 1) {
     TnPlan p;
     p.gy = cdiv(K, 128);
     p.gz = cdiv(N, 128);
     p.kt = cdiv(cdiv(K, p.gy), 32);
     p.ntl = cdiv(cdiv(N, p.gz), 32);
-    int target = 1024 / (p.gy * p.gz);
+    int target = 1024 / (p.gy * p.gz * G);
     if (target < 1) target = 1;
-    int ns = M / 256;
+    const int Mg = M / G;
+    int ns = Mg / 256;
     if (ns > target) ns = target;
     if (ns < 1) ns = 1;
-    p.rows_per = cdiv(cdiv(M, ns), TN_BM) * TN_BM;
-    p.nsplit = cdiv(M, p.rows_per);
+    p.rows_per = cdiv(cdiv(Mg, ns), TN_BM) * TN_BM;
+    p.nspg = cdiv(Mg, p.rows_per);
+    p.nsplit = G * p.nspg;
     return p;
 }
 
-int64_t gemm_tn_part_elems(int M, int N, int K) {
-    TnPlan p = tn_plan(M, N, K);
+int64_t gemm_tn_part_elems(int M, int N, int K, int G) {
+    TnPlan p = tn_plan(M, N, K, G);
     return (int64_t)p.nsplit * K * N;
 }
 
 template <int KT, int NTL, bool VEC>
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* __restrict__ part, int M, int N, int K,
-                                                         int rows_per) {
+                                                         int rows_per, int nspg, int Mg, int G,
+                                                         const float* __restrict__ pro_stats) {
     constexpr int TK = 32 * KT, TNn = 32 * NTL;
     constexpr int NTILES = KT * NTL;
     constexpr int PER_WAVE = (NTILES + 3) / 4;
@@ -423,10 +429,24 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* 
     const int lane = tid & 63, wave = tid >> 6;
     const int lcol = lane & 31, lk = lane >> 5;
     const int k0 = blockIdx.y * TK, n0 = blockIdx.z * TNn;
-    const int64_t mbeg = (int64_t)blockIdx.x * rows_per;
+    const int grp = blockIdx.x / nspg;
+    const int64_t gend = (int64_t)(grp + 1) * Mg;
+    const int64_t mbeg = (int64_t)grp * Mg + (int64_t)(blockIdx.x % nspg) * rows_per;
     int64_t mend = mbeg + rows_per;
-    if (mend > M) mend = M;
+    if (mend > gend) mend = gend;
     f32x16 acc[PER_WAVE];
+    // optional prologue: A <- scale[g][k] * A + shift[g][k] (BatchNorm apply of the layer that produced A's raw
+    // values: the normalised tensor is recomputed here instead of being read from HBM); VEC path only
+    float psc[NA], psh[NA];
+    if (VEC && pro_stats) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int kk = (((tid + 256 * (i / 2)) % (TK / 2)) * 2) + (i & 1);
+            const bool okk = (k0 + kk) < K;
+            psc[i] = okk ? pro_stats[2 * G * K + grp * K + k0 + kk] : 0.0f;
+            psh[i] = okk ? pro_stats[3 * G * K + grp * K + k0 + kk] : 0.0f;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j)
 #pragma unroll
@@ -441,7 +461,13 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* 
                 const int r = idx / (TK / 2), kk = (idx % (TK / 2)) * 2;
                 const int64_t m = m0 + r;
                 float2 v = make_float2(0.0f, 0.0f);
-                if (m < mend && (k0 + kk) < K) v = *reinterpret_cast<const float2*>(&A.p[m * A.ld + A.coff + k0 + kk]);
+                if (m < mend && (k0 + kk) < K) {
+                    v = *reinterpret_cast<const float2*>(&A.p[m * A.ld + A.coff + k0 + kk]);
+                    if (pro_stats) {
+                        v.x = fmaf(psc[2 * i], v.x, psh[2 * i]);
+                        v.y = fmaf(psc[2 * i + 1], v.y, psh[2 * i + 1]);
+                    }
+                }
                 ra[2 * i] = v.x;
                 ra[2 * i + 1] = v.y;
             }
@@ -573,35 +599,46 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float* __restrict
 }
 
 template <int KT, bool VEC>
-static void launch_tn(int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp) {
+static void launch_tn(int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp, int nspg,
+                      int Mg, int G, const float* ps) {
     switch (ntl) {
-        case 1: hipLaunchKernelGGL((gemm_tn_kernel<KT, 1, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
-        case 2: hipLaunchKernelGGL((gemm_tn_kernel<KT, 2, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
-        case 3: hipLaunchKernelGGL((gemm_tn_kernel<KT, 3, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
-        default: hipLaunchKernelGGL((gemm_tn_kernel<KT, 4, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp); break;
+        case 1: hipLaunchKernelGGL((gemm_tn_kernel<KT, 1, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
+        case 2: hipLaunchKernelGGL((gemm_tn_kernel<KT, 2, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
+        case 3: hipLaunchKernelGGL((gemm_tn_kernel<KT, 3, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
+        default: hipLaunchKernelGGL((gemm_tn_kernel<KT, 4, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
     }
 }
 
 template <bool VEC>
-static void launch_tn_k(int kt, int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp) {
+static void launch_tn_k(int kt, int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp,
+                        int nspg, int Mg, int G, const float* ps) {
     switch (kt) {
-        case 1: launch_tn<1, VEC>(ntl, grid, st, A, D, part, M, N, K, rp); break;
-        case 2: launch_tn<2, VEC>(ntl, grid, st, A, D, part, M, N, K, rp); break;
-        case 3: launch_tn<3, VEC>(ntl, grid, st, A, D, part, M, N, K, rp); break;
-        default: launch_tn<4, VEC>(ntl, grid, st, A, D, part, M, N, K, rp); break;
+        case 1: launch_tn<1, VEC>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
+        case 2: launch_tn<2, VEC>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
+        case 3: launch_tn<3, VEC>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
+        default: launch_tn<4, VEC>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
     }
 }
 
-int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st) {
-    TnPlan p = tn_plan(M, N, K);
+int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G,
+            const float* pro_stats) {
+    if (G < 1 || M % G != 0) {
+        set_error("gemm_tn: M=%d is not a multiple of G=%d", M, G);
+        return -1;
+    }
+    TnPlan p = tn_plan(M, N, K, G);
     dim3 grid(p.nsplit, p.gy, p.gz);
     auto even = [](const View& v) {
         return (v.ld % 2 == 0) && (v.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 7) == 0);
     };
     // float2 path: every row start and every 32-wide tile start is 8-byte aligned
     const bool vec = even(A) && even(D) && (K % 2 == 0) && (N % 2 == 0);
-    if (vec) launch_tn_k<true>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per);
-    else launch_tn_k<false>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per);
+    if (pro_stats && !vec) {
+        set_error("gemm_tn: the BatchNorm prologue needs even, 8-byte aligned operands");
+        return -1;
+    }
+    if (vec) launch_tn_k<true>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per, p.nspg, M / G, G, pro_stats);
+    else launch_tn_k<false>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per, p.nspg, M / G, G, pro_stats);
     CDRL_LAUNCH_CHECK();
     const int64_t n = (int64_t)K * N;
     return reduce_partials_f32(part, p.nsplit, n, n, Cout, accumulate, st);

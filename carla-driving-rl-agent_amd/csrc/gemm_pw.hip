@@ -1,0 +1,335 @@
+// Pointwise (1x1) convolution of the ShuffleNet unit as a *persistent skinny GEMM* with the neighbouring
+// BatchNorm work folded in (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// Reference: core/architectures.py:130,140 (Conv2D(k=1) -> BatchNormalization per time slice).  At the tower's
+// channel counts (K, N <= 128) the GEMM C[M,N] = A[M,K] W[K,N] is HBM-bound (arithmetic intensity ~15-30 flop/B):
+// what matters is that A is read once, C is written once, enough loads are in flight, and nothing else touches
+// the tensors.  So, unlike the generic tiled gemm_nn:
+//   * W lives in REGISTERS as MFMA B fragments for the whole kernel (K/2 steps x column tiles <= 192 VGPRs), loaded
+//     once per workgroup; LDS only stages the A tile (conflict-free ds_read_b32 of the A fragment, stride 2*KSM+2);
+//   * a workgroup walks over a contiguous range of row tiles inside ONE BatchNorm group (time slice), prefetching
+//     the next A tile into registers while the MFMAs of the current tile run;
+//   * prologue  PRO_BNAPPLY: a = scale[g][k] * a + shift[g][k] on the way into LDS (BN apply of the previous
+//                            layer: its normalised output is never written to HBM);
+//   * epilogue  EPI_STATS:   per-workgroup (sum c, sum c^2) per output channel -> statistics partials of the
+//                            following BatchNorm (no separate pass over C);
+//               EPI_BNRED:   (sum c, sum c * xhat) with xhat from the raw input `ey` of the BatchNorm that C is the
+//                            output-gradient of (backward-data GEMM feeding a BN backward: no separate reduce pass).
+// Partials are double, one row per workgroup, combined in fixed order by bn_finalize / bn_bwd_finalize.
+#include "cdrl_kernels.h"
+
+namespace cdrl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PwArgs {
+    View A;
+    const float* pro_stats;     // [4][G][K]
+    const float* W;
+    int sbk, sbn;
+    const float* bias;
+    View C;
+    int accumulate;
+    const float* ey;            // EPI_BNRED: [M][N] dense
+    const float* epi_stats;     // EPI_BNRED: [4][G][N]
+    double* part;               // [G][nbpg][2][N]
+    int N, K, G, Mg, nbpg, tpb;
+};
+
+// register budget: W fragments (NTW*KSM) + accumulators + one prefetched A tile; the K > 64 and 3-column-tile variants
+// need more than 256 VGPRs -> one workgroup per CU (AGPRs used as well), the others run two per CU
+constexpr int pw_occ(int ksm, int nt) { return ((ksm == 32 && nt == 3) || (ksm == 64 && nt <= 2)) ? 1 : 2; }
+// wave grid: one 32-column tile per wave whenever the 4 waves can be spread over the column tiles (NT = 1, 2, 4):
+// the W fragments then cost only KSM VGPRs per wave and 2+ workgroups fit a CU even at K = 128
+constexpr int pw_wc(int nt) { return nt == 3 ? 1 : nt; }
+
+template <int KSM, int NT, int PRO, int EPI>
+__global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a) {
+    constexpr int WC = pw_wc(NT);                   // wave columns
+    constexpr int WR = 4 / WC;                      // wave rows
+    constexpr int NTW = NT / WC;                    // column tiles per wave
+    constexpr int BM = 32 * WR;
+    constexpr int LDA = 2 * KSM + 2;
+    constexpr int NA2 = BM * KSM / 256;             // float2 loads per thread per tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                               // [BM][LDA]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WR, wc = wave / WR;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int g = blockIdx.x / a.nbpg, b = blockIdx.x % a.nbpg;
+    const int K = a.K, N = a.N, K2 = K >> 1;
+    const int64_t mbeg = (int64_t)g * a.Mg, mend = mbeg + a.Mg;
+    const int tiles_g = (a.Mg + BM - 1) / BM;
+    // even split of the group's tiles over its nbpg workgroups (grid = a whole number of resident waves of blocks)
+    const int t0 = (int)((int64_t)b * tiles_g / a.nbpg), t1 = (int)((int64_t)(b + 1) * tiles_g / a.nbpg);
+
+    // ---- W fragments -> registers (once)
+    float breg[NTW][KSM];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = (wc + j * WC) * 32 + lrow;
+#pragma unroll
+        for (int s = 0; s < KSM; ++s) {
+            const int k = 2 * s + lk;
+            breg[j][s] = (k < K && n < N) ? a.W[(int64_t)k * a.sbk + (int64_t)n * a.sbn] : 0.0f;
+        }
+    }
+    float bv[NTW], emean[NTW], einv[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = (wc + j * WC) * 32 + lrow;
+        bv[j] = (a.bias && n < N) ? a.bias[n] : 0.0f;
+        emean[j] = einv[j] = 0.0f;
+        if (EPI == 2 && n < N) {
+            emean[j] = a.epi_stats[0 * a.G * N + g * N + n];
+            einv[j] = a.epi_stats[1 * a.G * N + g * N + n];
+        }
+    }
+    // prologue coefficients: a thread always handles the same two k columns (256 % KSM == 0)
+    float psc0 = 1.0f, psc1 = 1.0f, psh0 = 0.0f, psh1 = 0.0f;
+    if (PRO == 1) {
+        const int k = 2 * (tid % KSM);
+        if (k < K) {
+            psc0 = a.pro_stats[2 * a.G * K + g * K + k];
+            psh0 = a.pro_stats[3 * a.G * K + g * K + k];
+        }
+        if (k + 1 < K) {
+            psc1 = a.pro_stats[2 * a.G * K + g * K + k + 1];
+            psh1 = a.pro_stats[3 * a.G * K + g * K + k + 1];
+        }
+    }
+    double s1[NTW], s2[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) s1[j] = s2[j] = 0.0;
+
+    // A tiles are prefetched into registers TWO tiles ahead (one tile of loads in flight per workgroup left the
+    // kernel latency-bound: ~2 us per tile step); the wide-row variants (NA2 > 16) keep a single register set
+    constexpr bool PF2 = false;     // measured: the second register set costs a wave of occupancy and loses (25.6 -> 29.4 us)
+    float2 ra0[NA2], ra1[PF2 ? NA2 : 1];
+    auto load_tile = [&](int t, float2* ra) {
+        const int64_t m0 = mbeg + (int64_t)t * BM;
+#pragma unroll
+        for (int i = 0; i < NA2; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / KSM, kk = idx % KSM;
+            const int64_t m = m0 + r;
+            ra[i] = make_float2(0.0f, 0.0f);
+            if (m < mend && kk < K2) ra[i] = *reinterpret_cast<const float2*>(&a.A.p[m * a.A.ld + a.A.coff + 2 * kk]);
+        }
+    };
+    auto store_tile = [&](int t, const float2* ra) {
+        const int64_t m0 = mbeg + (int64_t)t * BM;
+#pragma unroll
+        for (int i = 0; i < NA2; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / KSM, kk = idx % KSM;
+            float2 v = ra[i];
+            if (PRO == 1) {
+                if (m0 + r < mend && kk < K2) {
+                    v.x = fmaf(psc0, v.x, psh0);
+                    v.y = fmaf(psc1, v.y, psh1);
+                }
+            }
+            *reinterpret_cast<float2*>(&As[r * LDA + 2 * kk]) = v;
+        }
+    };
+    auto compute_tile = [&](int t) {
+        f32x16 acc[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        const float* arow = &As[(wr * 32 + lrow) * LDA + lk];
+#pragma unroll
+        for (int s = 0; s < KSM; ++s) {
+            // keep the scheduler from hoisting all KSM fragment reads above the MFMA chain (64 extra live VGPRs)
+            if (KSM > 16 && (s % 16) == 0) __builtin_amdgcn_sched_barrier(0);
+            const float av = arow[2 * s];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[j][s], acc[j], 0, 0, 0);
+        }
+        // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        const int64_t m0 = mbeg + (int64_t)t * BM + wr * 32;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = (wc + j * WC) * 32 + lrow;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m < mend) {
+                    float* c = &a.C.p[m * a.C.ld + a.C.coff + n];
+                    float v = acc[j][r] + bv[j];
+                    if (EPI == 1) {
+                        s1[j] += (double)v;
+                        s2[j] += (double)v * (double)v;
+                    } else if (EPI == 2) {
+                        const float xh = (a.ey[m * N + n] - emean[j]) * einv[j];
+                        s1[j] += (double)v;
+                        s2[j] += (double)v * (double)xh;
+                    }
+                    if (a.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    };
+
+    if (PF2) {
+        if (t0 < t1) load_tile(t0, ra0);
+        if (t0 + 1 < t1) load_tile(t0 + 1, ra1);
+        for (int t = t0; t < t1; t += 2) {
+            store_tile(t, ra0);
+            __syncthreads();
+            if (t + 2 < t1) load_tile(t + 2, ra0);
+            compute_tile(t);
+            __syncthreads();             // all fragment reads of As done before the next store_tile
+            if (t + 1 < t1) {
+                store_tile(t + 1, ra1);
+                __syncthreads();
+                if (t + 3 < t1) load_tile(t + 3, ra1);
+                compute_tile(t + 1);
+                __syncthreads();
+            }
+        }
+    } else {
+        if (t0 < t1) load_tile(t0, ra0);
+        for (int t = t0; t < t1; ++t) {
+            store_tile(t, ra0);
+            __syncthreads();
+            if (t + 1 < t1) load_tile(t + 1, ra0);
+            compute_tile(t);
+            __syncthreads();
+        }
+    }
+    if (EPI != 0) {
+        double* red = reinterpret_cast<double*>(smem);      // [WR][2][32*NT]; As is dead
+        constexpr int NP = 32 * NT;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+            if (lk == 0) {
+                const int nl = (wc + j * WC) * 32 + lrow;
+                red[(wr * 2 + 0) * NP + nl] = s1[j];
+                red[(wr * 2 + 1) * NP + nl] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * NP; i += 256) {
+            const int q = i / NP, nl = i % NP;
+            if (nl < N) {
+                double s = 0.0;
+#pragma unroll
+                for (int w = 0; w < WR; ++w) s += red[(w * 2 + q) * NP + nl];
+                a.part[(((int64_t)g * a.nbpg + b) * 2 + q) * N + nl] = s;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int pw_ksm(int K) { return K <= 32 ? 16 : (K <= 64 ? 32 : 64); }
+
+bool pw_nn_supported(View A, int N, int K) {
+    if (K > 128 || N > 128 || (K & 1) || N < 1) return false;
+    const int nt = cdiv(N, 32), ksm = pw_ksm(K);
+    if (nt == 3 && ksm > 32) return false;
+    return (A.ld % 2 == 0) && (A.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(A.p) & 7) == 0);
+}
+
+PwPlan pw_nn_plan(int G, int Mg, int N, int K) {
+    PwPlan p;
+    const int nt = cdiv(N, 32), ksm = pw_ksm(K);
+    p.bm = 32 * (4 / pw_wc(nt));
+    const int tiles_g = cdiv(Mg, p.bm);
+    // grid = exactly the number of workgroups that are resident at once (256 CUs x occupancy of the variant), so every
+    // CU gets the same share; the tiles of a group are split evenly over its workgroups
+    const int occ = pw_occ(ksm, nt) == 1 ? 1 : ((ksm <= 32 && nt != 1) ? 3 : 2);
+    int target = 256 * occ / G;
+    if (target < 1) target = 1;
+    p.nbpg = tiles_g < target ? tiles_g : target;
+    p.tpb = cdiv(tiles_g, p.nbpg);
+    return p;
+}
+
+template <int KSM, int NT, int PRO, int EPI>
+static int launch_pw(const PwArgs& a, hipStream_t st) {
+    constexpr int WR = 4 / pw_wc(NT);
+    constexpr int BM = 32 * WR;
+    size_t lds = (size_t)(BM * (2 * KSM + 2)) * sizeof(float);
+    const size_t red = (size_t)WR * 2 * 32 * NT * sizeof(double);
+    if (lds < red) lds = red;
+    auto kern = pw_nn_kernel<KSM, NT, PRO, EPI>;
+    if (lds > 64 * 1024) CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg), dim3(256), lds, st, a);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int KSM, int NT>
+static int launch_pw_pe(int pro, int epi, const PwArgs& a, hipStream_t st) {
+    if (pro == 0 && epi == 0) return launch_pw<KSM, NT, 0, 0>(a, st);
+    if (pro == 0 && epi == 1) return launch_pw<KSM, NT, 0, 1>(a, st);
+    if (pro == 0 && epi == 2) return launch_pw<KSM, NT, 0, 2>(a, st);
+    if (pro == 1 && epi == 0) return launch_pw<KSM, NT, 1, 0>(a, st);
+    if (pro == 1 && epi == 1) return launch_pw<KSM, NT, 1, 1>(a, st);
+    set_error("pw_nn: unsupported prologue/epilogue combination %d/%d", pro, epi);
+    return -1;
+}
+
+template <int KSM>
+static int launch_pw_nt(int nt, int pro, int epi, const PwArgs& a, hipStream_t st) {
+    switch (nt) {
+        case 1: return launch_pw_pe<KSM, 1>(pro, epi, a, st);
+        case 2: return launch_pw_pe<KSM, 2>(pro, epi, a, st);
+        case 3:
+            if constexpr (KSM <= 32) return launch_pw_pe<KSM, 3>(pro, epi, a, st);
+            break;
+        case 4: return launch_pw_pe<KSM, 4>(pro, epi, a, st);
+    }
+    set_error("pw_nn: unsupported tile shape");
+    return -1;
+}
+
+int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, const float* bias, View C, int accumulate, int G,
+          int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st) {
+    if (!pw_nn_supported(A, N, K)) {
+        set_error("pw_nn: shape K=%d N=%d / alignment not supported", K, N);
+        return -1;
+    }
+    if (epilogue != 0 && !part) {
+        set_error("pw_nn: epilogue needs a partial buffer");
+        return -1;
+    }
+    const PwPlan p = pw_nn_plan(G, Mg, N, K);
+    PwArgs a;
+    a.A = A;
+    a.pro_stats = pro_stats;
+    a.W = W;
+    a.sbk = sbk;
+    a.sbn = sbn;
+    a.bias = bias;
+    a.C = C;
+    a.accumulate = accumulate;
+    a.ey = ey;
+    a.epi_stats = epi_stats;
+    a.part = part;
+    a.N = N;
+    a.K = K;
+    a.G = G;
+    a.Mg = Mg;
+    a.nbpg = p.nbpg;
+    a.tpb = p.tpb;
+    const int nt = cdiv(N, 32), pro = pro_stats ? 1 : 0;
+    switch (pw_ksm(K)) {
+        case 16: return launch_pw_nt<16>(nt, pro, epilogue, a, st);
+        case 32: return launch_pw_nt<32>(nt, pro, epilogue, a, st);
+        default: return launch_pw_nt<64>(nt, pro, epilogue, a, st);
+    }
+}
+
+}  // namespace cdrl

@@ -191,6 +191,18 @@ int cdrl_dwconv_bwd_data(const float* dy, const float* w, float* da, int N, int 
 int64_t cdrl_dwconv_bwd_workspace_doubles(int N, int H, int W, int C, int stride);
 int cdrl_dwconv_bwd_filter(const float* a, const float* dy, float* dw, float* db, int N, int H, int W, int C, int stride,
                            double* workspace, void* stream);
+/* Pointwise Conv2D(k=1) of the ShuffleNet unit (core/architectures.py:130,140) as a persistent skinny GEMM for
+ * K, N <= 128 with the neighbouring per-time-slice BatchNormalization folded in.  Rows: G groups of Mg rows.
+ *   pro_stats != NULL (4*G*K block of the previous BN): a <- scale[g][k]*a + shift[g][k] on load;
+ *   epilogue 1: part[g][b][2][N] = (sum c, sum c^2) of the output -> statistics of the following BN;
+ *   epilogue 2: part[g][b][2][N] = (sum c, sum c*xhat) with xhat = (epi_y - mean)*invstd from epi_stats (4*G*N):
+ *               BN-backward sums when c is the gradient w.r.t. that BN's output (backward-data GEMM, B = W^T via
+ *               sbk/sbn as in cdrl_gemm_nn).
+ * b < cdrl_pwconv_fused_partial_rows(G, Mg, N, K); returns -1 (cdrl_last_error) for unsupported shapes/alignment. */
+int cdrl_pwconv_fused_partial_rows(int G, int Mg, int N, int K);
+int cdrl_pwconv_fused(const float* a, int lda, int a_coff, const float* pro_stats, const float* w, int sbk, int sbn,
+                      const float* bias, float* c, int ldc, int c_coff, int accumulate, int G, int Mg, int N, int K,
+                      int epilogue, const float* epi_y, const float* epi_stats, double* part, void* stream);
 /* Fused depthwise block of the ShuffleNet unit: [BatchNormalization + ReLU6 of the previous 1x1 conv, applied on
  * load] -> DepthwiseConv2D(3, stride, 'same') -> statistics of the BatchNormalization that follows
  * (core/architectures.py:130-139; per-time-slice BN :44-57).  Whole frames are staged in LDS; the normalised

@@ -65,6 +65,47 @@ def test_gemm_tn(lib, M, K, N):
     assert rel_err(out.cpu().numpy(), ref) < 1e-5
 
 
+@pytest.mark.parametrize('G,Mg,K,N,pro,epi,bt', [(4, 700, 58, 58, 0, 1, 0), (4, 333, 116, 116, 1, 1, 0), (2, 1000, 24, 58, 0, 1, 0),
+                                                (4, 130, 58, 92, 1, 1, 0), (4, 257, 24, 24, 1, 1, 0), (1, 5000, 116, 116, 0, 0, 0),
+                                                (4, 513, 116, 116, 0, 2, 1), (4, 300, 92, 58, 0, 2, 1), (4, 200, 58, 24, 0, 0, 1),
+                                                (4, 20000, 58, 58, 1, 1, 0), (4, 64, 116, 58, 0, 2, 1)])
+def test_pwconv_fused(lib, G, Mg, K, N, pro, epi, bt):
+    """Persistent skinny GEMM with BN-apply prologue and statistics / BN-backward-sum epilogues."""
+    rng = np.random.default_rng(G * Mg + K + N)
+    M = G * Mg
+    lda, coff = K + 6, 2
+    a = rng.standard_normal((M, lda)).astype(np.float32)
+    w = rng.standard_normal((N, K) if bt else (K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    pst = rng.uniform(0.5, 1.5, (4, G, K)).astype(np.float32)
+    est = rng.uniform(0.5, 1.5, (4, G, N)).astype(np.float32)
+    ey = rng.standard_normal((M, N)).astype(np.float32)
+    a64 = a[:, coff:coff + K].astype(np.float64).reshape(G, Mg, K)
+    if pro:
+        a64 = a64 * pst[2][:, None, :] + pst[3][:, None, :]
+    w64 = w.astype(np.float64).T if bt else w.astype(np.float64)
+    ref = (a64 @ w64 + (0.0 if bt else bias)).reshape(M, N)
+    nb = int(lib.cdrl_pwconv_fused_partial_rows(G, Mg, N, K))
+    A, Wd, Bd, PS, ES, EY = dev(a), dev(w), dev(bias), dev(pst), dev(est), dev(ey)
+    out = torch.full((M, N + 3), 1.0, device=DEV)
+    part = torch.zeros((G, nb, 2, N), dtype=torch.float64, device=DEV)
+    sbk, sbn = (1, K) if bt else (N, 1)
+    _lib.check(lib.cdrl_pwconv_fused(P(A), lda, coff, P(PS) if pro else None, P(Wd), sbk, sbn, None if bt else P(Bd), P(out), N + 3, 1,
+                                     1 if bt else 0, G, Mg, N, K, epi, P(EY), P(ES), P(part), S()))
+    got = out.cpu().numpy()
+    assert rel_err(got[:, 1:1 + N], ref + (1.0 if bt else 0.0)) < 1e-5
+    assert np.all(got[:, 0] == 1.0) and np.all(got[:, N + 1:] == 1.0)
+    if epi:
+        ps = part.sum(dim=1).cpu().numpy()              # (G, 2, N)
+        r3 = ref.reshape(G, Mg, N)
+        assert rel_err(ps[:, 0], r3.sum(axis=1)) < 1e-5
+        if epi == 1:
+            assert rel_err(ps[:, 1], (r3 * r3).sum(axis=1)) < 1e-5
+        else:
+            xh = (ey.astype(np.float64).reshape(G, Mg, N) - est[0][:, None, :]) * est[1][:, None, :]
+            assert rel_err(ps[:, 1], (r3 * xh).sum(axis=1)) < 1e-5
+
+
 @pytest.mark.parametrize('B,T,H,W', [(2, 4, 41, 58), (3, 2, 90, 120)])
 def test_stem(lib, B, T, H, W):
     rng = np.random.default_rng(1)

@@ -115,3 +115,27 @@ if __name__ == '__main__':
         bench_bn()
     if which in ('dw', 'all'):
         bench_dw()
+
+
+def bench_pw():
+    """fused persistent pointwise GEMM vs the generic tiled gemm_nn at the tower's K, N <= 128 shapes"""
+    print(f'{"shape":<28}{"gemm_nn us":>11}{"pw us":>9}{"pw+stats":>10}{"pw+pro+st":>10}{"ideal us":>9}')
+    for px, K, N in [(660, 24, 58), (165, 58, 92), (165, 24, 24), (165, 58, 58), (48, 116, 116), (165, 92, 58), (660, 58, 24)]:
+        G, Mg = 4, 256 * px
+        M = G * Mg
+        a = torch.randn(M, K, device=DEV)
+        w = torch.randn(K, N, device=DEV)
+        b = torch.randn(N, device=DEV)
+        y = torch.empty(M, N, device=DEV)
+        st = torch.rand(4 * G * K, device=DEV)
+        nb = int(lib.cdrl_pwconv_fused_partial_rows(G, Mg, N, K))
+        part = torch.zeros(G * nb * 2 * N, dtype=torch.float64, device=DEV)
+        t0 = timeit(lambda: lib.cdrl_gemm_nn(P(a), K, 0, P(w), N, 1, P(b), P(y), N, 0, M, N, K, 0, S()))
+        t1 = timeit(lambda: lib.cdrl_pwconv_fused(P(a), K, 0, None, P(w), N, 1, P(b), P(y), N, 0, 0, G, Mg, N, K, 0, None, None, None, S()))
+        t2 = timeit(lambda: lib.cdrl_pwconv_fused(P(a), K, 0, None, P(w), N, 1, P(b), P(y), N, 0, 0, G, Mg, N, K, 1, None, None, P(part), S()))
+        t3 = timeit(lambda: lib.cdrl_pwconv_fused(P(a), K, 0, P(st), P(w), N, 1, P(b), P(y), N, 0, 0, G, Mg, N, K, 1, None, None, P(part), S()))
+        print(f'M={M:<8} K={K:<4} N={N:<4} {t0:11.1f}{t1:9.1f}{t2:10.1f}{t3:10.1f}{4.0 * M * (K + N) / 5e6:9.1f}')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'pw':
+    bench_pw()
