@@ -94,6 +94,8 @@ PROTOTYPES = {
     'cdrl_dwconv_bwd_filter': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp]),
     'cdrl_pwconv_fused_partial_rows': (_i, [_i, _i, _i, _i]),
     'cdrl_pwconv_fused': (_i, [_fp, _i, _i, _fp, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp]),
+    'cdrl_pwconv_bn_bwd_workspace_bytes': (_i64, [_i, _i, _i, _i]),
+    'cdrl_pwconv_bn_bwd': (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
     'cdrl_dwconv_bn_workspace_doubles': (_i64, [_i] * 6),
     'cdrl_dwconv_bn_fwd': (_i, [_fp] * 5 + [_i] * 6 + [_fp] * 4 + [_i, _fp, _fp, _fp]),
     'cdrl_dwconv_bn_bwd': (_i, [_fp] * 6 + [_i] * 6 + [_fp] * 11),

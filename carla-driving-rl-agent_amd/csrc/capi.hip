@@ -348,6 +348,39 @@ int cdrl_pwconv_fused(const float* a, int lda, int a_coff, const float* pro_stat
                  accumulate, G, Mg, N, K, epilogue, epi_y, epi_stats, part, S(stream));
 }
 
+static int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
+
+int64_t cdrl_pwconv_bn_bwd_workspace_bytes(int G, int Mg, int N, int K) {
+    const int64_t nbr = vcol_geom(Mg, N).nb, nbp = pw_nn_plan(G, Mg, K, N).nbpg;
+    return al256((int64_t)G * nbr * 2 * N * 8) + al256((int64_t)G * nbp * N * 8) + al256(gemm_tn_part_elems(G * Mg, N, K, G) * 4);
+}
+
+int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
+                       const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
+                       int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
+                       int dx_coff, int accumulate, float* dw, float* db, void* workspace, void* stream) {
+    hipStream_t st = S(stream);
+    const int act = relu6 ? ACT_RELU6 : ACT_NONE;
+    const int nbr = vcol_geom(Mg, N).nb, nbp = pw_nn_plan(G, Mg, K, N).nbpg;
+    char* ws = static_cast<char*>(workspace);
+    double* part = reinterpret_cast<double*>(ws);
+    ws += al256((int64_t)G * nbr * 2 * N * 8);
+    double* part2 = reinterpret_cast<double*>(ws);
+    ws += al256((int64_t)G * nbp * N * 8);
+    float* tn = reinterpret_cast<float*>(ws);
+    View vd = make_view(const_cast<float*>(dout), dout_ld, dout_coff), vy = make_view(const_cast<float*>(y), N);
+    View vx = make_view(const_cast<float*>(x), x_ld, x_coff);
+    CDRL_TRY(bn_bwd_reduce(vd, shuffle_ctot, vy, G, Mg, N, stats, act, part, st, nullptr));
+    CDRL_TRY(bn_bwd_finalize(part, nbr, G, Mg, N, stats, dgamma, dbeta, coef, st));
+    PwBnBwd bb{y, stats, coef, shuffle_ctot, act, part2};
+    // dx[m,k] = sum_n dy[m,n] W[k,n]: GEMM with "K" = N (reduction over the conv outputs) and "N" = K
+    CDRL_TRY(pw_nn(vd, nullptr, w, 1, N, nullptr, make_view(dx, dx_ld, dx_coff), accumulate, G, Mg, K, N, 0, nullptr, nullptr, nullptr,
+                   st, &bb));
+    CDRL_TRY(reduce_partials(part2, G * nbp, N, N, db, 0, st));
+    TnBnBwd tb{y, stats, coef, shuffle_ctot, act};
+    return gemm_tn(vx, vd, dw, G * Mg, N, K, tn, 0, st, G, x_pro_stats, &tb);
+}
+
 int64_t cdrl_dwconv_bn_workspace_doubles(int G, int B, int H, int W, int C, int stride) {
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int64_t nb_out = vcol_geom(B * Ho * Wo, C).nb, nb_in = vcol_geom(B * H * W, C).nb;

@@ -59,9 +59,19 @@ int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C
             int accumulate, hipStream_t st);
 // Cout[K,N] = sum_m A[m,K]^T * D[m,N]  (split over M; partial buffer `part` >= gemm_tn_part_elems)
 // G > 1: rows are G equal BatchNorm groups; pro_stats ([4][G][K]) != null applies A <- scale[g][k]*A + shift[g][k] on load.
+// dpro != null: D[m,n] <- k1*(dz - k2 - xhat*k3) on load (BatchNorm-backward apply; D views the gradient w.r.t. the BN
+// output, optionally through the channel-shuffle gather / ReLU6 mask); needs gemm_tn_dpro_supported(N) and G groups.
+struct TnBnBwd {
+    const float* y;         // raw BN input [M][N] dense
+    const float* stats;     // [4][G][N]
+    const float* coef;      // [3][G][N]
+    int shuffle_ctot;
+    int act;
+};
+bool gemm_tn_dpro_supported(int N);
 int64_t gemm_tn_part_elems(int M, int N, int K, int G = 1);
 int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G = 1,
-            const float* pro_stats = nullptr);
+            const float* pro_stats = nullptr, const TnBnBwd* dpro = nullptr);
 
 // ---------------------------------------------------------------- fused pointwise conv (gemm_pw.hip)
 // Persistent skinny GEMM for K, N <= 128: C[m,n] (+)= sum_k pro(A[m,k]) W(k,n) + bias[n] over G groups of Mg rows.
@@ -71,10 +81,21 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
 struct PwPlan {
     int bm, tpb, nbpg;     // rows per tile, tiles per workgroup, workgroups (= partial rows) per group
 };
+// BatchNorm-backward prologue: A[m,k] = k1*(dz - k2 - xhat*k3), dz = (A view, gathered through the shuffle map when
+// shuffle_ctot != 0) masked by ReLU6 of the BN output when act == ACT_RELU6, xhat from the BN's raw input y [M][K].
+struct PwBnBwd {
+    const float* y;
+    const float* stats;     // [4][G][K]
+    const float* coef;      // [3][G][K]
+    int shuffle_ctot;
+    int act;
+    double* part2;          // optional [G][nbpg][K]: column sums of the transformed A (bias gradient partials)
+};
 bool pw_nn_supported(View A, int N, int K);
 PwPlan pw_nn_plan(int G, int Mg, int N, int K);
 int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, const float* bias, View C, int accumulate, int G,
-          int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st);
+          int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st,
+          const PwBnBwd* bnbwd = nullptr);
 // out[i] (+)= sum_p part[p*stride + i] for float partials (double accumulation, fixed order)
 int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride, float* out, int accumulate,
                         hipStream_t st);

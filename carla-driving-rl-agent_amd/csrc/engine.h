@@ -69,6 +69,14 @@ struct PwFuse {
     bool bwd_pw = false;                 // backward-data through the persistent skinny GEMM
     const float* bwd_ey = nullptr;       // backward epilogue: BN-backward sums of the BN whose raw input is bwd_ey
     const float* bwd_epi_stats = nullptr;
+    // BatchNorm-backward apply of the BN that follows this conv, done as the operand prologue of the backward-data and
+    // filter-gradient GEMMs (the gradient w.r.t. the conv output is never materialised)
+    bool bb = false;
+    const float* bb_stats = nullptr;     // that BN's statistics / backward coefficients (filled by its own backward op)
+    const float* bb_coef = nullptr;
+    View bb_dz{nullptr, 0, 0};           // gradient w.r.t. the BN output; p == nullptr: the current scratch slot (dense)
+    int bb_shuffle = 0, bb_act = 0;
+    bool bb_claim_slot = false;          // this op claims the rotating scratch slot (nobody upstream did)
 };
 
 class Learner {
@@ -137,6 +145,7 @@ private:
     struct BnRec {
         int G, Mg, C, nb;
         float* stats = nullptr;            // [4][G][C] of this BatchNorm
+        float* coef = nullptr;             // [3][G][C] backward coefficients
         float* y = nullptr;                // its (dense) input
         int act = 0;
         // set by the op that produces this BN's incoming gradient when it also accumulates the BN-backward
@@ -156,7 +165,8 @@ private:
     // dx == nullptr: tower mode, the gradient w.r.t. the BN input goes to the current scratch slot
     // stats_nb > 0: the statistics partials were already written by the producing op (that many rows per group)
     BnRec add_bn(std::vector<Op>& ops, int model, const std::string& prefix, View x, int G, int Mg, int C, bool bessel,
-                 int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx, int stats_nb = 0);
+                 int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx, int stats_nb = 0,
+                 bool defer_apply = false);
     void add_pw(std::vector<Op>& ops, const std::string& prefix, View in, int rows, int Cin, int Cout, float* y,
                 View din, int din_acc, BnRec bn_after, PwFuse fuse = PwFuse());
     void add_dw(std::vector<Op>& ops, const std::string& prefix, View in, int N, int H, int W, int C, int stride,
@@ -170,8 +180,9 @@ private:
     // Returns the post-BN statistics block.
     float* add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw, const char* bn_post,
                         float* x, int H, int W, int C, int stride, float* y2, View out, View dout, View din,
-                        int pre_stats_nb = 0, bool post_apply = true, int post_bwd_nb = 0);
-    bool fused_dw_ = true, fused_pw_ = true;
+                        int pre_stats_nb = 0, bool post_apply = true, int post_bwd_nb = 0, float* stats1_ext = nullptr,
+                        float* coef1_ext = nullptr, bool pre_defer_apply = false);
+    bool fused_dw_ = true, fused_pw_ = true, fused_bb_ = true;
     void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
                    View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);
     void add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,

@@ -234,7 +234,7 @@ void Learner::note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn
 // ------------------------------------------------------------------------------------------
 Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::string& prefix, View x, int G, int Mg, int C,
                                bool bessel, int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx,
-                               int stats_nb) {
+                               int stats_nb, bool defer_apply) {
     PRef gamma = param(model, prefix + ".gamma", {C}, true);
     PRef beta = param(model, prefix + ".beta", {C}, true);
     PRef mm = param(model, prefix + ".moving_mean", {C}, false);
@@ -249,6 +249,7 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     rec.C = C;
     rec.nb = nb;
     rec.stats = stats;
+    rec.coef = coef;
     rec.y = (x.ld == C && x.coff == 0) ? x.p : nullptr;
     rec.act = act;
     rec.reduce_fused = std::make_shared<bool>(false);
@@ -264,6 +265,7 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     op.bwd = [=](hipStream_t st) -> int {
         if (!*fused) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st));
         CDRL_TRY(bn_bwd_finalize(sc->part, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
+        if (defer_apply) return 0;      // applied by the consumer GEMMs on load (PwFuse::bb)
         if (dx) return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, sc->part2, st);
         CDRL_TRY(next_slot(st));       // tower: dy + db partials go to a rotating scratch slot
         return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dys_[slot_], part2s_[slot_], st);
@@ -277,7 +279,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     PRef w = param(M_TRUNK, prefix + ".w", {1, 1, Cin, Cout}, true);
     PRef b = param(M_TRUNK, prefix + ".b", {Cout}, true);
     const int G = cfg_.T, Mg = rows / G;
-    const int tn_groups = fuse.pro_stats ? G : 1;
+    const int tn_groups = (fuse.pro_stats || fuse.bb) ? G : 1;
     note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin, tn_groups));
     if (fuse.epi_stats) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cout, Cin).nbpg * 2 * Cout, 0, 0, 0);
     if (fuse.bwd_ey) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cin, Cout).nbpg * 2 * Cin, 0, 0, 0);
@@ -288,7 +290,24 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
                          nullptr, nullptr, scr_main_.part, st);
         return gemm_nn(in, w.p, Cout, 1, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
     };
+    const int nbp_bwd = fuse.bb ? pw_nn_plan(G, Mg, Cin, Cout).nbpg : 0;
+    if (fuse.bb) note_scratch(0, (size_t)G * nbp_bwd * Cout, 0, 0);
     op.bwd = [=](hipStream_t st) -> int {
+        if (fuse.bb) {
+            // BN-backward apply fused into the operand loads: dz (+ raw y, statistics, coefficients) instead of dy
+            if (fuse.bb_claim_slot) CDRL_TRY(next_slot(st));
+            const View dz = fuse.bb_dz.p ? fuse.bb_dz : make_view(dys_[slot_], Cout);
+            hipStream_t side = fork_side(st);
+            TnBnBwd tb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act};
+            CDRL_TRY(gemm_tn(in, dz, w.g, rows, Cout, Cin, tns_[slot_], 0, side, G, fuse.pro_stats, &tb));
+            CDRL_TRY(done_side(side));
+            PwBnBwd pb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act, part2s_[slot_]};
+            CDRL_TRY(pw_nn(dz, nullptr, w.p, 1, Cout, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
+                           fuse.bwd_epi_stats, scr_main_.part, st, &pb));
+            side = fork_side(st);       // bias gradient = column sums of the (virtual) dy, reduced from the GEMM's partials
+            CDRL_TRY(reduce_partials(part2s_[slot_], G * nbp_bwd, Cout, Cout, b.g, 0, side));
+            return done_side(side);
+        }
         float* dy = dys_[slot_];
         // side stream: bias gradient (column sums of dy, reduced per block by bn_bwd_apply) + filter gradient
         hipStream_t side = fork_side(st);
@@ -336,7 +355,8 @@ void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, i
 
 float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw,
                              const char* bn_post, float* x, int H, int W, int C, int stride, float* y2, View out, View dout,
-                             View din, int pre_stats_nb, bool post_apply, int post_bwd_nb) {
+                             View din, int pre_stats_nb, bool post_apply, int post_bwd_nb, float* stats1_ext, float* coef1_ext,
+                             bool pre_defer_apply) {
     const int B = cfg_.B, G = cfg_.T, N = B * G;
     const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
     const int Mi = B * H * W, Mo = B * Ho * Wo;
@@ -349,8 +369,8 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
         b1 = param(M_TRUNK, n1 + ".beta", {C}, true);
         mm1 = param(M_TRUNK, n1 + ".moving_mean", {C}, false);
         mv1 = param(M_TRUNK, n1 + ".moving_var", {C}, false);
-        stats1 = alloc((size_t)4 * G * C);
-        coef1 = alloc((size_t)3 * G * C);
+        stats1 = stats1_ext ? stats1_ext : alloc((size_t)4 * G * C);
+        coef1 = coef1_ext ? coef1_ext : alloc((size_t)3 * G * C);
     }
     PRef w = param(M_TRUNK, unit + "." + dw + ".w", {3, 3, C, 1}, true);
     PRef b = param(M_TRUNK, unit + "." + dw + ".b", {C}, true);
@@ -377,6 +397,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
         };
         op.bwd = [=](hipStream_t st) -> int {
             CDRL_TRY(bn_bwd_finalize(scr_main_.part, nbf, G, Mi, C, stats1, g1.g, b1.g, coef1, st));
+            if (pre_defer_apply) return 0;                 // the 1x1 conv in front applies it on load (PwFuse::bb)
             const float* dz = dys_[slot_];                 // masked gradient left there by the depthwise op
             CDRL_TRY(next_slot(st));
             return bn_bwd_apply(make_view(const_cast<float*>(dz), C), 0, xv, G, Mi, C, stats1, coef1, ACT_NONE, dys_[slot_],
@@ -565,6 +586,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         fused_dw_ = !(e && atoi(e) == 0);
         const char* e2 = getenv("CDRL_FUSED_PW");       // 0 -> generic tiled GEMM + separate BN passes around the 1x1 convs
         fused_pw_ = !(e2 && atoi(e2) == 0);
+        const char* e3 = getenv("CDRL_FUSED_BB");       // 0 -> BN-backward apply as a separate pass (materialised dy)
+        fused_bb_ = !(e3 && atoi(e3) == 0);
     }
 
     // ---- stem (core/architectures.py:159-161)
@@ -649,16 +672,28 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                                  pw_nn_supported(y2.v(), main_out, mid) && pw_nn_supported(y3.v(), mid, main_out) &&
                                  pw_nn_supported(y1.v(), main_in, mid);
                 if (fpw) {
+                    // BN-backward apply as GEMM operand prologue (needs the filter-gradient GEMM's fixed column mapping)
+                    const bool bb1 = fused_bb_ && gemm_tn_dpro_supported(mid);
+                    const bool bb3 = fused_bb_ && gemm_tn_dpro_supported(main_out);
+                    float* stats1 = alloc((size_t)4 * T * mid);
+                    float* coef1 = alloc((size_t)3 * T * mid);
                     PwFuse f1;
                     f1.fwd_pw = true;
                     f1.epi_stats = true;
                     f1.bwd_pw = true;
+                    if (bb1) {
+                        f1.bb = true;
+                        f1.bb_stats = stats1;
+                        f1.bb_coef = coef1;          // dz = masked gradient in the current scratch slot (written by the dw op)
+                    }
                     add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off), stride == 2 ? 1 : 0,
                            bnrec(T, Mg_in, mid), f1);
                     const int nb1 = pw_nn_plan(T, Mg_in, mid, main_in).nbpg;
                     const int nbb = pw_nn_plan(T, Mg_out, mid, main_out).nbpg;        // pw2 backward-data epilogue rows
                     float* stats2 = add_dw_block(ops, pre, "bn1", "dw", "bn2", y1.p, curH, curW, mid, stride, y2.p, a2.v(), a2.gv(),
-                                                 View{nullptr, 0, 0}, nb1, false, nbb);
+                                                 View{nullptr, 0, 0}, nb1, false, nbb, stats1, coef1, bb1);
+                    // BN3's statistics / coefficient blocks are allocated by add_bn below; bump-allocate them here first so
+                    // that pw2 (which precedes bn3 in the op list) can reference them
                     PwFuse f2;
                     f2.fwd_pw = true;
                     f2.pro_stats = stats2;
@@ -666,9 +701,22 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     f2.bwd_pw = true;
                     f2.bwd_ey = y2.p;
                     f2.bwd_epi_stats = stats2;
+                    const size_t pw2_at = ops.size();
                     add_pw(ops, pre + ".pw2", y2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out), f2);
-                    add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C, out.gv(sc_c), C,
-                           nullptr, pw_nn_plan(T, Mg_out, main_out, mid).nbpg);
+                    BnRec r3 = add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C,
+                                      out.gv(sc_c), C, nullptr, pw_nn_plan(T, Mg_out, main_out, mid).nbpg, bb3);
+                    if (bb3) {      // rebuild pw2 with the BN3 blocks known (same parameters -> same arena slots)
+                        f2.bb = true;
+                        f2.bb_stats = r3.stats;
+                        f2.bb_coef = r3.coef;
+                        f2.bb_dz = out.gv(sc_c);
+                        f2.bb_shuffle = C;
+                        f2.bb_act = ACT_RELU6;
+                        f2.bb_claim_slot = true;
+                        std::vector<Op> tmp;
+                        add_pw(tmp, pre + ".pw2", y2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out), f2);
+                        ops[pw2_at] = tmp[0];
+                    }
                 } else {
                     add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off), stride == 2 ? 1 : 0,
                            bnrec(T, Mg_in, mid));

@@ -415,10 +415,10 @@ int64_t gemm_tn_part_elems(int M, int N, int K, int G) {
     return (int64_t)p.nsplit * K * N;
 }
 
-template <int KT, int NTL, bool VEC>
+template <int KT, int NTL, bool VEC, bool DPRO>
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* __restrict__ part, int M, int N, int K,
                                                          int rows_per, int nspg, int Mg, int G,
-                                                         const float* __restrict__ pro_stats) {
+                                                         const float* __restrict__ pro_stats, TnBnBwd db) {
     constexpr int TK = 32 * KT, TNn = 32 * NTL;
     constexpr int NTILES = KT * NTL;
     constexpr int PER_WAVE = (NTILES + 3) / 4;
@@ -452,6 +452,33 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     float ra[NA], rd[ND];
+    // optional prologue on D: D[m,n] <- k1*(dz - k2 - xhat*k3), the BatchNorm-backward apply of the layer whose output
+    // gradient D views (see gemm_pw.hip PRO_BNBWD); VEC path with a fixed column pair per thread (256 % (TNn/2) == 0)
+    constexpr bool dpro = VEC && DPRO;
+    float2 ry[dpro ? ND / 2 : 1];
+    const int nn_t = (tid % (TNn / 2)) * 2;
+    // the 7 per-column coefficients live in LDS (read back at transform time): registers are the scarce resource here
+    __shared__ float qc[DPRO ? 7 : 1][DPRO ? TNn : 1];
+    int dcol0 = 0, dcol1 = 0;
+    if (dpro) {
+        const int GN = G * N;
+        for (int i = tid; i < TNn; i += 256) {
+            const bool okn = (n0 + i) < N;
+            const int o = grp * N + n0 + i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) qc[q][i] = okn ? db.stats[q * GN + o] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) qc[4 + q][i] = okn ? db.coef[q * GN + o] : 0.0f;
+        }
+    }
+    if (dpro && (n0 + nn_t) < N) {
+        dcol0 = D.coff + n0 + nn_t;
+        dcol1 = dcol0 + 1;
+        if (db.shuffle_ctot) {
+            dcol0 = shuffle_dst(dcol0, db.shuffle_ctot);
+            dcol1 = shuffle_dst(dcol1, db.shuffle_ctot);
+        }
+    }
 
     auto load_rows = [&](int64_t m0) {
         if (VEC) {
@@ -477,7 +504,16 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* 
                 const int r = idx / (TNn / 2), nn = (idx % (TNn / 2)) * 2;
                 const int64_t m = m0 + r;
                 float2 v = make_float2(0.0f, 0.0f);
-                if (m < mend && (n0 + nn) < N) v = *reinterpret_cast<const float2*>(&D.p[m * D.ld + D.coff + n0 + nn]);
+                if (dpro) {
+                    ry[i] = make_float2(0.0f, 0.0f);
+                    if (m < mend && (n0 + nn) < N) {
+                        v.x = D.p[m * D.ld + dcol0];
+                        v.y = D.p[m * D.ld + dcol1];
+                        ry[i] = *reinterpret_cast<const float2*>(&db.y[m * N + n0 + nn]);
+                    }
+                } else if (m < mend && (n0 + nn) < N) {
+                    v = *reinterpret_cast<const float2*>(&D.p[m * D.ld + D.coff + n0 + nn]);
+                }
                 rd[2 * i] = v.x;
                 rd[2 * i + 1] = v.y;
             }
@@ -498,7 +534,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* 
             }
         }
     };
-    auto store_rows = [&](int buf) {
+    auto store_rows = [&](int buf, int64_t m0) {
         if (VEC) {
 #pragma unroll
             for (int i = 0; i < NA / 2; ++i) {
@@ -510,7 +546,19 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* 
             for (int i = 0; i < ND / 2; ++i) {
                 const int idx = tid + 256 * i;
                 const int r = idx / (TNn / 2), nn = (idx % (TNn / 2)) * 2;
-                *reinterpret_cast<float2*>(&Ds[buf][r][nn]) = make_float2(rd[2 * i], rd[2 * i + 1]);
+                float2 v = make_float2(rd[2 * i], rd[2 * i + 1]);
+                if (dpro && (m0 + r) < mend && (n0 + nn) < N) {
+                    const float2 yv = ry[i];
+                    if (db.act == ACT_RELU6) {
+                        const float z0 = fmaf(qc[2][nn], yv.x, qc[3][nn]), z1 = fmaf(qc[2][nn + 1], yv.y, qc[3][nn + 1]);
+                        if (!(z0 > 0.0f && z0 < 6.0f)) v.x = 0.0f;
+                        if (!(z1 > 0.0f && z1 < 6.0f)) v.y = 0.0f;
+                    }
+                    const float xh0 = (yv.x - qc[0][nn]) * qc[1][nn], xh1 = (yv.y - qc[0][nn + 1]) * qc[1][nn + 1];
+                    v.x = qc[4][nn] * (v.x - qc[5][nn] - xh0 * qc[6][nn]);
+                    v.y = qc[4][nn + 1] * (v.y - qc[5][nn + 1] - xh1 * qc[6][nn + 1]);
+                }
+                *reinterpret_cast<float2*>(&Ds[buf][r][nn]) = v;
             }
         } else {
 #pragma unroll
@@ -527,7 +575,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* 
     };
 
     load_rows(mbeg);
-    store_rows(0);
+    store_rows(0, mbeg);
     __syncthreads();
     int buf = 0;
     for (int64_t m0 = mbeg; m0 < mend; m0 += TN_BM) {
@@ -546,7 +594,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* 
                 }
             }
         }
-        if (more) store_rows(buf ^ 1);
+        if (more) store_rows(buf ^ 1, m0 + TN_BM);
         __syncthreads();
         buf ^= 1;
     }
@@ -598,30 +646,35 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float* __restrict
     }
 }
 
-template <int KT, bool VEC>
+template <int KT, bool VEC, bool DPRO>
 static void launch_tn(int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp, int nspg,
-                      int Mg, int G, const float* ps) {
+                      int Mg, int G, const float* ps, TnBnBwd db) {
     switch (ntl) {
-        case 1: hipLaunchKernelGGL((gemm_tn_kernel<KT, 1, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
-        case 2: hipLaunchKernelGGL((gemm_tn_kernel<KT, 2, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
-        case 3: hipLaunchKernelGGL((gemm_tn_kernel<KT, 3, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
-        default: hipLaunchKernelGGL((gemm_tn_kernel<KT, 4, VEC>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
+        case 1: hipLaunchKernelGGL((gemm_tn_kernel<KT, 1, VEC, DPRO>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
+        case 2: hipLaunchKernelGGL((gemm_tn_kernel<KT, 2, VEC, DPRO>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
+        case 3: hipLaunchKernelGGL((gemm_tn_kernel<KT, 3, VEC, false>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
+        default: hipLaunchKernelGGL((gemm_tn_kernel<KT, 4, VEC, DPRO>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
     }
 }
 
-template <bool VEC>
+template <bool VEC, bool DPRO>
 static void launch_tn_k(int kt, int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp,
-                        int nspg, int Mg, int G, const float* ps) {
+                        int nspg, int Mg, int G, const float* ps, TnBnBwd db) {
     switch (kt) {
-        case 1: launch_tn<1, VEC>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
-        case 2: launch_tn<2, VEC>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
-        case 3: launch_tn<3, VEC>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
-        default: launch_tn<4, VEC>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps); break;
+        case 1: launch_tn<1, VEC, DPRO>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
+        case 2: launch_tn<2, VEC, DPRO>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
+        case 3: launch_tn<3, VEC, DPRO>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
+        default: launch_tn<4, VEC, DPRO>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
     }
+}
+
+bool gemm_tn_dpro_supported(int N) {
+    const int gz = cdiv(N, 128), ntl = cdiv(cdiv(N, gz), 32);
+    return ntl != 3 && (N % 2 == 0);
 }
 
 int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G,
-            const float* pro_stats) {
+            const float* pro_stats, const TnBnBwd* dpro) {
     if (G < 1 || M % G != 0) {
         set_error("gemm_tn: M=%d is not a multiple of G=%d", M, G);
         return -1;
@@ -633,12 +686,24 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     };
     // float2 path: every row start and every 32-wide tile start is 8-byte aligned
     const bool vec = even(A) && even(D) && (K % 2 == 0) && (N % 2 == 0);
-    if (pro_stats && !vec) {
+    TnBnBwd db{};
+    bool vecd = vec;
+    if (dpro) {
+        db = *dpro;
+        // the D operand is gathered element-wise through db; only A and the raw BN input need the float2 alignment
+        vecd = even(A) && (K % 2 == 0) && (N % 2 == 0) && ((reinterpret_cast<uintptr_t>(db.y) & 7) == 0);
+        if (!vecd || !gemm_tn_dpro_supported(N)) {
+            set_error("gemm_tn: BatchNorm-backward prologue not supported for N=%d / this alignment", N);
+            return -1;
+        }
+    }
+    if (pro_stats && !vecd) {
         set_error("gemm_tn: the BatchNorm prologue needs even, 8-byte aligned operands");
         return -1;
     }
-    if (vec) launch_tn_k<true>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per, p.nspg, M / G, G, pro_stats);
-    else launch_tn_k<false>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per, p.nspg, M / G, G, pro_stats);
+    if (vecd && dpro) launch_tn_k<true, true>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per, p.nspg, M / G, G, pro_stats, db);
+    else if (vecd) launch_tn_k<true, false>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per, p.nspg, M / G, G, pro_stats, db);
+    else launch_tn_k<false, false>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per, p.nspg, M / G, G, pro_stats, db);
     CDRL_LAUNCH_CHECK();
     const int64_t n = (int64_t)K * N;
     return reduce_partials_f32(part, p.nsplit, n, n, Cout, accumulate, st);

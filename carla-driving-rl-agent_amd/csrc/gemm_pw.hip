@@ -11,6 +11,11 @@
 //     the next A tile into registers while the MFMAs of the current tile run;
 //   * prologue  PRO_BNAPPLY: a = scale[g][k] * a + shift[g][k] on the way into LDS (BN apply of the previous
 //                            layer: its normalised output is never written to HBM);
+//               PRO_BNBWD:   a = k1 * (dz - k2 - xhat * k3) with dz gathered (optionally through the channel-shuffle
+//                            map, optionally ReLU6-masked) from the gradient of the BN OUTPUT and xhat from the BN's
+//                            raw input: the BatchNorm backward "apply" happens on load, dy is never written to
+//                            HBM; the column sums of a (bias gradient of the conv in front of that BN) come out
+//                            as per-workgroup partials;
 //   * epilogue  EPI_STATS:   per-workgroup (sum c, sum c^2) per output channel -> statistics partials of the
 //                            following BatchNorm (no separate pass over C);
 //               EPI_BNRED:   (sum c, sum c * xhat) with xhat from the raw input `ey` of the BatchNorm that C is the
@@ -23,7 +28,12 @@ namespace cdrl {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct PwArgs {
-    View A;
+    View A;                     // PRO_BNBWD: gradient w.r.t. the BN output (the dz source)
+    int a_shuffle;              // PRO_BNBWD: channel-shuffle gather on the columns of A (0 = none)
+    int a_act;                  // PRO_BNBWD: ReLU6 mask from the BN output
+    const float* a_y;           // PRO_BNBWD: raw BN input [M][K] dense
+    const float* pro_coef;      // PRO_BNBWD: [3][G][K] (k1, k2, k3)
+    double* part2;              // PRO_BNBWD: [G][nbpg][K] column sums of the transformed A (or null)
     const float* pro_stats;     // [4][G][K]
     const float* W;
     int sbk, sbn;
@@ -87,51 +97,100 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
         }
     }
     // prologue coefficients: a thread always handles the same two k columns (256 % KSM == 0)
+    const int kk_t = tid % KSM;                     // float2 column of this thread
+    const bool kon = kk_t < K2;
     float psc0 = 1.0f, psc1 = 1.0f, psh0 = 0.0f, psh1 = 0.0f;
-    if (PRO == 1) {
-        const int k = 2 * (tid % KSM);
-        if (k < K) {
-            psc0 = a.pro_stats[2 * a.G * K + g * K + k];
-            psh0 = a.pro_stats[3 * a.G * K + g * K + k];
-        }
-        if (k + 1 < K) {
-            psc1 = a.pro_stats[2 * a.G * K + g * K + k + 1];
-            psh1 = a.pro_stats[3 * a.G * K + g * K + k + 1];
-        }
+    // PRO_BNBWD: the 7 per-column coefficients stay in LDS (registers are the scarce resource of this kernel)
+    float* qc = smem + BM * LDA;                    // [7][2*KSM]: mean, invstd, scale, shift, k1, k2, k3
+    int dcol0 = 0, dcol1 = 0;
+    if (PRO == 1 && kon) {
+        const int k = 2 * kk_t, GK = a.G * K, o = g * K + k;
+        psc0 = a.pro_stats[2 * GK + o];
+        psc1 = a.pro_stats[2 * GK + o + 1];
+        psh0 = a.pro_stats[3 * GK + o];
+        psh1 = a.pro_stats[3 * GK + o + 1];
     }
+    if (PRO == 2) {
+        const int GK = a.G * K;
+        for (int i = tid; i < 2 * KSM; i += 256) {
+            const bool okk = i < K;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) qc[q * 2 * KSM + i] = okk ? a.pro_stats[q * GK + g * K + i] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) qc[(4 + q) * 2 * KSM + i] = okk ? a.pro_coef[q * GK + g * K + i] : 0.0f;
+        }
+        if (kon) {
+            dcol0 = a.A.coff + 2 * kk_t;
+            dcol1 = dcol0 + 1;
+            if (a.a_shuffle) {
+                dcol0 = shuffle_dst(dcol0, a.a_shuffle);
+                dcol1 = shuffle_dst(dcol1, a.a_shuffle);
+            }
+        }
+        __syncthreads();
+    }
+    double cs0 = 0.0, cs1 = 0.0;                    // PRO_BNBWD: column sums of the transformed A
     double s1[NTW], s2[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) s1[j] = s2[j] = 0.0;
 
-    // A tiles are prefetched into registers TWO tiles ahead (one tile of loads in flight per workgroup left the
-    // kernel latency-bound: ~2 us per tile step); the wide-row variants (NA2 > 16) keep a single register set
-    constexpr bool PF2 = false;     // measured: the second register set costs a wave of occupancy and loses (25.6 -> 29.4 us)
-    float2 ra0[NA2], ra1[PF2 ? NA2 : 1];
-    auto load_tile = [&](int t, float2* ra) {
+    // the next A tile is prefetched into registers while the MFMAs of the current one run (a second register set,
+    // two tiles ahead, was measured slower: it costs a wave of occupancy, 25.6 -> 29.4 us at K = N = 58)
+    const bool dz_vec = PRO == 2 && !a.a_shuffle && (a.A.ld % 2 == 0) && (a.A.coff % 2 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(a.A.p) & 7) == 0);
+    float2 ra0[NA2], ry0[PRO == 2 ? NA2 : 1];
+    auto load_tile = [&](int t, float2* ra, float2* ry) {
         const int64_t m0 = mbeg + (int64_t)t * BM;
 #pragma unroll
         for (int i = 0; i < NA2; ++i) {
-            const int idx = tid + 256 * i;
-            const int r = idx / KSM, kk = idx % KSM;
+            const int r = (tid + 256 * i) / KSM;
             const int64_t m = m0 + r;
             ra[i] = make_float2(0.0f, 0.0f);
-            if (m < mend && kk < K2) ra[i] = *reinterpret_cast<const float2*>(&a.A.p[m * a.A.ld + a.A.coff + 2 * kk]);
+            if (PRO == 2) ry[i] = make_float2(0.0f, 0.0f);
+            if (m < mend && kon) {
+                if (PRO == 2) {
+                    if (dz_vec) {       // dense gradient (no shuffle map): one 8-byte load
+                        ra[i] = *reinterpret_cast<const float2*>(&a.A.p[m * a.A.ld + dcol0]);
+                    } else {
+                        ra[i].x = a.A.p[m * a.A.ld + dcol0];
+                        ra[i].y = a.A.p[m * a.A.ld + dcol1];
+                    }
+                    ry[i] = *reinterpret_cast<const float2*>(&a.a_y[m * K + 2 * kk_t]);
+                } else {
+                    ra[i] = *reinterpret_cast<const float2*>(&a.A.p[m * a.A.ld + a.A.coff + 2 * kk_t]);
+                }
+            }
         }
     };
-    auto store_tile = [&](int t, const float2* ra) {
+    auto store_tile = [&](int t, const float2* ra, const float2* ry) {
         const int64_t m0 = mbeg + (int64_t)t * BM;
 #pragma unroll
         for (int i = 0; i < NA2; ++i) {
-            const int idx = tid + 256 * i;
-            const int r = idx / KSM, kk = idx % KSM;
+            const int r = (tid + 256 * i) / KSM;
             float2 v = ra[i];
             if (PRO == 1) {
-                if (m0 + r < mend && kk < K2) {
+                if (m0 + r < mend && kon) {
                     v.x = fmaf(psc0, v.x, psh0);
                     v.y = fmaf(psc1, v.y, psh1);
                 }
+            } else if (PRO == 2) {
+                if (m0 + r < mend && kon) {
+                    const float2 yv = ry[i];
+                    const float* q0 = qc + 2 * kk_t;
+                    if (a.a_act == ACT_RELU6) {
+                        const float z0 = fmaf(q0[2 * 2 * KSM], yv.x, q0[3 * 2 * KSM]);
+                        const float z1 = fmaf(q0[2 * 2 * KSM + 1], yv.y, q0[3 * 2 * KSM + 1]);
+                        if (!(z0 > 0.0f && z0 < 6.0f)) v.x = 0.0f;
+                        if (!(z1 > 0.0f && z1 < 6.0f)) v.y = 0.0f;
+                    }
+                    const float xh0 = (yv.x - q0[0]) * q0[2 * KSM], xh1 = (yv.y - q0[1]) * q0[2 * KSM + 1];
+                    v.x = q0[4 * 2 * KSM] * (v.x - q0[5 * 2 * KSM] - xh0 * q0[6 * 2 * KSM]);
+                    v.y = q0[4 * 2 * KSM + 1] * (v.y - q0[5 * 2 * KSM + 1] - xh1 * q0[6 * 2 * KSM + 1]);
+                    cs0 += (double)v.x;
+                    cs1 += (double)v.y;
+                }
             }
-            *reinterpret_cast<float2*>(&As[r * LDA + 2 * kk]) = v;
+            *reinterpret_cast<float2*>(&As[r * LDA + 2 * kk_t]) = v;
         }
     };
     auto compute_tile = [&](int t) {
@@ -176,32 +235,27 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
         }
     };
 
-    if (PF2) {
-        if (t0 < t1) load_tile(t0, ra0);
-        if (t0 + 1 < t1) load_tile(t0 + 1, ra1);
-        for (int t = t0; t < t1; t += 2) {
-            store_tile(t, ra0);
-            __syncthreads();
-            if (t + 2 < t1) load_tile(t + 2, ra0);
-            compute_tile(t);
-            __syncthreads();             // all fragment reads of As done before the next store_tile
-            if (t + 1 < t1) {
-                store_tile(t + 1, ra1);
-                __syncthreads();
-                if (t + 3 < t1) load_tile(t + 3, ra1);
-                compute_tile(t + 1);
-                __syncthreads();
-            }
+    if (t0 < t1) load_tile(t0, ra0, ry0);
+    for (int t = t0; t < t1; ++t) {
+        store_tile(t, ra0, ry0);
+        __syncthreads();
+        if (t + 1 < t1) load_tile(t + 1, ra0, ry0);
+        compute_tile(t);
+        __syncthreads();             // all fragment reads of As done before the next store_tile
+    }
+    if (PRO == 2 && a.part2) {
+        // column sums of the transformed A: threads tid = kk + KSM*j share a column pair
+        double* red2 = reinterpret_cast<double*>(smem);     // [256/KSM][2*KSM]
+        red2[(tid / KSM) * 2 * KSM + 2 * kk_t] = cs0;
+        red2[(tid / KSM) * 2 * KSM + 2 * kk_t + 1] = cs1;
+        __syncthreads();
+        for (int k = tid; k < K; k += 256) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 256 / KSM; ++j) s += red2[j * 2 * KSM + k];
+            a.part2[((int64_t)g * a.nbpg + b) * K + k] = s;
         }
-    } else {
-        if (t0 < t1) load_tile(t0, ra0);
-        for (int t = t0; t < t1; ++t) {
-            store_tile(t, ra0);
-            __syncthreads();
-            if (t + 1 < t1) load_tile(t + 1, ra0);
-            compute_tile(t);
-            __syncthreads();
-        }
+        __syncthreads();
     }
     if (EPI != 0) {
         double* red = reinterpret_cast<double*>(smem);      // [WR][2][32*NT]; As is dead
@@ -243,7 +297,7 @@ bool pw_nn_supported(View A, int N, int K) {
 
 PwPlan pw_nn_plan(int G, int Mg, int N, int K) {
     PwPlan p;
-    const int nt = cdiv(N, 32), ksm = pw_ksm(K);
+    const int nt = N <= 128 ? cdiv(N, 32) : 4, ksm = pw_ksm(K);     // (N > 128 is not supported: plan stays well-defined)
     p.bm = 32 * (4 / pw_wc(nt));
     const int tiles_g = cdiv(Mg, p.bm);
     // grid = exactly the number of workgroups that are resident at once (256 CUs x occupancy of the variant), so every
@@ -260,9 +314,10 @@ template <int KSM, int NT, int PRO, int EPI>
 static int launch_pw(const PwArgs& a, hipStream_t st) {
     constexpr int WR = 4 / pw_wc(NT);
     constexpr int BM = 32 * WR;
-    size_t lds = (size_t)(BM * (2 * KSM + 2)) * sizeof(float);
+    size_t lds = (size_t)(BM * (2 * KSM + 2) + (PRO == 2 ? 14 * KSM : 0)) * sizeof(float);
     const size_t red = (size_t)WR * 2 * 32 * NT * sizeof(double);
     if (lds < red) lds = red;
+    if (lds < (size_t)512 * sizeof(double)) lds = (size_t)512 * sizeof(double);      // PRO_BNBWD column-sum scratch
     auto kern = pw_nn_kernel<KSM, NT, PRO, EPI>;
     if (lds > 64 * 1024) CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg), dim3(256), lds, st, a);
@@ -277,6 +332,8 @@ static int launch_pw_pe(int pro, int epi, const PwArgs& a, hipStream_t st) {
     if (pro == 0 && epi == 2) return launch_pw<KSM, NT, 0, 2>(a, st);
     if (pro == 1 && epi == 0) return launch_pw<KSM, NT, 1, 0>(a, st);
     if (pro == 1 && epi == 1) return launch_pw<KSM, NT, 1, 1>(a, st);
+    if (pro == 2 && epi == 0) return launch_pw<KSM, NT, 2, 0>(a, st);
+    if (pro == 2 && epi == 2) return launch_pw<KSM, NT, 2, 2>(a, st);
     set_error("pw_nn: unsupported prologue/epilogue combination %d/%d", pro, epi);
     return -1;
 }
@@ -296,8 +353,9 @@ static int launch_pw_nt(int nt, int pro, int epi, const PwArgs& a, hipStream_t s
 }
 
 int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, const float* bias, View C, int accumulate, int G,
-          int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st) {
-    if (!pw_nn_supported(A, N, K)) {
+          int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st,
+          const PwBnBwd* bb) {
+    if (!pw_nn_supported(bb ? make_view(const_cast<float*>(bb->y), K) : A, N, K)) {
         set_error("pw_nn: shape K=%d N=%d / alignment not supported", K, N);
         return -1;
     }
@@ -308,6 +366,12 @@ int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, cons
     const PwPlan p = pw_nn_plan(G, Mg, N, K);
     PwArgs a;
     a.A = A;
+    a.a_shuffle = bb ? bb->shuffle_ctot : 0;
+    a.a_act = bb ? bb->act : 0;
+    a.a_y = bb ? bb->y : nullptr;
+    a.pro_coef = bb ? bb->coef : nullptr;
+    a.part2 = bb ? bb->part2 : nullptr;
+    if (bb) pro_stats = bb->stats;
     a.pro_stats = pro_stats;
     a.W = W;
     a.sbk = sbk;
@@ -324,7 +388,7 @@ int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, cons
     a.Mg = Mg;
     a.nbpg = p.nbpg;
     a.tpb = p.tpb;
-    const int nt = cdiv(N, 32), pro = pro_stats ? 1 : 0;
+    const int nt = cdiv(N, 32), pro = bb ? 2 : (pro_stats ? 1 : 0);
     switch (pw_ksm(K)) {
         case 16: return launch_pw_nt<16>(nt, pro, epilogue, a, st);
         case 32: return launch_pw_nt<32>(nt, pro, epilogue, a, st);

@@ -203,6 +203,18 @@ int cdrl_pwconv_fused_partial_rows(int G, int Mg, int N, int K);
 int cdrl_pwconv_fused(const float* a, int lda, int a_coff, const float* pro_stats, const float* w, int sbk, int sbn,
                       const float* bias, float* c, int ldc, int c_coff, int accumulate, int G, int Mg, int N, int K,
                       int epilogue, const float* epi_y, const float* epi_stats, double* part, void* stream);
+/* Backward of [Conv2D(k=1) -> BatchNormalization(training, per time slice) (+ReLU6) (+channel_shuffle on the store)]
+ * (core/architectures.py:130-131,140-145) without materialising the gradient w.r.t. the conv output: the BN-backward
+ * "apply" runs as the operand prologue of the two GEMMs.  dout: gradient w.r.t. the BN output (view ld/coff, read through
+ * the shuffle map when shuffle_ctot != 0); y: raw conv output [G*Mg][N]; stats: that BN's 4*G*N block; x: conv input
+ * view [G*Mg][K]; x_pro_stats != NULL: the conv input is BN-apply(x) with those statistics (4*G*K) as in
+ * cdrl_pwconv_fused.  Outputs: dgamma, dbeta, coef (3*G*N scratch), dx (view, accumulate flag), dw (K x N), db (N).
+ * workspace: cdrl_pwconv_bn_bwd_workspace_bytes().  Shapes as cdrl_pwconv_fused (K, N <= 128, even). */
+int64_t cdrl_pwconv_bn_bwd_workspace_bytes(int G, int Mg, int N, int K);
+int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
+                       const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
+                       int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
+                       int dx_coff, int accumulate, float* dw, float* db, void* workspace, void* stream);
 /* Fused depthwise block of the ShuffleNet unit: [BatchNormalization + ReLU6 of the previous 1x1 conv, applied on
  * load] -> DepthwiseConv2D(3, stride, 'same') -> statistics of the BatchNormalization that follows
  * (core/architectures.py:130-139; per-time-slice BN :44-57).  Whole frames are staged in LDS; the normalised

@@ -106,6 +106,59 @@ def test_pwconv_fused(lib, G, Mg, K, N, pro, epi, bt):
             assert rel_err(ps[:, 1], (r3 * xh).sum(axis=1)) < 1e-5
 
 
+@pytest.mark.parametrize('G,Mg,K,N,relu,shuffle,xpro', [(4, 330, 58, 58, 1, 1, 0), (4, 96, 116, 116, 1, 1, 1), (2, 500, 24, 58, 1, 0, 0),
+                                                        (4, 257, 58, 24, 0, 0, 1), (4, 1500, 116, 116, 1, 1, 1), (1, 64, 58, 116, 0, 0, 0)])
+def test_pwconv_bn_bwd(lib, G, Mg, K, N, relu, shuffle, xpro):
+    """Backward of conv1x1 -> BN(train, per time slice) (+ReLU6) (+shuffled store) with the BN-backward apply fused
+    into the operand loads of the backward-data and filter-gradient GEMMs: against torch autograd."""
+    rng = np.random.default_rng(G * Mg + K + N)
+    M = G * Mg
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    xst = np.stack([np.zeros((G, K)), np.ones((G, K)), rng.uniform(0.5, 1.5, (G, K)), rng.uniform(-0.5, 0.5, (G, K))]).astype(np.float32)
+    p = {'b.gamma': torch.tensor(rng.uniform(0.5, 1.5, N), dtype=torch.float64).requires_grad_(True),
+         'b.beta': torch.tensor(rng.uniform(1.0, 3.0, N), dtype=torch.float64).requires_grad_(True),
+         'b.moving_mean': torch.zeros(N, dtype=torch.float64), 'b.moving_var': torch.ones(N, dtype=torch.float64)}
+    xt = torch.tensor(x, dtype=torch.float64).reshape(G, Mg, K).requires_grad_(True)
+    wt = torch.tensor(w, dtype=torch.float64).requires_grad_(True)
+    bt = torch.tensor(bias, dtype=torch.float64).requires_grad_(True)
+    xin = xt * torch.tensor(xst[2], dtype=torch.float64)[:, None, :] + torch.tensor(xst[3], dtype=torch.float64)[:, None, :] if xpro else xt
+    yt = xin @ wt + bt                                                   # (G, Mg, N)
+    out = OM.bn_slices(yt.permute(0, 2, 1)[:, None], p, 'b', True, True)   # (G,1,N,Mg)
+    if relu:
+        out = OM.relu6(out)
+    ctot = 2 * N if shuffle else N
+    coff = N if shuffle else 0
+    dout = rng.standard_normal((M, ctot)).astype(np.float32)
+    idx = [((coff + c) & 1) * (ctot // 2) + ((coff + c) >> 1) for c in range(N)] if shuffle else list(range(N))
+    out.backward(torch.tensor(dout[:, idx], dtype=torch.float64).reshape(G, Mg, N).permute(0, 2, 1)[:, None])
+    # GPU: forward statistics through the fused forward GEMM + finalize (cdrl_bn_train_fwd on y)
+    X, Wd, Bd, XS, DO = dev(x), dev(w), dev(bias), dev(xst), dev(dout)
+    y = dev(yt.detach().reshape(M, N).float().numpy())
+    stats = torch.zeros(4 * G * N, device=DEV)
+    tmp = torch.zeros((M, N), device=DEV)
+    ws0 = torch.zeros(G * 256 * 2 * N, dtype=torch.float64, device=DEV)
+    gam, bet = dev(p['b.gamma'].detach().float()), dev(p['b.beta'].detach().float())
+    mm, mv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    _lib.check(lib.cdrl_bn_train_fwd(P(y), G, Mg, N, P(gam), P(bet), P(mm), P(mv), 1, relu, P(tmp), N, 0, 0, P(stats), P(ws0), S()))
+    ws = torch.zeros(int(lib.cdrl_pwconv_bn_bwd_workspace_bytes(G, Mg, N, K)), dtype=torch.uint8, device=DEV)
+    dg, dbt, coef = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV), torch.zeros(3 * G * N, device=DEV)
+    dx = torch.full((M, K + 4), 2.0, device=DEV)
+    dw, db = torch.zeros((K, N), device=DEV), torch.zeros(N, device=DEV)
+    _lib.check(lib.cdrl_pwconv_bn_bwd(P(DO), ctot, coff, ctot if shuffle else 0, relu, P(y), P(stats), P(X), K, 0, P(XS) if xpro else None,
+                                      P(Wd), G, Mg, N, K, P(dg), P(dbt), P(coef), P(dx), K + 4, 2, 1, P(dw), P(db), P(ws), S()))
+    assert rel_err(dg.cpu().numpy(), p['b.gamma'].grad.numpy()) < 2e-5
+    assert rel_err(dbt.cpu().numpy(), p['b.beta'].grad.numpy()) < 2e-5
+    # dx is the gradient w.r.t. the conv INPUT after the optional affine: d(xin) = d(x) / scale
+    got = dx.cpu().numpy()
+    ref_dxin = (xt.grad.reshape(M, K).numpy() / xst[2].astype(np.float64).repeat(Mg, axis=0)) if xpro else xt.grad.reshape(M, K).numpy()
+    assert rel_err(got[:, 2:2 + K] - 2.0, ref_dxin) < 3e-5
+    assert np.all(got[:, :2] == 2.0) and np.all(got[:, 2 + K:] == 2.0)
+    assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < 3e-5
+    assert np.abs(db.cpu().numpy()).max() < 1e-4 * np.abs(dw.cpu().numpy()).max()
+
+
 @pytest.mark.parametrize('B,T,H,W', [(2, 4, 41, 58), (3, 2, 90, 120)])
 def test_stem(lib, B, T, H, W):
     rng = np.random.default_rng(1)
