@@ -31,17 +31,21 @@
 namespace cdrl {
 
 static constexpr size_t DWF_LDS_BUDGET = 76 * 1024;      // 2 workgroups per CU (160 KB LDS)
-#define DWF_T_FWD 1024                                   // threads per workgroup, forward / backward
+#define DWF_T_FWD 512                                    // threads per workgroup, forward / backward
 #define DWF_T_BWD 512
 #define DWF_T_FWD_DEFAULT 512                            // (tunable: CDRL_DWF_TF / CDRL_DWF_TB, <= the maxima above)
 #define DWF_T_BWD_DEFAULT 256
+#define DWF_UF 8                                         // forward: loads in flight per thread (one tensor)
 #define DWF_U 4                                          // global loads in flight per thread in the tile loads
 
 DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     DwfGeom g;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     g.vec = (C % 4 == 0) ? 4 : ((C % 2 == 0) ? 2 : 1);
-    const size_t per_c = (size_t)(H * W + Ho * Wo) * sizeof(float);
+    // tiles are zero-padded by one pixel per side: input always, output-gradient tile for stride 1
+    const size_t a_px = (size_t)(H + 2) * (W + 2);
+    const size_t d_px = stride == 1 ? (size_t)(Ho + 2) * (Wo + 2) : (size_t)Ho * Wo;
+    const size_t per_c = (a_px + d_px) * sizeof(float);
     int maxc = (int)(DWF_LDS_BUDGET / per_c) / g.vec * g.vec;
     if (maxc < g.vec) maxc = g.vec;
     if (maxc > 256) maxc = 256;
@@ -78,8 +82,8 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     if (g.cy_bwd < 1) g.cy_bwd = 1;
     const size_t red_f = (size_t)2 * g.cy * g.vec * g.cx * sizeof(double);
     const size_t red_b = (size_t)10 * g.cy_bwd * g.vec_bwd * g.cx_bwd * sizeof(double);
-    g.lds_fwd = (size_t)H * W * g.cchunk * sizeof(float);
-    g.lds_bwd = (size_t)(H * W + Ho * Wo) * g.cchunk * sizeof(float);
+    g.lds_fwd = a_px * g.cchunk * sizeof(float);
+    g.lds_bwd = (a_px + d_px) * g.cchunk * sizeof(float);
     if (g.lds_fwd < red_f) g.lds_fwd = red_f;
     if (g.lds_bwd < red_b) g.lds_bwd = red_b;
     return g;
@@ -159,27 +163,37 @@ __global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.0;
     const int P = H * W, Po = Ho * Wo;
+    // The tile is zero-padded by one pixel on every side ([H+2][W+2][cc]): the 9 taps of every output pixel are then
+    // plain LDS reads at constant offsets from one base address -- no per-tap bounds tests, no integer divisions
+    // (the kernel was VALU-bound on exactly that index arithmetic: a wave64 instruction costs 4 issue cycles).
+    const int Wp = W + 2, Hp = H + 2;
+    {
+        const int nthr = CX * CY, tid = ty * CX + tx;
+        for (int i = tid; i < Hp * Wp * cchunk; i += nthr) tile[i] = 0.0f;      // border stays zero for every frame
+    }
+    const float invW = 1.0f / (float)W, invWo = 1.0f / (float)Wo;
     for (int f = 0; f < fpb; ++f) {
         const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f;
-        if (f) __syncthreads();
+        __syncthreads();
         if (on) {
             const float* xp = x + n * P * C + c;
-            for (int p0 = ty; p0 < P; p0 += CY * DWF_U) {        // DWF_U independent loads in flight per thread
-                VecF<VEC> v[DWF_U];
+            for (int p0 = ty; p0 < P; p0 += CY * DWF_UF) {       // DWF_UF independent loads in flight per thread
+                VecF<VEC> v[DWF_UF];
 #pragma unroll
-                for (int u = 0; u < DWF_U; ++u) {
+                for (int u = 0; u < DWF_UF; ++u) {
                     const int p = p0 + u * CY;
                     if (p < P) v[u] = vload<VEC>(xp + (int64_t)p * C);
                 }
 #pragma unroll
-                for (int u = 0; u < DWF_U; ++u) {
+                for (int u = 0; u < DWF_UF; ++u) {
                     const int p = p0 + u * CY;
                     if (p < P) {
                         if (PRE) {
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) v[u].v[i] = fminf(fmaxf(fmaf(sc.v[i], v[u].v[i], sh.v[i]), 0.0f), 6.0f);
                         }
-                        vstore<VEC>(&tile[p * cchunk + tx * VEC], v[u]);
+                        const int iy = (int)(((float)p + 0.5f) * invW), ix = p - iy * W;
+                        vstore<VEC>(&tile[((iy + 1) * Wp + ix + 1) * cchunk + tx * VEC], v[u]);
                     }
                 }
             }
@@ -188,21 +202,17 @@ __global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restr
         if (on) {
             float* yp = y + n * Po * C + c;
             for (int p = ty; p < Po; p += CY) {
-                const int oy = p / Wo, ox = p - oy * Wo;
-                VecF<VEC> acc = bv;
+                const int oy = (int)(((float)p + 0.5f) * invWo), ox = p - oy * Wo;
+                const int o0 = ((oy * S + 1 - pt) * Wp + ox * S + 1 - pl) * cchunk + tx * VEC;    // (index, not pointer:
+                VecF<VEC> acc = bv;                                                               //  keeps ds_read)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int iy = oy * S + ky - pt;
-                    if (iy < 0 || iy >= H) continue;
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int ix = ox * S + kx - pl;
-                        if (ix < 0 || ix >= W) continue;
-                        const VecF<VEC> a = vload<VEC>(&tile[(iy * W + ix) * cchunk + tx * VEC]);
+                        const VecF<VEC> a = vload<VEC>(&tile[o0 + (ky * Wp + kx) * cchunk]);
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(a.v[i], wk[ky * 3 + kx].v[i], acc.v[i]);
                     }
-                }
                 vstore<VEC>(yp + (int64_t)p * C, acc);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -213,6 +223,7 @@ __global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restr
             }
         }
     }
+    __syncthreads();
     double* sm = reinterpret_cast<double*>(tile);
     double sq[2][VEC];
 #pragma unroll
@@ -240,8 +251,17 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
     const bool on = tx * VEC < cc;
     const int c = cbase + tx * VEC;
     const int P = H * W, Po = Ho * Wo;
-    float* tA = tile;
-    float* tD = tile + (size_t)P * cchunk;
+    // zero-padded tiles (see the forward kernel): A = [H+2][W+2][cc] always; D = [Ho+2][Wo+2][cc] for stride 1 (the
+    // transposed conv then needs no bounds tests either), unpadded for stride 2 (parity tests remain there)
+    const int Wp = W + 2, Hp = H + 2;
+    const int Wdp = S == 1 ? Wo + 2 : Wo, Hdp = S == 1 ? Ho + 2 : Ho, dpad = S == 1 ? 1 : 0;
+    const int dbase = Hp * Wp * cchunk;          // tile D starts here (indices into `tile`, not pointers: keeps ds_* ops)
+    {
+        const int nthr = CX * CY, tid = ty * CX + tx;
+        const int tot = (Hp * Wp + Hdp * Wdp) * cchunk;
+        for (int i = tid; i < tot; i += nthr) tile[i] = 0.0f;
+    }
+    const float invW = 1.0f / (float)W, invWo = 1.0f / (float)Wo;
     VecF<VEC> wk[9], sc, sh, mean1, inv1, mean2, inv2, k1, k2, k3;
     if (on) {
 #pragma unroll
@@ -258,40 +278,32 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
         k2 = vload<VEC>(post_coef + 1 * GC + g * C + c);
         k3 = vload<VEC>(post_coef + 2 * GC + g * C + c);
     }
-    double gw[10][VEC], gb1[VEC], gb2[VEC];
+    // filter / bias gradient accumulators: float over the (<= 8) frames of this workgroup (a few hundred fmaf per lane),
+    // double from the block reduction on -- 40 fewer VGPRs than double accumulators, one more wave per SIMD
+    float gf[10][VEC];
+    double gb1[VEC], gb2[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         gb1[i] = gb2[i] = 0.0;
 #pragma unroll
-        for (int k = 0; k < 10; ++k) gw[k][i] = 0.0;
+        for (int k = 0; k < 10; ++k) gf[k][i] = 0.0f;
     }
     for (int f = 0; f < fpb; ++f) {
         const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f;
-        if (f) __syncthreads();
+        __syncthreads();
+        const float* xp = x + n * P * C + c;
         if (on) {
-            // tile A holds the RAW input (y1 when PRE): the BN1 + ReLU6 affine is re-applied on every LDS read (3 VALU
-            // ops) so that xhat1 for the BN1 sums also comes from LDS instead of a second global read
-            const float* xp = x + n * P * C + c;
-            for (int p0 = ty; p0 < P; p0 += CY * DWF_U) {
-                VecF<VEC> v[DWF_U];
-#pragma unroll
-                for (int u = 0; u < DWF_U; ++u) {
-                    const int p = p0 + u * CY;
-                    if (p < P) v[u] = vload<VEC>(xp + (int64_t)p * C);
-                }
-#pragma unroll
-                for (int u = 0; u < DWF_U; ++u) {
-                    const int p = p0 + u * CY;
-                    if (p < P) vstore<VEC>(&tA[p * cchunk + tx * VEC], v[u]);
-                }
-            }
+            // one merged load loop for the three tensors (x, dout, y2): 3*DWF_U independent loads in flight per thread.
+            // Tile A holds the ACTIVATED input relu6(scale1*y1+shift1) (x itself without a pre-BN); tile D the
+            // BatchNorm-backward-applied gradient of the depthwise output.
             const float* dp = dout + n * Po * C + c;
             const float* yp = y2 + n * Po * C + c;
-            for (int p0 = ty; p0 < Po; p0 += CY * DWF_U) {
-                VecF<VEC> d[DWF_U], v[DWF_U];
+            for (int p0 = ty; p0 < P; p0 += CY * DWF_U) {
+                VecF<VEC> xa[DWF_U], d[DWF_U], v[DWF_U];
 #pragma unroll
                 for (int u = 0; u < DWF_U; ++u) {
                     const int p = p0 + u * CY;
+                    if (p < P) xa[u] = vload<VEC>(xp + (int64_t)p * C);
                     if (p < Po) {
                         d[u] = vload<VEC>(dp + (int64_t)p * C);
                         v[u] = vload<VEC>(yp + (int64_t)p * C);
@@ -300,6 +312,14 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
 #pragma unroll
                 for (int u = 0; u < DWF_U; ++u) {
                     const int p = p0 + u * CY;
+                    if (p < P) {
+                        if (PRE) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) xa[u].v[i] = fminf(fmaxf(fmaf(sc.v[i], xa[u].v[i], sh.v[i]), 0.0f), 6.0f);
+                        }
+                        const int iy = (int)(((float)p + 0.5f) * invW), ix = p - iy * W;
+                        vstore<VEC>(&tile[((iy + 1) * Wp + ix + 1) * cchunk + tx * VEC], xa[u]);
+                    }
                     if (p < Po) {
                         VecF<VEC> o;
 #pragma unroll
@@ -307,7 +327,8 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
                             const float xh = (v[u].v[i] - mean2.v[i]) * inv2.v[i];
                             o.v[i] = k1.v[i] * (d[u].v[i] - k2.v[i] - xh * k3.v[i]);
                         }
-                        vstore<VEC>(&tD[p * cchunk + tx * VEC], o);
+                        const int oy = (int)(((float)p + 0.5f) * invWo), ox = p - oy * Wo;
+                        vstore<VEC>(&tile[dbase + ((oy + dpad) * Wdp + ox + dpad) * cchunk + tx * VEC], o);
                     }
                 }
             }
@@ -316,58 +337,63 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
         if (on) {
             // filter / bias gradient: every output pixel contributes D * A(window)
             for (int p = ty; p < Po; p += CY) {
-                const int oy = p / Wo, ox = p - oy * Wo;
-                const VecF<VEC> d = vload<VEC>(&tD[p * cchunk + tx * VEC]);
+                const int oy = (int)(((float)p + 0.5f) * invWo), ox = p - oy * Wo;
+                const VecF<VEC> d = vload<VEC>(&tile[dbase + ((oy + dpad) * Wdp + ox + dpad) * cchunk + tx * VEC]);
+                const int o0 = ((oy * S + 1 - pt) * Wp + ox * S + 1 - pl) * cchunk + tx * VEC;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int iy = oy * S + ky - pt;
-                    if (iy < 0 || iy >= H) continue;
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int ix = ox * S + kx - pl;
-                        if (ix < 0 || ix >= W) continue;
-                        VecF<VEC> a = vload<VEC>(&tA[(iy * W + ix) * cchunk + tx * VEC]);
-                        if (PRE) {
+                        const VecF<VEC> av = vload<VEC>(&tile[o0 + (ky * Wp + kx) * cchunk]);
 #pragma unroll
-                            for (int i = 0; i < VEC; ++i) a.v[i] = fminf(fmaxf(fmaf(sc.v[i], a.v[i], sh.v[i]), 0.0f), 6.0f);
-                        }
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) gw[ky * 3 + kx][i] += (double)(a.v[i] * d.v[i]);
+                        for (int i = 0; i < VEC; ++i) gf[ky * 3 + kx][i] = fmaf(av.v[i], d.v[i], gf[ky * 3 + kx][i]);
                     }
-                }
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) gw[9][i] += (double)d.v[i];
+                for (int i = 0; i < VEC; ++i) gf[9][i] += d.v[i];
             }
             // gradient w.r.t. the depthwise input (transposed conv), masked by ReLU6 of the pre BN
             for (int p = ty; p < P; p += CY) {
-                const int iy = p / W, ix = p - iy * W;
+                const int iy = (int)(((float)p + 0.5f) * invW), ix = p - iy * W;
                 VecF<VEC> acc;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc.v[i] = 0.0f;
+                if (S == 1) {
+                    // D is zero-padded: da[iy][ix] = sum_k D[iy + pt - ky][ix + pl - kx] * w[k], no bounds tests
+                    const int o0 = dbase + ((iy + pt + 1) * Wdp + ix + pl + 1) * cchunk + tx * VEC;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int ny = iy + pt - ky;
-                    if (ny < 0 || (ny % S) != 0) continue;
-                    const int oy = ny / S;
-                    if (oy >= Ho) continue;
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int nx = ix + pl - kx;
-                        if (nx < 0 || (nx % S) != 0) continue;
-                        const int ox = nx / S;
-                        if (ox >= Wo) continue;
-                        const VecF<VEC> d = vload<VEC>(&tD[(oy * Wo + ox) * cchunk + tx * VEC]);
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const VecF<VEC> d = vload<VEC>(&tile[o0 - (ky * Wdp + kx) * cchunk]);
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(d.v[i], wk[ky * 3 + kx].v[i], acc.v[i]);
+                            for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(d.v[i], wk[ky * 3 + kx].v[i], acc.v[i]);
+                        }
+                } else {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int ny = iy + pt - ky;
+                        if (ny < 0 || (ny & 1)) continue;
+                        const int oy = ny >> 1;
+                        if (oy >= Ho) continue;
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int nx = ix + pl - kx;
+                            if (nx < 0 || (nx & 1)) continue;
+                            const int ox = nx >> 1;
+                            if (ox >= Wo) continue;
+                            const VecF<VEC> d = vload<VEC>(&tile[dbase + (oy * Wo + ox) * cchunk + tx * VEC]);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(d.v[i], wk[ky * 3 + kx].v[i], acc.v[i]);
+                        }
                     }
                 }
                 const int64_t row = n * P + p;
                 if (PRE) {
-                    const VecF<VEC> v = vload<VEC>(&tA[p * cchunk + tx * VEC]);
+                    const VecF<VEC> av = vload<VEC>(&tile[((iy + 1) * Wp + ix + 1) * cchunk + tx * VEC]);
+                    const VecF<VEC> v = vload<VEC>(xp + (int64_t)p * C);      // L2-resident re-read of y1 for xhat1
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
-                        const float z = fmaf(sc.v[i], v.v[i], sh.v[i]);
-                        if (!(z > 0.0f && z < 6.0f)) acc.v[i] = 0.0f;
+                        if (!(av.v[i] > 0.0f && av.v[i] < 6.0f)) acc.v[i] = 0.0f;
                         const float xh = (v.v[i] - mean1.v[i]) * inv1.v[i];
                         gb1[i] += (double)acc.v[i];
                         gb2[i] += (double)acc.v[i] * (double)xh;
@@ -377,7 +403,13 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
             }
         }
     }
+    __syncthreads();
     double* sm = reinterpret_cast<double*>(tile);
+    double gw[10][VEC];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gw[k][i] = (double)gf[k][i];
     block_colsum_all<10, VEC>(sm, gw, tx, ty, CX, CY, on, part_w + ((int64_t)g * nb + b) * 10 * C + c, C);
     if (PRE) {
         double gq[2][VEC];

@@ -5,7 +5,7 @@
 // results carry plain fp32 rounding (needed for the 1e-4 parity bar) at the matrix-core rate.
 //
 //   gemm_nn : C[M,N] (+)= A[M,K] * B(k,n) + bias     (forward, backward-data via strided B)
-//   gemm_tn : W[K,N]  = sum_m A[m,K]^T D[m,N]        (backward-filter; split over M, two-stage
+//   gemm_tn : W[K,N]  = sum_m A[m,K]^T D[m,N]        (backward-filter: gemm_tn_direct.hip; split over M, two-stage
 //                                                      deterministic reduction, no atomics)
 //
 // Tiling: 256-thread workgroups = 4 wavefronts.  gemm_nn: 128 x (32*NT) output tile, every
@@ -375,247 +375,7 @@ int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------
-// TN: W[K,N] = A^T D, reduction over M.
-// Block output tile: (32*KT) x (32*NTL) <= 128x128; the KT*NTL 32x32 MFMA tiles are dealt
-// round-robin to the 4 waves (<= 4 tiles = 64 accumulator VGPRs per wave).
-// ------------------------------------------------------------------------------------------
-#define TN_BM 32
-
-struct TnPlan {
-    int kt, ntl;        // 32-wide tiles per block along K and N
-    int gy, gz;         // blocks along K and N
-    int nsplit;         // blocks along M
-    int nspg;           // ... per group
-    int rows_per;       // rows per split (multiple of TN_BM)
-};
-
-// G > 1: the M rows are G equal groups (BatchNorm time slices) and no split straddles a group boundary, so that a
-// per-(group, k) affine prologue on A needs one group index per workgroup.
-static TnPlan tn_plan(int M, int N, int K, int G = 1) {
-    TnPlan p;
-    p.gy = cdiv(K, 128);
-    p.gz = cdiv(N, 128);
-    p.kt = cdiv(cdiv(K, p.gy), 32);
-    p.ntl = cdiv(cdiv(N, p.gz), 32);
-    int target = 1024 / (p.gy * p.gz * G);
-    if (target < 1) target = 1;
-    const int Mg = M / G;
-    int ns = Mg / 256;
-    if (ns > target) ns = target;
-    if (ns < 1) ns = 1;
-    p.rows_per = cdiv(cdiv(Mg, ns), TN_BM) * TN_BM;
-    p.nspg = cdiv(Mg, p.rows_per);
-    p.nsplit = G * p.nspg;
-    return p;
-}
-
-int64_t gemm_tn_part_elems(int M, int N, int K, int G) {
-    TnPlan p = tn_plan(M, N, K, G);
-    return (int64_t)p.nsplit * K * N;
-}
-
-template <int KT, int NTL, bool VEC, bool DPRO>
-__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(View A, View D, float* __restrict__ part, int M, int N, int K,
-                                                         int rows_per, int nspg, int Mg, int G,
-                                                         const float* __restrict__ pro_stats, TnBnBwd db) {
-    constexpr int TK = 32 * KT, TNn = 32 * NTL;
-    constexpr int NTILES = KT * NTL;
-    constexpr int PER_WAVE = (NTILES + 3) / 4;
-    constexpr int NA = (TN_BM * TK) / 256, ND = (TN_BM * TNn) / 256;     // 4*KT, 4*NTL elements per thread
-    __shared__ float As[2][TN_BM][TK];
-    __shared__ float Ds[2][TN_BM][TNn];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int lcol = lane & 31, lk = lane >> 5;
-    const int k0 = blockIdx.y * TK, n0 = blockIdx.z * TNn;
-    const int grp = blockIdx.x / nspg;
-    const int64_t gend = (int64_t)(grp + 1) * Mg;
-    const int64_t mbeg = (int64_t)grp * Mg + (int64_t)(blockIdx.x % nspg) * rows_per;
-    int64_t mend = mbeg + rows_per;
-    if (mend > gend) mend = gend;
-    f32x16 acc[PER_WAVE];
-    // optional prologue: A <- scale[g][k] * A + shift[g][k] (BatchNorm apply of the layer that produced A's raw
-    // values: the normalised tensor is recomputed here instead of being read from HBM); VEC path only
-    float psc[NA], psh[NA];
-    if (VEC && pro_stats) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int kk = (((tid + 256 * (i / 2)) % (TK / 2)) * 2) + (i & 1);
-            const bool okk = (k0 + kk) < K;
-            psc[i] = okk ? pro_stats[2 * G * K + grp * K + k0 + kk] : 0.0f;
-            psh[i] = okk ? pro_stats[3 * G * K + grp * K + k0 + kk] : 0.0f;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-    float ra[NA], rd[ND];
-    // optional prologue on D: D[m,n] <- k1*(dz - k2 - xhat*k3), the BatchNorm-backward apply of the layer whose output
-    // gradient D views (see gemm_pw.hip PRO_BNBWD); VEC path with a fixed column pair per thread (256 % (TNn/2) == 0)
-    constexpr bool dpro = VEC && DPRO;
-    float2 ry[dpro ? ND / 2 : 1];
-    const int nn_t = (tid % (TNn / 2)) * 2;
-    // the 7 per-column coefficients live in LDS (read back at transform time): registers are the scarce resource here
-    __shared__ float qc[DPRO ? 7 : 1][DPRO ? TNn : 1];
-    int dcol0 = 0, dcol1 = 0;
-    if (dpro) {
-        const int GN = G * N;
-        for (int i = tid; i < TNn; i += 256) {
-            const bool okn = (n0 + i) < N;
-            const int o = grp * N + n0 + i;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) qc[q][i] = okn ? db.stats[q * GN + o] : 0.0f;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) qc[4 + q][i] = okn ? db.coef[q * GN + o] : 0.0f;
-        }
-    }
-    if (dpro && (n0 + nn_t) < N) {
-        dcol0 = D.coff + n0 + nn_t;
-        dcol1 = dcol0 + 1;
-        if (db.shuffle_ctot) {
-            dcol0 = shuffle_dst(dcol0, db.shuffle_ctot);
-            dcol1 = shuffle_dst(dcol1, db.shuffle_ctot);
-        }
-    }
-
-    auto load_rows = [&](int64_t m0) {
-        if (VEC) {
-#pragma unroll
-            for (int i = 0; i < NA / 2; ++i) {
-                const int idx = tid + 256 * i;
-                const int r = idx / (TK / 2), kk = (idx % (TK / 2)) * 2;
-                const int64_t m = m0 + r;
-                float2 v = make_float2(0.0f, 0.0f);
-                if (m < mend && (k0 + kk) < K) {
-                    v = *reinterpret_cast<const float2*>(&A.p[m * A.ld + A.coff + k0 + kk]);
-                    if (pro_stats) {
-                        v.x = fmaf(psc[2 * i], v.x, psh[2 * i]);
-                        v.y = fmaf(psc[2 * i + 1], v.y, psh[2 * i + 1]);
-                    }
-                }
-                ra[2 * i] = v.x;
-                ra[2 * i + 1] = v.y;
-            }
-#pragma unroll
-            for (int i = 0; i < ND / 2; ++i) {
-                const int idx = tid + 256 * i;
-                const int r = idx / (TNn / 2), nn = (idx % (TNn / 2)) * 2;
-                const int64_t m = m0 + r;
-                float2 v = make_float2(0.0f, 0.0f);
-                if (dpro) {
-                    ry[i] = make_float2(0.0f, 0.0f);
-                    if (m < mend && (n0 + nn) < N) {
-                        v.x = D.p[m * D.ld + dcol0];
-                        v.y = D.p[m * D.ld + dcol1];
-                        ry[i] = *reinterpret_cast<const float2*>(&db.y[m * N + n0 + nn]);
-                    }
-                } else if (m < mend && (n0 + nn) < N) {
-                    v = *reinterpret_cast<const float2*>(&D.p[m * D.ld + D.coff + n0 + nn]);
-                }
-                rd[2 * i] = v.x;
-                rd[2 * i + 1] = v.y;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int idx = tid + 256 * i;
-                const int r = idx / TK, kk = idx % TK;
-                const int64_t m = m0 + r;
-                ra[i] = (m < mend && (k0 + kk) < K) ? A.p[m * A.ld + A.coff + k0 + kk] : 0.0f;
-            }
-#pragma unroll
-            for (int i = 0; i < ND; ++i) {
-                const int idx = tid + 256 * i;
-                const int r = idx / TNn, nn = idx % TNn;
-                const int64_t m = m0 + r;
-                rd[i] = (m < mend && (n0 + nn) < N) ? D.p[m * D.ld + D.coff + n0 + nn] : 0.0f;
-            }
-        }
-    };
-    auto store_rows = [&](int buf, int64_t m0) {
-        if (VEC) {
-#pragma unroll
-            for (int i = 0; i < NA / 2; ++i) {
-                const int idx = tid + 256 * i;
-                const int r = idx / (TK / 2), kk = (idx % (TK / 2)) * 2;
-                *reinterpret_cast<float2*>(&As[buf][r][kk]) = make_float2(ra[2 * i], ra[2 * i + 1]);
-            }
-#pragma unroll
-            for (int i = 0; i < ND / 2; ++i) {
-                const int idx = tid + 256 * i;
-                const int r = idx / (TNn / 2), nn = (idx % (TNn / 2)) * 2;
-                float2 v = make_float2(rd[2 * i], rd[2 * i + 1]);
-                if (dpro && (m0 + r) < mend && (n0 + nn) < N) {
-                    const float2 yv = ry[i];
-                    if (db.act == ACT_RELU6) {
-                        const float z0 = fmaf(qc[2][nn], yv.x, qc[3][nn]), z1 = fmaf(qc[2][nn + 1], yv.y, qc[3][nn + 1]);
-                        if (!(z0 > 0.0f && z0 < 6.0f)) v.x = 0.0f;
-                        if (!(z1 > 0.0f && z1 < 6.0f)) v.y = 0.0f;
-                    }
-                    const float xh0 = (yv.x - qc[0][nn]) * qc[1][nn], xh1 = (yv.y - qc[0][nn + 1]) * qc[1][nn + 1];
-                    v.x = qc[4][nn] * (v.x - qc[5][nn] - xh0 * qc[6][nn]);
-                    v.y = qc[4][nn + 1] * (v.y - qc[5][nn + 1] - xh1 * qc[6][nn + 1]);
-                }
-                *reinterpret_cast<float2*>(&Ds[buf][r][nn]) = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int idx = tid + 256 * i;
-                As[buf][idx / TK][idx % TK] = ra[i];
-            }
-#pragma unroll
-            for (int i = 0; i < ND; ++i) {
-                const int idx = tid + 256 * i;
-                Ds[buf][idx / TNn][idx % TNn] = rd[i];
-            }
-        }
-    };
-
-    load_rows(mbeg);
-    store_rows(0, mbeg);
-    __syncthreads();
-    int buf = 0;
-    for (int64_t m0 = mbeg; m0 < mend; m0 += TN_BM) {
-        const bool more = (m0 + TN_BM) < mend;
-        if (more) load_rows(m0 + TN_BM);
-#pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) {
-            const int tile = wave + 4 * j;
-            if (tile < NTILES) {
-                const int ki = tile / NTL, nj = tile % NTL;
-#pragma unroll
-                for (int mm = 0; mm < TN_BM; mm += 2) {
-                    const float a = As[buf][mm + lk][ki * 32 + lcol];
-                    const float b = Ds[buf][mm + lk][nj * 32 + lcol];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
-                }
-            }
-        }
-        if (more) store_rows(buf ^ 1, m0 + TN_BM);
-        __syncthreads();
-        buf ^= 1;
-    }
-    float* out = part + (int64_t)blockIdx.x * K * N;
-#pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
-        const int tile = wave + 4 * j;
-        if (tile < NTILES) {
-            const int ki = tile / NTL, nj = tile % NTL;
-            const int n = n0 + nj * 32 + lcol;
-            if (n < N) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = k0 + ki * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (k < K) out[(int64_t)k * N + n] = acc[j][r];
-                }
-            }
-        }
-    }
-}
-
+// (the filter-gradient GEMM lives in gemm_tn_direct.hip; its split-M partials are reduced here)
 // 16 output lanes x 16 split lanes per block: the split partials are summed in parallel with
 // coalesced loads and combined in a fixed order (deterministic).
 __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t n,
@@ -644,69 +404,6 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float* __restrict
         for (int y = 0; y < 64; ++y) s += sm[y][tx];
         out[i] = accumulate ? out[i] + (float)s : (float)s;
     }
-}
-
-template <int KT, bool VEC, bool DPRO>
-static void launch_tn(int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp, int nspg,
-                      int Mg, int G, const float* ps, TnBnBwd db) {
-    switch (ntl) {
-        case 1: hipLaunchKernelGGL((gemm_tn_kernel<KT, 1, VEC, DPRO>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
-        case 2: hipLaunchKernelGGL((gemm_tn_kernel<KT, 2, VEC, DPRO>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
-        case 3: hipLaunchKernelGGL((gemm_tn_kernel<KT, 3, VEC, false>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
-        default: hipLaunchKernelGGL((gemm_tn_kernel<KT, 4, VEC, DPRO>), grid, dim3(256), 0, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
-    }
-}
-
-template <bool VEC, bool DPRO>
-static void launch_tn_k(int kt, int ntl, dim3 grid, hipStream_t st, View A, View D, float* part, int M, int N, int K, int rp,
-                        int nspg, int Mg, int G, const float* ps, TnBnBwd db) {
-    switch (kt) {
-        case 1: launch_tn<1, VEC, DPRO>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
-        case 2: launch_tn<2, VEC, DPRO>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
-        case 3: launch_tn<3, VEC, DPRO>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
-        default: launch_tn<4, VEC, DPRO>(ntl, grid, st, A, D, part, M, N, K, rp, nspg, Mg, G, ps, db); break;
-    }
-}
-
-bool gemm_tn_dpro_supported(int N) {
-    const int gz = cdiv(N, 128), ntl = cdiv(cdiv(N, gz), 32);
-    return ntl != 3 && (N % 2 == 0);
-}
-
-int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G,
-            const float* pro_stats, const TnBnBwd* dpro) {
-    if (G < 1 || M % G != 0) {
-        set_error("gemm_tn: M=%d is not a multiple of G=%d", M, G);
-        return -1;
-    }
-    TnPlan p = tn_plan(M, N, K, G);
-    dim3 grid(p.nsplit, p.gy, p.gz);
-    auto even = [](const View& v) {
-        return (v.ld % 2 == 0) && (v.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 7) == 0);
-    };
-    // float2 path: every row start and every 32-wide tile start is 8-byte aligned
-    const bool vec = even(A) && even(D) && (K % 2 == 0) && (N % 2 == 0);
-    TnBnBwd db{};
-    bool vecd = vec;
-    if (dpro) {
-        db = *dpro;
-        // the D operand is gathered element-wise through db; only A and the raw BN input need the float2 alignment
-        vecd = even(A) && (K % 2 == 0) && (N % 2 == 0) && ((reinterpret_cast<uintptr_t>(db.y) & 7) == 0);
-        if (!vecd || !gemm_tn_dpro_supported(N)) {
-            set_error("gemm_tn: BatchNorm-backward prologue not supported for N=%d / this alignment", N);
-            return -1;
-        }
-    }
-    if (pro_stats && !vecd) {
-        set_error("gemm_tn: the BatchNorm prologue needs even, 8-byte aligned operands");
-        return -1;
-    }
-    if (vecd && dpro) launch_tn_k<true, true>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per, p.nspg, M / G, G, pro_stats, db);
-    else if (vecd) launch_tn_k<true, false>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per, p.nspg, M / G, G, pro_stats, db);
-    else launch_tn_k<false, false>(p.kt, p.ntl, grid, st, A, D, part, M, N, K, p.rows_per, p.nspg, M / G, G, pro_stats, db);
-    CDRL_LAUNCH_CHECK();
-    const int64_t n = (int64_t)K * N;
-    return reduce_partials_f32(part, p.nsplit, n, n, Cout, accumulate, st);
 }
 
 int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride, float* out, int accumulate,

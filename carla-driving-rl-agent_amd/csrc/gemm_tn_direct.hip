@@ -1,0 +1,234 @@
+// Filter-gradient GEMM  W[K,N] = sum_m A[m,K]^T D[m,N]  with MFMA operands loaded STRAIGHT from global memory
+// (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// For the transposed-A product the MFMA operand layout IS the row-major memory layout: the "A" fragment of one
+// 32x32x2 step wants lane (k = lane%32, h = lane/32) to hold A[m0+h][k0+k], the "B" fragment wants D[m0+h][n0+n] --
+// consecutive lanes read consecutive floats of one row (128-byte coalesced segments), two rows per instruction.  So
+// there is no LDS staging, no barrier and no bank conflict: every wave is an independent stream of
+//     (1 + NJ) coalesced loads  ->  NJ MFMAs           per pair of rows,
+// with U row pairs of loads in flight per lane.  The LDS-tiled gemm_tn it replaces was a chain of load -> LDS ->
+// barrier -> MFMA steps (~8 us per 32 rows for 0.4 us of MFMA work) on < 1 workgroup per CU: 78-100 us for the
+// 49152 x 116 x 116 filter gradients that cost ~10 us of HBM time.
+//
+// Work split: grid = (row splits, 128-blocks of K, 128-blocks of N).  Inside a workgroup the 4 waves are spread over
+// the k tiles first, then over the n tiles, and whatever factor is left splits the workgroup's rows (those waves write
+// separate partial slots).  Partials are float [slot][K][N], summed in fixed order by tn_reduce_kernel (deterministic).
+// Optional operand prologues, same formulas as gemm_pw.hip:
+//   A <- scale[g][k]*A + shift[g][k]                    (BatchNorm apply of the layer that produced A's raw values)
+//   D <- k1*(dz - k2 - xhat*k3), dz = D (shuffle-gathered, ReLU6-masked), xhat from the BN's raw input y
+// (both need the row splits aligned to the G BatchNorm groups, which the plan guarantees).
+#include "cdrl_kernels.h"
+
+namespace cdrl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct TnDirectArgs {
+    View A, D;
+    float* part;
+    int M, N, K, G, Mg;
+    int rows_per, nspg;         // rows per workgroup, workgroups per group
+    int WK, NSPL, NJW, RS;      // wave mapping: waves along k, n-splits, n tiles per wave, row splits
+    const float* a_stats;       // [4][G][K] or null
+    TnBnBwd db;                 // y == null: no D prologue
+};
+
+
+template <int NJW, bool APRO, bool DPRO>
+__global__ void __launch_bounds__(256) tn_direct_kernel(TnDirectArgs a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, lh = lane >> 5;
+    const int K = a.K, N = a.N;
+    const int k0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
+    const int KT = min(4, (K - k0 + 31) / 32), NT = min(4, (N - n0 + 31) / 32);
+    const int wk = wave % a.WK, rest = wave / a.WK;
+    const int nsp = rest % a.NSPL, rs = rest / a.NSPL;
+    const int ki = wk, nj0 = nsp * NJW;
+    const int njn = min(NJW, NT - nj0);
+    if (ki >= KT || njn <= 0) return;                         // idle wave (3 k tiles, or fewer n tiles than splits)
+    const int grp = blockIdx.x / a.nspg;
+    const int64_t gend = (int64_t)(grp + 1) * a.Mg;
+    int64_t mbeg = (int64_t)grp * a.Mg + (int64_t)(blockIdx.x % a.nspg) * a.rows_per;
+    int64_t mend = mbeg + a.rows_per;
+    if (mend > gend) mend = gend;
+    {   // this wave's share of the workgroup's rows (even number of rows per share)
+        const int64_t len = mend - mbeg;
+        const int64_t per = ((len + a.RS - 1) / a.RS + 1) / 2 * 2;
+        mbeg += rs * per;
+        if (mbeg + per < mend) mend = mbeg + per;
+    }
+    const int k = k0 + ki * 32 + l32;
+    const bool kon = k < K;
+    float asc = 1.0f, ash = 0.0f;
+    if (APRO && kon) {
+        asc = a.a_stats[2 * a.G * K + grp * K + k];
+        ash = a.a_stats[3 * a.G * K + grp * K + k];
+    }
+    int ncol[NJW], dcol[NJW];
+    bool non[NJW];
+    float qm[NJW], qi[NJW], qsc[NJW], qsh[NJW], qk1[NJW], qk2[NJW], qk3[NJW];
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) {
+        const int n = n0 + (nj0 + j) * 32 + l32;
+        ncol[j] = n;
+        non[j] = j < njn && n < N;
+        dcol[j] = a.D.coff + n;
+        if (DPRO) {
+            if (a.db.shuffle_ctot) dcol[j] = shuffle_dst(dcol[j], a.db.shuffle_ctot);
+            const int GN = a.G * N, o = grp * N + n;
+            qm[j] = non[j] ? a.db.stats[0 * GN + o] : 0.0f;
+            qi[j] = non[j] ? a.db.stats[1 * GN + o] : 0.0f;
+            qsc[j] = non[j] ? a.db.stats[2 * GN + o] : 0.0f;
+            qsh[j] = non[j] ? a.db.stats[3 * GN + o] : 0.0f;
+            qk1[j] = non[j] ? a.db.coef[0 * GN + o] : 0.0f;
+            qk2[j] = non[j] ? a.db.coef[1 * GN + o] : 0.0f;
+            qk3[j] = non[j] ? a.db.coef[2 * GN + o] : 0.0f;
+        }
+    }
+    f32x16 acc[NJW];
+#pragma unroll
+    for (int j = 0; j < NJW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    // one batch of U row pairs in flight per wave; latency is hidden by the other waves of the SIMD (a second
+    // register set for software pipelining was measured slower: it halves the occupancy)
+    constexpr int U = 4;
+    const float* Ap = a.A.p + a.A.coff + k;
+    float av0[U], dv0[U][NJW], yv0[DPRO ? U : 1][DPRO ? NJW : 1];
+    auto load_batch = [&](int64_t m0, float* av, float (*dv)[NJW], float (*yv)[DPRO ? NJW : 1]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + 2 * u + lh;
+            const bool mon = m < mend;
+            av[u] = (mon && kon) ? Ap[m * a.A.ld] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < NJW; ++j) {
+                dv[u][j] = (mon && non[j]) ? a.D.p[m * a.D.ld + dcol[j]] : 0.0f;
+                if (DPRO) yv[u][j] = (mon && non[j]) ? a.db.y[m * N + ncol[j]] : 0.0f;
+            }
+        }
+    };
+    auto mma_batch = [&](int64_t m0, const float* av, const float (*dv)[NJW], const float (*yv)[DPRO ? NJW : 1]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + 2 * u + lh;
+            const bool mon = m < mend;
+            float x = av[u];
+            if (APRO && mon && kon) x = fmaf(asc, x, ash);
+#pragma unroll
+            for (int j = 0; j < NJW; ++j) {
+                float d = dv[u][j];
+                if (DPRO && mon && non[j]) {
+                    const float y = yv[u][j];
+                    if (a.db.act == ACT_RELU6) {
+                        const float z = fmaf(qsc[j], y, qsh[j]);
+                        if (!(z > 0.0f && z < 6.0f)) d = 0.0f;
+                    }
+                    const float xh = (y - qm[j]) * qi[j];
+                    d = qk1[j] * (d - qk2[j] - xh * qk3[j]);
+                }
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, d, acc[j], 0, 0, 0);
+            }
+        }
+    };
+    for (int64_t m0 = mbeg; m0 < mend; m0 += 2 * U) {
+        load_batch(m0, av0, dv0, yv0);
+        mma_batch(m0, av0, dv0, yv0);
+    }
+    // C/D layout: column (n) = lane&31, row (k) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* out = a.part + ((int64_t)blockIdx.x * a.RS + rs) * K * N;
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) {
+        if (!non[j]) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = k0 + ki * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (kk < K) out[(int64_t)kk * N + ncol[j]] = acc[j][r];
+        }
+    }
+}
+
+struct TndPlan {
+    int gy, gz, nspg, nsplit, rows_per;
+    int WK, NSPL, NJW, RS;
+};
+
+static TndPlan tnd_plan(int M, int N, int K, int G) {
+    TndPlan p;
+    p.gy = cdiv(K, 128);
+    p.gz = cdiv(N, 128);
+    const int KT = K >= 128 ? 4 : cdiv(K, 32), NT = N >= 128 ? 4 : cdiv(N, 32);   // tiles of the (first) 128-block
+    p.WK = KT >= 3 ? 4 : KT;
+    const int left = 4 / p.WK;                  // 1, 2 or 4 waves left for n tiles / row splits
+    p.NSPL = left < NT ? left : NT;
+    p.NJW = cdiv(NT, p.NSPL);
+    if (p.NJW == 3) p.NJW = 4;                   // instantiated widths: 1, 2, 4
+    p.RS = left / p.NSPL;
+    const int Mg = M / G;
+    // enough workgroups to fill the chip a few times over, but >= 128 rows each so that the partial buffer stays small
+    int target = 2048 / (p.gy * p.gz * G * p.RS);
+    if (target < 1) target = 1;
+    int ns = Mg / 128;
+    if (ns > target) ns = target;
+    if (ns < 1) ns = 1;
+    p.rows_per = cdiv(cdiv(Mg, ns), 2) * 2;
+    p.nspg = cdiv(Mg, p.rows_per);
+    p.nsplit = G * p.nspg;
+    return p;
+}
+
+int64_t gemm_tn_part_elems(int M, int N, int K, int G) {
+    const TndPlan p = tnd_plan(M, N, K, G);
+    return (int64_t)p.nsplit * p.RS * K * N;
+}
+
+bool gemm_tn_dpro_supported(int) { return true; }
+
+template <int NJW>
+static void launch_tnd(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a) {
+    if (apro && dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, true>), grid, dim3(256), 0, st, a);
+    else if (apro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, false>), grid, dim3(256), 0, st, a);
+    else if (dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((tn_direct_kernel<NJW, false, false>), grid, dim3(256), 0, st, a);
+}
+
+int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G,
+            const float* pro_stats, const TnBnBwd* dpro) {
+    if (G < 1 || M % G != 0) {
+        set_error("gemm_tn: M=%d is not a multiple of G=%d", M, G);
+        return -1;
+    }
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const TndPlan p = tnd_plan(M, N, K, G);
+    TnDirectArgs a;
+    a.A = A;
+    a.D = D;
+    a.part = part;
+    a.M = M;
+    a.N = N;
+    a.K = K;
+    a.G = G;
+    a.Mg = M / G;
+    a.rows_per = p.rows_per;
+    a.nspg = p.nspg;
+    a.WK = p.WK;
+    a.NSPL = p.NSPL;
+    a.NJW = p.NJW;
+    a.RS = p.RS;
+    a.a_stats = pro_stats;
+    a.db = TnBnBwd{};
+    if (dpro) a.db = *dpro;
+    dim3 grid(p.nsplit, p.gy, p.gz);
+    switch (p.NJW) {
+        case 1: launch_tnd<1>(pro_stats != nullptr, dpro != nullptr, grid, st, a); break;
+        case 2: launch_tnd<2>(pro_stats != nullptr, dpro != nullptr, grid, st, a); break;
+        default: launch_tnd<4>(pro_stats != nullptr, dpro != nullptr, grid, st, a); break;
+    }
+    CDRL_LAUNCH_CHECK();
+    const int64_t n = (int64_t)K * N;
+    return reduce_partials_f32(part, p.nsplit * p.RS, n, n, Cout, accumulate, st);
+}
+
+}  // namespace cdrl

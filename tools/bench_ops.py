@@ -139,3 +139,19 @@ def bench_pw():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'pw':
     bench_pw()
+
+
+def bench_tn():
+    print(f'{"TN shape":<30}{"us":>9}{"ideal us":>10}')
+    for px, K, N in [(660, 24, 58), (165, 58, 92), (165, 24, 24), (165, 58, 58), (48, 116, 116), (12, 232, 232), (12, 464, 768)]:
+        M = FRAMES * px
+        a = torch.randn(M, K, device=DEV)
+        d = torch.randn(M, N, device=DEV)
+        dw = torch.empty(K, N, device=DEV)
+        ws = torch.empty(int(lib.cdrl_gemm_tn_workspace_elems(M, N, K)), device=DEV)
+        t = timeit(lambda: lib.cdrl_gemm_tn(P(a), K, 0, P(d), N, 0, P(dw), M, N, K, P(ws), 0, S()))
+        print(f'M={M:<8} K={K:<4} N={N:<4} {t:9.1f}{4.0 * M * (K + N) / 5e6:10.1f}')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'tn':
+    bench_tn()

@@ -10,4 +10,4 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   python3 tools/rocpd_pmc.py $out/step_${ctr}_results.db cdrl > $out/step_$ctr.txt 2>&1
   rm -f $out/*_results.db
 done
-tail -3 $out/cal_FETCH_SIZE.txt $out/cal_WRITE_SIZE.txt; tail -2 $out/step_FETCH_SIZE.txt $out/step_WRITE_SIZE.txt; tail -2 $out/cal_FETCH_SIZE.log
+for f in cal_FETCH_SIZE cal_WRITE_SIZE step_FETCH_SIZE step_WRITE_SIZE; do echo == $f; tail -n 3 $out/$f.txt; done
