@@ -182,7 +182,8 @@ private:
                         float* x, int H, int W, int C, int stride, float* y2, View out, View dout, View din,
                         int pre_stats_nb = 0, bool post_apply = true, int post_bwd_nb = 0, float* stats1_ext = nullptr,
                         float* coef1_ext = nullptr, bool pre_defer_apply = false);
-    bool fused_dw_ = true, fused_pw_ = true, fused_bb_ = true;
+    bool fused_dw_ = true, fused_pw_ = true, fused_pw_wide_ = false;
+    int fused_bb_ = 1;
     void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
                    View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);
     void add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,

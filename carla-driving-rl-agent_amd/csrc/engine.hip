@@ -586,8 +586,11 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         fused_dw_ = !(e && atoi(e) == 0);
         const char* e2 = getenv("CDRL_FUSED_PW");       // 0 -> generic tiled GEMM + separate BN passes around the 1x1 convs
         fused_pw_ = !(e2 && atoi(e2) == 0);
-        const char* e3 = getenv("CDRL_FUSED_BB");       // 0 -> BN-backward apply as a separate pass (materialised dy)
-        fused_bb_ = !(e3 && atoi(e3) == 0);
+        fused_pw_wide_ = e2 && atoi(e2) == 2;
+        // BN-backward apply as GEMM operand prologue: bit 0 -> for the unit's first 1x1 conv (bn1), bit 1 -> for the second
+        // (bn3, gathered through the shuffle map); 0 -> separate apply passes with a materialised dy
+        const char* e3 = getenv("CDRL_FUSED_BB");
+        fused_bb_ = e3 ? atoi(e3) : 1;      // measured: 1 -> 25.5, 0 -> 25.8, 3 -> 26.0, 2 -> 26.2 ms/update-step
     }
 
     // ---- stem (core/architectures.py:159-161)
@@ -668,13 +671,16 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 Tens y2 = tens(rows_out, mid, false), a2 = tens(rows_out, mid);
                 Tens y3 = tens(rows_out, main_out, false);
                 // BatchNorm work folded into the 1x1-conv GEMMs (K, N <= 128: stages 0 and 1)
-                const bool fpw = fused_dw_ && fused_pw_ && pw_nn_supported(X.v(main_off), mid, main_in) &&
+                // (the K, N = 232 variants of stage 2 run at one workgroup per CU -- 116 W-fragment VGPRs per wave -- and were
+                //  measured 0.15 ms/update-step slower than the tiled GEMM + separate BN passes: opt-in via CDRL_FUSED_PW=2)
+                const bool fpw = fused_dw_ && fused_pw_ && (fused_pw_wide_ || (mid <= 128 && main_in <= 128 && main_out <= 128)) &&
+                                 pw_nn_supported(X.v(main_off), mid, main_in) &&
                                  pw_nn_supported(y2.v(), main_out, mid) && pw_nn_supported(y3.v(), mid, main_out) &&
                                  pw_nn_supported(y1.v(), main_in, mid);
                 if (fpw) {
                     // BN-backward apply as GEMM operand prologue (needs the filter-gradient GEMM's fixed column mapping)
-                    const bool bb1 = fused_bb_ && gemm_tn_dpro_supported(mid);
-                    const bool bb3 = fused_bb_ && gemm_tn_dpro_supported(main_out);
+                    const bool bb1 = (fused_bb_ & 1) && gemm_tn_dpro_supported(mid);
+                    const bool bb3 = (fused_bb_ & 2) && gemm_tn_dpro_supported(main_out);
                     float* stats1 = alloc((size_t)4 * T * mid);
                     float* coef1 = alloc((size_t)3 * T * mid);
                     PwFuse f1;

@@ -48,7 +48,7 @@ struct PwArgs {
 
 // register budget: W fragments (NTW*KSM) + accumulators + one prefetched A tile; the K > 64 and 3-column-tile variants
 // need more than 256 VGPRs -> one workgroup per CU (AGPRs used as well), the others run two per CU
-constexpr int pw_occ(int ksm, int nt) { return ((ksm == 32 && nt == 3) || (ksm == 64 && nt <= 2)) ? 1 : 2; }
+constexpr int pw_occ(int ksm, int nt) { return ((ksm == 32 && nt == 3) || (ksm == 64 && nt <= 2) || ksm == 128) ? 1 : 2; }
 // wave grid: one 32-column tile per wave whenever the 4 waves can be spread over the column tiles (NT = 1, 2, 4):
 // the W fragments then cost only KSM VGPRs per wave and 2+ workgroups fit a CU even at K = 128
 constexpr int pw_wc(int nt) { return nt == 3 ? 1 : nt; }
@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
     const int wr = wave % WR, wc = wave / WR;
     const int lrow = lane & 31, lk = lane >> 5;
     const int g = blockIdx.x / a.nbpg, b = blockIdx.x % a.nbpg;
+    const int nb0 = blockIdx.y * 128;               // column block (N > 128: stage-2 convs, 232 = 128 + 104)
     const int K = a.K, N = a.N, K2 = K >> 1;
     const int64_t mbeg = (int64_t)g * a.Mg, mend = mbeg + a.Mg;
     const int tiles_g = (a.Mg + BM - 1) / BM;
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
     float breg[NTW][KSM];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-        const int n = (wc + j * WC) * 32 + lrow;
+        const int n = nb0 + (wc + j * WC) * 32 + lrow;
 #pragma unroll
         for (int s = 0; s < KSM; ++s) {
             const int k = 2 * s + lk;
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
     float bv[NTW], emean[NTW], einv[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-        const int n = (wc + j * WC) * 32 + lrow;
+        const int n = nb0 + (wc + j * WC) * 32 + lrow;
         bv[j] = (a.bias && n < N) ? a.bias[n] : 0.0f;
         emean[j] = einv[j] = 0.0f;
         if (EPI == 2 && n < N) {
@@ -103,6 +104,9 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
     // PRO_BNBWD: the 7 per-column coefficients stay in LDS (registers are the scarce resource of this kernel)
     float* qc = smem + BM * LDA;                    // [7][2*KSM]: mean, invstd, scale, shift, k1, k2, k3
     int dcol0 = 0, dcol1 = 0;
+    // ... except in the epilogue-free variant, which has the VGPRs to spare: 14 LDS reads less per element pair
+    constexpr bool QREG = PRO == 2 && EPI == 0 && (NT == 2 || NT == 4);
+    float qr[QREG ? 7 : 1][2];
     if (PRO == 1 && kon) {
         const int k = 2 * kk_t, GK = a.G * K, o = g * K + k;
         psc0 = a.pro_stats[2 * GK + o];
@@ -118,6 +122,18 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
             for (int q = 0; q < 4; ++q) qc[q * 2 * KSM + i] = okk ? a.pro_stats[q * GK + g * K + i] : 0.0f;
 #pragma unroll
             for (int q = 0; q < 3; ++q) qc[(4 + q) * 2 * KSM + i] = okk ? a.pro_coef[q * GK + g * K + i] : 0.0f;
+        }
+        if (QREG && kon) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                qr[q][0] = a.pro_stats[q * GK + g * K + 2 * kk_t];
+                qr[q][1] = a.pro_stats[q * GK + g * K + 2 * kk_t + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                qr[4 + q][0] = a.pro_coef[q * GK + g * K + 2 * kk_t];
+                qr[4 + q][1] = a.pro_coef[q * GK + g * K + 2 * kk_t + 1];
+            }
         }
         if (kon) {
             dcol0 = a.A.coff + 2 * kk_t;
@@ -176,6 +192,20 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
             } else if (PRO == 2) {
                 if (m0 + r < mend && kon) {
                     const float2 yv = ry[i];
+                    if (QREG) {
+                        if (a.a_act == ACT_RELU6) {
+                            const float z0 = fmaf(qr[2][0], yv.x, qr[3][0]), z1 = fmaf(qr[2][1], yv.y, qr[3][1]);
+                            if (!(z0 > 0.0f && z0 < 6.0f)) v.x = 0.0f;
+                            if (!(z1 > 0.0f && z1 < 6.0f)) v.y = 0.0f;
+                        }
+                        const float xh0 = (yv.x - qr[0][0]) * qr[1][0], xh1 = (yv.y - qr[0][1]) * qr[1][1];
+                        v.x = qr[4][0] * (v.x - qr[5][0] - xh0 * qr[6][0]);
+                        v.y = qr[4][1] * (v.y - qr[5][1] - xh1 * qr[6][1]);
+                        cs0 += (double)v.x;
+                        cs1 += (double)v.y;
+                        *reinterpret_cast<float2*>(&As[r * LDA + 2 * kk_t]) = v;
+                        continue;
+                    }
                     const float* q0 = qc + 2 * kk_t;
                     if (a.a_act == ACT_RELU6) {
                         const float z0 = fmaf(q0[2 * 2 * KSM], yv.x, q0[3 * 2 * KSM]);
@@ -212,7 +242,7 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
         const int64_t m0 = mbeg + (int64_t)t * BM + wr * 32;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-            const int n = (wc + j * WC) * 32 + lrow;
+            const int n = nb0 + (wc + j * WC) * 32 + lrow;
             if (n >= N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -243,7 +273,7 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
         compute_tile(t);
         __syncthreads();             // all fragment reads of As done before the next store_tile
     }
-    if (PRO == 2 && a.part2) {
+    if (PRO == 2 && a.part2 && blockIdx.y == 0) {
         // column sums of the transformed A: threads tid = kk + KSM*j share a column pair
         double* red2 = reinterpret_cast<double*>(smem);     // [256/KSM][2*KSM]
         red2[(tid / KSM) * 2 * KSM + 2 * kk_t] = cs0;
@@ -273,11 +303,11 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
         __syncthreads();
         for (int i = tid; i < 2 * NP; i += 256) {
             const int q = i / NP, nl = i % NP;
-            if (nl < N) {
+            if (nb0 + nl < N) {
                 double s = 0.0;
 #pragma unroll
                 for (int w = 0; w < WR; ++w) s += red[(w * 2 + q) * NP + nl];
-                a.part[(((int64_t)g * a.nbpg + b) * 2 + q) * N + nl] = s;
+                a.part[(((int64_t)g * a.nbpg + b) * 2 + q) * N + nb0 + nl] = s;
             }
         }
     }
@@ -286,24 +316,25 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int pw_ksm(int K) { return K <= 32 ? 16 : (K <= 64 ? 32 : 64); }
+static int pw_ksm(int K) { return K <= 32 ? 16 : (K <= 64 ? 32 : (K <= 128 ? 64 : 128)); }
 
 bool pw_nn_supported(View A, int N, int K) {
-    if (K > 128 || N > 128 || (K & 1) || N < 1) return false;
-    const int nt = cdiv(N, 32), ksm = pw_ksm(K);
+    if (K > 256 || N > 256 || (K & 1) || N < 1) return false;
+    const int nt = N > 128 ? 4 : cdiv(N, 32), ksm = pw_ksm(K);
     if (nt == 3 && ksm > 32) return false;
+    if (ksm == 128 && nt != 4) return false;        // K > 128 is instantiated for 4 column tiles per block only
     return (A.ld % 2 == 0) && (A.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(A.p) & 7) == 0);
 }
 
 PwPlan pw_nn_plan(int G, int Mg, int N, int K) {
     PwPlan p;
-    const int nt = N <= 128 ? cdiv(N, 32) : 4, ksm = pw_ksm(K);     // (N > 128 is not supported: plan stays well-defined)
+    const int nt = N <= 128 ? cdiv(N, 32) : 4, ksm = pw_ksm(K);     // N > 128: column blocks of 128 (grid.y)
     p.bm = 32 * (4 / pw_wc(nt));
     const int tiles_g = cdiv(Mg, p.bm);
     // grid = exactly the number of workgroups that are resident at once (256 CUs x occupancy of the variant), so every
     // CU gets the same share; the tiles of a group are split evenly over its workgroups
     const int occ = pw_occ(ksm, nt) == 1 ? 1 : ((ksm <= 32 && nt != 1) ? 3 : 2);
-    int target = 256 * occ / G;
+    int target = 256 * occ / (G * cdiv(N, 128));
     if (target < 1) target = 1;
     p.nbpg = tiles_g < target ? tiles_g : target;
     p.tpb = cdiv(tiles_g, p.nbpg);
@@ -320,7 +351,7 @@ static int launch_pw(const PwArgs& a, hipStream_t st) {
     if (lds < (size_t)512 * sizeof(double)) lds = (size_t)512 * sizeof(double);      // PRO_BNBWD column-sum scratch
     auto kern = pw_nn_kernel<KSM, NT, PRO, EPI>;
     if (lds > 64 * 1024) CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg, cdiv(a.N, 128)), dim3(256), lds, st, a);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -388,11 +419,12 @@ int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, cons
     a.Mg = Mg;
     a.nbpg = p.nbpg;
     a.tpb = p.tpb;
-    const int nt = cdiv(N, 32), pro = bb ? 2 : (pro_stats ? 1 : 0);
+    const int nt = N > 128 ? 4 : cdiv(N, 32), pro = bb ? 2 : (pro_stats ? 1 : 0);
     switch (pw_ksm(K)) {
         case 16: return launch_pw_nt<16>(nt, pro, epilogue, a, st);
         case 32: return launch_pw_nt<32>(nt, pro, epilogue, a, st);
-        default: return launch_pw_nt<64>(nt, pro, epilogue, a, st);
+        case 64: return launch_pw_nt<64>(nt, pro, epilogue, a, st);
+        default: return launch_pw_pe<128, 4>(pro, epilogue, a, st);
     }
 }
 

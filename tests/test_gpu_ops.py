@@ -68,7 +68,8 @@ def test_gemm_tn(lib, M, K, N):
 @pytest.mark.parametrize('G,Mg,K,N,pro,epi,bt', [(4, 700, 58, 58, 0, 1, 0), (4, 333, 116, 116, 1, 1, 0), (2, 1000, 24, 58, 0, 1, 0),
                                                 (4, 130, 58, 92, 1, 1, 0), (4, 257, 24, 24, 1, 1, 0), (1, 5000, 116, 116, 0, 0, 0),
                                                 (4, 513, 116, 116, 0, 2, 1), (4, 300, 92, 58, 0, 2, 1), (4, 200, 58, 24, 0, 0, 1),
-                                                (4, 20000, 58, 58, 1, 1, 0), (4, 64, 116, 58, 0, 2, 1)])
+                                                (4, 20000, 58, 58, 1, 1, 0), (4, 64, 116, 58, 0, 2, 1), (4, 300, 232, 232, 1, 1, 0),
+                                                (4, 200, 232, 232, 0, 2, 1), (2, 150, 116, 232, 0, 1, 0)])
 def test_pwconv_fused(lib, G, Mg, K, N, pro, epi, bt):
     """Persistent skinny GEMM with BN-apply prologue and statistics / BN-backward-sum epilogues."""
     rng = np.random.default_rng(G * Mg + K + N)
@@ -107,7 +108,8 @@ def test_pwconv_fused(lib, G, Mg, K, N, pro, epi, bt):
 
 
 @pytest.mark.parametrize('G,Mg,K,N,relu,shuffle,xpro', [(4, 330, 58, 58, 1, 1, 0), (4, 96, 116, 116, 1, 1, 1), (2, 500, 24, 58, 1, 0, 0),
-                                                        (4, 257, 58, 24, 0, 0, 1), (4, 1500, 116, 116, 1, 1, 1), (1, 64, 58, 116, 0, 0, 0)])
+                                                        (4, 257, 58, 24, 0, 0, 1), (4, 1500, 116, 116, 1, 1, 1), (1, 64, 58, 116, 0, 0, 0),
+                                                        (4, 120, 232, 232, 1, 1, 1)])
 def test_pwconv_bn_bwd(lib, G, Mg, K, N, relu, shuffle, xpro):
     """Backward of conv1x1 -> BN(train, per time slice) (+ReLU6) (+shuffled store) with the BN-backward apply fused
     into the operand loads of the backward-data and filter-gradient GEMMs: against torch autograd."""

@@ -120,7 +120,7 @@ if __name__ == '__main__':
 def bench_pw():
     """fused persistent pointwise GEMM vs the generic tiled gemm_nn at the tower's K, N <= 128 shapes"""
     print(f'{"shape":<28}{"gemm_nn us":>11}{"pw us":>9}{"pw+stats":>10}{"pw+pro+st":>10}{"ideal us":>9}')
-    for px, K, N in [(660, 24, 58), (165, 58, 92), (165, 24, 24), (165, 58, 58), (48, 116, 116), (165, 92, 58), (660, 58, 24)]:
+    for px, K, N in [(660, 24, 58), (165, 58, 92), (165, 24, 24), (165, 58, 58), (48, 116, 116), (165, 92, 58), (660, 58, 24), (12, 232, 232), (12, 116, 232)]:
         G, Mg = 4, 256 * px
         M = G * Mg
         a = torch.randn(M, K, device=DEV)
