@@ -276,6 +276,48 @@ int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const
                                               pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps);
 }
 
+// BN-backward sums of a BatchNorm+ReLU6 whose output feeds a 3x3/s2 max-pool, in SCATTER form: iterate over the POOLED
+// gradient (4x fewer elements than the pre-pool tensor) -- every pooled element contributes dp to exactly one pre-pool
+// location (its saved argmax), so  sum_a dz[a] = sum_o dp[o]*mask(a(o))  and  sum_a dz[a]*xhat[a] = sum_o dp[o]*mask*xhat(y[a(o)]).
+// Traffic: dp + argmax + one gathered y per pooled element, instead of y + up to 4 window probes per pre-pool element
+// (the gather form took 506 us on the 255 MB stem tensor for ~70 us of HBM time).
+template <int VEC>
+struct PoolBnReduceF {
+    PoolSrc ps;
+    const float* y;         // pre-pool BN input [N][H][W][C]
+    const float* stats;
+    int GC, C;
+    __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
+        const int ox = (int)(row % ps.Wo);
+        const int64_t q = row / ps.Wo;
+        const int oy = (int)(q % ps.Ho);
+        const int64_t n = q / ps.Ho;
+        const VecF<VEC> d = vload<VEC>(ps.dp + row * C + c0);
+        const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
+        const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
+        uint32_t am = 0;
+        if (VEC == 4) am = *reinterpret_cast<const uint32_t*>(ps.argmax + row * C + c0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int k = VEC == 4 ? (int)((am >> (8 * i)) & 0xffu) : (int)ps.argmax[row * C + c0 + i];
+            const int ky = k / 3, kx = k - 3 * ky;
+            const int iy = 2 * oy - ps.pt + ky, ix = 2 * ox - ps.pl + kx;
+            const float v = y[((n * ps.H + iy) * ps.W + ix) * C + c0 + i];
+            const float z = fmaf(sc.v[i], v, sh.v[i]);
+            if (z > 0.0f && z < 6.0f) {
+                const float xh = (v - mean.v[i]) * invstd.v[i];
+                acc[0][i] += (double)d.v[i];
+                acc[1][i] += (double)d.v[i] * (double)xh;
+            }
+        }
+    }
+};
+
+int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_group, int C, const float* stats, double* part,
+                       hipStream_t st) {
+    return launch_vcolreduce<2, PoolBnReduceF>(G, frames_per_group * ps.Ho * ps.Wo, C, part, st, NB_STATS, ps, y, stats, G * C, C);
+}
+
 __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg,
                                                               int C, const float* __restrict__ stats,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -369,18 +411,23 @@ int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const 
                                              dy, pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps);
 }
 
+// Block = (CX outputs, 1024/CX partial lanes).  CX = 16 gives 128-byte row segments; CX = 4 is used when there are few
+// outputs (n/16 workgroups would leave most of the 256 CUs idle while each workgroup walks hundreds of KB alone: the
+// 1392-output / 2048-partial reductions of the first unit took ~300 us that way).
+template <int CX>
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __restrict__ part, int nparts, int n,
                                                               int64_t stride, float* __restrict__ out, int accumulate) {
-    __shared__ double sm[FIN_PY][FIN_CX];
+    constexpr int PY = 1024 / CX;
+    __shared__ double sm[PY][CX];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int i = blockIdx.x * FIN_CX + tx;
+    const int i = blockIdx.x * CX + tx;
     double s = 0.0;
     if (i < n) {
-        for (int p0 = ty; p0 < nparts; p0 += FIN_PY * FIN_U) {      // FIN_U independent loads in flight
+        for (int p0 = ty; p0 < nparts; p0 += PY * FIN_U) {      // FIN_U independent loads in flight
             double v[FIN_U];
 #pragma unroll
             for (int u = 0; u < FIN_U; ++u) {
-                const int p = p0 + u * FIN_PY;
+                const int p = p0 + u * PY;
                 v[u] = p < nparts ? part[(int64_t)p * stride + i] : 0.0;
             }
 #pragma unroll
@@ -389,18 +436,29 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __r
     }
     sm[ty][tx] = s;
     __syncthreads();
+    // fold the PY lane sums: 64 lanes first (one per ty < 64), then lane 0 -- fixed order
+    if (PY > 64) {
+        if (ty < 64) {
+            double a = 0.0;
+            for (int y = ty; y < PY; y += 64) a += sm[y][tx];
+            sm[ty][tx] = a;
+        }
+        __syncthreads();
+    }
     if (i < n && ty == 0) {
         s = 0.0;
 #pragma unroll
-        for (int y = 0; y < FIN_PY; ++y) s += sm[y][tx];
+        for (int y = 0; y < 64; ++y) s += sm[y][tx];
         out[i] = accumulate ? out[i] + (float)s : (float)s;
     }
 }
 
 int reduce_partials(const double* part, int nparts, int n, int64_t stride, float* out, int accumulate,
                     hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, FIN_CX)), dim3(FIN_CX, FIN_PY), 0, st, part, nparts, n, stride,
-                       out, accumulate);
+    if (cdiv(n, 16) >= 128 || nparts <= 64)
+        hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3(cdiv(n, 16)), dim3(16, 64), 0, st, part, nparts, n, stride, out, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(cdiv(n, 4)), dim3(4, 256), 0, st, part, nparts, n, stride, out, accumulate);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

@@ -339,6 +339,27 @@ int cdrl_dwconv_bwd_filter(const float* a, const float* dy, float* dw, float* db
     return dw_bwd_filter(make_view(const_cast<float*>(a), C), dy, dw, db, N, H, W, C, stride, workspace, S(stream));
 }
 
+int64_t cdrl_stem_block_bwd_workspace_doubles(int B, int T, int H, int W, int Cout) {
+    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
+    return (int64_t)T * vcol_geom(B * Hp * Wp, Cout).nb * 2 * Cout + stem_bwd_part_elems(B, T, H, W, Cout);
+}
+
+int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, int B, int T,
+                        int H, int W, int Cout, float* dgamma, float* dbeta, float* coef, float* dw, float* db,
+                        double* workspace, void* stream) {
+    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
+    hipStream_t st = S(stream);
+    const PoolSrc ps = make_pool_src(argmax, dp, Ho, Wo);
+    const int nb = vcol_geom(B * Hp * Wp, Cout).nb;
+    double* part = workspace;
+    double* fpart = workspace + (int64_t)T * nb * 2 * Cout;
+    CDRL_TRY(pool_bn_bwd_reduce(ps, y, T, B, Cout, stats, part, st));
+    CDRL_TRY(bn_bwd_finalize(part, nb, T, B * Ho * Wo, Cout, stats, dgamma, dbeta, coef, st));
+    return stem_bwd_filter_fused(x, ps, y, stats, coef, dw, db, B, T, H, W, Cout, fpart, st);
+}
+
 int cdrl_pwconv_fused_partial_rows(int G, int Mg, int N, int K) { return pw_nn_plan(G, Mg, N, K).nbpg; }
 
 int cdrl_pwconv_fused(const float* a, int lda, int a_coff, const float* pro_stats, const float* w, int sbk, int sbn,

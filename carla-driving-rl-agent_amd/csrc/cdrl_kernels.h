@@ -29,6 +29,10 @@ struct PoolSrc {
 // Backward: reduce (sum dz, sum dz*xhat) -> part [G][nb][2][C]
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
                   double* part, hipStream_t st, const PoolSrc* pool = nullptr);
+// Same sums for a BN+ReLU6 that feeds a 3x3/s2 max-pool, in scatter form over the POOLED gradient (ps.dp, ps.argmax);
+// y: the BN's raw input [G*frames_per_group][ps.H][ps.W][C]; part [G][nb][2][C], nb = vcol_geom(frames*Ho*Wo, C).nb
+int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_group, int C, const float* stats, double* part,
+                       hipStream_t st);
 // dgamma/dbeta (+= over groups; `accumulate` keeps previous content) and coefficients coef[3][G][C]
 int bn_bwd_finalize(const double* part, int nb, int G, int Mg, int C, const float* stats, float* dgamma,
                     float* dbeta, float* coef, hipStream_t st);
@@ -105,6 +109,11 @@ int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride
 int stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
              hipStream_t st);
 int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout);
+// stem filter gradient with the stem BatchNorm's backward apply + max-pool gather fused into the operand load (dy is
+// never materialised); y: raw stem conv output, stats/coef: the stem BN's [4|3][T][Cout] blocks
+bool stem_bwd_fused_supported(int Cout);
+int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, const float* stats, const float* coef, float* dw,
+                          float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st);
 int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,
                     double* part, hipStream_t st);
 // depthwise 3x3, TF 'SAME' (asymmetric) padding, stride 1|2.  N = frames.

@@ -124,9 +124,20 @@ struct StemBwdF {
 typedef float f32x16_c __attribute__((ext_vector_type(16)));
 #define STEM_NBLK 1024
 
+// FUSED: dy is not read but computed on the fly, dy = k1*(dz - k2 - xhat*k3) with dz gathered from the pooled gradient
+// through the max-pool argmax (pool_gather) and masked by ReLU6: the stem BatchNorm's backward "apply" and the 255 MB
+// dy tensor disappear from the critical stream (this kernel runs on the side stream).
+struct StemBnBwd {
+    PoolSrc ps;
+    const float* y;         // raw stem conv output [rows][Cout]
+    const float* stats;     // [4][T][Cout]
+    const float* coef;      // [3][T][Cout]
+};
+
+template <bool FUSED>
 __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ part, int B, int T, int H, int W, int Ho,
-                                                            int Wo, int Cout, int rows, int rows_per) {
+                                                            int Wo, int Cout, int rows, int rows_per, StemBnBwd bb) {
     __shared__ float P[4][32][33];
     __shared__ float D[4][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -167,10 +178,37 @@ __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restr
                 P[wave][r][half * 14 + jj] = val;
             }
         }
-        for (int idx = lane; idx < 32 * Cout; idx += 64) {
-            const int r = idx / Cout, c = idx - r * Cout;
-            const int row = wrow0 + r;
-            D[wave][r][c] = row < r1 ? dy[(int64_t)row * Cout + c] : 0.0f;
+        if (FUSED) {
+            const int C4 = Cout >> 2, GC = T * Cout;
+            for (int idx = lane; idx < 32 * C4; idx += 64) {
+                const int r = idx / C4, c0 = (idx - r * C4) * 4;
+                const int row = wrow0 + r;
+                VecF<4> o;
+                o.v[0] = o.v[1] = o.v[2] = o.v[3] = 0.0f;
+                if (row < r1) {
+                    const int g = (row / (Ho * Wo)) / B;              // frame f = t*B + b -> time slice t
+                    VecF<4> d = pool_gather<4>(bb.ps, row, c0, Cout);
+                    const VecF<4> v = vload<4>(bb.y + (int64_t)row * Cout + c0);
+                    const float* sp = bb.stats + g * Cout + c0;
+                    const float* cp = bb.coef + g * Cout + c0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float z = fmaf(sp[2 * GC + i], v.v[i], sp[3 * GC + i]);
+                        float dz = d.v[i];
+                        if (!(z > 0.0f && z < 6.0f)) dz = 0.0f;
+                        const float xh = (v.v[i] - sp[i]) * sp[GC + i];
+                        o.v[i] = cp[i] * (dz - cp[GC + i] - xh * cp[2 * GC + i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) D[wave][r][c0 + i] = o.v[i];
+            }
+        } else {
+            for (int idx = lane; idx < 32 * Cout; idx += 64) {
+                const int r = idx / Cout, c = idx - r * Cout;
+                const int row = wrow0 + r;
+                D[wave][r][c] = row < r1 ? dy[(int64_t)row * Cout + c] : 0.0f;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -207,8 +245,8 @@ int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B
         float* pf = reinterpret_cast<float*>(part);
         int rows_per = cdiv(cdiv(rows, STEM_NBLK), 128) * 128;
         const int nblk = cdiv(rows, rows_per);
-        hipLaunchKernelGGL(stem_bwd_mfma_kernel, dim3(nblk), dim3(256), 0, st, x, dy, pf, B, T, H, W, Ho, Wo, Cout, rows,
-                           rows_per);
+        hipLaunchKernelGGL(stem_bwd_mfma_kernel<false>, dim3(nblk), dim3(256), 0, st, x, dy, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                           rows_per, StemBnBwd{});
         CDRL_LAUNCH_CHECK();
         CDRL_TRY(reduce_partials_f32(pf, nblk, (int64_t)27 * Cout, (int64_t)28 * Cout, dw, 0, st));
         return reduce_partials_f32(pf + 27 * Cout, nblk, Cout, (int64_t)28 * Cout, db, 0, st);
@@ -219,6 +257,27 @@ int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B
     CDRL_TRY(reduce_partials(part, g.nb, 27 * Cout, (int64_t)28 * Cout, dw, 0, st));
     CDRL_TRY(reduce_partials(part + 27 * Cout, g.nb, Cout, (int64_t)28 * Cout, db, 0, st));
     return 0;
+}
+
+bool stem_bwd_fused_supported(int Cout) { return Cout <= 32 && (Cout % 4) == 0; }
+
+int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, const float* stats, const float* coef, float* dw,
+                          float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st) {
+    if (!stem_bwd_fused_supported(Cout)) {
+        set_error("stem_bwd_filter_fused: Cout=%d not supported", Cout);
+        return -1;
+    }
+    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    const int rows = B * T * Ho * Wo;
+    float* pf = reinterpret_cast<float*>(part);
+    int rows_per = cdiv(cdiv(rows, STEM_NBLK), 128) * 128;
+    const int nblk = cdiv(rows, rows_per);
+    StemBnBwd bb{ps, y, stats, coef};
+    hipLaunchKernelGGL(stem_bwd_mfma_kernel<true>, dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                       rows_per, bb);
+    CDRL_LAUNCH_CHECK();
+    CDRL_TRY(reduce_partials_f32(pf, nblk, (int64_t)27 * Cout, (int64_t)28 * Cout, dw, 0, st));
+    return reduce_partials_f32(pf + 27 * Cout, nblk, Cout, (int64_t)28 * Cout, db, 0, st);
 }
 
 // ------------------------------------------------------------------------------------------

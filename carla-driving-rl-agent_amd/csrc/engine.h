@@ -243,17 +243,19 @@ private:
     // filter reductions, db) are off the critical path dy -> bwd-data -> next layer, so they run on a
     // second HIP stream and overlap the latency-bound main chain.  NSLOT rotating scratch sets
     // (dy, db partials, split-M partials, filter partials) + events make the hand-off race-free.
-    static constexpr int NSLOT = 4;
-    float* dys_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-    double* part2s_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-    float* tns_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-    double* fparts_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NSLOT = 8;
+    float* dys_[NSLOT] = {};
+    double* part2s_[NSLOT] = {};
+    float* tns_[NSLOT] = {};
+    double* fparts_[NSLOT] = {};
     hipStream_t side_ = nullptr;
-    hipEvent_t ev_main_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_side_[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux_ = nullptr;          // feature nets + small GRUs (forward and backward)
+    bool aux_pending_ = false;
+    hipEvent_t ev_main_[NSLOT] = {};
+    hipEvent_t ev_side_[NSLOT] = {};
     hipEvent_t ev_join_ = nullptr;
     bool side_enabled_ = true;
-    bool slot_used_[NSLOT] = {false, false, false, false};
+    bool slot_used_[NSLOT] = {};
     int slot_ = 0;
     int next_slot(hipStream_t st);                       // main: claim a scratch slot (waits for its last side job)
     hipStream_t fork_side(hipStream_t st);               // main -> side dependency for the current slot

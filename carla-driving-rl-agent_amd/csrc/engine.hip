@@ -53,6 +53,7 @@ Learner::~Learner() {
     if (ev_aux_fork_) (void)hipEventDestroy(ev_aux_fork_);
     if (ev_aux_done_) (void)hipEventDestroy(ev_aux_done_);
     if (side_) (void)hipStreamDestroy(side_);
+    if (aux_) (void)hipStreamDestroy(aux_);
 }
 
 void Learner::drop_graphs() {
@@ -128,6 +129,10 @@ int Learner::join_side(hipStream_t st) {
     if (!side_enabled_) return 0;
     CDRL_HIP(hipEventRecord(ev_join_, side_));
     CDRL_HIP(hipStreamWaitEvent(st, ev_join_, 0));
+    if (aux_pending_) {
+        CDRL_HIP(hipStreamWaitEvent(st, ev_aux_done_, 0));
+        aux_pending_ = false;
+    }
     for (int i = 0; i < NSLOT; ++i) slot_used_[i] = false;
     return 0;
 }
@@ -540,9 +545,9 @@ void Learner::add_aux_fork(std::vector<Op>& ops) {
     op.fwd = [=](hipStream_t st, int training) -> int {
         if (!side_enabled_) return run_fwd(aux_ops_, st, training);
         CDRL_HIP(hipEventRecord(ev_aux_fork_, st));           // parameters / inputs produced on the main stream
-        CDRL_HIP(hipStreamWaitEvent(side_, ev_aux_fork_, 0));
-        CDRL_TRY(run_fwd(aux_ops_, side_, training));
-        CDRL_HIP(hipEventRecord(ev_aux_done_, side_));
+        CDRL_HIP(hipStreamWaitEvent(aux_, ev_aux_fork_, 0));
+        CDRL_TRY(run_fwd(aux_ops_, aux_, training));
+        CDRL_HIP(hipEventRecord(ev_aux_done_, aux_));
         return 0;
     };
     op.bwd = [](hipStream_t) -> int { return 0; };
@@ -557,9 +562,14 @@ void Learner::add_aux_join(std::vector<Op>& ops) {
     };
     op.bwd = [=](hipStream_t st) -> int {
         if (!side_enabled_) return run_bwd(aux_ops_, st);
+        // Own stream: ~90 tiny dependent kernels (0.8 ms).  On the filter-gradient side stream they blocked, in stream
+        // order, the slot events the main stream waits on (measured: a 0.84 ms hole in the critical stream per pass).
         CDRL_HIP(hipEventRecord(ev_aux_fork_, st));           // gradient of the concat is ready
-        CDRL_HIP(hipStreamWaitEvent(side_, ev_aux_fork_, 0));
-        return run_bwd(aux_ops_, side_);                      // joined by join_side() at the end of the backward
+        CDRL_HIP(hipStreamWaitEvent(aux_, ev_aux_fork_, 0));
+        CDRL_TRY(run_bwd(aux_ops_, aux_));
+        CDRL_HIP(hipEventRecord(ev_aux_done_, aux_));
+        aux_pending_ = true;                                  // joined by join_side() at the end of the backward
+        return 0;
     };
     ops.push_back(op);
 }
@@ -602,7 +612,21 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         Op op;
         const int H = c.H, W = c.W, Cs = c.stem;
         op.fwd = [=](hipStream_t st, int) -> int { return stem_fwd(in_image_, w.p, b.p, y.p, B, T, H, W, Cs, st); };
+        const bool stem_fused = stem_bwd_fused_supported(Cs) && !(getenv("CDRL_FUSED_STEM") && atoi(getenv("CDRL_FUSED_STEM")) == 0);
+        // blocks of the stem BatchNorm (allocated here: the stem conv's backward consumes them in the fused form)
+        float* stem_stats = alloc((size_t)4 * T * Cs);
+        float* stem_coef = alloc((size_t)3 * T * Cs);
+        const int Hp0 = same_out_h(Hs, 2), Wp0 = same_out_h(Ws, 2);
+        Tens pool = tens(N * Hp0 * Wp0, c.stem);
+        uint8_t* argmax = reinterpret_cast<uint8_t*>(alloc(((size_t)N * Hp0 * Wp0 * c.stem + 3) / 4));
         op.bwd = [=](hipStream_t st) -> int {
+            if (stem_fused) {
+                CDRL_TRY(next_slot(st));
+                hipStream_t side = fork_side(st);
+                PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
+                CDRL_TRY(stem_bwd_filter_fused(in_image_, ps, y.p, stem_stats, stem_coef, w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side));
+                return done_side(side);
+            }
             hipStream_t side = fork_side(st);
             CDRL_TRY(stem_bwd_filter(in_image_, dys_[slot_], w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side));
             return done_side(side);
@@ -611,19 +635,18 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         // stem BN + ReLU6 + max-pool as one fused block: the BN op only produces statistics in the forward
         // (no apply), the pool kernel applies scale/shift/ReLU6 on the raw conv output while pooling, and the
         // BN backward gathers its incoming gradient straight from the pooled gradient through the argmax.
-        const int Hp = same_out_h(Hs, 2), Wp = same_out_h(Ws, 2);
-        Tens pool = tens(N * Hp * Wp, c.stem);
-        uint8_t* argmax = reinterpret_cast<uint8_t*>(alloc(((size_t)N * Hp * Wp * c.stem + 3) / 4));
+        const int Hp = Hp0, Wp = Wp0;
         {
             const int G = T, Mg = B * Hs * Ws, C = c.stem;
             PRef gamma = param(M_TRUNK, "img.stem.bn.gamma", {C}, true);
             PRef beta = param(M_TRUNK, "img.stem.bn.beta", {C}, true);
             PRef mm = param(M_TRUNK, "img.stem.bn.moving_mean", {C}, false);
             PRef mv = param(M_TRUNK, "img.stem.bn.moving_var", {C}, false);
-            float* stats = alloc((size_t)4 * G * C);
-            float* coef = alloc((size_t)3 * G * C);
+            float* stats = stem_stats;
+            float* coef = stem_coef;
             const int nb = vcol_geom(Mg, C).nb;
-            note_scratch((size_t)G * nb * 2 * C, (size_t)G * nb * C, 0, 0);
+            const int nb_pool = vcol_geom(B * Hp * Wp, C).nb;
+            note_scratch((size_t)G * std::max(nb, nb_pool) * 2 * C, (size_t)G * nb * C, 0, 0);
             View yv = y.v();
             Op bn;
             bn.fwd = [=](hipStream_t st, int training) -> int {
@@ -634,6 +657,10 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             bn.bwd = [=](hipStream_t st) -> int {
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
                 View none{nullptr, 0, 0};
+                if (stem_fused) {       // sums in scatter form over the pooled gradient; the apply happens inside the stem filter-gradient GEMM
+                    CDRL_TRY(pool_bn_bwd_reduce(ps, y.p, G, B, C, stats, scr_main_.part, st));
+                    return bn_bwd_finalize(scr_main_.part, nb_pool, G, Mg, C, stats, gamma.g, beta.g, coef, st);
+                }
                 CDRL_TRY(bn_bwd_reduce(none, 0, yv, G, Mg, C, stats, ACT_RELU6, scr_main_.part, st, &ps));
                 CDRL_TRY(bn_bwd_finalize(scr_main_.part, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
                 CDRL_TRY(next_slot(st));
@@ -981,6 +1008,7 @@ int Learner::bind(const Buffers& b) {
             CDRL_HIP(hipEventCreateWithFlags(&ev_side_[i], hipEventDisableTiming));
         }
         CDRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        CDRL_HIP(hipStreamCreateWithPriority(&aux_, hipStreamNonBlocking, prio_lo));
         CDRL_HIP(hipEventCreateWithFlags(&ev_aux_fork_, hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_aux_done_, hipEventDisableTiming));
     }

@@ -376,20 +376,22 @@ int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C
 }
 
 // (the filter-gradient GEMM lives in gemm_tn_direct.hip; its split-M partials are reduced here)
-// 16 output lanes x 16 split lanes per block: the split partials are summed in parallel with
-// coalesced loads and combined in a fixed order (deterministic).
+// (CX output lanes) x (1024/CX split lanes) per block: the split partials are summed in parallel and combined in a
+// fixed order (deterministic).  CX = 4 when there are few outputs (see reduce_partials_kernel in bn.hip).
+template <int CX>
 __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t n,
                                                          int64_t stride, float* __restrict__ out, int accumulate) {
-    __shared__ double sm[64][16];
+    constexpr int PY = 1024 / CX;
+    __shared__ double sm[PY][CX];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * 16 + tx;
+    const int64_t i = (int64_t)blockIdx.x * CX + tx;
     double s = 0.0;
     if (i < n) {
-        for (int p0 = ty; p0 < nsplit; p0 += 64 * 8) {       // 8 independent loads in flight per thread
+        for (int p0 = ty; p0 < nsplit; p0 += PY * 8) {       // 8 independent loads in flight per thread
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int p = p0 + u * 64;
+                const int p = p0 + u * PY;
                 v[u] = p < nsplit ? part[(int64_t)p * stride + i] : 0.0f;
             }
 #pragma unroll
@@ -398,6 +400,14 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float* __restrict
     }
     sm[ty][tx] = s;
     __syncthreads();
+    if (PY > 64) {
+        if (ty < 64) {
+            double a = 0.0;
+            for (int y = ty; y < PY; y += 64) a += sm[y][tx];
+            sm[ty][tx] = a;
+        }
+        __syncthreads();
+    }
     if (i < n && ty == 0) {
         s = 0.0;
 #pragma unroll
@@ -408,8 +418,10 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float* __restrict
 
 int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride, float* out, int accumulate,
                         hipStream_t st) {
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64(n, 16)), dim3(16, 64), 0, st, part, nparts, n, stride, out,
-                       accumulate);
+    if (cdiv64(n, 16) >= 128 || nparts <= 64)
+        hipLaunchKernelGGL(tn_reduce_kernel<16>, dim3((unsigned)cdiv64(n, 16)), dim3(16, 64), 0, st, part, nparts, n, stride, out, accumulate);
+    else
+        hipLaunchKernelGGL(tn_reduce_kernel<4>, dim3((unsigned)cdiv64(n, 4)), dim3(4, 256), 0, st, part, nparts, n, stride, out, accumulate);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

@@ -17,6 +17,8 @@
 //   A <- scale[g][k]*A + shift[g][k]                    (BatchNorm apply of the layer that produced A's raw values)
 //   D <- k1*(dz - k2 - xhat*k3), dz = D (shuffle-gathered, ReLU6-masked), xhat from the BN's raw input y
 // (both need the row splits aligned to the G BatchNorm groups, which the plan guarantees).
+#include <stdlib.h>
+
 #include "cdrl_kernels.h"
 
 namespace cdrl {
@@ -168,7 +170,8 @@ static TndPlan tnd_plan(int M, int N, int K, int G) {
     p.RS = left / p.NSPL;
     const int Mg = M / G;
     // enough workgroups to fill the chip a few times over, but >= 128 rows each so that the partial buffer stays small
-    int target = 2048 / (p.gy * p.gz * G * p.RS);
+    static const int tn_target = getenv("CDRL_TN_TARGET") ? atoi(getenv("CDRL_TN_TARGET")) : 2048;
+    int target = tn_target / (p.gy * p.gz * G * p.RS);
     if (target < 1) target = 1;
     int ns = Mg / 128;
     if (ns > target) ns = target;

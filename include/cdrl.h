@@ -253,6 +253,16 @@ int cdrl_maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_pe
 int cdrl_bn_train_bwd_pooled(const uint8_t* argmax, const float* dp, int H, int W, const float* y, int G, int Mg, int C,
                              const float* stats, float* dgamma, float* dbeta, float* dy, float* coef, double* workspace,
                              void* stream);
+/* Backward of the whole stem block Conv2D(3x3,s2,valid) -> BatchNormalization+ReLU6 -> MaxPooling2D(3,2,'same')
+ * (core/architectures.py:159-161) from the POOLED gradient dp, without materialising any pre-pool gradient: the BN sums
+ * are taken in scatter form over dp (one gathered y per pooled element), the BN-backward apply and the pool gather run
+ * inside the operand load of the filter-gradient GEMM.  x: observations (B,T,H,W,3); y: raw conv output
+ * [(t*B+b)][Ho][Wo][Cout]; stats: the BN's 4*T*Cout block; argmax/dp: [T*B][Hp][Wp][Cout].  Outputs dgamma, dbeta, coef
+ * (3*T*Cout scratch), dw (3,3,3,Cout), db.  workspace: cdrl_stem_block_bwd_workspace_doubles().  Cout % 4 == 0, <= 32. */
+int64_t cdrl_stem_block_bwd_workspace_doubles(int B, int T, int H, int W, int Cout);
+int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, int B, int T,
+                        int H, int W, int Cout, float* dgamma, float* dbeta, float* coef, float* dw, float* db,
+                        double* workspace, void* stream);
 /* CARLAgent.policy_objective / value_objective on linear head outputs (core/carla_agent.py:394-428,
  * 469-486); writes d(loss)/d(lin) and 16 metric floats. */
 int cdrl_beta_ppo_loss(const float* lin, const float* adv, const float* old_logp, const float* speed,

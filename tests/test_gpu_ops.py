@@ -403,6 +403,55 @@ def test_fused_stem_block(lib, B, T, H, W):
     assert rel_err(dy.cpu().numpy(), yt.grad.permute(0, 1, 3, 4, 2).reshape(N * H * W, Cc).numpy()) < 2e-5
 
 
+@pytest.mark.parametrize('B,T,H,W', [(3, 4, 41, 58), (2, 2, 90, 120), (5, 1, 31, 33)])
+def test_stem_block_bwd(lib, B, T, H, W):
+    """Backward of conv3x3/s2 -> BN+ReLU6 -> max-pool from the pooled gradient only (scatter-form BN sums, BN-backward
+    apply + pool gather fused into the filter-gradient GEMM): against torch autograd of the unfused composition."""
+    Cc, N = 24, B * T
+    rng = np.random.default_rng(B * H + W)
+    x = rng.uniform(0.0, 1.0, (B, T, H, W, 3)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, Cc)) * 0.4).astype(np.float32)
+    b = rng.standard_normal(Cc).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, Cc).astype(np.float32)
+    gamma[::5] *= -1.0
+    beta = rng.uniform(0.5, 2.5, Cc).astype(np.float32)
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    Hp, Wp = -(-Ho // 2), -(-Wo // 2)
+    p = {'b.gamma': torch.tensor(gamma, dtype=torch.float64).requires_grad_(True),
+         'b.beta': torch.tensor(beta, dtype=torch.float64).requires_grad_(True),
+         'b.moving_mean': torch.zeros(Cc, dtype=torch.float64), 'b.moving_var': torch.ones(Cc, dtype=torch.float64)}
+    wt = torch.tensor(w, dtype=torch.float64).requires_grad_(True)
+    bt = torch.tensor(b, dtype=torch.float64).requires_grad_(True)
+    xt = torch.tensor(x, dtype=torch.float64).permute(1, 0, 4, 2, 3).reshape(N, 3, H, W)          # frames f = t*B + b
+    yt = F.conv2d(xt, wt.permute(3, 2, 0, 1), bt, stride=2)                                         # (N,Cc,Ho,Wo)
+    a = OM.relu6(OM.bn_slices(yt.reshape(T, B, Cc, Ho, Wo), p, 'b', True, True))
+    ph, pw = OM.same_pad(Ho, 3, 2), OM.same_pad(Wo, 3, 2)
+    ref = F.max_pool2d(F.pad(a.reshape(N, Cc, Ho, Wo), (pw[0], pw[1], ph[0], ph[1]), value=float('-inf')), 3, 2)
+    dp = rng.standard_normal((N, Hp, Wp, Cc)).astype(np.float32)
+    ref.backward(torch.tensor(dp, dtype=torch.float64).permute(0, 3, 1, 2))
+    # GPU forward pieces (stem conv, statistics, fused pool) to get y / stats / argmax, then the fused backward
+    X, Wd, Bd, Gm, Bt, DP = dev(x), dev(w), dev(b), dev(gamma), dev(beta), dev(dp)
+    y = torch.zeros((N, Ho, Wo, Cc), device=DEV)
+    _lib.check(lib.cdrl_stem_fwd(P(X), P(Wd), P(Bd), P(y), B, T, H, W, Cc, S()))
+    MM, MV = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    stats = torch.zeros(4 * T * Cc, device=DEV)
+    ws0 = torch.zeros(T * 256 * 2 * Cc, dtype=torch.float64, device=DEV)
+    scratch = torch.zeros((N * Ho * Wo, Cc), device=DEV)
+    _lib.check(lib.cdrl_bn_train_fwd(P(y), T, B * Ho * Wo, Cc, P(Gm), P(Bt), P(MM), P(MV), 1, 1, P(scratch), Cc, 0, 0, P(stats), P(ws0), S()))
+    pool = torch.zeros((N, Hp, Wp, Cc), device=DEV)
+    am = torch.zeros((N, Hp, Wp, Cc), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cdrl_maxpool_bn_fwd(P(y), P(stats), T, B, P(pool), P(am), N, Ho, Wo, Cc, S()))
+    assert rel_err(pool.cpu().numpy(), ref.detach().permute(0, 2, 3, 1).numpy()) < 1e-5
+    ws = torch.zeros(int(lib.cdrl_stem_block_bwd_workspace_doubles(B, T, H, W, Cc)), dtype=torch.float64, device=DEV)
+    dg, dbt, coef = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(3 * T * Cc, device=DEV)
+    dw, db = torch.zeros((3, 3, 3, Cc), device=DEV), torch.zeros(Cc, device=DEV)
+    _lib.check(lib.cdrl_stem_block_bwd(P(X), P(y), P(stats), P(am), P(DP), B, T, H, W, Cc, P(dg), P(dbt), P(coef), P(dw), P(db), P(ws), S()))
+    assert rel_err(dg.cpu().numpy(), p['b.gamma'].grad.numpy()) < 2e-5
+    assert rel_err(dbt.cpu().numpy(), p['b.beta'].grad.numpy()) < 2e-5
+    assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < 3e-5
+    assert np.abs(db.cpu().numpy()).max() < 1e-4 * np.abs(dw.cpu().numpy()).max()
+
+
 @pytest.mark.parametrize('B,A,faithful', [(256, 2, True), (37, 3, False), (1024, 2, True)])
 def test_policy_loss(lib, B, A, faithful):
     rng = np.random.default_rng(B + A)
