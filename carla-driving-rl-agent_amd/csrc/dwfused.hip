@@ -42,9 +42,9 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     DwfGeom g;
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     g.vec = (C % 4 == 0) ? 4 : ((C % 2 == 0) ? 2 : 1);
-    // tiles are zero-padded by one pixel per side: input always, output-gradient tile for stride 1
+    // tiles are zero-padded by one pixel per side
     const size_t a_px = (size_t)(H + 2) * (W + 2);
-    const size_t d_px = stride == 1 ? (size_t)(Ho + 2) * (Wo + 2) : (size_t)Ho * Wo;
+    const size_t d_px = (size_t)(Ho + 2) * (Wo + 2);
     const size_t per_c = (a_px + d_px) * sizeof(float);
     int maxc = (int)(DWF_LDS_BUDGET / per_c) / g.vec * g.vec;
     if (maxc < g.vec) maxc = g.vec;
@@ -135,6 +135,31 @@ __device__ __forceinline__ void block_colsum_all(double* sm, double (&a)[NQ][VEC
     }
 }
 
+// zero the one-pixel border of a padded [Hp][Wp][cchunk] LDS tile (the interior is overwritten by every frame)
+template <int VEC>
+__device__ __forceinline__ void zero_border(float* t, int Hp, int Wp, int cchunk, int tx, int ty, int CY) {
+    VecF<VEC> z;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) z.v[i] = 0.0f;
+    if (tx * VEC >= cchunk) return;
+    const int nb = 2 * Wp + 2 * (Hp - 2);
+    for (int j = ty; j < nb; j += CY) {
+        int y, x;
+        if (j < Wp) {
+            y = 0;
+            x = j;
+        } else if (j < 2 * Wp) {
+            y = Hp - 1;
+            x = j - Wp;
+        } else {
+            const int k = j - 2 * Wp;
+            y = 1 + (k >> 1);
+            x = (k & 1) ? Wp - 1 : 0;
+        }
+        vstore<VEC>(&t[(y * Wp + x) * cchunk + tx * VEC], z);
+    }
+}
+
 template <int S, int VEC, bool PRE>
 __global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pre_stats,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
@@ -167,10 +192,7 @@ __global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restr
     // plain LDS reads at constant offsets from one base address -- no per-tap bounds tests, no integer divisions
     // (the kernel was VALU-bound on exactly that index arithmetic: a wave64 instruction costs 4 issue cycles).
     const int Wp = W + 2, Hp = H + 2;
-    {
-        const int nthr = CX * CY, tid = ty * CX + tx;
-        for (int i = tid; i < Hp * Wp * cchunk; i += nthr) tile[i] = 0.0f;      // border stays zero for every frame
-    }
+    zero_border<VEC>(tile, Hp, Wp, cchunk, tx, ty, CY);              // the border stays zero for every frame
     const float invW = 1.0f / (float)W, invWo = 1.0f / (float)Wo;
     for (int f = 0; f < fpb; ++f) {
         const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f;
@@ -251,16 +273,13 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
     const bool on = tx * VEC < cc;
     const int c = cbase + tx * VEC;
     const int P = H * W, Po = Ho * Wo;
-    // zero-padded tiles (see the forward kernel): A = [H+2][W+2][cc] always; D = [Ho+2][Wo+2][cc] for stride 1 (the
-    // transposed conv then needs no bounds tests either), unpadded for stride 2 (parity tests remain there)
+    // zero-padded tiles (see the forward kernel): A = [H+2][W+2][cc], D = [Ho+2][Wo+2][cc]: neither the filter-gradient
+    // windows nor the transposed conv need bounds tests
     const int Wp = W + 2, Hp = H + 2;
-    const int Wdp = S == 1 ? Wo + 2 : Wo, Hdp = S == 1 ? Ho + 2 : Ho, dpad = S == 1 ? 1 : 0;
+    const int Wdp = Wo + 2, Hdp = Ho + 2, dpad = 1;
     const int dbase = Hp * Wp * cchunk;          // tile D starts here (indices into `tile`, not pointers: keeps ds_* ops)
-    {
-        const int nthr = CX * CY, tid = ty * CX + tx;
-        const int tot = (Hp * Wp + Hdp * Wdp) * cchunk;
-        for (int i = tid; i < tot; i += nthr) tile[i] = 0.0f;
-    }
+    zero_border<VEC>(tile, Hp, Wp, cchunk, tx, ty, CY);
+    zero_border<VEC>(tile + dbase, Hdp, Wdp, cchunk, tx, ty, CY);
     const float invW = 1.0f / (float)W, invWo = 1.0f / (float)Wo;
     VecF<VEC> wk[9], sc, sh, mean1, inv1, mean2, inv2, k1, k2, k3;
     if (on) {
@@ -369,21 +388,32 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
                             for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(d.v[i], wk[ky * 3 + kx].v[i], acc.v[i]);
                         }
                 } else {
+                    // stride 2: which taps reach an input pixel depends only on the parity of (iy+pt, ix+pl) -- 1, 2 or 4
+                    // of the 9; D is zero-padded, so the out-of-range neighbours read zeros (no bounds tests)
+                    const int ny = iy + pt, nx = ix + pl;
+                    const int o00 = dbase + (((ny >> 1) + 1) * Wdp + (nx >> 1) + 1) * cchunk + tx * VEC;   // D[oy0][ox0]
+                    const int up = Wdp * cchunk, lf = cchunk;                                            // oy0-1 / ox0-1
+                    auto tap = [&](int o, int k) {
+                        const VecF<VEC> d = vload<VEC>(&tile[o]);
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int ny = iy + pt - ky;
-                        if (ny < 0 || (ny & 1)) continue;
-                        const int oy = ny >> 1;
-                        if (oy >= Ho) continue;
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int nx = ix + pl - kx;
-                            if (nx < 0 || (nx & 1)) continue;
-                            const int ox = nx >> 1;
-                            if (ox >= Wo) continue;
-                            const VecF<VEC> d = vload<VEC>(&tile[dbase + (oy * Wo + ox) * cchunk + tx * VEC]);
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(d.v[i], wk[ky * 3 + kx].v[i], acc.v[i]);
+                        for (int i = 0; i < VEC; ++i) acc.v[i] = fmaf(d.v[i], wk[k].v[i], acc.v[i]);
+                    };
+                    if (ny & 1) {
+                        if (nx & 1) {
+                            tap(o00, 4);
+                        } else {
+                            tap(o00, 3);
+                            tap(o00 - lf, 5);
+                        }
+                    } else {
+                        if (nx & 1) {
+                            tap(o00, 1);
+                            tap(o00 - up, 7);
+                        } else {
+                            tap(o00, 0);
+                            tap(o00 - lf, 2);
+                            tap(o00 - up, 6);
+                            tap(o00 - up - lf, 8);
                         }
                     }
                 }
