@@ -45,6 +45,68 @@ def pmc_traffic(B, T, H, W):
     return best
 
 
+def kernel_rooflines(B, T):
+    """Isolated roofline points of the three kernel families that carry the tower (stage-1 shapes of the benchmark
+    workload: B*T frames of 6x8 pixels, 116 channels per branch), timed with HIP events on the launch stream through the
+    C ABI.  achieved = algorithmic bytes of the launch / average duration (back-to-back launches of the same call, so
+    the figure includes the ~3 us launch gap; inputs are L2/MALL-warm, i.e. an upper bound of what the step sees)."""
+    import ctypes as C
+    import torch
+    from carla_driving_rl_agent_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def timeit(fn, iters=30):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    out = []
+    G, px, Cc = T, 48, 116
+    Mg = B * px
+    M = G * Mg
+    a = torch.randn(M, Cc, device=dev)
+    w = torch.randn(Cc, Cc, device=dev)
+    bias = torch.randn(Cc, device=dev)
+    y = torch.empty(M, Cc, device=dev)
+    nb = int(lib.cdrl_pwconv_fused_partial_rows(G, Mg, Cc, Cc))
+    part = torch.zeros(G * nb * 2 * Cc, dtype=torch.float64, device=dev)
+    t = timeit(lambda: lib.cdrl_pwconv_fused(P(a), Cc, 0, None, P(w), Cc, 1, P(bias), P(y), Cc, 0, 0, G, Mg, Cc, Cc, 1, None, None,
+                                             P(part), S()))
+    by = 4.0 * M * 2 * Cc
+    out.append(dict(kernel='pw_nn_kernel<64,4,0,1> (1x1 conv + BN statistics epilogue)', shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1),
+                    algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1), frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4)))
+    dw = torch.empty(Cc, Cc, device=dev)
+    ws = torch.empty(int(lib.cdrl_gemm_tn_workspace_elems(M, Cc, Cc)), device=dev)
+    t = timeit(lambda: lib.cdrl_gemm_tn(P(a), Cc, 0, P(y), Cc, 0, P(dw), M, Cc, Cc, P(ws), 0, S()))
+    out.append(dict(kernel='tn_direct_kernel<4> + tn_reduce (filter gradient)', shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1),
+                    algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1), frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4)))
+    N, Hh, Ww = G * B, 6, 8
+    x = torch.randn(N, Hh, Ww, Cc, device=dev)
+    wd = torch.randn(3, 3, Cc, 1, device=dev)
+    yd = torch.empty(N, Hh, Ww, Cc, device=dev)
+    st = torch.rand(4 * G * Cc, device=dev) + 0.5
+    pst = torch.zeros(4 * G * Cc, device=dev)
+    ones, zeros = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    mm, mv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    wsd = torch.zeros(int(lib.cdrl_dwconv_bn_workspace_doubles(G, B, Hh, Ww, Cc, 1)), dtype=torch.float64, device=dev)
+    t = timeit(lambda: lib.cdrl_dwconv_bn_fwd(P(x), P(st), P(wd), P(bias), P(yd), G, B, Hh, Ww, Cc, 1, P(ones), P(zeros), P(mm), P(mv), 1,
+                                              P(pst), P(wsd), S()))
+    byd = 4.0 * 2 * x.numel()
+    out.append(dict(kernel='dwf_fwd_kernel<1,4,true> + bn_finalize (BN+ReLU6 -> dw3x3 -> BN statistics)', shape=f'{N}x{Hh}x{Ww}x{Cc}',
+                    us=round(t * 1e6, 1), algorithmic_bytes=byd, achieved_GBs=round(byd / t / 1e9, 1),
+                    frac=round(byd / t / 1e9 / HBM_PEAK_GBS, 4)))
+    return out
+
+
 def cpu_baseline(B_sample, T, H, W, threads, seed=42):
     """Oracle (PyTorch-CPU restatement of the reference TF path) timed on the host cores on a bounded
     sample: update-steps at minibatch B_sample, scaled to 256-sample update-steps/s."""
@@ -203,7 +265,7 @@ def main():
                                         f'CARLANetwork fwd/bwd + PPO/value loss + clip + Adam, fp32',
                                per_gpu_batch=B, global_batch=B * world, time_horizon=T, image=[H, W, 3],
                                parallelism=f'dp{world}', passes_per_step=2),
-                   roofline=roof, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3),
+                   roofline=roof, kernel_rooflines=kernel_rooflines(B, T) if world == 1 else None, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3),
                    final_losses=dict(policy=loss_p, value=loss_v))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = run_cpu_baseline_child(args.cpu_sample_batch, T, H, W, args.cpu_threads)
