@@ -92,6 +92,8 @@ PROTOTYPES = {
     'cdrl_dwconv_bwd_data': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),
     'cdrl_dwconv_bwd_workspace_doubles': (_i64, [_i, _i, _i, _i, _i]),
     'cdrl_dwconv_bwd_filter': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp]),
+    'cdrl_augment_workspace_floats': (_i64, [_i, _i, _i]),
+    'cdrl_augment_images': (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp]),
     'cdrl_stem_block_bwd_workspace_doubles': (_i64, [_i] * 5),
     'cdrl_stem_block_bwd': (_i, [_fp] * 5 + [_i] * 5 + [_fp] * 7),
     'cdrl_pwconv_fused_partial_rows': (_i, [_i, _i, _i, _i]),

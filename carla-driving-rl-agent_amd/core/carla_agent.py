@@ -118,9 +118,9 @@ class CARLAgent(PPOAgent):
                                                                           and isinstance(clip_norm[2], float))
         self.dynamics_lr = DynamicParameter.create(value=dynamics_lr)
         self.dynamics_lr.load(config=self.config.get('dynamics_lr', {}))
-        if aug_intensity > 0.0:
-            warnings.warn('rollout-time image augmentation (aug_intensity > 0) is not implemented natively yet; '
-                          'observations are stored un-augmented (SURVEY.md §8(f) item 3)')
+        self._augmenter = None
+        self._aug_rng = np.random.default_rng(self.seed)
+        self._aug_calls = 0
 
     def hyper_parameters(self) -> dict:
         hp = super().hyper_parameters()
@@ -194,12 +194,29 @@ class CARLAgent(PPOAgent):
     def preprocess(self):
         """Stacks a list of T per-step observation dicts (real CARLAEnv) or passes a dict of (T, ...)
         arrays through, prefixing keys with 'state_' when needed."""
-        def fn(state):
+        def prepare(state):
             if isinstance(state, (list, tuple)):
                 keys = state[0].keys()
                 state = {k: np.stack([np.asarray(s[k], dtype=np.float32) for s in state], axis=0) for k in keys}
             return {(k if k.startswith('state_') else f'state_{k}'): v for k, v in state.items()}
-        return fn
+
+        alpha = self.aug_intensity
+        if alpha <= 0.0:
+            return prepare
+
+        from ..rl.augmentations import Augmenter, draw_plan
+
+        def augment_fn(state):
+            """CARLAgent.augment (core/carla_agent.py:527-579): the image stack of every observation is augmented with
+            probability-gated ops of intensity `aug_intensity`, on the device."""
+            state = prepare(state)
+            if self._augmenter is None:
+                self._augmenter = Augmenter(self.device)
+            self._aug_calls += 1
+            plan = draw_plan(alpha, self._aug_rng, offset=self._aug_calls)
+            state['state_image'] = self._augmenter(state['state_image'], plan)
+            return state
+        return augment_fn
 
     def evaluate(self, *args, **kwargs):
         raise NotImplementedError('CARLAgent.evaluate drives a CARLA simulator (collision / waypoint metrics); '

@@ -339,6 +339,20 @@ int cdrl_dwconv_bwd_filter(const float* a, const float* dy, float* dw, float* db
     return dw_bwd_filter(make_view(const_cast<float*>(a), C), dy, dw, db, N, H, W, C, stride, workspace, S(stream));
 }
 
+int64_t cdrl_augment_workspace_floats(int T, int H, int W) { return (int64_t)2 * T * H * W * 3 + 5 * T; }
+
+int cdrl_augment_images(const float* in, float* out, int T, int H, int W, const cdrl_aug_plan* plan, float* workspace,
+                        void* stream) {
+    static_assert(sizeof(cdrl_aug_plan) == sizeof(AugPlan), "cdrl_aug_plan / AugPlan layout mismatch");
+    if (!plan || in == out) {
+        set_error("cdrl_augment_images: null plan or aliased in/out");
+        return -1;
+    }
+    AugPlan p;
+    memcpy(&p, plan, sizeof(p));
+    return augment_images(in, out, T, H, W, p, workspace, S(stream));
+}
+
 int64_t cdrl_stem_block_bwd_workspace_doubles(int B, int T, int H, int W, int Cout) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);

@@ -208,6 +208,25 @@ int beta_sample(const float* alpha, const float* beta, int rows, int A, int ld, 
                 float* du_da, float* du_db, hipStream_t st);
 int gamma_implicit_grad(const double* a, const double* g, int n, double* out, hipStream_t st);
 
+// ---------------------------------------------------------------- rollout-time augmentation (augment.hip)
+struct AugPlan {           // same layout as cdrl_aug_plan (include/cdrl.h)
+    int jitter;
+    float brightness, contrast, saturation, hue;
+    int blur_size;
+    float blur_kernel[75];
+    int salt_pepper;
+    float sp_amount, sp_prob;
+    int gauss_noise;
+    float gn_amount, gn_std;
+    int normalize;
+    int cutout_size, cutout_cell;
+    int dropout_size;
+    float dropout_amount;
+    uint64_t seed, offset;
+};
+// in/out: [T][H][W][3] floats; workspace: 2*T*H*W*3 + 5*T floats
+int augment_images(const float* in, float* out, int T, int H, int W, const AugPlan& plan, float* workspace, hipStream_t st);
+
 // ---------------------------------------------------------------- optimiser (optim.hip)
 // Device hyper-parameter block, refreshed by the host before each step (graph-replay safe).
 struct DevHP {

@@ -14,52 +14,9 @@
 //   * u = g1/(g1+g2), du/dalpha = dg1/da * g2/(g1+g2)^2, du/dbeta = -dg2/db * g1/(g1+g2)^2.
 // B*A is a few hundred elements: one thread per element, latency-bound.
 #include "cdrl_kernels.h"
+#include "philox.h"
 
 namespace cdrl {
-
-struct Philox {
-    uint32_t c[4], k[2], out[4];
-    int used;
-    __device__ Philox(uint64_t seed, uint64_t offset, uint64_t idx) {
-        k[0] = (uint32_t)seed;
-        k[1] = (uint32_t)(seed >> 32);
-        c[0] = (uint32_t)idx;
-        c[1] = (uint32_t)(idx >> 32);
-        c[2] = (uint32_t)offset;
-        c[3] = (uint32_t)(offset >> 32);
-        used = 4;
-    }
-    __device__ void round(uint32_t* ctr, const uint32_t* key) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0];
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ ctr[1] ^ key[0];
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ ctr[3] ^ key[1];
-        const uint32_t n3 = (uint32_t)p0;
-        ctr[0] = n0; ctr[1] = n1; ctr[2] = n2; ctr[3] = n3;
-    }
-    __device__ void refill() {
-        uint32_t ctr[4] = {c[0], c[1], c[2], c[3]};
-        uint32_t key[2] = {k[0], k[1]};
-        for (int i = 0; i < 10; ++i) {
-            round(ctr, key);
-            key[0] += 0x9E3779B9u;
-            key[1] += 0xBB67AE85u;
-        }
-        out[0] = ctr[0]; out[1] = ctr[1]; out[2] = ctr[2]; out[3] = ctr[3];
-        // next block of the stream for this element
-        if (++c[2] == 0) ++c[3];
-        used = 0;
-    }
-    __device__ double uniform() {       // (0, 1), 32 bits
-        if (used >= 4) refill();
-        return ((double)out[used++] + 0.5) * (1.0 / 4294967296.0);
-    }
-    __device__ double normal() {        // Box-Muller (one of the pair)
-        const double u1 = uniform(), u2 = uniform();
-        return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-    }
-};
 
 __device__ double digamma_s(double x) {
     double r = 0.0;

@@ -263,6 +263,30 @@ int64_t cdrl_stem_block_bwd_workspace_doubles(int B, int T, int H, int W, int Co
 int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, int B, int T,
                         int H, int W, int Cout, float* dgamma, float* dbeta, float* coef, float* dw, float* db,
                         double* workspace, void* stream);
+/* Rollout-time image augmentation of one observation stack (CARLAgent.augment, core/carla_agent.py:545-577; ops of
+ * rl/augmentations/augmentations.py and simclr.color_jitter): color jitter (brightness -> contrast -> saturation -> hue ->
+ * clip) -> random-kernel blur -> salt & pepper -> gaussian noise -> per-image min-max normalisation -> cutout -> coarse
+ * dropout.  The plan says which ops fire and with which scalars (the host draws it, as tf_chance / tf.image.random_* do in
+ * the reference); per-pixel random fields are Philox-4x32-10 streams of (seed, offset).  in/out: [T][H][W][3] floats on
+ * the device (may not alias); workspace: cdrl_augment_workspace_floats(T, H, W) floats. */
+typedef struct {
+    int jitter;                 /* 1: color jitter with the four scalars below */
+    float brightness, contrast, saturation, hue;
+    int blur_size;              /* 0 (off), 3 or 5 */
+    float blur_kernel[75];      /* [k][k][3], used [0, 3*k*k) */
+    int salt_pepper;            /* 1: tf_salt_and_pepper_batch(amount, prob) */
+    float sp_amount, sp_prob;
+    int gauss_noise;            /* 1: tf_gaussian_noise_batch(amount, std) */
+    float gn_amount, gn_std;
+    int normalize;              /* 1: tf_normalize_batch */
+    int cutout_size, cutout_cell;   /* size 0 = off; the zeroed cell (row-major index in the size x size grid) */
+    int dropout_size;           /* 0 = off; size x size Bernoulli(1 - amount) grid, nearest-neighbour upsampled */
+    float dropout_amount;
+    uint64_t seed, offset;
+} cdrl_aug_plan;
+int64_t cdrl_augment_workspace_floats(int T, int H, int W);
+int cdrl_augment_images(const float* in, float* out, int T, int H, int W, const cdrl_aug_plan* plan, float* workspace,
+                        void* stream);
 /* CARLAgent.policy_objective / value_objective on linear head outputs (core/carla_agent.py:394-428,
  * 469-486); writes d(loss)/d(lin) and 16 metric floats. */
 int cdrl_beta_ppo_loss(const float* lin, const float* adv, const float* old_logp, const float* speed,
