@@ -59,8 +59,10 @@ int gather_rows(const float* src, const int* idx, float* dst, int nrows, int64_t
 // ---------------------------------------------------------------- GEMM (gemm.hip)
 // C[M,N] (view) (+)= A[M,K] (view) * B(k,n) + bias[n];  B(k,n) = Bp[k*sbk + n*sbn].
 // fp32 MFMA (v_mfma_f32_32x32x2_f32): results are bit-identical to a k-ordered fmaf chain.
+// splitk_ws (>= gemm_nn_splitk_elems floats, or null): enables split-K for small-M / long-K products
+int64_t gemm_nn_splitk_elems(int M, int N, int K);
 int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C, int M, int N, int K,
-            int accumulate, hipStream_t st);
+            int accumulate, hipStream_t st, float* splitk_ws = nullptr);
 // Cout[K,N] = sum_m A[m,K]^T * D[m,N]  (split over M; partial buffer `part` >= gemm_tn_part_elems)
 // G > 1: rows are G equal BatchNorm groups; pro_stats ([4][G][K]) != null applies A <- scale[g][k]*A + shift[g][k] on load.
 // dpro != null: D[m,n] <- k1*(dz - k2 - xhat*k3) on load (BatchNorm-backward apply; D views the gradient w.r.t. the BN

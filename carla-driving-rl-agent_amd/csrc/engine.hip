@@ -497,14 +497,21 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
     View xv = x.v();
     View xg = x.gv();
     Scratch* sc = build_scr_;
+    // split-K scratch for the projections (small M = B or T*B, K = In / u / 3u): own buffer per GRU, the GRUs of different
+    // modalities run on different streams
+    size_t skn = 0;
+    for (int64_t e : {gemm_nn_splitk_elems(T * B, U3, In), gemm_nn_splitk_elems(B, U3, u), gemm_nn_splitk_elems(B, u, U3),
+                      gemm_nn_splitk_elems(T * B, In, U3)})
+        skn = std::max(skn, (size_t)e);
+    float* sk = skn ? alloc(skn) : nullptr;
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
         CDRL_TRY(fill(Hs, (int64_t)B * u, 0.0f, st));
-        CDRL_TRY(gemm_nn(xv, Kp.p, U3, 1, bp.p, make_view(XP, U3), T * B, U3, In, 0, st));
+        CDRL_TRY(gemm_nn(xv, Kp.p, U3, 1, bp.p, make_view(XP, U3), T * B, U3, In, 0, st, sk));
         for (int t = 0; t < T; ++t) {
             float* h = Hs + (size_t)t * B * u;
             float* hp = HP + (size_t)t * B * U3;
-            CDRL_TRY(gemm_nn(make_view(h, u), Rp.p, U3, 1, bp.p + U3, make_view(hp, U3), B, U3, u, 0, st));
+            CDRL_TRY(gemm_nn(make_view(h, u), Rp.p, U3, 1, bp.p + U3, make_view(hp, U3), B, U3, u, 0, st, sk));
             CDRL_TRY(gru_gates_fwd(XP + (size_t)t * B * U3, hp, h, Z + (size_t)t * B * u, R + (size_t)t * B * u,
                                    HH + (size_t)t * B * u, Hs + (size_t)(t + 1) * B * u, B, u, st));
         }
@@ -519,7 +526,7 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
             CDRL_TRY(gru_gates_bwd(cur, Z + (size_t)t * B * u, R + (size_t)t * B * u, HH + (size_t)t * B * u,
                                    HP + (size_t)t * B * U3, Hs + (size_t)t * B * u, dXP + (size_t)t * B * U3, dhp, nxt, B,
                                    u, st));
-            CDRL_TRY(gemm_nn(make_view(dhp, U3), Rp.p, 1, U3, nullptr, make_view(nxt, u), B, u, U3, 1, st));
+            CDRL_TRY(gemm_nn(make_view(dhp, U3), Rp.p, 1, U3, nullptr, make_view(nxt, u), B, u, U3, 1, st, sk));
             float* tmp = cur;
             cur = nxt;
             nxt = tmp;
@@ -530,7 +537,7 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
         CDRL_TRY(gemm_tn(make_view(Hs, u), make_view(dHP, U3), Rp.g, T * B, U3, u, sc->tn, 0, st));
         CDRL_TRY(colsum(make_view(dHP, U3), T * B, U3, sc->part, st));
         CDRL_TRY(reduce_partials(sc->part, nbc, U3, U3, bp.g + U3, 0, st));
-        if (need_dx) CDRL_TRY(gemm_nn(make_view(dXP, U3), Kp.p, 1, U3, nullptr, xg, T * B, In, U3, 0, st));
+        if (need_dx) CDRL_TRY(gemm_nn(make_view(dXP, U3), Kp.p, 1, U3, nullptr, xg, T * B, In, U3, 0, st, sk));
         return 0;
     };
     ops.push_back(op);

@@ -33,8 +33,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //                      smaller workgroups: balances the late, small-M layers over 256 CUs).
 template <int NT, bool BT, bool VEC, int WR>
 __global__ void __launch_bounds__(256, 2) gemm_nn_kernel(View A, const float* __restrict__ Bp, int sbk, int sbn,
-                                                         const float* __restrict__ bias, View C, int M, int N, int K,
-                                                         int accumulate) {
+                                                         const float* __restrict__ bias, View C, int M, int N, int Kfull,
+                                                         int accumulate, int kchunk, int64_t cz_stride) {
+    // split-K: blockIdx.z owns the K range [kb, kb + K) and writes its own dense partial slab (C.p + z * cz_stride)
+    const int kb = blockIdx.z * kchunk;
+    const int K = min(kchunk, Kfull - kb);
+    A.coff += kb;
+    Bp += (int64_t)kb * sbk;
+    C.p += (int64_t)blockIdx.z * cz_stride;
     constexpr int BM = 32 * WR;
     constexpr int WC = 4 / WR;                   // wave columns
     constexpr int NTW = NT / WC;                 // column tiles per wave
@@ -316,21 +322,69 @@ static int launch_nn_persist(bool bt, bool vec, hipStream_t st, View A, const fl
 
 template <int NT, int WR>
 static void launch_nn(bool bt, bool vec, dim3 grid, hipStream_t st, View A, const float* Bp, int sbk, int sbn,
-                      const float* bias, View C, int M, int N, int K, int acc) {
+                      const float* bias, View C, int M, int N, int K, int acc, int kchunk = 1 << 30, int64_t czs = 0) {
     if (bt) {
-        if (vec) hipLaunchKernelGGL((gemm_nn_kernel<NT, true, true, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
-        else hipLaunchKernelGGL((gemm_nn_kernel<NT, true, false, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+        if (vec) hipLaunchKernelGGL((gemm_nn_kernel<NT, true, true, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc, kchunk, czs);
+        else hipLaunchKernelGGL((gemm_nn_kernel<NT, true, false, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc, kchunk, czs);
     } else {
-        if (vec) hipLaunchKernelGGL((gemm_nn_kernel<NT, false, true, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
-        else hipLaunchKernelGGL((gemm_nn_kernel<NT, false, false, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+        if (vec) hipLaunchKernelGGL((gemm_nn_kernel<NT, false, true, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc, kchunk, czs);
+        else hipLaunchKernelGGL((gemm_nn_kernel<NT, false, false, WR>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc, kchunk, czs);
     }
 }
 
 static int g_nn_bm64_threshold = -1;
 
+// C(view) (+)= bias + sum_z part[z]  (fixed order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int M, int N, const float* __restrict__ bias,
+                                     View C, int accumulate) {
+    const int64_t n = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / N;
+        const int c = (int)(i - m * N);
+        float s = bias ? bias[c] : 0.0f;
+        for (int z = 0; z < nsplit; ++z) s += part[(int64_t)z * n + i];
+        float* o = &C.p[m * C.ld + C.coff + c];
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+int64_t gemm_nn_splitk_elems(int M, int N, int K) {
+    if (M > 2048 || K < 256) return 0;
+    return (int64_t)8 * M * N;
+}
+
 int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C, int M, int N, int K,
-            int accumulate, hipStream_t st) {
+            int accumulate, hipStream_t st, float* splitk_ws) {
     if (M <= 0 || N <= 0) return 0;
+    if (splitk_ws && gemm_nn_splitk_elems(M, N, K) > 0) {
+        // few output tiles, long reduction (GRU projections: M = B or T*B, K = 256 / 768): split K over blockIdx.z so that
+        // the chip is filled, partial slabs + fixed-order reduction (the 4x2-workgroup launch took 60 us for 0.1 GFLOP)
+        int nt = cdiv(N, 32);
+        if (nt > 4) nt = 4;
+        const int ncb = cdiv(N, 32 * nt);
+        nt = cdiv(cdiv(N, ncb), 32);
+        if (nt % 2 == 0) {
+            const int gy = cdiv(N, 32 * nt), gx = cdiv(M, 64);
+            int nsplit = cdiv(512, gx * gy);
+            if (nsplit > 8) nsplit = 8;
+            int kchunk = cdiv(cdiv(K, nsplit), 32) * 32;
+            nsplit = cdiv(K, kchunk);
+            if (nsplit > 1) {
+                const bool bt = sbn != 1;
+                const bool vec = (K % 2 == 0) && (A.ld % 2 == 0) && (A.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(A.p) & 7) == 0);
+                dim3 grid(gx, gy, nsplit);
+                View P = make_view(splitk_ws, N);
+                if (nt == 2) launch_nn<2, 2>(bt, vec, grid, st, A, Bp, sbk, sbn, nullptr, P, M, N, K, 0, kchunk, (int64_t)M * N);
+                else launch_nn<4, 2>(bt, vec, grid, st, A, Bp, sbk, sbn, nullptr, P, M, N, K, 0, kchunk, (int64_t)M * N);
+                CDRL_LAUNCH_CHECK();
+                const int64_t n = (int64_t)M * N;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st,
+                                   splitk_ws, nsplit, M, N, bias, C, accumulate);
+                CDRL_LAUNCH_CHECK();
+                return 0;
+            }
+        }
+    }
     if (g_nn_bm64_threshold < 0) {
         const char* e = getenv("CDRL_NN_BM64_BLOCKS");      // tuning knob: use 64-row tiles below this many 128-row blocks
         g_nn_bm64_threshold = e ? atoi(e) : (1 << 30);   // measured: 64-row tiles win at every learner shape
