@@ -455,10 +455,12 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
     note_scratch((size_t)vcol_geom(M, N).nb * N, 0, 0, (size_t)gemm_tn_part_elems(M, N, K));
     const int nb = vcol_geom(M, N).nb;
     Scratch* sc = build_scr_;
+    const size_t dskn = (size_t)std::max(gemm_nn_splitk_elems(M, N, K), gemm_nn_splitk_elems(M, K, N));
+    float* dsk = dskn ? alloc(dskn) : nullptr;          // split-K scratch (batch-sized M, K >= 256)
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
-        if (act == ACT_NONE) return gemm_nn(in, w.p, N, 1, b.p, out, M, N, K, 0, st);
-        CDRL_TRY(gemm_nn(in, w.p, N, 1, b.p, make_view(z, N), M, N, K, 0, st));
+        if (act == ACT_NONE) return gemm_nn(in, w.p, N, 1, b.p, out, M, N, K, 0, st, dsk);
+        CDRL_TRY(gemm_nn(in, w.p, N, 1, b.p, make_view(z, N), M, N, K, 0, st, dsk));
         return act_fwd(z, out.p, (int64_t)M * N, act, st);
     };
     op.bwd = [=](hipStream_t st) -> int {
@@ -469,7 +471,7 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
         }
         CDRL_TRY(colsum(dzv, M, N, sc->part, st));
         CDRL_TRY(reduce_partials(sc->part, nb, N, N, b.g, 0, st));
-        if (need_din) CDRL_TRY(gemm_nn(dzv, w.p, 1, N, nullptr, din, M, K, N, din_acc, st));
+        if (need_din) CDRL_TRY(gemm_nn(dzv, w.p, 1, N, nullptr, din, M, K, N, din_acc, st, dsk));
         return gemm_tn(in, dzv, w.g, M, N, K, sc->tn, 0, st);
     };
     ops.push_back(op);
