@@ -452,7 +452,7 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
         z = alloc((size_t)M * N);
         dz = alloc((size_t)M * N);
     }
-    note_scratch((size_t)vcol_geom(M, N).nb * N, 0, 0, (size_t)gemm_tn_part_elems(M, N, K));
+    note_scratch((size_t)vcol_geom(M, N).nb * N, (size_t)vcol_geom(M, N).nb * N, 0, (size_t)gemm_tn_part_elems(M, N, K));
     const int nb = vcol_geom(M, N).nb;
     Scratch* sc = build_scr_;
     const size_t dskn = (size_t)std::max(gemm_nn_splitk_elems(M, N, K), gemm_nn_splitk_elems(M, K, N));
@@ -469,9 +469,18 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
             CDRL_TRY(act_bwd(z, dout.p, dz, (int64_t)M * N, act, st));
             dzv = make_view(dz, N);
         }
+        // critical path first, then the weight / bias gradients on the side stream (main-stream layers only)
+        if (need_din) CDRL_TRY(gemm_nn(dzv, w.p, 1, N, nullptr, din, M, K, N, din_acc, st, dsk));
+        if (sc == &scr_main_) {
+            CDRL_TRY(next_slot(st));
+            hipStream_t side = fork_side(st);
+            CDRL_TRY(colsum(dzv, M, N, part2s_[slot_], side));
+            CDRL_TRY(reduce_partials(part2s_[slot_], nb, N, N, b.g, 0, side));
+            CDRL_TRY(gemm_tn(in, dzv, w.g, M, N, K, tns_[slot_], 0, side));
+            return done_side(side);
+        }
         CDRL_TRY(colsum(dzv, M, N, sc->part, st));
         CDRL_TRY(reduce_partials(sc->part, nb, N, N, b.g, 0, st));
-        if (need_din) CDRL_TRY(gemm_nn(dzv, w.p, 1, N, nullptr, din, M, K, N, din_acc, st, dsk));
         return gemm_tn(in, dzv, w.g, M, N, K, sc->tn, 0, st);
     };
     ops.push_back(op);
@@ -493,7 +502,7 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
     float* dHP = alloc((size_t)T * B * U3);
     float* dHa = alloc((size_t)B * u);
     float* dHb = alloc((size_t)B * u);
-    note_scratch((size_t)vcol_geom(T * B, U3).nb * U3, 0, 0,
+    note_scratch((size_t)vcol_geom(T * B, U3).nb * U3, (size_t)vcol_geom(T * B, U3).nb * U3, 0,
                  (size_t)std::max(gemm_tn_part_elems(T * B, U3, In), gemm_tn_part_elems(T * B, U3, u)));
     const int nbc = vcol_geom(T * B, U3).nb;
     View xv = x.v();
@@ -533,13 +542,27 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
             cur = nxt;
             nxt = tmp;
         }
-        CDRL_TRY(gemm_tn(xv, make_view(dXP, U3), Kp.g, T * B, U3, In, sc->tn, 0, st));
-        CDRL_TRY(colsum(make_view(dXP, U3), T * B, U3, sc->part, st));
-        CDRL_TRY(reduce_partials(sc->part, nbc, U3, U3, bp.g, 0, st));
-        CDRL_TRY(gemm_tn(make_view(Hs, u), make_view(dHP, U3), Rp.g, T * B, U3, u, sc->tn, 0, st));
-        CDRL_TRY(colsum(make_view(dHP, U3), T * B, U3, sc->part, st));
-        CDRL_TRY(reduce_partials(sc->part, nbc, U3, U3, bp.g + U3, 0, st));
+        // critical path first: the gradient w.r.t. the GRU input
         if (need_dx) CDRL_TRY(gemm_nn(make_view(dXP, U3), Kp.p, 1, U3, nullptr, xg, T * B, In, U3, 0, st, sk));
+        // weight / bias gradients: off the critical path -> side stream with a rotating scratch slot (main-stream GRU only;
+        // the small-modality GRUs already run on the aux stream with their own scratch)
+        hipStream_t ws = st;
+        float* tn = sc->tn;
+        double* part = sc->part;
+        const bool on_side = sc == &scr_main_;
+        if (on_side) {
+            CDRL_TRY(next_slot(st));
+            ws = fork_side(st);
+            tn = tns_[slot_];
+            part = part2s_[slot_];
+        }
+        CDRL_TRY(gemm_tn(xv, make_view(dXP, U3), Kp.g, T * B, U3, In, tn, 0, ws));
+        CDRL_TRY(colsum(make_view(dXP, U3), T * B, U3, part, ws));
+        CDRL_TRY(reduce_partials(part, nbc, U3, U3, bp.g, 0, ws));
+        CDRL_TRY(gemm_tn(make_view(Hs, u), make_view(dHP, U3), Rp.g, T * B, U3, u, tn, 0, ws));
+        CDRL_TRY(colsum(make_view(dHP, U3), T * B, U3, part, ws));
+        CDRL_TRY(reduce_partials(part, nbc, U3, U3, bp.g + U3, 0, ws));
+        if (on_side) CDRL_TRY(done_side(ws));
         return 0;
     };
     ops.push_back(op);
