@@ -189,7 +189,8 @@ __device__ __forceinline__ float apply_act(float z, int act) {
 template <int VEC>
 __global__ void __launch_bounds__(256) bn_apply_kernel(View y, int Mg, int C, int rb, int nloop, int GC,
                                                        const float* __restrict__ stats, int act, View dst,
-                                                       int shuffle_ctot, bool al_in, bool al_out) {
+                                                       int shuffle_ctot, bool al_in, bool al_out, View psrc, View pdst,
+                                                       bool al_ps) {
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int CX = blockDim.x, CY = blockDim.y;
     const int g = blockIdx.y;
@@ -214,21 +215,31 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(View y, int Mg, int C, in
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v.v[i] = apply_act(fmaf(sc.v[i], v.v[i], sh.v[i]), act);
             vstore_view<VEC>(dst, row, c0, shuffle_ctot, al_out, v);
+            if (psrc.p) {       // the unit's identity half goes through the same concat + shuffle store (same C channels)
+                const VecF<VEC> pv = vload_view<VEC>(psrc, row, c0, 0, al_ps);
+                vstore_view<VEC>(pdst, row, c0, shuffle_ctot, false, pv);
+            }
         }
     }
 }
 
 int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
-             hipStream_t st) {
+             hipStream_t st, const View* pass_src, const View* pass_dst) {
     VColGeom g = vcol_geom(Mg, C, 2048);
     const bool ai = view_aligned(y, g.vec), ao = view_aligned(dst, g.vec);
+    View ps{nullptr, 0, 0}, pd{nullptr, 0, 0};
+    if (pass_src && pass_dst) {
+        ps = *pass_src;
+        pd = *pass_dst;
+    }
+    const bool aps = ps.p && view_aligned(ps, g.vec);
     dim3 grid(g.nb, G), block(g.cx, g.cy);
     if (g.vec == 4)
-        hipLaunchKernelGGL(bn_apply_kernel<4>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao);
+        hipLaunchKernelGGL(bn_apply_kernel<4>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao, ps, pd, aps);
     else if (g.vec == 2)
-        hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao);
+        hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao, ps, pd, aps);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao);
+        hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao, ps, pd, aps);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -246,10 +257,16 @@ struct BnBwdReduceF {
     bool al_da, al_y;
     bool use_pool;
     PoolSrc pool;
+    View pgsrc, pgdst;      // optional: gradient of the unit's identity half, gathered through the same shuffle map
+    bool al_pg;
     __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
         VecF<VEC> d = use_pool ? pool_gather<VEC>(pool, row, c0, C) : vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
         const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_y);
         const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
+        if (pgsrc.p) {
+            const VecF<VEC> pv = vload_view<VEC>(pgsrc, row, c0, shuffle_ctot, false);
+            vstore_view<VEC>(pgdst, row, c0, 0, al_pg, pv);
+        }
         if (act == ACT_RELU6) {
             const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
 #pragma unroll
@@ -268,12 +285,18 @@ struct BnBwdReduceF {
 };
 
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
-                  double* part, hipStream_t st, const PoolSrc* pool) {
+                  double* part, hipStream_t st, const PoolSrc* pool, const View* pass_gsrc, const View* pass_gdst) {
     const int vec = vcol_geom(Mg, C).vec;
     PoolSrc ps{};
     if (pool) ps = *pool;
+    View pgs{nullptr, 0, 0}, pgd{nullptr, 0, 0};
+    if (pass_gsrc && pass_gdst) {
+        pgs = *pass_gsrc;
+        pgd = *pass_gdst;
+    }
     return launch_vcolreduce<2, BnBwdReduceF>(G, Mg, C, part, st, NB_STATS, da, shuffle_ctot, y, stats, G * C, C, act,
-                                              pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps);
+                                              pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps,
+                                              pgs, pgd, pgd.p && view_aligned(pgd, vec));
 }
 
 // BN-backward sums of a BatchNorm+ReLU6 whose output feeds a 3x3/s2 max-pool, in SCATTER form: iterate over the POOLED

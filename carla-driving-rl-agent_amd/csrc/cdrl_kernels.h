@@ -16,8 +16,10 @@ int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* g
                 hipStream_t st);
 // dst = act(scale*y + shift); optional de-interleave shuffle on the destination channel index.
 // stats == nullptr -> plain copy.
+// pass_src / pass_dst: optional second tensor with the same C channels copied through the same shuffle store (the
+// identity half of a ShuffleNet unit: concat + shuffle of both halves in one launch)
 int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
-             hipStream_t st);
+             hipStream_t st, const View* pass_src = nullptr, const View* pass_dst = nullptr);
 // Gradient source "through a 3x3/s2 SAME max-pool": d(a)[n,iy,ix,c] = sum of dp over the windows whose
 // saved argmax points at (iy,ix).  Lets the stem BatchNorm backward read the pooled gradient directly
 // (the 255 MB pre-pool gradient tensor is never written or re-read).
@@ -28,7 +30,8 @@ struct PoolSrc {
 };
 // Backward: reduce (sum dz, sum dz*xhat) -> part [G][nb][2][C]
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
-                  double* part, hipStream_t st, const PoolSrc* pool = nullptr);
+                  double* part, hipStream_t st, const PoolSrc* pool = nullptr, const View* pass_gsrc = nullptr,
+                  const View* pass_gdst = nullptr);     // pass_*: gradient of the identity half gathered in the same pass
 // Same sums for a BN+ReLU6 that feeds a 3x3/s2 max-pool, in scatter form over the POOLED gradient (ps.dp, ps.argmax);
 // y: the BN's raw input [G*frames_per_group][ps.H][ps.W][C]; part [G][nb][2][C], nb = vcol_geom(frames*Ho*Wo, C).nb
 int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_group, int C, const float* stats, double* part,

@@ -61,6 +61,13 @@ struct Op {
     std::function<int(hipStream_t)> bwd;
 };
 
+// Identity half of a ShuffleNet unit carried by the unit's last BatchNorm op: forward = copy through the concat + shuffle
+// store of the BN-apply kernel, backward = gather of its gradient inside the BN-backward reduction (no separate launches)
+struct Passthrough {
+    View fsrc{nullptr, 0, 0}, fdst{nullptr, 0, 0};     // forward: X[:, :C] -> out (shuffled, channel offset 0)
+    View gsrc{nullptr, 0, 0}, gdst{nullptr, 0, 0};     // backward: out.g (shuffled) -> X.g[:, :C]
+};
+
 // BatchNorm work folded into a pointwise conv (gemm_pw.hip); all optional
 struct PwFuse {
     bool fwd_pw = false;                 // forward through the persistent skinny GEMM
@@ -166,7 +173,7 @@ private:
     // stats_nb > 0: the statistics partials were already written by the producing op (that many rows per group)
     BnRec add_bn(std::vector<Op>& ops, int model, const std::string& prefix, View x, int G, int Mg, int C, bool bessel,
                  int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx, int stats_nb = 0,
-                 bool defer_apply = false);
+                 bool defer_apply = false, Passthrough pass = Passthrough());
     void add_pw(std::vector<Op>& ops, const std::string& prefix, View in, int rows, int Cin, int Cout, float* y,
                 View din, int din_acc, BnRec bn_after, PwFuse fuse = PwFuse());
     void add_dw(std::vector<Op>& ops, const std::string& prefix, View in, int N, int H, int W, int C, int stride,

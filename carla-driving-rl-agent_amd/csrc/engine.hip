@@ -239,7 +239,7 @@ void Learner::note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn
 // ------------------------------------------------------------------------------------------
 Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::string& prefix, View x, int G, int Mg, int C,
                                bool bessel, int act, View out, int out_shuffle, View dout, int dout_shuffle, float* dx,
-                               int stats_nb, bool defer_apply) {
+                               int stats_nb, bool defer_apply, Passthrough pass) {
     PRef gamma = param(model, prefix + ".gamma", {C}, true);
     PRef beta = param(model, prefix + ".beta", {C}, true);
     PRef mm = param(model, prefix + ".moving_mean", {C}, false);
@@ -265,10 +265,12 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     op.fwd = [=](hipStream_t st, int training) -> int {
         if (training && !stats_nb) CDRL_TRY(colstats(x, G, Mg, C, sc->part, st));
         CDRL_TRY(bn_finalize(sc->part, stats_nb ? stats_nb : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
+        if (pass.fsrc.p) return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st, &pass.fsrc, &pass.fdst);
         return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st);
     };
     op.bwd = [=](hipStream_t st) -> int {
-        if (!*fused) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st));
+        if (pass.gsrc.p) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, &pass.gsrc, &pass.gdst));
+        else if (!*fused) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st));
         CDRL_TRY(bn_bwd_finalize(sc->part, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
         if (defer_apply) return 0;      // applied by the consumer GEMMs on load (PwFuse::bb)
         if (dx) return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, sc->part2, st);
@@ -717,7 +719,15 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 const int Mg_in = B * curH * curW, Mg_out = B * Ho * Wo;
                 const std::string pre = "img.s" + std::to_string(s) + ".u" + std::to_string(u);
                 Tens out = tens(rows_out, C);
-                if (stride == 1) {
+                Passthrough pass;
+                static const bool fuse_pass = !(getenv("CDRL_FUSED_PASS") && atoi(getenv("CDRL_FUSED_PASS")) == 0);
+                if (stride == 1 && fuse_pass && sc_c == C - sc_c) {
+                    // identity half: carried by the unit's last BatchNorm op (same channel count as the main half)
+                    pass.fsrc = X.v(0);
+                    pass.fdst = out.v(0);
+                    pass.gsrc = out.gv(0);
+                    pass.gdst = X.gv(0);
+                } else if (stride == 1) {
                     Op cp;                      // shortcut half: identity through concat + shuffle
                     View src = X.v(0), dst = out.v(0), gsrc = out.gv(0), gdst = X.gv(0);
                     cp.fwd = [=](hipStream_t st, int) -> int {
@@ -769,7 +779,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     const size_t pw2_at = ops.size();
                     add_pw(ops, pre + ".pw2", y2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out), f2);
                     BnRec r3 = add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C,
-                                      out.gv(sc_c), C, nullptr, pw_nn_plan(T, Mg_out, main_out, mid).nbpg, bb3);
+                                      out.gv(sc_c), C, nullptr, pw_nn_plan(T, Mg_out, main_out, mid).nbpg, bb3, pass);
                     if (bb3) {      // rebuild pw2 with the BN3 blocks known (same parameters -> same arena slots)
                         f2.bb = true;
                         f2.bb_stats = r3.stats;
@@ -797,7 +807,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     }
                     add_pw(ops, pre + ".pw2", a2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out));
                     add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C, out.gv(sc_c), C,
-                           nullptr);
+                           nullptr, 0, false, pass);
                 }
                 if (stride == 2) {
                     Tens ys1 = tens(rows_out, sc_c, false), b1 = tens(rows_out, sc_c);
