@@ -748,7 +748,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                                  pw_nn_supported(y1.v(), main_in, mid);
                 if (fpw) {
                     // BN-backward apply as GEMM operand prologue (needs the filter-gradient GEMM's fixed column mapping)
-                    const bool bb1 = (fused_bb_ & 1) && gemm_tn_dpro_supported(mid);
+                    // (not for N <= 32 outputs of the backward-data GEMM, i.e. the first unit's 24 input channels: the 128-row
+                    //  variant of the prologue kernel runs at 248 us vs ~165 us for apply + plain GEMM)
+                    const bool bb1 = (fused_bb_ & 1) && gemm_tn_dpro_supported(mid) && (main_in > 32 || (fused_bb_ & 4));
                     const bool bb3 = (fused_bb_ & 2) && gemm_tn_dpro_supported(main_out);
                     float* stats1 = alloc((size_t)4 * T * mid);
                     float* coef1 = alloc((size_t)3 * T * mid);
