@@ -448,7 +448,9 @@ int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const 
 // 1392-output / 2048-partial reductions of the first unit took ~300 us that way).
 template <int CX>
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __restrict__ part, int nparts, int n,
-                                                              int64_t stride, float* __restrict__ out, int accumulate) {
+                                                              int64_t stride, float* __restrict__ out, int accumulate,
+                                                              int n1, float* __restrict__ out2) {
+    // columns [0, n1) go to out, [n1, n) to out2 (two parameter tensors reduced by one launch, e.g. filter + bias)
     constexpr int PY = 1024 / CX;
     __shared__ double sm[PY][CX];
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -481,18 +483,25 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __r
         s = 0.0;
 #pragma unroll
         for (int y = 0; y < 64; ++y) s += sm[y][tx];
-        out[i] = accumulate ? out[i] + (float)s : (float)s;
+        float* o = i < n1 ? &out[i] : &out2[i - n1];
+        *o = accumulate ? *o + (float)s : (float)s;
     }
+}
+
+int reduce_partials2(const double* part, int nparts, int n1, int n2, int64_t stride, float* out1, float* out2, int accumulate,
+                     hipStream_t st) {
+    const int n = n1 + n2;
+    if (cdiv(n, 16) >= 128 || nparts <= 64)
+        hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3(cdiv(n, 16)), dim3(16, 64), 0, st, part, nparts, n, stride, out1, accumulate, n1, out2);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(cdiv(n, 4)), dim3(4, 256), 0, st, part, nparts, n, stride, out1, accumulate, n1, out2);
+    CDRL_LAUNCH_CHECK();
+    return 0;
 }
 
 int reduce_partials(const double* part, int nparts, int n, int64_t stride, float* out, int accumulate,
                     hipStream_t st) {
-    if (cdiv(n, 16) >= 128 || nparts <= 64)
-        hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3(cdiv(n, 16)), dim3(16, 64), 0, st, part, nparts, n, stride, out, accumulate);
-    else
-        hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(cdiv(n, 4)), dim3(4, 256), 0, st, part, nparts, n, stride, out, accumulate);
-    CDRL_LAUNCH_CHECK();
-    return 0;
+    return reduce_partials2(part, nparts, n, 0, stride, out, nullptr, accumulate, st);
 }
 
 __global__ void __launch_bounds__(256) gather_view_kernel(View src, int shuffle_ctot, int rows, int C, int rb,

@@ -45,6 +45,9 @@ int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const 
 // out[i] (+)= sum_p part[p*stride + i], i < n
 int reduce_partials(const double* part, int nparts, int n, int64_t stride, float* out, int accumulate,
                     hipStream_t st);
+// two outputs from one partial row: columns [0, n1) -> out1, [n1, n1+n2) -> out2 (filter + bias in one launch)
+int reduce_partials2(const double* part, int nparts, int n1, int n2, int64_t stride, float* out1, float* out2, int accumulate,
+                     hipStream_t st);
 // column sums of a view: part [nb][C] with nb = col_geom(rows, C).nb
 int colsum(View x, int rows, int C, double* part, hipStream_t st);
 // dst(view) = src(view) gathered through the shuffle map on the *source* (backward of shuffle)

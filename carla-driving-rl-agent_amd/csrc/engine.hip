@@ -423,8 +423,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
             const View dx = pre ? make_view(dys_[slot_], C) : din;
             CDRL_TRY(dwf_bwd(x, stats1, dout.p, y2, stats2, coef2, w.p, dx, scr_main_.part, pw, G, B, H, W, C, stride, st));
             hipStream_t side = fork_side(st);
-            CDRL_TRY(reduce_partials(pw, G * nbf, 9 * C, (int64_t)10 * C, w.g, 0, side));
-            CDRL_TRY(reduce_partials(pw + 9 * C, G * nbf, C, (int64_t)10 * C, b.g, 0, side));
+            CDRL_TRY(reduce_partials2(pw, G * nbf, 9 * C, C, (int64_t)10 * C, w.g, b.g, 0, side));
             return done_side(side);
         };
         ops.push_back(op);
