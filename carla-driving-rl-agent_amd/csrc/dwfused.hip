@@ -373,9 +373,10 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
             // gradient w.r.t. the depthwise input (transposed conv), masked by ReLU6 of the pre BN
             for (int p = ty; p < P; p += CY) {
                 const int iy = (int)(((float)p + 0.5f) * invW), ix = p - iy * W;
-                VecF<VEC> acc;
+                VecF<VEC> acc, yre;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc.v[i] = 0.0f;
+                if (PRE) yre = vload<VEC>(xp + (int64_t)p * C);     // L2-resident re-read of y1 for xhat1, issued before the taps
                 if (S == 1) {
                     // D is zero-padded: da[iy][ix] = sum_k D[iy + pt - ky][ix + pl - kx] * w[k], no bounds tests
                     const int o0 = dbase + ((iy + pt + 1) * Wdp + ix + pl + 1) * cchunk + tx * VEC;
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
                 const int64_t row = n * P + p;
                 if (PRE) {
                     const VecF<VEC> av = vload<VEC>(&tile[((iy + 1) * Wp + ix + 1) * cchunk + tx * VEC]);
-                    const VecF<VEC> v = vload<VEC>(xp + (int64_t)p * C);      // L2-resident re-read of y1 for xhat1
+                    const VecF<VEC> v = yre;
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
                         if (!(av.v[i] > 0.0f && av.v[i] < 6.0f)) acc.v[i] = 0.0f;
