@@ -116,6 +116,11 @@ int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride
 // x: (B,T,H,W,3) reference layout -> y: [(t*B+b)][Ho][Wo][Cout], 3x3 stride 2 valid.
 int stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
              hipStream_t st);
+// stem conv + (sum, sum^2) partials of its output per time slice: part [T][nb][2][Cout], nb = stem_fwd_stats_nb()
+bool stem_fwd_stats_supported(int Cout);
+int stem_fwd_stats_nb(int B, int H, int W);
+int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* part, int B, int T, int H, int W, int Cout,
+                   hipStream_t st);
 int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout);
 // stem filter gradient with the stem BatchNorm's backward apply + max-pool gather fused into the operand load (dy is
 // never materialised); y: raw stem conv output, stats/coef: the stem BN's [4|3][T][Cout] blocks

@@ -75,6 +75,94 @@ __global__ void __launch_bounds__(256) stem_fwd_scalar_kernel(const float* __res
     }
 }
 
+// Stem conv with the following BatchNorm's statistics in the epilogue: one workgroup = a contiguous pixel range of ONE
+// time slice, block = (Cout/4 channel lanes, pixel lanes); per-thread (sum, sum of squares) in double, LDS fold over the
+// pixel lanes, one partial row per workgroup in bn_finalize's [T][nb][2][Cout] layout (no second pass over the 255 MB y).
+__global__ void __launch_bounds__(256) stem_fwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             double* __restrict__ part, int B, int T, int H, int W, int Ho,
+                                                             int Wo, int Cout, int rb) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];      // [27][Cout] + [Cout], then the reduction scratch
+    const int CX = blockDim.x, CY = blockDim.y, tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * CX + tx, nthr = CX * CY;
+    for (int i = tid; i < 27 * Cout; i += nthr) ws[i] = w[i];
+    for (int i = tid; i < Cout; i += nthr) ws[27 * Cout + i] = bias[i];
+    __syncthreads();
+    const int g = blockIdx.y, nb = gridDim.x;
+    const int Mg = B * Ho * Wo;
+    const int r0 = blockIdx.x * rb, r1 = min(r0 + rb, Mg);
+    const int co = tx * 4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = r0 + ty; r < r1; r += CY) {
+        const int ox = r % Wo;
+        const int t2 = r / Wo;
+        const int oy = t2 % Ho;
+        const int b = t2 / Ho;                                     // frame inside the time slice g: f = g*B + b
+        const float* xp = x + ((((int64_t)b * T + g) * H + 2 * oy) * W + 2 * ox) * 3;
+        float4 acc = *reinterpret_cast<const float4*>(&ws[27 * Cout + co]);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const float xv = xp[(int64_t)ky * W * 3 + j];
+                const float4 wv = *reinterpret_cast<const float4*>(&ws[(ky * 9 + j) * Cout + co]);
+                acc.x = fmaf(xv, wv.x, acc.x);
+                acc.y = fmaf(xv, wv.y, acc.y);
+                acc.z = fmaf(xv, wv.z, acc.z);
+                acc.w = fmaf(xv, wv.w, acc.w);
+            }
+        *reinterpret_cast<float4*>(&y[((int64_t)g * Mg + r) * Cout + co]) = acc;
+        const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] += (double)a4[i];
+            q[i] += (double)a4[i] * (double)a4[i];
+        }
+    }
+    __syncthreads();
+    double* sm = reinterpret_cast<double*>(ws);                     // [2][4][CY][CX]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sm[((0 * 4 + i) * CY + ty) * CX + tx] = s[i];
+        sm[((1 * 4 + i) * CY + ty) * CX + tx] = q[i];
+    }
+    __syncthreads();
+    for (int j = ty; j < 8; j += CY) {                              // 8 (quantity, channel-in-group) columns per channel lane
+        double a = 0.0;
+        for (int yy = 0; yy < CY; ++yy) a += sm[(j * CY + yy) * CX + tx];
+        const int qq = j >> 2, i = j & 3;
+        part[(((int64_t)g * nb + blockIdx.x) * 2 + qq) * Cout + co + i] = a;
+    }
+}
+
+bool stem_fwd_stats_supported(int Cout) { return (Cout % 4) == 0 && Cout <= 64; }
+
+int stem_fwd_stats_nb(int B, int H, int W) {
+    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    const int Mg = B * Ho * Wo;
+    const int rb = cdiv(Mg, NB_STATS);
+    return cdiv(Mg, rb);
+}
+
+int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* part, int B, int T, int H, int W, int Cout,
+                   hipStream_t st) {
+    if (!stem_fwd_stats_supported(Cout) || (reinterpret_cast<uintptr_t>(y) & 15) != 0) {
+        set_error("stem_fwd_stats: Cout=%d / alignment not supported", Cout);
+        return -1;
+    }
+    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    const int Mg = B * Ho * Wo;
+    const int rb = cdiv(Mg, NB_STATS);
+    const int nb = cdiv(Mg, rb);
+    const int cx = Cout / 4, cy = 256 / cx;
+    size_t lds = (size_t)(27 * Cout + Cout) * sizeof(float);
+    const size_t red = (size_t)8 * cy * cx * sizeof(double);
+    if (lds < red) lds = red;
+    hipLaunchKernelGGL(stem_fwd_stats_kernel, dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
 int stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
              hipStream_t st) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;

@@ -644,7 +644,13 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         note_scratch(0, 0, (size_t)N * Hs * Ws * c.stem, 0, (size_t)stem_bwd_part_elems(B, T, c.H, c.W, c.stem));
         Op op;
         const int H = c.H, W = c.W, Cs = c.stem;
-        op.fwd = [=](hipStream_t st, int) -> int { return stem_fwd(in_image_, w.p, b.p, y.p, B, T, H, W, Cs, st); };
+        // forward: BN statistics in the conv's epilogue (training only; inference uses the moving statistics)
+        const bool stem_fstats = stem_fwd_stats_supported(Cs) && !(getenv("CDRL_FUSED_STEM") && atoi(getenv("CDRL_FUSED_STEM")) == 0);
+        const int nb_stem = stem_fstats ? stem_fwd_stats_nb(B, H, W) : 0;
+        op.fwd = [=](hipStream_t st, int training) -> int {
+            if (stem_fstats && training) return stem_fwd_stats(in_image_, w.p, b.p, y.p, scr_main_.part, B, T, H, W, Cs, st);
+            return stem_fwd(in_image_, w.p, b.p, y.p, B, T, H, W, Cs, st);
+        };
         const bool stem_fused = stem_bwd_fused_supported(Cs) && !(getenv("CDRL_FUSED_STEM") && atoi(getenv("CDRL_FUSED_STEM")) == 0);
         // blocks of the stem BatchNorm (allocated here: the stem conv's backward consumes them in the fused form)
         float* stem_stats = alloc((size_t)4 * T * Cs);
@@ -679,12 +685,13 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             float* coef = stem_coef;
             const int nb = vcol_geom(Mg, C).nb;
             const int nb_pool = vcol_geom(B * Hp * Wp, C).nb;
-            note_scratch((size_t)G * std::max(nb, nb_pool) * 2 * C, (size_t)G * nb * C, 0, 0);
+            note_scratch((size_t)G * std::max(std::max(nb, nb_pool), nb_stem) * 2 * C, (size_t)G * nb * C, 0, 0);
             View yv = y.v();
             Op bn;
             bn.fwd = [=](hipStream_t st, int training) -> int {
-                if (training) CDRL_TRY(colstats(yv, G, Mg, C, scr_main_.part, st));
-                CDRL_TRY(bn_finalize(scr_main_.part, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, 1, training, stats, st));
+                if (training && !stem_fstats) CDRL_TRY(colstats(yv, G, Mg, C, scr_main_.part, st));
+                CDRL_TRY(bn_finalize(scr_main_.part, stem_fstats ? nb_stem : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, 1, training, stats,
+                                     st));
                 return maxpool_bn_fwd(y.p, stats, G, B, pool.p, argmax, N, Hs, Ws, C, st);
             };
             bn.bwd = [=](hipStream_t st) -> int {

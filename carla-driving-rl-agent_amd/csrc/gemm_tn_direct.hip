@@ -170,7 +170,7 @@ static TndPlan tnd_plan(int M, int N, int K, int G) {
     p.RS = left / p.NSPL;
     const int Mg = M / G;
     // enough workgroups to fill the chip a few times over, but >= 128 rows each so that the partial buffer stays small
-    static const int tn_target = getenv("CDRL_TN_TARGET") ? atoi(getenv("CDRL_TN_TARGET")) : 2048;
+    static const int tn_target = getenv("CDRL_TN_TARGET") ? atoi(getenv("CDRL_TN_TARGET")) : 1024;     // 2048 doubles the split-M partial traffic (8.8 GB/update-step) for no measurable gain
     int target = tn_target / (p.gy * p.gz * G * p.RS);
     if (target < 1) target = 1;
     int ns = Mg / 128;
