@@ -269,9 +269,25 @@ def main():
                    final_losses=dict(policy=loss_p, value=loss_v))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = run_cpu_baseline_child(args.cpu_sample_batch, T, H, W, args.cpu_threads)
-        print(json.dumps(out))
+    else:
+        out = None
+    # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): every rank flushes it BEFORE
+    # the final barrier so that rank 0's JSON line is the last line on the job's stdout
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
