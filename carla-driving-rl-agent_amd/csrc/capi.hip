@@ -1,4 +1,5 @@
 // extern "C" surface of libcdrl_hip.so (declared in include/cdrl.h).
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -356,7 +357,9 @@ int cdrl_augment_images(const float* in, float* out, int T, int H, int W, const 
 int64_t cdrl_stem_block_bwd_workspace_doubles(int B, int T, int H, int W, int Cout) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
-    return (int64_t)T * vcol_geom(B * Hp * Wp, Cout).nb * 2 * Cout + stem_bwd_part_elems(B, T, H, W, Cout);
+    const int64_t two_pass = (int64_t)T * vcol_geom(B * Hp * Wp, Cout).nb * 2 * Cout + stem_bwd_part_elems(B, T, H, W, Cout);
+    const int64_t one_pass = (stem_bwd_direct_ws_floats(B, T, H, W) + 1) / 2;
+    return two_pass > one_pass ? two_pass : one_pass;
 }
 
 int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, int B, int T,
@@ -366,6 +369,9 @@ int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, cons
     const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
     hipStream_t st = S(stream);
     const PoolSrc ps = make_pool_src(argmax, dp, Ho, Wo);
+    static const bool one_pass = getenv("CDRL_STEM_DIRECT") && atoi(getenv("CDRL_STEM_DIRECT")) == 1;
+    if (one_pass && stem_bwd_direct_supported(Cout))        // one pass: BN sums + filter sums together (stem_bwd.hip), opt-in
+        return stem_bwd_direct(x, ps, y, stats, dgamma, dbeta, coef, dw, db, B, T, H, W, Cout, reinterpret_cast<float*>(workspace), st);
     const int nb = vcol_geom(B * Hp * Wp, Cout).nb;
     double* part = workspace;
     double* fpart = workspace + (int64_t)T * nb * 2 * Cout;

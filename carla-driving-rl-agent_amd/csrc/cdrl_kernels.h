@@ -124,6 +124,12 @@ int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, 
 int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout);
 // stem filter gradient with the stem BatchNorm's backward apply + max-pool gather fused into the operand load (dy is
 // never materialised); y: raw stem conv output, stats/coef: the stem BN's [4|3][T][Cout] blocks
+// (stem_bwd.hip) ONE pass from the pooled gradient: BN sums + the three filter sums as MFMA products with operands
+// generated into the fragment registers, then a finalize kernel -> dgamma, dbeta, coef, dw, db.  ws: stem_bwd_direct_ws_floats()
+bool stem_bwd_direct_supported(int Cout);
+int64_t stem_bwd_direct_ws_floats(int B, int T, int H, int W);
+int stem_bwd_direct(const float* x, const PoolSrc& ps, const float* y, const float* stats, float* dgamma, float* dbeta, float* coef,
+                    float* dw, float* db, int B, int T, int H, int W, int Cout, float* ws, hipStream_t st);
 bool stem_bwd_fused_supported(int Cout);
 int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, const float* stats, const float* coef, float* dw,
                           float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st);

@@ -658,7 +658,14 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         const int Hp0 = same_out_h(Hs, 2), Wp0 = same_out_h(Ws, 2);
         Tens pool = tens(N * Hp0 * Wp0, c.stem);
         uint8_t* argmax = reinterpret_cast<uint8_t*>(alloc(((size_t)N * Hp0 * Wp0 * c.stem + 3) / 4));
+        // one-pass form (stem_bwd.hip): BN sums and filter sums together, everything in the BN op's backward.  Opt-in
+        // (CDRL_STEM_DIRECT=1): measured 747 us (three accumulator tiles, 64 KB LDS -> two workgroups per CU) against
+        // 206 + 453 us for the two-pass form whose second pass overlaps on the side stream: 22.3 vs 22.0 ms/update-step.
+        const bool stem_direct = stem_fused && stem_bwd_direct_supported(Cs) &&
+                                 (getenv("CDRL_STEM_DIRECT") && atoi(getenv("CDRL_STEM_DIRECT")) == 1);
+        float* stem_ws = stem_direct ? alloc((size_t)stem_bwd_direct_ws_floats(B, T, H, W)) : nullptr;
         op.bwd = [=](hipStream_t st) -> int {
+            if (stem_direct) return 0;
             if (stem_fused) {
                 CDRL_TRY(next_slot(st));
                 hipStream_t side = fork_side(st);
@@ -697,6 +704,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             bn.bwd = [=](hipStream_t st) -> int {
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
                 View none{nullptr, 0, 0};
+                if (stem_direct)
+                    return stem_bwd_direct(in_image_, ps, y.p, stats, gamma.g, beta.g, coef, w.g, b.g, B, T, H, W, C, stem_ws, st);
                 if (stem_fused) {       // sums in scatter form over the pooled gradient; the apply happens inside the stem filter-gradient GEMM
                     CDRL_TRY(pool_bn_bwd_reduce(ps, y.p, G, B, C, stats, scr_main_.part, st));
                     return bn_bwd_finalize(scr_main_.part, nb_pool, G, Mg, C, stats, gamma.g, beta.g, coef, st);
