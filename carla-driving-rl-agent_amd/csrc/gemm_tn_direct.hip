@@ -48,7 +48,9 @@ __global__ void __launch_bounds__(256) tn_direct_kernel(TnDirectArgs a) {
     const int nsp = rest % a.NSPL, rs = rest / a.NSPL;
     const int ki = wk, nj0 = nsp * NJW;
     const int njn = min(NJW, NT - nj0);
-    if (ki >= KT || njn <= 0) return;                         // idle wave (3 k tiles, or fewer n tiles than splits)
+    // idle waves: a 4th wave for 3 k tiles, fewer n tiles than splits, or a leftover wave when the waves that remain
+    // after the k tiles do not divide evenly into n splits x row splits (e.g. 4 waves over 3 n tiles: RS = 1)
+    if (ki >= KT || njn <= 0 || rs >= a.RS) return;
     const int grp = blockIdx.x / a.nspg;
     const int64_t gend = (int64_t)(grp + 1) * a.Mg;
     int64_t mbeg = (int64_t)grp * a.Mg + (int64_t)(blockIdx.x % a.nspg) * a.rows_per;

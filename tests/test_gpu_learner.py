@@ -253,6 +253,63 @@ def test_determinism():
     assert torch.equal(g1, eng.grads)
 
 
+def test_full_size_properties():
+    """BASELINE.json's full size (B=256, T=4, 90x120x3) is too large for the CPU oracle in a test, so the engine is checked
+    there through size-independent properties: (1) bit-wise determinism, (2) exact linearity of every gradient in the
+    data-parallel gradient scale (power-of-two scale -> exact), (3) invariance under a permutation of the minibatch rows
+    (BatchNorm statistics, losses and gradients are symmetric in the samples: only the summation order changes),
+    (4) equivariance of the trunk output under the same permutation."""
+    from carla_driving_rl_agent_amd.engine import LearnerEngine
+    from carla_driving_rl_agent_amd.init import init_engine_parameters
+    from carla_driving_rl_agent_amd import synthetic
+    B, T, H, W = 256, 4, 90, 120
+    eng = LearnerEngine(B, device='cuda:0', T=T, H=H, W=W)
+    init_engine_parameters(eng, seed=42)
+    r = synthetic.make_rollout(B, T=T, H=H, W=W, seed=7)
+    states = {k: torch.as_tensor(v).cuda() for k, v in r['states'].items()}
+    adv = torch.as_tensor(np.random.default_rng(1).standard_normal(B).astype(np.float32)).cuda()
+    pol = dict(states=states, advantages=adv, old_log_prob=torch.as_tensor(r['old_log_prob']).cuda(),
+               speed=(torch.as_tensor(r['speed'][:, 0]) / 100.0).cuda().contiguous(),
+               similarity=torch.as_tensor(r['similarity'][:, 0]).cuda().contiguous(), u=torch.as_tensor(r['action']).cuda(),
+               du_da=None, du_db=None)
+    moving = {k: v.clone() for k, v in eng.param_views('trunk').items() if 'moving' in k}
+
+    def grads(batch, scale=1.0):
+        for k, v in eng.param_views('trunk').items():       # the forward updates the moving statistics: restore them
+            if 'moving' in k:
+                v.copy_(moving[k])
+        eng.policy_forward_backward(batch, grad_scale=scale)
+        torch.cuda.synchronize()
+        return eng.grads.clone(), eng.metrics('policy')['loss']
+
+    g1, l1 = grads(pol)
+    assert torch.isfinite(g1).all() and np.isfinite(l1)
+    g2, l2 = grads(pol)
+    assert torch.equal(g1, g2) and l1 == l2                                   # (1)
+    gh, _ = grads(pol, scale=0.5)
+    assert torch.equal(gh, g1 * 0.5)                                          # (2)
+    perm = torch.as_tensor(np.random.default_rng(3).permutation(B)).cuda()
+    ppol = {k: (v[perm].contiguous() if torch.is_tensor(v) else v) for k, v in pol.items() if k != 'states'}
+    ppol['states'] = {k: v[perm].contiguous() for k, v in states.items()}
+    gp, lp = grads(ppol)
+    assert abs(lp - l1) < 1e-5 * max(1.0, abs(l1))
+    # (3) ReLU6 / max-pool decisions are taken on identical values, only reduction orders differ -> fp32 summation noise
+    worst = (gp - g1).abs().max().item() / g1.abs().max().item()
+    assert worst < 2e-4, worst
+    # (4) forward equivariance: the trunk output of the permuted batch is the permuted trunk output
+    for k, v in eng.param_views('trunk').items():
+        if 'moving' in k:
+            v.copy_(moving[k])
+    eng.trunk_forward_train(states)
+    torch.cuda.synchronize()
+    d0 = eng.buffer(0, (B, eng.cfg.dyn)).clone()
+    eng.trunk_forward_train(ppol['states'])
+    torch.cuda.synchronize()
+    d1 = eng.buffer(0, (B, eng.cfg.dyn)).clone()
+    assert torch.isfinite(d0).all()
+    assert (d1 - d0[perm]).abs().max().item() < 1e-4 * max(1.0, d0.abs().max().item())
+
+
 def test_bad_inputs_fail_loudly():
     B, H, W = 2, 48, 64
     _, eng = make_pair(B, H, W, seed=1)

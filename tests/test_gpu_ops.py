@@ -52,7 +52,8 @@ def test_gemm_nn(lib, M, K, N):
 
 
 @pytest.mark.parametrize('M,K,N', [(5000, 58, 58), (3000, 116, 116), (2049, 24, 58), (1500, 232, 232), (700, 464, 768),
-                                   (256, 512, 320), (33, 16, 96)])
+                                   (256, 512, 320), (33, 16, 96), (40000, 16, 96), (30000, 32, 96), (50000, 24, 92), (20000, 96, 24),
+                                   (12288, 232, 232), (3000, 464, 768)])
 def test_gemm_tn(lib, M, K, N):
     rng = np.random.default_rng(M + K + N)
     a = rng.standard_normal((M, K + 5)).astype(np.float32)
