@@ -175,7 +175,8 @@ static TndPlan tnd_plan(int M, int N, int K, int G) {
     static const int tn_target = getenv("CDRL_TN_TARGET") ? atoi(getenv("CDRL_TN_TARGET")) : 1024;     // 2048 doubles the split-M partial traffic (8.8 GB/update-step) for no measurable gain
     int target = tn_target / (p.gy * p.gz * G * p.RS);
     if (target < 1) target = 1;
-    int ns = Mg / 128;
+    static const int tn_minrows = getenv("CDRL_TN_MINROWS") ? atoi(getenv("CDRL_TN_MINROWS")) : 128;
+    int ns = Mg / tn_minrows;
     if (ns > target) ns = target;
     if (ns < 1) ns = 1;
     p.rows_per = cdiv(cdiv(Mg, ns), 2) * 2;
