@@ -105,14 +105,18 @@ int Learner::launch(hipStream_t caller, std::vector<uint64_t> key, bool graphabl
     return 0;
 }
 
+static const int g_diag_noev = getenv("CDRL_DIAG_NOEV") ? atoi(getenv("CDRL_DIAG_NOEV")) : 0;   // timing diagnostics only (racy)
+
 int Learner::next_slot(hipStream_t st) {
     slot_ = (slot_ + 1) % NSLOT;
+    if (g_diag_noev & 1) return 0;
     if (side_enabled_ && slot_used_[slot_]) CDRL_HIP(hipStreamWaitEvent(st, ev_side_[slot_], 0));
     return 0;
 }
 
 hipStream_t Learner::fork_side(hipStream_t st) {
     if (!side_enabled_) return st;
+    if (g_diag_noev & 2) return side_;
     if (hipEventRecord(ev_main_[slot_], st) != hipSuccess) return st;
     if (hipStreamWaitEvent(side_, ev_main_[slot_], 0) != hipSuccess) return st;
     return side_;
@@ -120,6 +124,7 @@ hipStream_t Learner::fork_side(hipStream_t st) {
 
 int Learner::done_side(hipStream_t side) {
     if (!side_enabled_ || side != side_) return 0;
+    if (g_diag_noev & 4) return 0;
     CDRL_HIP(hipEventRecord(ev_side_[slot_], side_));
     slot_used_[slot_] = true;
     return 0;

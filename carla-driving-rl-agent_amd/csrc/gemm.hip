@@ -320,6 +320,134 @@ static int launch_nn_persist(bool bt, bool vec, hipStream_t st, View A, const fl
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Row-stacked variant for the wide late layers (stage-3 units K = N = 232, head conv 464 -> 768): a (32*RT) x 128
+// tile, wave w owns column tile w and RT row tiles, so one B fragment feeds RT MFMAs (LDS reads per MFMA: (RT+1)/RT
+// instead of 3/2) and M = 12288 splits into exactly 256 workgroups at RT = 3 (the 64 x 128 tiling gave 384 = 1.5
+// rounds over 256 CUs: 33 us for 8.4 us of MFMA time).  A and B slices are fetched with 16-byte loads (the generic
+// kernel issues 16 scalar B loads per thread and slice), the K tail (232 = 7*32 + 8) runs only the k-steps that exist.
+// Requires K % 4 == 0, 16-byte aligned A rows and weight rows (N % 4 == 0 forward, K % 4 == 0 transposed).
+// ------------------------------------------------------------------------------------------
+template <int RT, bool BT>
+__global__ void __launch_bounds__(256, 2) gemm_nn_rt_kernel(View A, const float* __restrict__ Bp, int sbk, int sbn,
+                                                            const float* __restrict__ bias, View C, int M, int N, int K,
+                                                            int accumulate) {
+    constexpr int BM = 32 * RT, BN = 128;
+    constexpr int NA4 = (BM * BK / 4) / 256;     // float4 loads of A per thread and slice (RT)
+    constexpr int NB4 = (BK * BN / 4) / 256;     // 4
+    __shared__ float As[2][BM][BK + 1];
+    __shared__ float Bs[2][BK][BN + 1];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    f32x16 acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    float4 ra[NA4], rb[NB4];
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+    auto load_slice = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 3, kk = (idx & 7) * 4;
+            const int64_t m = m0 + r;
+            ra[i] = (m < M && (k0 + kk) < K) ? *reinterpret_cast<const float4*>(&A.p[m * A.ld + A.coff + k0 + kk]) : z4;
+        }
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {
+            const int idx = tid + 256 * i;
+            if (BT) {       // W^T: contiguous along k
+                const int kk = (idx & 7) * 4, nn = idx >> 3;
+                rb[i] = ((k0 + kk) < K && (n0 + nn) < N)
+                            ? *reinterpret_cast<const float4*>(&Bp[(int64_t)(k0 + kk) * sbk + (int64_t)(n0 + nn) * sbn]) : z4;
+            } else {        // W: contiguous along n
+                const int kk = idx >> 5, nn = (idx & 31) * 4;
+                rb[i] = ((k0 + kk) < K && (n0 + nn) < N)
+                            ? *reinterpret_cast<const float4*>(&Bp[(int64_t)(k0 + kk) * sbk + (int64_t)(n0 + nn) * sbn]) : z4;
+            }
+        }
+    };
+    auto store_slice = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 3, kk = (idx & 7) * 4;
+            As[buf][r][kk] = ra[i].x;
+            As[buf][r][kk + 1] = ra[i].y;
+            As[buf][r][kk + 2] = ra[i].z;
+            As[buf][r][kk + 3] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {
+            const int idx = tid + 256 * i;
+            if (BT) {
+                const int kk = (idx & 7) * 4, nn = idx >> 3;
+                Bs[buf][kk][nn] = rb[i].x;
+                Bs[buf][kk + 1][nn] = rb[i].y;
+                Bs[buf][kk + 2][nn] = rb[i].z;
+                Bs[buf][kk + 3][nn] = rb[i].w;
+            } else {
+                const int kk = idx >> 5, nn = (idx & 31) * 4;
+                Bs[buf][kk][nn] = rb[i].x;
+                Bs[buf][kk][nn + 1] = rb[i].y;
+                Bs[buf][kk][nn + 2] = rb[i].z;
+                Bs[buf][kk][nn + 3] = rb[i].w;
+            }
+        }
+    };
+
+    load_slice(0);
+    store_slice(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        const bool more = (k0 + BK) < K;
+        if (more) load_slice(k0 + BK);
+        const int kmax = min(BK, K - k0);        // K % 4 == 0 -> even
+#pragma unroll 4
+        for (int kk = 0; kk < kmax; kk += 2) {
+            const float b = Bs[buf][kk + lk][wave * 32 + lrow];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const float a = As[buf][i * 32 + lrow][kk + lk];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            }
+        }
+        if (more) store_slice(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int n = n0 + wave * 32 + lrow;
+    if (n >= N) return;
+    const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < M) {
+                float* c = &C.p[m * C.ld + C.coff + n];
+                float v = acc[i][r] + bv;
+                if (accumulate) v += *c;
+                *c = v;
+            }
+        }
+    }
+}
+
+template <int RT>
+static void launch_nn_rt(bool bt, hipStream_t st, View A, const float* Bp, int sbk, int sbn, const float* bias, View C, int M,
+                         int N, int K, int acc) {
+    dim3 grid(cdiv(M, 32 * RT), cdiv(N, 128));
+    if (bt) hipLaunchKernelGGL((gemm_nn_rt_kernel<RT, true>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+    else hipLaunchKernelGGL((gemm_nn_rt_kernel<RT, false>), grid, dim3(256), 0, st, A, Bp, sbk, sbn, bias, C, M, N, K, acc);
+}
+
 template <int NT, int WR>
 static void launch_nn(bool bt, bool vec, dim3 grid, hipStream_t st, View A, const float* Bp, int sbk, int sbn,
                       const float* bias, View C, int M, int N, int K, int acc, int kchunk = 1 << 30, int64_t czs = 0) {
@@ -397,6 +525,20 @@ int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C
     const int gy = cdiv(N, 32 * nt);
     const bool bt = sbn != 1;
     const bool vec = (K % 2 == 0) && (A.ld % 2 == 0) && (A.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(A.p) & 7) == 0);
+    {   // row-stacked tiles for the wide late layers
+        static const int rt = getenv("CDRL_NN_RT") ? atoi(getenv("CDRL_NN_RT")) : 3;
+        static const int rt_minn = getenv("CDRL_NN_RT_MINN") ? atoi(getenv("CDRL_NN_RT_MINN")) : 129;
+        const bool a16 = (K % 4 == 0) && (A.ld % 4 == 0) && (A.coff % 4 == 0) && ((reinterpret_cast<uintptr_t>(A.p) & 15) == 0);
+        const bool b16 = ((reinterpret_cast<uintptr_t>(Bp) & 15) == 0) &&
+                         (bt ? (sbk == 1 && sbn % 4 == 0) : (sbn == 1 && sbk % 4 == 0 && N % 4 == 0));
+        if (rt >= 2 && rt <= 4 && N >= rt_minn && K >= 64 && M >= 2048 && a16 && b16) {
+            if (rt == 2) launch_nn_rt<2>(bt, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate);
+            else if (rt == 3) launch_nn_rt<3>(bt, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate);
+            else launch_nn_rt<4>(bt, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate);
+            CDRL_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     static int persist = -1;
     if (persist < 0) {
         // measured at B=256 (768 tiles of 64 rows over 512 resident workgroups): 40.8 us vs 26.7 us for the
@@ -470,8 +612,66 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float* __restrict
     }
 }
 
+// float4 variant: TX lanes x 4 consecutive outputs (16-byte loads, 256-byte row segments at TX = 16) x 256/TX split
+// lanes, 8 independent 16-byte loads in flight per thread.  The CX = 16 scalar kernel above read 64-byte segments with
+// 1024-thread blocks: 31 us for the 384 x 116 x 116 partials of a stage-1 filter gradient (0.66 TB/s).
+template <int TX>
+__global__ void __launch_bounds__(256) tn_reduce_v4_kernel(const float* __restrict__ part, int nsplit, int64_t n,
+                                                           int64_t stride, float* __restrict__ out, int accumulate) {
+    constexpr int TY = 256 / TX;
+    __shared__ double sm[TY][TX][4];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int64_t i = ((int64_t)blockIdx.x * TX + tx) * 4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < n) {
+        const float* src = part + i;
+        for (int p0 = ty; p0 < nsplit; p0 += TY * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = p0 + u * TY;
+                v[u] = p < nsplit ? *reinterpret_cast<const float4*>(src + (int64_t)p * stride) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s0 += (double)v[u].x;
+                s1 += (double)v[u].y;
+                s2 += (double)v[u].z;
+                s3 += (double)v[u].w;
+            }
+        }
+    }
+    sm[ty][tx][0] = s0;
+    sm[ty][tx][1] = s1;
+    sm[ty][tx][2] = s2;
+    sm[ty][tx][3] = s3;
+    __syncthreads();
+    // fixed-order fold over the TY split lanes: thread (c, tx) of the first 4*TX threads owns output i + c
+    if (threadIdx.x < 4 * TX) {
+        const int c = threadIdx.x % 4, x = threadIdx.x / 4;
+        const int64_t o = ((int64_t)blockIdx.x * TX + x) * 4 + c;
+        if (o < n) {
+            double s = 0.0;
+#pragma unroll 8
+            for (int y = 0; y < TY; ++y) s += sm[y][x][c];
+            out[o] = accumulate ? out[o] + (float)s : (float)s;
+        }
+    }
+}
+
 int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride, float* out, int accumulate,
                         hipStream_t st) {
+    static const bool v4 = !(getenv("CDRL_TNRED_V4") && atoi(getenv("CDRL_TNRED_V4")) == 0);
+    if (v4 && n % 4 == 0 && stride % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0 && nparts >= 16) {
+        if (cdiv64(n, 64) >= 160)
+            hipLaunchKernelGGL(tn_reduce_v4_kernel<16>, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, st, part, nparts, n, stride, out, accumulate);
+        else if (cdiv64(n, 16) >= 128 || nparts < 128)
+            hipLaunchKernelGGL(tn_reduce_v4_kernel<4>, dim3((unsigned)cdiv64(n, 16)), dim3(256), 0, st, part, nparts, n, stride, out, accumulate);
+        else
+            hipLaunchKernelGGL(tn_reduce_v4_kernel<1>, dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, st, part, nparts, n, stride, out, accumulate);
+        CDRL_LAUNCH_CHECK();
+        return 0;
+    }
     if (cdiv64(n, 16) >= 128 || nparts <= 64)
         hipLaunchKernelGGL(tn_reduce_kernel<16>, dim3((unsigned)cdiv64(n, 16)), dim3(16, 64), 0, st, part, nparts, n, stride, out, accumulate);
     else

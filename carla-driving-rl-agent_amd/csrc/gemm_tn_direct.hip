@@ -31,15 +31,18 @@ struct TnDirectArgs {
     int M, N, K, G, Mg;
     int rows_per, nspg;         // rows per workgroup, workgroups per group
     int WK, NSPL, NJW, RS;      // wave mapping: waves along k, n-splits, n tiles per wave, row splits
+    int RS2;                    // 2: a second set of 4 waves takes the other half of every wave's rows; the two halves
+                                // are added through LDS before the partial is written (half the split-M partials)
     const float* a_stats;       // [4][G][K] or null
     TnBnBwd db;                 // y == null: no D prologue
 };
 
 
-template <int NJW, bool APRO, bool DPRO>
-__global__ void __launch_bounds__(256) tn_direct_kernel(TnDirectArgs a) {
+template <int NJW, bool APRO, bool DPRO, int U>
+__global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
+    extern __shared__ float tnd_red[];          // RS2 == 2: [4 waves][NJW][16][64]
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = (tid >> 6) & 3, half = tid >> 8;
     const int l32 = lane & 31, lh = lane >> 5;
     const int K = a.K, N = a.N;
     const int k0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
@@ -50,7 +53,7 @@ __global__ void __launch_bounds__(256) tn_direct_kernel(TnDirectArgs a) {
     const int njn = min(NJW, NT - nj0);
     // idle waves: a 4th wave for 3 k tiles, fewer n tiles than splits, or a leftover wave when the waves that remain
     // after the k tiles do not divide evenly into n splits x row splits (e.g. 4 waves over 3 n tiles: RS = 1)
-    if (ki >= KT || njn <= 0 || rs >= a.RS) return;
+    const bool active = !(ki >= KT || njn <= 0 || rs >= a.RS);
     const int grp = blockIdx.x / a.nspg;
     const int64_t gend = (int64_t)(grp + 1) * a.Mg;
     int64_t mbeg = (int64_t)grp * a.Mg + (int64_t)(blockIdx.x % a.nspg) * a.rows_per;
@@ -58,9 +61,11 @@ __global__ void __launch_bounds__(256) tn_direct_kernel(TnDirectArgs a) {
     if (mend > gend) mend = gend;
     {   // this wave's share of the workgroup's rows (even number of rows per share)
         const int64_t len = mend - mbeg;
-        const int64_t per = ((len + a.RS - 1) / a.RS + 1) / 2 * 2;
-        mbeg += rs * per;
+        const int TS = a.RS * a.RS2;
+        const int64_t per = ((len + TS - 1) / TS + 1) / 2 * 2;
+        mbeg += (rs * a.RS2 + half) * per;
         if (mbeg + per < mend) mend = mbeg + per;
+        if (!active) mend = mbeg;
     }
     const int k = k0 + ki * 32 + l32;
     const bool kon = k < K;
@@ -96,21 +101,42 @@ __global__ void __launch_bounds__(256) tn_direct_kernel(TnDirectArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
-    // one batch of U row pairs in flight per wave; latency is hidden by the other waves of the SIMD (a second
-    // register set for software pipelining was measured slower: it halves the occupancy)
-    constexpr int U = 4;
-    const float* Ap = a.A.p + a.A.coff + k;
+    // one batch of U row pairs in flight per wave.  The launches of the learner put only 1.5-2 waves on a SIMD (the
+    // row splits are kept coarse so that the partial buffer stays small), so a wave alternates between "wait for the
+    // batch" (~2 us) and U*NJW MFMAs: the batch must be deep -- U = 4 ran the 49152 x 116 x 116 gradient in 37 us
+    // (16 exposed latencies per wave) for 10 us of MFMA time.
+    // Loads go through buffer descriptors: the row offset of a batch is wave-uniform (SGPR soffset), the lane's column
+    // offset is a fixed 32-bit voffset, masked lanes point out of range (the bounds check returns 0) -- no 64-bit address
+    // arithmetic and no per-load select in the steady state, which is what lets U = 8 / 16 fit in registers.
+    const uint32_t OOR = 0x80000000u;           // host checks that every tensor is < 2 GB
+    const __amdgpu_buffer_rsrc_t rA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A.p), 0, (int)((int64_t)a.M * a.A.ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D.p), 0, (int)((int64_t)a.M * a.D.ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(DPRO ? a.db.y : a.D.p), 0, (int)((int64_t)a.M * (DPRO ? N : a.D.ld) * 4), 0x00020000);
+    const uint32_t voA = kon ? (uint32_t)(lh * a.A.ld + a.A.coff + k) * 4u : OOR;
+    uint32_t voD[NJW], voY[NJW];
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) {
+        voD[j] = non[j] ? (uint32_t)(lh * a.D.ld + dcol[j]) * 4u : OOR;
+        voY[j] = non[j] ? (uint32_t)(lh * N + ncol[j]) * 4u : OOR;
+    }
+    const uint32_t sA = (uint32_t)a.A.ld * 4u, sD = (uint32_t)a.D.ld * 4u, sY = (uint32_t)N * 4u;      // row strides in bytes
     float av0[U], dv0[U][NJW], yv0[DPRO ? U : 1][DPRO ? NJW : 1];
     auto load_batch = [&](int64_t m0, float* av, float (*dv)[NJW], float (*yv)[DPRO ? NJW : 1]) {
+        const uint32_t mu = (uint32_t)__builtin_amdgcn_readfirstlane((int)m0);          // wave-uniform by construction
+        const bool full = m0 + 2 * U <= mend;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t m = m0 + 2 * u + lh;
-            const bool mon = m < mend;
-            av[u] = (mon && kon) ? Ap[m * a.A.ld] : 0.0f;
+            const uint32_t r = mu + 2 * u;
+            // tail batch: rows past the end of the share are masked per lane (the pair may straddle an odd end)
+            const bool mon = full || (int64_t)(m0 + 2 * u + lh) < mend;
+            av[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, mon ? voA : OOR, r * sA, 0));
 #pragma unroll
             for (int j = 0; j < NJW; ++j) {
-                dv[u][j] = (mon && non[j]) ? a.D.p[m * a.D.ld + dcol[j]] : 0.0f;
-                if (DPRO) yv[u][j] = (mon && non[j]) ? a.db.y[m * N + ncol[j]] : 0.0f;
+                dv[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rD, mon ? voD[j] : OOR, r * sD, 0));
+                if (DPRO) yv[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rY, mon ? voY[j] : OOR, r * sY, 0));
             }
         }
     };
@@ -141,6 +167,23 @@ __global__ void __launch_bounds__(256) tn_direct_kernel(TnDirectArgs a) {
         load_batch(m0, av0, dv0, yv0);
         mma_batch(m0, av0, dv0, yv0);
     }
+    if (a.RS2 == 2) {       // fold the second half's accumulators into the first half's (fixed order)
+        float* red = tnd_red + (size_t)wave * NJW * 16 * 64 + lane;
+        if (half == 1 && active) {
+#pragma unroll
+            for (int j = 0; j < NJW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(j * 16 + r) * 64] = acc[j][r];
+        }
+        __syncthreads();
+        if (half == 0 && active) {
+#pragma unroll
+            for (int j = 0; j < NJW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] += red[(j * 16 + r) * 64];
+        }
+    }
+    if (half != 0 || !active) return;
     // C/D layout: column (n) = lane&31, row (k) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* out = a.part + ((int64_t)blockIdx.x * a.RS + rs) * K * N;
 #pragma unroll
@@ -156,7 +199,7 @@ __global__ void __launch_bounds__(256) tn_direct_kernel(TnDirectArgs a) {
 
 struct TndPlan {
     int gy, gz, nspg, nsplit, rows_per;
-    int WK, NSPL, NJW, RS;
+    int WK, NSPL, NJW, RS, RS2;
 };
 
 static TndPlan tnd_plan(int M, int N, int K, int G) {
@@ -176,7 +219,10 @@ static TndPlan tnd_plan(int M, int N, int K, int G) {
     int target = tn_target / (p.gy * p.gz * G * p.RS);
     if (target < 1) target = 1;
     static const int tn_minrows = getenv("CDRL_TN_MINROWS") ? atoi(getenv("CDRL_TN_MINROWS")) : 128;
-    int ns = Mg / tn_minrows;
+    // in-workgroup row halves (8 waves): the same rows per wave, twice the rows per partial
+    static const int tn_rs2 = getenv("CDRL_TN_RS2") ? atoi(getenv("CDRL_TN_RS2")) : 2;
+    p.RS2 = (tn_rs2 == 2 && Mg >= 2 * tn_minrows) ? 2 : 1;
+    int ns = Mg / (tn_minrows * p.RS2);
     if (ns > target) ns = target;
     if (ns < 1) ns = 1;
     p.rows_per = cdiv(cdiv(Mg, ns), 2) * 2;
@@ -192,12 +238,22 @@ int64_t gemm_tn_part_elems(int M, int N, int K, int G) {
 
 bool gemm_tn_dpro_supported(int) { return true; }
 
+template <int NJW, int U>
+static void launch_tnd_u(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a) {
+    const dim3 blk(256 * a.RS2);
+    const size_t lds = a.RS2 == 2 ? (size_t)4 * NJW * 16 * 64 * sizeof(float) : 0;     // <= 64 KB
+    if (apro && dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, true, U>), grid, blk, lds, st, a);
+    else if (apro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, false, U>), grid, blk, lds, st, a);
+    else if (dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, false, true, U>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((tn_direct_kernel<NJW, false, false, U>), grid, blk, lds, st, a);
+}
+
 template <int NJW>
 static void launch_tnd(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a) {
-    if (apro && dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, true>), grid, dim3(256), 0, st, a);
-    else if (apro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, false>), grid, dim3(256), 0, st, a);
-    else if (dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, false, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((tn_direct_kernel<NJW, false, false>), grid, dim3(256), 0, st, a);
+    static const int u = getenv("CDRL_TN_U") ? atoi(getenv("CDRL_TN_U")) : 8;
+    if (u >= 16 && !dpro) launch_tnd_u<NJW, 16>(apro, dpro, grid, st, a);      // (U = 16 with the D prologue spills)
+    else if (u >= 8) launch_tnd_u<NJW, 8>(apro, dpro, grid, st, a);
+    else launch_tnd_u<NJW, 4>(apro, dpro, grid, st, a);
 }
 
 int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G,
@@ -207,6 +263,12 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
         return -1;
     }
     if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if ((int64_t)M * A.ld * 4 >= (1ll << 31) || (int64_t)M * D.ld * 4 >= (1ll << 31) || (int64_t)M * N * 4 >= (1ll << 31)) {
+        set_error("gemm_tn: operands of 2 GB or more are not supported (M=%d)", M);
+        return -1;
+    }
+    static const bool diag_skip = getenv("CDRL_DIAG_SKIP_TN") && atoi(getenv("CDRL_DIAG_SKIP_TN")) == 1;   // timing diagnostics only
+    if (diag_skip) return 0;
     const TndPlan p = tnd_plan(M, N, K, G);
     TnDirectArgs a;
     a.A = A;
@@ -223,6 +285,7 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     a.NSPL = p.NSPL;
     a.NJW = p.NJW;
     a.RS = p.RS;
+    a.RS2 = p.RS2;
     a.a_stats = pro_stats;
     a.db = TnBnBwd{};
     if (dpro) a.db = *dpro;

@@ -31,7 +31,8 @@ def P(t):
 
 @pytest.mark.parametrize('M,K,N', [(1000, 58, 58), (777, 116, 116), (300, 24, 58), (513, 232, 232), (130, 464, 768),
                                    (5001, 58, 58), (9000, 116, 116), (4100, 24, 58), (70000, 116, 116), (4097, 57, 116),
-                                   (256, 320, 2), (64, 9, 16), (5, 3, 1)])
+                                   (256, 320, 2), (64, 9, 16), (5, 3, 1),
+                                   (2500, 232, 232), (2111, 464, 768), (4099, 232, 464), (12288, 232, 232)])   # row-stacked tiles
 def test_gemm_nn(lib, M, K, N):
     rng = np.random.default_rng(M + K + N)
     a = rng.standard_normal((M, K)).astype(np.float32)
