@@ -222,16 +222,26 @@ struct StemBnBwd {
     const float* coef;      // [3][T][Cout]
 };
 
-template <bool FUSED>
+// wave-private LDS tiles: ordering between a wave's own ds_write / ds_read needs no workgroup barrier
+__device__ __forceinline__ void stem_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool FUSED, int NCH>
 __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ part, int B, int T, int H, int W, int Ho,
                                                             int Wo, int Cout, int rows, int rows_per, StemBnBwd bb) {
     __shared__ float P[4][32][33];
     __shared__ float D[4][32][33];
+    __shared__ float CF[2][7][32];      // FUSED: BatchNorm statistics / coefficients of the (at most two) time slices of this block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lcol = lane & 31, lk = lane >> 5;
     const int r0 = blockIdx.x * rows_per;
     const int r1 = min(r0 + rows_per, rows);
+    const int rows_per_group = B * Ho * Wo;
+    const int g0 = r0 / rows_per_group;
     f32x16_c acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -239,66 +249,127 @@ __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restr
         (&P[wave][0][0])[i] = 0.0f;
         (&D[wave][0][0])[i] = 0.0f;
     }
+    if (FUSED) {
+        const int GC = T * Cout;
+        for (int i = tid; i < 2 * 7 * 32; i += 256) {
+            const int gg = i / (7 * 32), q = (i / 32) % 7, c = i % 32;
+            const int g = min(g0 + gg, T - 1);
+            float v = 0.0f;
+            if (c < Cout) v = q < 4 ? bb.stats[q * GC + g * Cout + c] : bb.coef[(q - 4) * GC + g * Cout + c];
+            CF[gg][q][c] = v;
+        }
+        __syncthreads();
+    }
+    constexpr int nch = NCH;                         // 16-byte channel chunks per half-wave lane (3 for 24 channels)
+    __amdgpu_buffer_rsrc_t rsDP, rsAM, rsY;
+    if (FUSED) {
+        const int64_t pel = (int64_t)B * T * bb.ps.Ho * bb.ps.Wo * Cout;
+        rsDP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.ps.dp), 0, (int)(pel * 4), 0x00020000);
+        rsAM = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bb.ps.argmax), 0, (int)pel, 0x00020000);
+        rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.y), 0, (int)((int64_t)rows * Cout * 4), 0x00020000);
+    }
     for (int base = r0; base < r1; base += 128) {
         const int wrow0 = base + wave * 32;
-        __syncthreads();
-        // patch tile: 32 rows x 28 (27 taps + ones column).  Lane l owns row (l & 31) and the 14 columns
-        // [14*(l>>5), 14*(l>>5)+14): ONE row decode per lane per slice, tap offsets are compile-time constants.
-        {
-            const int r = lane & 31, half = lane >> 5;
-            const int row = wrow0 + r;
-            const bool ok = row < r1;
-            const float* xp = x;
-            if (ok) {
-                const int ox = row % Wo;
-                const int q = row / Wo;
-                const int oy = q % Ho;
-                const int f = q / Ho;
-                const int t = f / B, b = f - t * B;
-                xp = x + ((((int64_t)b * T + t) * H + 2 * oy) * W + 2 * ox) * 3;
-            }
+        stem_wave_sync();
+        // Lane l owns row (l & 31); ONE row decode per lane and slice (32-bit), shared by the patch tile and the gradient tile.
+        const int r = lane & 31, half = lane >> 5;
+        const int row = wrow0 + r;
+        const bool ok = row < r1;
+        int ox = 0, oy = 0, f = 0, t = 0;
+        const float* xp = x;
+        if (ok) {
+            ox = row % Wo;
+            const int q = row / Wo;
+            oy = q % Ho;
+            f = q / Ho;
+            t = f / B;
+            const int b = f - t * B;
+            xp = x + ((((int64_t)b * T + t) * H + 2 * oy) * W + 2 * ox) * 3;
+        }
+        // patch tile: 32 rows x 28 (27 taps + ones column); the lane's 14 columns [14*half, 14*half+14), tap offsets are
+        // compile-time constants
 #pragma unroll
-            for (int jj = 0; jj < 14; ++jj) {
-                const int64_t o0 = (int64_t)(jj / 9) * W * 3 + (jj % 9);
-                const int64_t o1 = (int64_t)((14 + jj) / 9) * W * 3 + ((14 + jj) % 9);
-                float val = 0.0f;
-                if (ok) val = (half && jj == 13) ? 1.0f : xp[half ? o1 : o0];
-                P[wave][r][half * 14 + jj] = val;
-            }
+        for (int jj = 0; jj < 14; ++jj) {
+            const int64_t o0 = (int64_t)(jj / 9) * W * 3 + (jj % 9);
+            const int64_t o1 = (int64_t)((14 + jj) / 9) * W * 3 + ((14 + jj) % 9);
+            float val = 0.0f;
+            if (ok) val = (half && jj == 13) ? 1.0f : xp[half ? o1 : o0];
+            P[wave][r][half * 14 + jj] = val;
         }
         if (FUSED) {
-            const int C4 = Cout >> 2, GC = T * Cout;
-            for (int idx = lane; idx < 32 * C4; idx += 64) {
-                const int r = idx / C4, c0 = (idx - r * C4) * 4;
-                const int row = wrow0 + r;
-                VecF<4> o;
-                o.v[0] = o.v[1] = o.v[2] = o.v[3] = 0.0f;
-                if (row < r1) {
-                    const int g = (row / (Ho * Wo)) / B;              // frame f = t*B + b -> time slice t
-                    VecF<4> d = pool_gather<4>(bb.ps, row, c0, Cout);
-                    const VecF<4> v = vload<4>(bb.y + (int64_t)row * Cout + c0);
-                    const float* sp = bb.stats + g * Cout + c0;
-                    const float* cp = bb.coef + g * Cout + c0;
+            // gradient tile: the lane's nch chunks of 4 channels of its row.  dz is gathered from the pooled gradient through
+            // the argmax (<= 4 candidate windows), masked by ReLU6, then dy = k1*(dz - k2 - xhat*k3).
+            // The 3x3 / stride-2 pool reaches a pre-pool pixel from at most 2 x 2 windows: ky = parity(oy + pt) and, for an
+            // even parity, ky + 2 (one pooled row up); same along x.  All candidate loads are issued unconditionally through
+            // buffer descriptors -- a window that does not exist gets an out-of-range offset and returns 0 -- so that the
+            // whole slice is ONE batch of independent loads (the branchy gather serialised up to 27 load/wait rounds per
+            // slice: 450 us for 470 MB).
+            const PoolSrc& ps = bb.ps;
+            const int gs = min(max(t - g0, 0), 1);
+            const uint32_t OOR = 0x80000000u;
+            const int kyA = (oy + ps.pt) & 1, kxA = (ox + ps.pl) & 1;
+            const int pyA = (oy + ps.pt - kyA) >> 1, pxA = (ox + ps.pl - kxA) >> 1;
+            const bool vyA = ok && pyA < ps.Ho, vyB = ok && kyA == 0 && pyA >= 1 && (pyA - 1) < ps.Ho;
+            const bool vxA = pxA < ps.Wo, vxB = kxA == 0 && pxA >= 1 && (pxA - 1) < ps.Wo;
+            const int pbase = ((f * ps.Ho + pyA) * ps.Wo + pxA) * Cout;          // window (A, A); (B, .) is one pooled row up
+            const int dyB = -ps.Wo * Cout, dxB = -Cout;
+            uint32_t wo[4];         // element offsets of the 4 candidate windows (or OOR)
+            uint32_t wk[4];         // their argmax codes ky*3 + kx
+            wo[0] = (vyA && vxA) ? (uint32_t)pbase : OOR;
+            wo[1] = (vyA && vxB) ? (uint32_t)(pbase + dxB) : OOR;
+            wo[2] = (vyB && vxA) ? (uint32_t)(pbase + dyB) : OOR;
+            wo[3] = (vyB && vxB) ? (uint32_t)(pbase + dyB + dxB) : OOR;
+            wk[0] = kyA * 3 + kxA;
+            wk[1] = kyA * 3 + kxA + 2;
+            wk[2] = (kyA + 2) * 3 + kxA;
+            wk[3] = (kyA + 2) * 3 + kxA + 2;
+            const uint32_t yo = ok ? (uint32_t)row * (uint32_t)Cout : OOR;
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t gd[NCH][4], gy[NCH];
+            uint32_t ga[NCH][4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float z = fmaf(sp[2 * GC + i], v.v[i], sp[3 * GC + i]);
-                        float dz = d.v[i];
-                        if (!(z > 0.0f && z < 6.0f)) dz = 0.0f;
-                        const float xh = (v.v[i] - sp[i]) * sp[GC + i];
-                        o.v[i] = cp[i] * (dz - cp[GC + i] - xh * cp[2 * GC + i]);
-                    }
+            for (int j = 0; j < NCH; ++j) {
+                const int c0 = (half * nch + j) * 4;
+                const bool on = c0 < Cout;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    const uint32_t eo = (on && wo[w4] != OOR) ? wo[w4] + c0 : OOR;
+                    gd[j][w4] = __builtin_amdgcn_raw_buffer_load_b128(rsDP, eo == OOR ? OOR : eo * 4u, 0, 0);
+                    ga[j][w4] = __builtin_amdgcn_raw_buffer_load_b32(rsAM, eo, 0, 0);
+                }
+                gy[j] = __builtin_amdgcn_raw_buffer_load_b128(rsY, (on && yo != OOR) ? (yo + c0) * 4u : OOR, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c0 = (half * nch + j) * 4;
+                if (c0 >= Cout) continue;
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float d = 0.0f;
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4)
+                        if (((ga[j][w4] >> (8 * i)) & 0xffu) == wk[w4]) d += __uint_as_float(gd[j][w4][i]);
+                    const float v = __uint_as_float(gy[j][i]);
+                    const float mean = CF[gs][0][c0 + i], inv = CF[gs][1][c0 + i], sc = CF[gs][2][c0 + i], sh = CF[gs][3][c0 + i];
+                    const float k1 = CF[gs][4][c0 + i], k2 = CF[gs][5][c0 + i], k3 = CF[gs][6][c0 + i];
+                    const float z = fmaf(sc, v, sh);
+                    if (!(z > 0.0f && z < 6.0f)) d = 0.0f;
+                    const float xh = (v - mean) * inv;
+                    o[i] = ok ? k1 * (d - k2 - xh * k3) : 0.0f;
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) D[wave][r][c0 + i] = o.v[i];
+                for (int i = 0; i < 4; ++i) D[wave][r][c0 + i] = o[i];
             }
         } else {
             for (int idx = lane; idx < 32 * Cout; idx += 64) {
-                const int r = idx / Cout, c = idx - r * Cout;
-                const int row = wrow0 + r;
-                D[wave][r][c] = row < r1 ? dy[(int64_t)row * Cout + c] : 0.0f;
+                const int rr = idx / Cout, c = idx - rr * Cout;
+                const int row2 = wrow0 + rr;
+                D[wave][rr][c] = row2 < r1 ? dy[(int64_t)row2 * Cout + c] : 0.0f;
             }
         }
-        __syncthreads();
+        stem_wave_sync();
 #pragma unroll
         for (int mm = 0; mm < 32; mm += 2) {
             const float a = P[wave][mm + lk][lcol];
@@ -333,7 +404,7 @@ int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B
         float* pf = reinterpret_cast<float*>(part);
         int rows_per = cdiv(cdiv(rows, STEM_NBLK), 128) * 128;
         const int nblk = cdiv(rows, rows_per);
-        hipLaunchKernelGGL(stem_bwd_mfma_kernel<false>, dim3(nblk), dim3(256), 0, st, x, dy, pf, B, T, H, W, Ho, Wo, Cout, rows,
+        hipLaunchKernelGGL((stem_bwd_mfma_kernel<false, 1>), dim3(nblk), dim3(256), 0, st, x, dy, pf, B, T, H, W, Ho, Wo, Cout, rows,
                            rows_per, StemBnBwd{});
         CDRL_LAUNCH_CHECK();
         CDRL_TRY(reduce_partials_f32(pf, nblk, (int64_t)27 * Cout, (int64_t)28 * Cout, dw, 0, st));
@@ -361,8 +432,12 @@ int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, con
     int rows_per = cdiv(cdiv(rows, STEM_NBLK), 128) * 128;
     const int nblk = cdiv(rows, rows_per);
     StemBnBwd bb{ps, y, stats, coef};
-    hipLaunchKernelGGL(stem_bwd_mfma_kernel<true>, dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
-                       rows_per, bb);
+    if (((Cout >> 2) + 1) / 2 <= 3)
+        hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, 3>), dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                           rows_per, bb);
+    else
+        hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, 4>), dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                           rows_per, bb);
     CDRL_LAUNCH_CHECK();
     CDRL_TRY(reduce_partials_f32(pf, nblk, (int64_t)27 * Cout, (int64_t)28 * Cout, dw, 0, st));
     return reduce_partials_f32(pf + 27 * Cout, nblk, Cout, (int64_t)28 * Cout, db, 0, st);

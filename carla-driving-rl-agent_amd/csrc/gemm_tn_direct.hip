@@ -124,27 +124,31 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
     }
     const uint32_t sA = (uint32_t)a.A.ld * 4u, sD = (uint32_t)a.D.ld * 4u, sY = (uint32_t)N * 4u;      // row strides in bytes
     float av0[U], dv0[U][NJW], yv0[DPRO ? U : 1][DPRO ? NJW : 1];
-    auto load_batch = [&](int64_t m0, float* av, float (*dv)[NJW], float (*yv)[DPRO ? NJW : 1]) {
-        const uint32_t mu = (uint32_t)__builtin_amdgcn_readfirstlane((int)m0);          // wave-uniform by construction
-        const bool full = m0 + 2 * U <= mend;
+    // row range of this wave as wave-uniform 32-bit scalars (the loop counter and the row offsets live in SGPRs)
+    const int mb = __builtin_amdgcn_readfirstlane((int)mbeg), me = __builtin_amdgcn_readfirstlane((int)mend);
+    // TAIL = false: all 2*U rows of the batch exist, no masks at all; TAIL = true: rows past the end of the share are
+    // masked per lane through the voffset (OR with the out-of-range bit: branch-free)
+    auto load_batch = [&](int m0, bool tail, float* av, float (*dv)[NJW], float (*yv)[DPRO ? NJW : 1]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t r = mu + 2 * u;
-            // tail batch: rows past the end of the share are masked per lane (the pair may straddle an odd end)
-            const bool mon = full || (int64_t)(m0 + 2 * u + lh) < mend;
-            av[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, mon ? voA : OOR, r * sA, 0));
+            const uint32_t r = (uint32_t)(m0 + 2 * u);
+            uint32_t msk = 0u;
+            if (tail) msk = (m0 + 2 * u + lh) < me ? 0u : OOR;
+            av[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, voA | msk, r * sA, 0));
 #pragma unroll
             for (int j = 0; j < NJW; ++j) {
-                dv[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rD, mon ? voD[j] : OOR, r * sD, 0));
-                if (DPRO) yv[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rY, mon ? voY[j] : OOR, r * sY, 0));
+                dv[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rD, voD[j] | msk, r * sD, 0));
+                if (DPRO) yv[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rY, voY[j] | msk, r * sY, 0));
             }
         }
+        // keep the whole batch of loads ahead of the MFMAs (left alone, the scheduler interleaves load / s_waitcnt 0 /
+        // MFMA one by one through two registers: every MFMA then pays a full memory latency)
+        __builtin_amdgcn_sched_barrier(0);
     };
-    auto mma_batch = [&](int64_t m0, const float* av, const float (*dv)[NJW], const float (*yv)[DPRO ? NJW : 1]) {
+    auto mma_batch = [&](int m0, const float* av, const float (*dv)[NJW], const float (*yv)[DPRO ? NJW : 1]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t m = m0 + 2 * u + lh;
-            const bool mon = m < mend;
+            const bool mon = (m0 + 2 * u + lh) < me;
             float x = av[u];
             if (APRO && mon && kon) x = fmaf(asc, x, ash);
 #pragma unroll
@@ -163,8 +167,26 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
             }
         }
     };
-    for (int64_t m0 = mbeg; m0 < mend; m0 += 2 * U) {
-        load_batch(m0, av0, dv0, yv0);
+    // steady state: two register sets, the loads of batch i+1 are in flight while the MFMAs of batch i run
+    float av1[U], dv1[U][NJW], yv1[DPRO ? U : 1][DPRO ? NJW : 1];
+    int m0 = mb;
+    bool has = m0 + 2 * U <= me;
+    if (has) load_batch(m0, false, av0, dv0, yv0);
+    while (has) {
+        const int m1 = m0 + 2 * U;
+        const bool has1 = m1 + 2 * U <= me;
+        if (has1) load_batch(m1, false, av1, dv1, yv1);
+        mma_batch(m0, av0, dv0, yv0);
+        m0 = m1;
+        if (!has1) break;
+        const int m2 = m1 + 2 * U;
+        has = m2 + 2 * U <= me;
+        if (has) load_batch(m2, false, av0, dv0, yv0);
+        mma_batch(m1, av1, dv1, yv1);
+        m0 = m2;
+    }
+    if (m0 < me) {
+        load_batch(m0, true, av0, dv0, yv0);
         mma_batch(m0, av0, dv0, yv0);
     }
     if (a.RS2 == 2) {       // fold the second half's accumulators into the first half's (fixed order)
@@ -250,9 +272,11 @@ static void launch_tnd_u(bool apro, bool dpro, dim3 grid, hipStream_t st, const 
 
 template <int NJW>
 static void launch_tnd(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a) {
-    static const int u = getenv("CDRL_TN_U") ? atoi(getenv("CDRL_TN_U")) : 8;
-    if (u >= 16 && !dpro) launch_tnd_u<NJW, 16>(apro, dpro, grid, st, a);      // (U = 16 with the D prologue spills)
-    else if (u >= 8) launch_tnd_u<NJW, 8>(apro, dpro, grid, st, a);
+    static const int u = getenv("CDRL_TN_U") ? atoi(getenv("CDRL_TN_U")) : 4;
+    static const int ud = getenv("CDRL_TN_UD") ? atoi(getenv("CDRL_TN_UD")) : 4;      // with the D prologue: U = 8 fills all 256 VGPRs
+    const int uu = dpro ? ud : u;
+    if (uu >= 16 && !dpro) launch_tnd_u<NJW, 16>(apro, dpro, grid, st, a);
+    else if (uu >= 8) launch_tnd_u<NJW, 8>(apro, dpro, grid, st, a);
     else launch_tnd_u<NJW, 4>(apro, dpro, grid, st, a);
 }
 
