@@ -370,13 +370,17 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) gf[9][i] += d.v[i];
             }
-            // gradient w.r.t. the depthwise input (transposed conv), masked by ReLU6 of the pre BN
-            for (int p = ty; p < P; p += CY) {
+            // gradient w.r.t. the depthwise input (transposed conv), masked by ReLU6 of the pre BN.
+            // Batches of DXU pixels: the L2-resident re-reads of y1 (for xhat1) of the NEXT batch are issued before the
+            // stores of this one and consumed after the next batch's taps.  gfx9 counts loads and stores in one in-order
+            // counter: with "load, taps, store, use" per pixel every iteration waited for its own store to complete
+            // (s_waitcnt vmcnt(0): ~21 exposed round trips per frame, 266 us for the 22x30 stride-2 block).
+            constexpr int DXU = (S == 2 && PRE) ? 4 : 1;      // (stride 1: deeper batches cost a wave of occupancy, measured slower)
+            auto taps = [&](int p) {
                 const int iy = (int)(((float)p + 0.5f) * invW), ix = p - iy * W;
-                VecF<VEC> acc, yre;
+                VecF<VEC> acc;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc.v[i] = 0.0f;
-                if (PRE) yre = vload<VEC>(xp + (int64_t)p * C);     // L2-resident re-read of y1 for xhat1, issued before the taps
                 if (S == 1) {
                     // D is zero-padded: da[iy][ix] = sum_k D[iy + pt - ky][ix + pl - kx] * w[k], no bounds tests
                     const int o0 = dbase + ((iy + pt + 1) * Wdp + ix + pl + 1) * cchunk + tx * VEC;
@@ -418,19 +422,48 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
                         }
                     }
                 }
-                const int64_t row = n * P + p;
-                if (PRE) {
+                if (PRE) {      // ReLU6 mask of BN1's output (the activated value is in tile A)
                     const VecF<VEC> av = vload<VEC>(&tile[((iy + 1) * Wp + ix + 1) * cchunk + tx * VEC]);
-                    const VecF<VEC> v = yre;
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
+                    for (int i = 0; i < VEC; ++i)
                         if (!(av.v[i] > 0.0f && av.v[i] < 6.0f)) acc.v[i] = 0.0f;
-                        const float xh = (v.v[i] - mean1.v[i]) * inv1.v[i];
-                        gb1[i] += (double)acc.v[i];
-                        gb2[i] += (double)acc.v[i] * (double)xh;
-                    }
                 }
-                vstore_view<VEC>(dx, row, c, 0, dx_al, acc);
+                return acc;
+            };
+            VecF<VEC> yb[DXU];
+            if (PRE) {
+#pragma unroll
+                for (int u = 0; u < DXU; ++u) yb[u] = vload<VEC>(xp + (int64_t)min(ty + u * CY, P - 1) * C);
+            }
+            for (int p0 = ty; p0 < P; p0 += CY * DXU) {
+                VecF<VEC> acc[DXU];
+#pragma unroll
+                for (int u = 0; u < DXU; ++u) {
+                    const int p = p0 + u * CY;
+                    if (p < P) acc[u] = taps(p);
+                }
+                if (PRE) {
+#pragma unroll
+                    for (int u = 0; u < DXU; ++u) {
+                        const int p = p0 + u * CY;
+                        if (p >= P) continue;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            const float xh = (yb[u].v[i] - mean1.v[i]) * inv1.v[i];
+                            gb1[i] += (double)acc[u].v[i];
+                            gb2[i] += (double)acc[u].v[i] * (double)xh;
+                        }
+                    }
+                    // next batch's y1 (clamped addresses: unconditional loads), ahead of this batch's stores
+#pragma unroll
+                    for (int u = 0; u < DXU; ++u) yb[u] = vload<VEC>(xp + (int64_t)min(p0 + (DXU + u) * CY, P - 1) * C);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int u = 0; u < DXU; ++u) {
+                    const int p = p0 + u * CY;
+                    if (p < P) vstore_view<VEC>(dx, n * P + p, c, 0, dx_al, acc[u]);
+                }
             }
         }
     }

@@ -267,6 +267,17 @@ private:
     int next_slot(hipStream_t st);                       // main: claim a scratch slot (waits for its last side job)
     hipStream_t fork_side(hipStream_t st);               // main -> side dependency for the current slot
     int done_side(hipStream_t side);                     // side job of the current slot finished
+    // Side jobs that hang off the main stream but are not urgent (partial reductions of bias / depthwise-filter gradients)
+    // are queued and enqueued by the NEXT fork_side (or join_side): one event record on the critical stream serves
+    // several side jobs (every record is a barrier packet between two dependent main-stream kernels).
+    struct Deferred {
+        int slot;
+        std::function<int(hipStream_t)> fn;
+    };
+    std::vector<Deferred> deferred_;
+    int deferred_rc_ = 0;
+    int defer_side(hipStream_t st, std::function<int(hipStream_t)> fn);
+    void flush_deferred();
     int join_side(hipStream_t st);
 
     std::vector<Op> trunk_ops_, policy_ops_, value_ops_, old_policy_ops_;

@@ -119,11 +119,40 @@ hipStream_t Learner::fork_side(hipStream_t st) {
     if (g_diag_noev & 2) return side_;
     if (hipEventRecord(ev_main_[slot_], st) != hipSuccess) return st;
     if (hipStreamWaitEvent(side_, ev_main_[slot_], 0) != hipSuccess) return st;
+    flush_deferred();
     return side_;
+}
+
+void Learner::flush_deferred() {
+    for (Deferred& d : deferred_) {
+        const int rc = d.fn(side_);
+        if (rc != 0 && deferred_rc_ == 0) deferred_rc_ = rc;
+        if (d.slot != slot_) {      // (a job of the current slot is covered by the done_side() that follows)
+            if (hipEventRecord(ev_side_[d.slot], side_) != hipSuccess && deferred_rc_ == 0) deferred_rc_ = -3;
+            slot_used_[d.slot] = true;
+        }
+    }
+    deferred_.clear();
+}
+
+int Learner::defer_side(hipStream_t st, std::function<int(hipStream_t)> fn) {
+    static const bool on = !(getenv("CDRL_DEFER_SIDE") && atoi(getenv("CDRL_DEFER_SIDE")) == 0);
+    if (!side_enabled_ || !on || (g_diag_noev & 2)) {
+        hipStream_t side = fork_side(st);
+        CDRL_TRY(fn(side));
+        return done_side(side);
+    }
+    deferred_.push_back(Deferred{slot_, std::move(fn)});
+    return 0;
 }
 
 int Learner::done_side(hipStream_t side) {
     if (!side_enabled_ || side != side_) return 0;
+    if (deferred_rc_ != 0) {
+        const int rc = deferred_rc_;
+        deferred_rc_ = 0;
+        return rc;
+    }
     if (g_diag_noev & 4) return 0;
     CDRL_HIP(hipEventRecord(ev_side_[slot_], side_));
     slot_used_[slot_] = true;
@@ -132,6 +161,10 @@ int Learner::done_side(hipStream_t side) {
 
 int Learner::join_side(hipStream_t st) {
     if (!side_enabled_) return 0;
+    if (!deferred_.empty()) {
+        hipStream_t side = fork_side(st);       // flushes the queue
+        CDRL_TRY(done_side(side));
+    }
     CDRL_HIP(hipEventRecord(ev_join_, side_));
     CDRL_HIP(hipStreamWaitEvent(st, ev_join_, 0));
     if (aux_pending_) {
@@ -316,9 +349,9 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             PwBnBwd pb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act, part2s_[slot_]};
             CDRL_TRY(pw_nn(dz, nullptr, w.p, 1, Cout, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
                            fuse.bwd_epi_stats, scr_main_.part, st, &pb));
-            side = fork_side(st);       // bias gradient = column sums of the (virtual) dy, reduced from the GEMM's partials
-            CDRL_TRY(reduce_partials(part2s_[slot_], G * nbp_bwd, Cout, Cout, b.g, 0, side));
-            return done_side(side);
+            // bias gradient = column sums of the (virtual) dy, reduced from the GEMM's partials: rides on the next fork
+            double* p2 = part2s_[slot_];
+            return defer_side(st, [=](hipStream_t sd) -> int { return reduce_partials(p2, G * nbp_bwd, Cout, Cout, b.g, 0, sd); });
         }
         float* dy = dys_[slot_];
         // side stream: bias gradient (column sums of dy, reduced per block by bn_bwd_apply) + filter gradient
@@ -427,9 +460,9 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
             double* pw = fparts_[slot_];
             const View dx = pre ? make_view(dys_[slot_], C) : din;
             CDRL_TRY(dwf_bwd(x, stats1, dout.p, y2, stats2, coef2, w.p, dx, scr_main_.part, pw, G, B, H, W, C, stride, st));
-            hipStream_t side = fork_side(st);
-            CDRL_TRY(reduce_partials2(pw, G * nbf, 9 * C, C, (int64_t)10 * C, w.g, b.g, 0, side));
-            return done_side(side);
+            return defer_side(st, [=](hipStream_t sd) -> int {
+                return reduce_partials2(pw, G * nbf, 9 * C, C, (int64_t)10 * C, w.g, b.g, 0, sd);
+            });
         };
         ops.push_back(op);
     }
