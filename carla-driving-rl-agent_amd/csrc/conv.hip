@@ -819,19 +819,30 @@ __global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const float* __rest
                 best.v[i] = -INFINITY;
                 bi[i] = 0;
             }
+            // all 9 window loads first, at clamped (always valid) addresses; validity is applied afterwards.  With the
+            // bounds tests around the loads every load sat in its own branch with its own s_waitcnt: 9 round trips per row.
+            VecF<VEC> xw[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = min(max(oy * 2 + ky - pt, 0), H - 1);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = min(max(ox * 2 + kx - pl, 0), W - 1);
+                    xw[ky * 3 + kx] = vload<VEC>(y + (((int64_t)n * H + iy) * W + ix) * C + c0);
+                }
+            }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = oy * 2 + ky - pt;
-                if (iy < 0 || iy >= H) continue;
+                const bool vy = iy >= 0 && iy < H;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int ix = ox * 2 + kx - pl;
-                    if (ix < 0 || ix >= W) continue;
-                    const VecF<VEC> x = vload<VEC>(y + (((int64_t)n * H + iy) * W + ix) * C + c0);
+                    const bool v = vy && ix >= 0 && ix < W;
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
-                        const float a = fminf(fmaxf(fmaf(sc.v[i], x.v[i], sh.v[i]), 0.0f), 6.0f);
-                        if (a > best.v[i]) {
+                        const float a = fminf(fmaxf(fmaf(sc.v[i], xw[ky * 3 + kx].v[i], sh.v[i]), 0.0f), 6.0f);
+                        if (v && a > best.v[i]) {
                             best.v[i] = a;
                             bi[i] = ky * 3 + kx;
                         }

@@ -629,8 +629,11 @@ __global__ void __launch_bounds__(256) tn_reduce_v4_kernel(const float* __restri
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
+                // clamped address + select AFTER the load: a conditional load becomes a branch with its own s_waitcnt
+                // (the 8 loads were issued one at a time)
                 const int p = p0 + u * TY;
-                v[u] = p < nsplit ? *reinterpret_cast<const float4*>(src + (int64_t)p * stride) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                v[u] = *reinterpret_cast<const float4*>(src + (int64_t)min(p, nsplit - 1) * stride);
+                if (p >= nsplit) v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -671,7 +674,10 @@ __global__ void __launch_bounds__(256) tn_reduce_few_kernel(const float* __restr
         float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            v[u] = (p0 + u) < nsplit ? *reinterpret_cast<const float4*>(part + (int64_t)(p0 + u) * stride + i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        {
+            v[u] = *reinterpret_cast<const float4*>(part + (int64_t)min(p0 + u, nsplit - 1) * stride + i);
+            if (p0 + u >= nsplit) v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             s0 += (double)v[u].x;
