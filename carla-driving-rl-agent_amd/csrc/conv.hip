@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256) stem_fwd_scalar_kernel(const float* __res
 // Stem conv with the following BatchNorm's statistics in the epilogue: one workgroup = a contiguous pixel range of ONE
 // time slice, block = (Cout/4 channel lanes, pixel lanes); per-thread (sum, sum of squares) in double, LDS fold over the
 // pixel lanes, one partial row per workgroup in bn_finalize's [T][nb][2][Cout] layout (no second pass over the 255 MB y).
+template <int NP>
 __global__ void __launch_bounds__(256) stem_fwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              double* __restrict__ part, int B, int T, int H, int W, int Ho,
@@ -93,30 +94,66 @@ __global__ void __launch_bounds__(256) stem_fwd_stats_kernel(const float* __rest
     const int r0 = blockIdx.x * rb, r1 = min(r0 + rb, Mg);
     const int co = tx * 4;
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int r = r0 + ty; r < r1; r += CY) {
-        const int ox = r % Wo;
-        const int t2 = r / Wo;
-        const int oy = t2 % Ho;
-        const int b = t2 / Ho;                                     // frame inside the time slice g: f = g*B + b
-        const float* xp = x + ((((int64_t)b * T + g) * H + 2 * oy) * W + 2 * ox) * 3;
-        float4 acc = *reinterpret_cast<const float4*>(&ws[27 * Cout + co]);
+    // NP output pixels per thread and iteration: their 27-float input windows (3 rows x 9 contiguous floats, 8-byte
+    // aligned -> 4 x 8 B + 4 B per row) are all requested before the first FMA, and every filter tap read from LDS feeds
+    // NP pixels.  One pixel per iteration exposed one memory round trip per pixel (62 per thread) and spent as much
+    // LDS bandwidth on the taps (27 ds_read_b128 per pixel) as the kernel needs HBM time.
+    const float4 bq = *reinterpret_cast<const float4*>(&ws[27 * Cout + co]);
+    const bool x8 = (reinterpret_cast<uintptr_t>(x) & 7) == 0 && ((W * 3) % 2) == 0;
+    for (int rr = r0 + ty; rr < r1; rr += CY * NP) {
+        float xv[NP][27];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int u = 0; u < NP; ++u) {
+            const int r = min(rr + u * CY, r1 - 1);                  // clamped: unconditional loads
+            const int ox = r % Wo;
+            const int t2 = r / Wo;
+            const int oy = t2 % Ho;
+            const int b = t2 / Ho;                                 // frame inside the time slice g: f = g*B + b
+            const float* xp = x + ((((int64_t)b * T + g) * H + 2 * oy) * W + 2 * ox) * 3;
+            if (x8) {
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const float xv = xp[(int64_t)ky * W * 3 + j];
-                const float4 wv = *reinterpret_cast<const float4*>(&ws[(ky * 9 + j) * Cout + co]);
-                acc.x = fmaf(xv, wv.x, acc.x);
-                acc.y = fmaf(xv, wv.y, acc.y);
-                acc.z = fmaf(xv, wv.z, acc.z);
-                acc.w = fmaf(xv, wv.w, acc.w);
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* xr = xp + (int64_t)ky * W * 3;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float2 t = *reinterpret_cast<const float2*>(xr + 2 * j);
+                        xv[u][ky * 9 + 2 * j] = t.x;
+                        xv[u][ky * 9 + 2 * j + 1] = t.y;
+                    }
+                    xv[u][ky * 9 + 8] = xr[8];
+                }
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) xv[u][ky * 9 + j] = xp[(int64_t)ky * W * 3 + j];
             }
-        *reinterpret_cast<float4*>(&y[((int64_t)g * Mg + r) * Cout + co]) = acc;
-        const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+        }
+        float4 acc[NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            s[i] += (double)a4[i];
-            q[i] += (double)a4[i] * (double)a4[i];
+        for (int u = 0; u < NP; ++u) acc[u] = bq;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const float4 wv = *reinterpret_cast<const float4*>(&ws[k * Cout + co]);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                acc[u].x = fmaf(xv[u][k], wv.x, acc[u].x);
+                acc[u].y = fmaf(xv[u][k], wv.y, acc[u].y);
+                acc[u].z = fmaf(xv[u][k], wv.z, acc[u].z);
+                acc[u].w = fmaf(xv[u][k], wv.w, acc[u].w);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int r = rr + u * CY;
+            if (r >= r1) continue;
+            *reinterpret_cast<float4*>(&y[((int64_t)g * Mg + r) * Cout + co]) = acc[u];
+            const float a4[4] = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[i] += (double)a4[i];
+                q[i] += (double)a4[i] * (double)a4[i];
+            }
         }
     }
     __syncthreads();
@@ -158,7 +195,10 @@ int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, 
     size_t lds = (size_t)(27 * Cout + Cout) * sizeof(float);
     const size_t red = (size_t)8 * cy * cx * sizeof(double);
     if (lds < red) lds = red;
-    hipLaunchKernelGGL(stem_fwd_stats_kernel, dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
+    static const int np = getenv("CDRL_STEM_NP") ? atoi(getenv("CDRL_STEM_NP")) : 4;
+    if (np >= 4) hipLaunchKernelGGL(stem_fwd_stats_kernel<4>, dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
+    else if (np >= 2) hipLaunchKernelGGL(stem_fwd_stats_kernel<2>, dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
+    else hipLaunchKernelGGL(stem_fwd_stats_kernel<1>, dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

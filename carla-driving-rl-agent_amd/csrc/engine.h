@@ -1,9 +1,12 @@
 // Learner engine: owns the layer graph of CARLANetwork (trunk + policy / old-policy / value
 // heads), the flat parameter-arena layout and the workspace plan for one batch size.
 #pragma once
+#include <condition_variable>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -258,6 +261,26 @@ private:
     hipStream_t side_ = nullptr;
     hipStream_t aux_ = nullptr;          // feature nets + small GRUs (forward and backward)
     bool aux_pending_ = false;
+    // Optional second host thread that ENQUEUES the ~340 launches per update-step of the small-modality nets (opt-in,
+    // CDRL_AUX_THREAD=1): the single-threaded enqueue of an update-step costs 12.3 ms of host time (8 us per launch incl.
+    // the event traffic), which bounds the step for small images.
+    struct AuxWorker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<int()> task;
+        bool has_task = false, busy = false, stop = false;
+        int rc = 0, device = 0;
+        std::string err;
+        explicit AuxWorker(int dev);
+        ~AuxWorker();
+        void submit(std::function<int()> fn);
+        int wait();             // blocks until the submitted task has been enqueued; returns its status
+        void loop();
+    };
+    std::unique_ptr<AuxWorker> aux_worker_;
+    bool aux_inflight_ = false;
+    int aux_wait();
     hipEvent_t ev_main_[NSLOT] = {};
     hipEvent_t ev_side_[NSLOT] = {};
     hipEvent_t ev_join_ = nullptr;
