@@ -468,6 +468,10 @@ int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, con
     }
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int rows = B * T * Ho * Wo;
+    if ((int64_t)rows * Cout * 4 >= (1ll << 31)) {       // 32-bit buffer-descriptor offsets
+        set_error("stem_bwd_filter_fused: conv output of 2 GB or more is not supported (rows=%d)", rows);
+        return -1;
+    }
     float* pf = reinterpret_cast<float*>(part);
     int rows_per = cdiv(cdiv(rows, STEM_NBLK), 128) * 128;
     const int nblk = cdiv(rows, rows_per);

@@ -347,80 +347,108 @@ __global__ void __launch_bounds__(256, 2) gemm_nn_rt_kernel(View A, const float*
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    float4 ra[NA4], rb[NB4];
+    // Three-stage pipeline: slice s is multiplied out of LDS while slice s+1 waits in one register set and the global
+    // loads of slice s+2 are issued into the other.  With the loads issued only one slice ahead (1.3 us of MFMA work) every
+    // slice waited ~1 us for HBM at one workgroup per CU: 29 us for the 12288 x 232 x 232 GEMM whose MFMA time is 9 us.
+    float4 ra[2][NA4], rb[2][NB4];
     const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
-    auto load_slice = [&](int k0) {
+    auto load_slice = [&](int k0, float4* qa, float4* qb) {
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
             const int idx = tid + 256 * i;
             const int r = idx >> 3, kk = (idx & 7) * 4;
             const int64_t m = m0 + r;
-            ra[i] = (m < M && (k0 + kk) < K) ? *reinterpret_cast<const float4*>(&A.p[m * A.ld + A.coff + k0 + kk]) : z4;
+            qa[i] = (m < M && (k0 + kk) < K) ? *reinterpret_cast<const float4*>(&A.p[m * A.ld + A.coff + k0 + kk]) : z4;
         }
 #pragma unroll
         for (int i = 0; i < NB4; ++i) {
             const int idx = tid + 256 * i;
             if (BT) {       // W^T: contiguous along k
                 const int kk = (idx & 7) * 4, nn = idx >> 3;
-                rb[i] = ((k0 + kk) < K && (n0 + nn) < N)
+                qb[i] = ((k0 + kk) < K && (n0 + nn) < N)
                             ? *reinterpret_cast<const float4*>(&Bp[(int64_t)(k0 + kk) * sbk + (int64_t)(n0 + nn) * sbn]) : z4;
             } else {        // W: contiguous along n
                 const int kk = idx >> 5, nn = (idx & 31) * 4;
-                rb[i] = ((k0 + kk) < K && (n0 + nn) < N)
+                qb[i] = ((k0 + kk) < K && (n0 + nn) < N)
                             ? *reinterpret_cast<const float4*>(&Bp[(int64_t)(k0 + kk) * sbk + (int64_t)(n0 + nn) * sbn]) : z4;
             }
         }
     };
-    auto store_slice = [&](int buf) {
+    auto store_slice = [&](int buf, const float4* qa, const float4* qb) {
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
             const int idx = tid + 256 * i;
             const int r = idx >> 3, kk = (idx & 7) * 4;
-            As[buf][r][kk] = ra[i].x;
-            As[buf][r][kk + 1] = ra[i].y;
-            As[buf][r][kk + 2] = ra[i].z;
-            As[buf][r][kk + 3] = ra[i].w;
+            As[buf][r][kk] = qa[i].x;
+            As[buf][r][kk + 1] = qa[i].y;
+            As[buf][r][kk + 2] = qa[i].z;
+            As[buf][r][kk + 3] = qa[i].w;
         }
 #pragma unroll
         for (int i = 0; i < NB4; ++i) {
             const int idx = tid + 256 * i;
             if (BT) {
                 const int kk = (idx & 7) * 4, nn = idx >> 3;
-                Bs[buf][kk][nn] = rb[i].x;
-                Bs[buf][kk + 1][nn] = rb[i].y;
-                Bs[buf][kk + 2][nn] = rb[i].z;
-                Bs[buf][kk + 3][nn] = rb[i].w;
+                Bs[buf][kk][nn] = qb[i].x;
+                Bs[buf][kk + 1][nn] = qb[i].y;
+                Bs[buf][kk + 2][nn] = qb[i].z;
+                Bs[buf][kk + 3][nn] = qb[i].w;
             } else {
                 const int kk = idx >> 5, nn = (idx & 31) * 4;
-                Bs[buf][kk][nn] = rb[i].x;
-                Bs[buf][kk][nn + 1] = rb[i].y;
-                Bs[buf][kk][nn + 2] = rb[i].z;
-                Bs[buf][kk][nn + 3] = rb[i].w;
+                Bs[buf][kk][nn] = qb[i].x;
+                Bs[buf][kk][nn + 1] = qb[i].y;
+                Bs[buf][kk][nn + 2] = qb[i].z;
+                Bs[buf][kk][nn + 3] = qb[i].w;
+            }
+        }
+    };
+    auto mma_slice = [&](int buf, int k0) {
+        const int kmax = min(BK, K - k0);        // K % 4 == 0 -> even
+        if (kmax == BK) {
+#pragma unroll
+            for (int h = 0; h < BK; h += 16) {
+                float bf[8], af[8][RT];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    bf[q] = Bs[buf][h + 2 * q + lk][wave * 32 + lrow];
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) af[q][i] = As[buf][i * 32 + lrow][h + 2 * q + lk];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i], bf[q], acc[i], 0, 0, 0);
+            }
+        } else {
+            for (int kk = 0; kk < kmax; kk += 2) {
+                const float b = Bs[buf][kk + lk][wave * 32 + lrow];
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const float a = As[buf][i * 32 + lrow][kk + lk];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                }
             }
         }
     };
 
-    load_slice(0);
-    store_slice(0);
+    load_slice(0, ra[0], rb[0]);
+    if (BK < K) load_slice(BK, ra[1], rb[1]);
+    store_slice(0, ra[0], rb[0]);
     __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        const bool more = (k0 + BK) < K;
-        if (more) load_slice(k0 + BK);
-        const int kmax = min(BK, K - k0);        // K % 4 == 0 -> even
-#pragma unroll 4
-        for (int kk = 0; kk < kmax; kk += 2) {
-            const float b = Bs[buf][kk + lk][wave * 32 + lrow];
-#pragma unroll
-            for (int i = 0; i < RT; ++i) {
-                const float a = As[buf][i * 32 + lrow][kk + lk];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-            }
-        }
-        if (more) store_slice(buf ^ 1);
+    // invariant at the top of step s (k0 = s*BK): LDS[s & 1] holds slice s, register set (s+1) & 1 holds slice s+1
+    for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+        // even step: LDS 0, next slice in set 1, fetch slice s+2 into set 0
+        if (k0 + 2 * BK < K) load_slice(k0 + 2 * BK, ra[0], rb[0]);
+        mma_slice(0, k0);
+        if (k0 + BK < K) store_slice(1, ra[1], rb[1]);
         __syncthreads();
-        buf ^= 1;
+        if (k0 + BK >= K) break;
+        // odd step: LDS 1, next slice in set 0, fetch slice s+2 into set 1
+        if (k0 + 3 * BK < K) load_slice(k0 + 3 * BK, ra[1], rb[1]);
+        mma_slice(1, k0 + BK);
+        if (k0 + 2 * BK < K) store_slice(0, ra[0], rb[0]);
+        __syncthreads();
     }
     const int n = n0 + wave * 32 + lrow;
     if (n >= N) return;
