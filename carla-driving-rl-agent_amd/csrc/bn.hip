@@ -59,7 +59,7 @@ int colsum(View x, int rows, int C, double* part, hipStream_t st) {
 // (a serial chain of nb dependent L2 round trips was 10 us of a 13 us kernel) and the lanes are combined through LDS
 // in a fixed order -> deterministic.
 #define FIN_CX 8
-#define FIN_PY 128
+#define FIN_PY_MAX 128
 #define FIN_U 8
 
 // (sum_b p0[b*step], sum_b p1[b*step]) over b = first, first+stride, ... < count; 2*FIN_U loads in flight
@@ -83,9 +83,18 @@ __device__ __forceinline__ void strided_sum2(const double* __restrict__ p0, cons
     }
 }
 
+// partial lanes of the finalize blocks (x 8 channel lanes = threads per block).  A 1024-thread block needs 16 free wave
+// slots on one CU before it starts; in the backward pass the side stream keeps the CUs busy and the finalize kernels of the
+// critical stream then queue behind it (outliers of 74 us for a 5.6 us kernel).  CDRL_FIN_PY = 128 | 64 | 32.
+static int fin_py() {
+    static const int v = getenv("CDRL_FIN_PY") ? atoi(getenv("CDRL_FIN_PY")) : 64;
+    return v >= 128 ? 128 : (v >= 64 ? 64 : 32);
+}
+
 __device__ __forceinline__ int fin_group_slots(int G) { return G <= 1 ? 1 : (G <= 2 ? 2 : (G <= 4 ? 4 : 8)); }
 
 // sums the [G][nb][2][C] partials of channel c for the groups g0 .. g0+Gp-1 into red[group slot][2][FIN_CX]
+template <int FIN_PY>
 __device__ __forceinline__ void fin_reduce(const double* __restrict__ part, int nb, int G, int C, int c, bool ok, int g0, int Gp,
                                            double (*sm)[FIN_PY][FIN_CX], double (*red)[2][FIN_CX]) {
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -108,7 +117,8 @@ __device__ __forceinline__ void fin_reduce(const double* __restrict__ part, int 
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(1024) bn_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
+template <int FIN_PY>
+__global__ void __launch_bounds__(FIN_CX * FIN_PY) bn_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ mov_mean, float* __restrict__ mov_var,
                                                           int bessel, int training, float* __restrict__ stats) {
@@ -143,7 +153,7 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const double* __restr
     const float corr = (bessel && Mg > 1) ? (float)(n / (n - 1.0)) : 1.0f;
     const int Gp = fin_group_slots(G);
     for (int g0 = 0; g0 < G; g0 += Gp) {
-        fin_reduce(part, nb, G, C, c, ok, g0, Gp, sm, red);
+        fin_reduce<FIN_PY>(part, nb, G, C, c, ok, g0, Gp, sm, red);
         if (ok && ty == 0) {
             const int ng = min(Gp, G - g0);
             for (int gg = 0; gg < ng; ++gg) {
@@ -172,8 +182,11 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const double* __restr
 
 int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* gamma, const float* beta,
                 float* mov_mean, float* mov_var, int bessel, int training, float* stats, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CX)), dim3(FIN_CX, FIN_PY), 0, st, part, nb, G, Mg, C, gamma,
-                       beta, mov_mean, mov_var, bessel, training, stats);
+    // block = (8 channel lanes, fin_py() partial lanes)
+    const int py = fin_py();
+    if (py == 128) hipLaunchKernelGGL(bn_finalize_kernel<128>, dim3(cdiv(C, FIN_CX)), dim3(FIN_CX, 128), 0, st, part, nb, G, Mg, C, gamma, beta, mov_mean, mov_var, bessel, training, stats);
+    else if (py == 64) hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3(cdiv(C, FIN_CX)), dim3(FIN_CX, 64), 0, st, part, nb, G, Mg, C, gamma, beta, mov_mean, mov_var, bessel, training, stats);
+    else hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3(cdiv(C, FIN_CX)), dim3(FIN_CX, 32), 0, st, part, nb, G, Mg, C, gamma, beta, mov_mean, mov_var, bessel, training, stats);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -341,7 +354,8 @@ int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_
     return launch_vcolreduce<2, PoolBnReduceF>(G, frames_per_group * ps.Ho * ps.Wo, C, part, st, NB_STATS, ps, y, stats, G * C, C);
 }
 
-__global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg,
+template <int FIN_PY>
+__global__ void __launch_bounds__(FIN_CX * FIN_PY) bn_bwd_finalize_kernel(const double* __restrict__ part, int nb, int G, int Mg,
                                                               int C, const float* __restrict__ stats,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef) {
@@ -362,7 +376,7 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const double* __r
 #pragma unroll
             for (int gg = 0; gg < 8; ++gg) k1v[gg] = (gg < Gp && g0 + gg < G) ? stats[2 * GC + (g0 + gg) * C + c] : 0.0f;
         }
-        fin_reduce(part, nb, G, C, c, ok, g0, Gp, sm, red);
+        fin_reduce<FIN_PY>(part, nb, G, C, c, ok, g0, Gp, sm, red);
         if (ok && ty == 0) {
             const int ng = min(Gp, G - g0);
 #pragma unroll
@@ -387,8 +401,10 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const double* __r
 
 int bn_bwd_finalize(const double* part, int nb, int G, int Mg, int C, const float* stats, float* dgamma,
                     float* dbeta, float* coef, hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CX)), dim3(FIN_CX, FIN_PY), 0, st, part, nb, G, Mg, C,
-                       stats, dgamma, dbeta, coef);
+    const int py = fin_py();
+    if (py == 128) hipLaunchKernelGGL(bn_bwd_finalize_kernel<128>, dim3(cdiv(C, FIN_CX)), dim3(FIN_CX, 128), 0, st, part, nb, G, Mg, C, stats, dgamma, dbeta, coef);
+    else if (py == 64) hipLaunchKernelGGL(bn_bwd_finalize_kernel<64>, dim3(cdiv(C, FIN_CX)), dim3(FIN_CX, 64), 0, st, part, nb, G, Mg, C, stats, dgamma, dbeta, coef);
+    else hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, dim3(cdiv(C, FIN_CX)), dim3(FIN_CX, 32), 0, st, part, nb, G, Mg, C, stats, dgamma, dbeta, coef);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -447,22 +463,26 @@ int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const 
 // outputs (n/16 workgroups would leave most of the 256 CUs idle while each workgroup walks hundreds of KB alone: the
 // 1392-output / 2048-partial reductions of the first unit took ~300 us that way).
 template <int CX>
-__global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __restrict__ part, int nparts, int n,
-                                                              int64_t stride, float* __restrict__ out, int accumulate,
-                                                              int n1, float* __restrict__ out2) {
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __restrict__ part, int nparts, int n,
+                                                             int64_t stride, float* __restrict__ out, int accumulate,
+                                                             int n1, float* __restrict__ out2) {
     // columns [0, n1) go to out, [n1, n) to out2 (two parameter tensors reduced by one launch, e.g. filter + bias)
-    constexpr int PY = 1024 / CX;
+    // 256-thread blocks: these reductions run on the side stream next to the main stream's kernels, and a 1024-thread
+    // block needs 16 free wave slots on ONE CU before it can start (measured 21 us per launch in the step, 5 us alone).
+    constexpr int PY = 256 / CX;
     __shared__ double sm[PY][CX];
-    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tx = threadIdx.x % CX, ty = threadIdx.x / CX;
     const int i = blockIdx.x * CX + tx;
     double s = 0.0;
     if (i < n) {
-        for (int p0 = ty; p0 < nparts; p0 += PY * FIN_U) {      // FIN_U independent loads in flight
+        const double* src = part + i;
+        for (int p0 = ty; p0 < nparts; p0 += PY * FIN_U) {      // FIN_U independent loads in flight (clamped addresses)
             double v[FIN_U];
 #pragma unroll
             for (int u = 0; u < FIN_U; ++u) {
                 const int p = p0 + u * PY;
-                v[u] = p < nparts ? part[(int64_t)p * stride + i] : 0.0;
+                v[u] = src[(int64_t)min(p, nparts - 1) * stride];
+                if (p >= nparts) v[u] = 0.0;
             }
 #pragma unroll
             for (int u = 0; u < FIN_U; ++u) s += v[u];
@@ -470,19 +490,11 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(const double* __r
     }
     sm[ty][tx] = s;
     __syncthreads();
-    // fold the PY lane sums: 64 lanes first (one per ty < 64), then lane 0 -- fixed order
-    if (PY > 64) {
-        if (ty < 64) {
-            double a = 0.0;
-            for (int y = ty; y < PY; y += 64) a += sm[y][tx];
-            sm[ty][tx] = a;
-        }
-        __syncthreads();
-    }
-    if (i < n && ty == 0) {
+    // fold the PY lane sums in a fixed order
+    if (ty == 0 && i < n) {
         s = 0.0;
-#pragma unroll
-        for (int y = 0; y < 64; ++y) s += sm[y][tx];
+#pragma unroll 8
+        for (int y = 0; y < PY; ++y) s += sm[y][tx];
         float* o = i < n1 ? &out[i] : &out2[i - n1];
         *o = accumulate ? *o + (float)s : (float)s;
     }
@@ -492,9 +504,9 @@ int reduce_partials2(const double* part, int nparts, int n1, int n2, int64_t str
                      hipStream_t st) {
     const int n = n1 + n2;
     if (cdiv(n, 16) >= 128 || nparts <= 64)
-        hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3(cdiv(n, 16)), dim3(16, 64), 0, st, part, nparts, n, stride, out1, accumulate, n1, out2);
+        hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3(cdiv(n, 16)), dim3(256), 0, st, part, nparts, n, stride, out1, accumulate, n1, out2);
     else
-        hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(cdiv(n, 4)), dim3(4, 256), 0, st, part, nparts, n, stride, out1, accumulate, n1, out2);
+        hipLaunchKernelGGL(reduce_partials_kernel<4>, dim3(cdiv(n, 4)), dim3(256), 0, st, part, nparts, n, stride, out1, accumulate, n1, out2);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
