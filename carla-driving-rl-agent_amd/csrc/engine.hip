@@ -750,11 +750,14 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         fused_dw_ = !(e && atoi(e) == 0);
         const char* e2 = getenv("CDRL_FUSED_PW");       // 0 -> generic tiled GEMM + separate BN passes around the 1x1 convs
         fused_pw_ = !(e2 && atoi(e2) == 0);
-        fused_pw_wide_ = e2 && atoi(e2) == 2;
+        fused_pw_wide_ = !(e2 && atoi(e2) == 1);        // K, N = 232 (stage-2 units) on the fused path too; 1 -> narrow layers only
         // BN-backward apply as GEMM operand prologue: bit 0 -> for the unit's first 1x1 conv (bn1), bit 1 -> for the second
         // (bn3, gathered through the shuffle map); 0 -> separate apply passes with a materialised dy
         const char* e3 = getenv("CDRL_FUSED_BB");
-        fused_bb_ = e3 ? atoi(e3) : 1;      // measured: 1 -> 25.5, 0 -> 25.8, 3 -> 26.0, 2 -> 26.2 ms/update-step
+        // measured at v19: 1 -> 25.5, 0 -> 25.8, 3 -> 26.0, 2 -> 26.2 ms/update-step; re-measured at v29 (buffer-load filter
+        // gradient: the shuffle gather costs nothing there any more): 3 -> 20.66, 1 -> 20.80, 0 -> 21.0, 2 -> 21.3, and with
+        // the wide fused pointwise path 3 -> 20.21
+        fused_bb_ = e3 ? atoi(e3) : 3;
     }
 
     // ---- stem (core/architectures.py:159-161)
@@ -876,8 +879,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 Tens y2 = tens(rows_out, mid, false), a2 = tens(rows_out, mid);
                 Tens y3 = tens(rows_out, main_out, false);
                 // BatchNorm work folded into the 1x1-conv GEMMs (K, N <= 128: stages 0 and 1)
-                // (the K, N = 232 variants of stage 2 run at one workgroup per CU -- 116 W-fragment VGPRs per wave -- and were
-                //  measured 0.15 ms/update-step slower than the tiled GEMM + separate BN passes: opt-in via CDRL_FUSED_PW=2)
+                // (the K, N = 232 variants of stage 2 run at one workgroup per CU -- 116 W-fragment VGPRs per wave; slower than the
+                //  tiled GEMM + separate BN passes at v19 (+0.15 ms), faster at v29 (-0.24 ms/update-step): CDRL_FUSED_PW=1 -> off)
                 const bool fpw = fused_dw_ && fused_pw_ && (fused_pw_wide_ || (mid <= 128 && main_in <= 128 && main_out <= 128)) &&
                                  pw_nn_supported(X.v(main_off), mid, main_in) &&
                                  pw_nn_supported(y2.v(), main_out, mid) && pw_nn_supported(y3.v(), mid, main_out) &&
