@@ -155,26 +155,52 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
     const bool dz_vec = PRO == 2 && !a.a_shuffle && (a.A.ld % 2 == 0) && (a.A.coff % 2 == 0) &&
                         ((reinterpret_cast<uintptr_t>(a.A.p) & 7) == 0);
     float2 ra0[NA2], ry0[PRO == 2 ? NA2 : 1];
+    // Tile loads through buffer descriptors: a thread's rows of a tile are r = tid / KSM + (256 / KSM) * i, so the row
+    // offset of load i is wave-uniform (SGPR soffset) and the thread's byte offset inside it is a constant voffset --
+    // no 64-bit address arithmetic and no address registers (the <64, 4, 2, 2> variant spilled 41 VGPRs with flat loads).
+    // Masked lanes (k beyond K, rows beyond the group in the last tile) point out of range and read 0.
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    constexpr int RSTEP = 256 / KSM;                 // rows between consecutive loads of a thread
+    const uint32_t OOR = 0x80000000u;               // host checks that the operands are < 2 GB
+    const int r_t = tid / KSM;
+    const int64_t Mtot = (int64_t)a.G * a.Mg;
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A.p), 0, (int)(Mtot * a.A.ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(PRO == 2 ? a.a_y : a.A.p), 0, (int)(Mtot * (PRO == 2 ? K : a.A.ld) * 4), 0x00020000);
+    uint32_t voA0 = OOR, voA1 = OOR, voY = OOR;
+    if (kon) {
+        if (PRO == 2) {
+            voA0 = (uint32_t)(r_t * a.A.ld + dcol0) * 4u;
+            voA1 = (uint32_t)(r_t * a.A.ld + dcol1) * 4u;
+            voY = (uint32_t)(r_t * K + 2 * kk_t) * 4u;
+        } else {
+            voA0 = (uint32_t)(r_t * a.A.ld + a.A.coff + 2 * kk_t) * 4u;
+        }
+    }
+    const uint32_t rowA = (uint32_t)a.A.ld * 4u, rowY = (uint32_t)K * 4u;
     auto load_tile = [&](int t, float2* ra, float2* ry) {
         const int64_t m0 = mbeg + (int64_t)t * BM;
+        const uint32_t mu = (uint32_t)m0;
+        const bool full = m0 + BM <= mend;
 #pragma unroll
         for (int i = 0; i < NA2; ++i) {
-            const int r = (tid + 256 * i) / KSM;
-            const int64_t m = m0 + r;
-            ra[i] = make_float2(0.0f, 0.0f);
-            if (PRO == 2) ry[i] = make_float2(0.0f, 0.0f);
-            if (m < mend && kon) {
-                if (PRO == 2) {
-                    if (dz_vec) {       // dense gradient (no shuffle map): one 8-byte load
-                        ra[i] = *reinterpret_cast<const float2*>(&a.A.p[m * a.A.ld + dcol0]);
-                    } else {
-                        ra[i].x = a.A.p[m * a.A.ld + dcol0];
-                        ra[i].y = a.A.p[m * a.A.ld + dcol1];
-                    }
-                    ry[i] = *reinterpret_cast<const float2*>(&a.a_y[m * K + 2 * kk_t]);
+            const uint32_t r = mu + (uint32_t)(i * RSTEP);
+            uint32_t msk = 0u;
+            if (!full) msk = (m0 + i * RSTEP + r_t) < mend ? 0u : OOR;      // last tile of the group only
+            if (PRO == 2) {
+                if (dz_vec) {       // dense gradient (no shuffle map): one 8-byte load
+                    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsA, voA0 | msk, r * rowA, 0);
+                    ra[i] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
                 } else {
-                    ra[i] = *reinterpret_cast<const float2*>(&a.A.p[m * a.A.ld + a.A.coff + 2 * kk_t]);
+                    ra[i].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsA, voA0 | msk, r * rowA, 0));
+                    ra[i].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsA, voA1 | msk, r * rowA, 0));
                 }
+                const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rsY, voY | msk, r * rowY, 0);
+                ry[i] = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
+            } else {
+                const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsA, voA0 | msk, r * rowA, 0);
+                ra[i] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
             }
         }
     };
@@ -407,6 +433,10 @@ int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, cons
     }
     if (epilogue != 0 && !part) {
         set_error("pw_nn: epilogue needs a partial buffer");
+        return -1;
+    }
+    if ((int64_t)G * Mg * A.ld * 4 >= (1ll << 31) || (int64_t)G * Mg * K * 4 >= (1ll << 31)) {     // 32-bit buffer offsets
+        set_error("pw_nn: operands of 2 GB or more are not supported (rows=%lld)", (long long)G * Mg);
         return -1;
     }
     const PwPlan p = pw_nn_plan(G, Mg, N, K);
