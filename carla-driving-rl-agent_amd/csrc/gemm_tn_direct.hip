@@ -31,6 +31,7 @@ struct TnDirectArgs {
     int M, N, K, G, Mg;
     int rows_per, nspg;         // rows per workgroup, workgroups per group
     int WK, NSPL, NJW, RS;      // wave mapping: waves along k, n-splits, n tiles per wave, row splits
+    int TR;                     // transposed wave mapping (tn_direct_tr_kernel)
     int RS2;                    // 2: a second set of 4 waves takes the other half of every wave's rows; the two halves
                                 // are added through LDS before the partial is written (half the split-M partials)
     const float* a_stats;       // [4][G][K] or null
@@ -219,16 +220,193 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
     }
 }
 
+// Transposed wave mapping for the launches with a D prologue: a wave owns ONE n tile and up to NJW k tiles, so the
+// BatchNorm-backward transform of a D element (2 loads + ~10 VALU) is computed once per workgroup instead of once per
+// k-tile wave (4x), and a row pair costs NJW + 2 loads instead of 2*NJW + 1.  The cheap side (A, at most one fma) is the
+// one that is re-read by the 4 waves.  Same partial layout and reduction as tn_direct_kernel.
+template <int NJW, bool APRO, bool DPRO, int U>
+__global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
+    extern __shared__ float tnd_red[];          // RS2 == 2: [4 waves][NJW][16][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = (tid >> 6) & 3, half = tid >> 8;
+    const int l32 = lane & 31, lh = lane >> 5;
+    const int K = a.K, N = a.N;
+    const int k0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
+    const int KT = min(4, (K - k0 + 31) / 32), NT = min(4, (N - n0 + 31) / 32);
+    const int ni = wave % a.WK, rest = wave / a.WK;           // WK = waves along n here
+    const int ksp = rest % a.NSPL, rs = rest / a.NSPL;        // NSPL = k splits
+    const int kj0 = ksp * NJW;
+    const int kjn = min(NJW, KT - kj0);
+    const bool active = !(ni >= NT || kjn <= 0 || rs >= a.RS);
+    const int grp = blockIdx.x / a.nspg;
+    const int64_t gend = (int64_t)(grp + 1) * a.Mg;
+    int64_t mbeg = (int64_t)grp * a.Mg + (int64_t)(blockIdx.x % a.nspg) * a.rows_per;
+    int64_t mend = mbeg + a.rows_per;
+    if (mend > gend) mend = gend;
+    {
+        const int64_t len = mend - mbeg;
+        const int TS = a.RS * a.RS2;
+        const int64_t per = ((len + TS - 1) / TS + 1) / 2 * 2;
+        mbeg += (rs * a.RS2 + half) * per;
+        if (mbeg + per < mend) mend = mbeg + per;
+        if (!active) mend = mbeg;
+    }
+    const int n = n0 + ni * 32 + l32;
+    const bool non = active && n < N;
+    int dcol = a.D.coff + n;
+    float qm = 0.0f, qi = 0.0f, qsc = 0.0f, qsh = 0.0f, qk1 = 0.0f, qk2 = 0.0f, qk3 = 0.0f;
+    if (DPRO) {
+        if (a.db.shuffle_ctot) dcol = shuffle_dst(dcol, a.db.shuffle_ctot);
+        if (non) {
+            const int GN = a.G * N, o = grp * N + n;
+            qm = a.db.stats[0 * GN + o];
+            qi = a.db.stats[1 * GN + o];
+            qsc = a.db.stats[2 * GN + o];
+            qsh = a.db.stats[3 * GN + o];
+            qk1 = a.db.coef[0 * GN + o];
+            qk2 = a.db.coef[1 * GN + o];
+            qk3 = a.db.coef[2 * GN + o];
+        }
+    }
+    int kcol[NJW];
+    bool kon[NJW];
+    float asc[NJW], ash[NJW];
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) {
+        const int k = k0 + (kj0 + j) * 32 + l32;
+        kcol[j] = k;
+        kon[j] = j < kjn && k < K;
+        asc[j] = 1.0f;
+        ash[j] = 0.0f;
+        if (APRO && kon[j]) {
+            asc[j] = a.a_stats[2 * a.G * K + grp * K + k];
+            ash[j] = a.a_stats[3 * a.G * K + grp * K + k];
+        }
+    }
+    f32x16 acc[NJW];
+#pragma unroll
+    for (int j = 0; j < NJW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    const uint32_t OOR = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A.p), 0, (int)((int64_t)a.M * a.A.ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D.p), 0, (int)((int64_t)a.M * a.D.ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(DPRO ? a.db.y : a.D.p), 0, (int)((int64_t)a.M * (DPRO ? N : a.D.ld) * 4), 0x00020000);
+    const uint32_t voD = non ? (uint32_t)(lh * a.D.ld + dcol) * 4u : OOR;
+    const uint32_t voY = non ? (uint32_t)(lh * N + n) * 4u : OOR;
+    uint32_t voA[NJW];
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) voA[j] = kon[j] ? (uint32_t)(lh * a.A.ld + a.A.coff + kcol[j]) * 4u : OOR;
+    const uint32_t sA = (uint32_t)a.A.ld * 4u, sD = (uint32_t)a.D.ld * 4u, sY = (uint32_t)N * 4u;
+    const int mb = __builtin_amdgcn_readfirstlane((int)mbeg), me = __builtin_amdgcn_readfirstlane((int)mend);
+    float av0[U][NJW], dv0[U], yv0[U], av1[U][NJW], dv1[U], yv1[U];
+    auto load_batch = [&](int m0, bool tail, float (*av)[NJW], float* dv, float* yv) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = (uint32_t)(m0 + 2 * u);
+            uint32_t msk = 0u;
+            if (tail) msk = (m0 + 2 * u + lh) < me ? 0u : OOR;
+            dv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rD, voD | msk, r * sD, 0));
+            if (DPRO) yv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rY, voY | msk, r * sY, 0));
+#pragma unroll
+            for (int j = 0; j < NJW; ++j) av[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, voA[j] | msk, r * sA, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma_batch = [&](int m0, const float (*av)[NJW], const float* dv, const float* yv) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool mon = (m0 + 2 * u + lh) < me;
+            float d = dv[u];
+            if (DPRO && mon && non) {
+                const float y = yv[u];
+                if (a.db.act == ACT_RELU6) {
+                    const float z = fmaf(qsc, y, qsh);
+                    if (!(z > 0.0f && z < 6.0f)) d = 0.0f;
+                }
+                const float xh = (y - qm) * qi;
+                d = qk1 * (d - qk2 - xh * qk3);
+            }
+#pragma unroll
+            for (int j = 0; j < NJW; ++j) {
+                float x = av[u][j];
+                if (APRO && mon && kon[j]) x = fmaf(asc[j], x, ash[j]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, d, acc[j], 0, 0, 0);
+            }
+        }
+    };
+    int m0 = mb;
+    bool has = m0 + 2 * U <= me;
+    if (has) load_batch(m0, false, av0, dv0, yv0);
+    while (has) {
+        const int m1 = m0 + 2 * U;
+        const bool has1 = m1 + 2 * U <= me;
+        if (has1) load_batch(m1, false, av1, dv1, yv1);
+        mma_batch(m0, av0, dv0, yv0);
+        m0 = m1;
+        if (!has1) break;
+        const int m2 = m1 + 2 * U;
+        has = m2 + 2 * U <= me;
+        if (has) load_batch(m2, false, av0, dv0, yv0);
+        mma_batch(m1, av1, dv1, yv1);
+        m0 = m2;
+    }
+    if (m0 < me) {
+        load_batch(m0, true, av0, dv0, yv0);
+        mma_batch(m0, av0, dv0, yv0);
+    }
+    if (a.RS2 == 2) {
+        float* red = tnd_red + (size_t)wave * NJW * 16 * 64 + lane;
+        if (half == 1 && active) {
+#pragma unroll
+            for (int j = 0; j < NJW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(j * 16 + r) * 64] = acc[j][r];
+        }
+        __syncthreads();
+        if (half == 0 && active) {
+#pragma unroll
+            for (int j = 0; j < NJW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] += red[(j * 16 + r) * 64];
+        }
+    }
+    if (half != 0 || !non) return;
+    // C/D layout: column (n) = lane&31, row (k) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* out = a.part + ((int64_t)blockIdx.x * a.RS + rs) * K * N;
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) {
+        if (j >= kjn) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = k0 + (kj0 + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (kk < K) out[(int64_t)kk * N + n] = acc[j][r];
+        }
+    }
+}
+
 struct TndPlan {
     int gy, gz, nspg, nsplit, rows_per;
     int WK, NSPL, NJW, RS, RS2;
+    int TR;                     // transposed wave mapping (waves along n, NJW k tiles per wave)
 };
 
-static TndPlan tnd_plan(int M, int N, int K, int G) {
+static TndPlan tnd_plan(int M, int N, int K, int G, bool dpro = false) {
     TndPlan p;
     p.gy = cdiv(K, 128);
     p.gz = cdiv(N, 128);
-    const int KT = K >= 128 ? 4 : cdiv(K, 32), NT = N >= 128 ? 4 : cdiv(N, 32);   // tiles of the (first) 128-block
+    int KT = K >= 128 ? 4 : cdiv(K, 32), NT = N >= 128 ? 4 : cdiv(N, 32);   // tiles of the (first) 128-block
+    static const bool tr_on = !(getenv("CDRL_TN_TR") && atoi(getenv("CDRL_TN_TR")) == 0);
+    p.TR = (dpro && tr_on) ? 1 : 0;
+    if (p.TR) {                                  // same mapping with the roles of k and n exchanged
+        const int t = KT;
+        KT = NT;
+        NT = t;
+    }
     p.WK = KT >= 3 ? 4 : KT;
     const int left = 4 / p.WK;                  // 1, 2 or 4 waves left for n tiles / row splits
     p.NSPL = left < NT ? left : NT;
@@ -254,8 +432,9 @@ static TndPlan tnd_plan(int M, int N, int K, int G) {
 }
 
 int64_t gemm_tn_part_elems(int M, int N, int K, int G) {
-    const TndPlan p = tnd_plan(M, N, K, G);
-    return (int64_t)p.nsplit * p.RS * K * N;
+    const TndPlan p = tnd_plan(M, N, K, G, false), q = tnd_plan(M, N, K, G, true);
+    const int64_t a = (int64_t)p.nsplit * p.RS * K * N, b = (int64_t)q.nsplit * q.RS * K * N;
+    return a > b ? a : b;
 }
 
 bool gemm_tn_dpro_supported(int) { return true; }
@@ -264,6 +443,11 @@ template <int NJW, int U>
 static void launch_tnd_u(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a) {
     const dim3 blk(256 * a.RS2);
     const size_t lds = a.RS2 == 2 ? (size_t)4 * NJW * 16 * 64 * sizeof(float) : 0;     // <= 64 KB
+    if (a.TR) {         // (planned only with a D prologue)
+        if (apro) hipLaunchKernelGGL((tn_direct_tr_kernel<NJW, true, true, U>), grid, blk, lds, st, a);
+        else hipLaunchKernelGGL((tn_direct_tr_kernel<NJW, false, true, U>), grid, blk, lds, st, a);
+        return;
+    }
     if (apro && dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, true, U>), grid, blk, lds, st, a);
     else if (apro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, false, U>), grid, blk, lds, st, a);
     else if (dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, false, true, U>), grid, blk, lds, st, a);
@@ -273,7 +457,7 @@ static void launch_tnd_u(bool apro, bool dpro, dim3 grid, hipStream_t st, const 
 template <int NJW>
 static void launch_tnd(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a) {
     static const int u = getenv("CDRL_TN_U") ? atoi(getenv("CDRL_TN_U")) : 4;
-    static const int ud = getenv("CDRL_TN_UD") ? atoi(getenv("CDRL_TN_UD")) : 4;      // with the D prologue: U = 8 fills all 256 VGPRs
+    static const int ud = getenv("CDRL_TN_UD") ? atoi(getenv("CDRL_TN_UD")) : 8;      // D prologue (transposed mapping: 200 VGPRs at U = 8; 19.6 -> 19.2 ms/update-step over U = 4)
     const int uu = dpro ? ud : u;
     if (uu >= 16 && !dpro) launch_tnd_u<NJW, 16>(apro, dpro, grid, st, a);
     else if (uu >= 8) launch_tnd_u<NJW, 8>(apro, dpro, grid, st, a);
@@ -293,7 +477,7 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     }
     static const bool diag_skip = getenv("CDRL_DIAG_SKIP_TN") && atoi(getenv("CDRL_DIAG_SKIP_TN")) == 1;   // timing diagnostics only
     if (diag_skip) return 0;
-    const TndPlan p = tnd_plan(M, N, K, G);
+    const TndPlan p = tnd_plan(M, N, K, G, dpro != nullptr);
     TnDirectArgs a;
     a.A = A;
     a.D = D;
@@ -310,6 +494,7 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     a.NJW = p.NJW;
     a.RS = p.RS;
     a.RS2 = p.RS2;
+    a.TR = p.TR;
     a.a_stats = pro_stats;
     a.db = TnBnBwd{};
     if (dpro) a.db = *dpro;
