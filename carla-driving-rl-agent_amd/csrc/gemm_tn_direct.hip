@@ -146,23 +146,27 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
         // MFMA one by one through two registers: every MFMA then pays a full memory latency)
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto mma_batch = [&](int m0, const float* av, const float (*dv)[NJW], const float (*yv)[DPRO ? NJW : 1]) {
+    // Branch-free transforms: masked lanes loaded zeros and have zero coefficients (q* = 0 when the column does not exist),
+    // so only the rows past the end of the share need a select, and only in the tail batch.  With the transforms inside
+    // `if (row and column exist)` every batch started with s_waitcnt vmcnt(0): the loads of the NEXT batch, already in
+    // flight, were waited for as well.
+    auto mma_batch = [&](int m0, bool tail, const float* av, const float (*dv)[NJW], const float (*yv)[DPRO ? NJW : 1]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool mon = (m0 + 2 * u + lh) < me;
+            const float keep = (!tail || (m0 + 2 * u + lh) < me) ? 1.0f : 0.0f;
             float x = av[u];
-            if (APRO && mon && kon) x = fmaf(asc, x, ash);
+            if (APRO) x = fmaf(asc, x, ash);          // rows past the end: x = ash, but their d is 0
 #pragma unroll
             for (int j = 0; j < NJW; ++j) {
                 float d = dv[u][j];
-                if (DPRO && mon && non[j]) {
+                if (DPRO) {
                     const float y = yv[u][j];
                     if (a.db.act == ACT_RELU6) {
                         const float z = fmaf(qsc[j], y, qsh[j]);
-                        if (!(z > 0.0f && z < 6.0f)) d = 0.0f;
+                        d = (z > 0.0f && z < 6.0f) ? d : 0.0f;
                     }
                     const float xh = (y - qm[j]) * qi[j];
-                    d = qk1[j] * (d - qk2[j] - xh * qk3[j]);
+                    d = keep * (qk1[j] * (d - qk2[j] - xh * qk3[j]));
                 }
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, d, acc[j], 0, 0, 0);
             }
@@ -177,18 +181,18 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
         const int m1 = m0 + 2 * U;
         const bool has1 = m1 + 2 * U <= me;
         if (has1) load_batch(m1, false, av1, dv1, yv1);
-        mma_batch(m0, av0, dv0, yv0);
+        mma_batch(m0, false, av0, dv0, yv0);
         m0 = m1;
         if (!has1) break;
         const int m2 = m1 + 2 * U;
         has = m2 + 2 * U <= me;
         if (has) load_batch(m2, false, av0, dv0, yv0);
-        mma_batch(m1, av1, dv1, yv1);
+        mma_batch(m1, false, av1, dv1, yv1);
         m0 = m2;
     }
     if (m0 < me) {
         load_batch(m0, true, av0, dv0, yv0);
-        mma_batch(m0, av0, dv0, yv0);
+        mma_batch(m0, true, av0, dv0, yv0);
     }
     if (a.RS2 == 2) {       // fold the second half's accumulators into the first half's (fixed order)
         float* red = tnd_red + (size_t)wave * NJW * 16 * 64 + lane;
@@ -317,24 +321,24 @@ __global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto mma_batch = [&](int m0, const float (*av)[NJW], const float* dv, const float* yv) {
+    auto mma_batch = [&](int m0, bool tail, const float (*av)[NJW], const float* dv, const float* yv) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool mon = (m0 + 2 * u + lh) < me;
+            const float keep = (!tail || (m0 + 2 * u + lh) < me) ? 1.0f : 0.0f;      // branch-free (see tn_direct_kernel)
             float d = dv[u];
-            if (DPRO && mon && non) {
+            if (DPRO) {
                 const float y = yv[u];
                 if (a.db.act == ACT_RELU6) {
                     const float z = fmaf(qsc, y, qsh);
-                    if (!(z > 0.0f && z < 6.0f)) d = 0.0f;
+                    d = (z > 0.0f && z < 6.0f) ? d : 0.0f;
                 }
                 const float xh = (y - qm) * qi;
-                d = qk1 * (d - qk2 - xh * qk3);
+                d = keep * (qk1 * (d - qk2 - xh * qk3));
             }
 #pragma unroll
             for (int j = 0; j < NJW; ++j) {
                 float x = av[u][j];
-                if (APRO && mon && kon[j]) x = fmaf(asc[j], x, ash[j]);
+                if (APRO) x = fmaf(asc[j], x, ash[j]);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, d, acc[j], 0, 0, 0);
             }
         }
@@ -346,18 +350,18 @@ __global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
         const int m1 = m0 + 2 * U;
         const bool has1 = m1 + 2 * U <= me;
         if (has1) load_batch(m1, false, av1, dv1, yv1);
-        mma_batch(m0, av0, dv0, yv0);
+        mma_batch(m0, false, av0, dv0, yv0);
         m0 = m1;
         if (!has1) break;
         const int m2 = m1 + 2 * U;
         has = m2 + 2 * U <= me;
         if (has) load_batch(m2, false, av0, dv0, yv0);
-        mma_batch(m1, av1, dv1, yv1);
+        mma_batch(m1, false, av1, dv1, yv1);
         m0 = m2;
     }
     if (m0 < me) {
         load_batch(m0, true, av0, dv0, yv0);
-        mma_batch(m0, av0, dv0, yv0);
+        mma_batch(m0, true, av0, dv0, yv0);
     }
     if (a.RS2 == 2) {
         float* red = tnd_red + (size_t)wave * NJW * 16 * 64 + lane;
