@@ -46,7 +46,8 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     const size_t a_px = (size_t)(H + 2) * (W + 2);
     const size_t d_px = (size_t)(Ho + 2) * (Wo + 2);
     const size_t per_c = (a_px + d_px) * sizeof(float);
-    int maxc = (int)(DWF_LDS_BUDGET / per_c) / g.vec * g.vec;
+    static const size_t lds_budget = getenv("CDRL_DWF_LDS_KB") ? (size_t)atoi(getenv("CDRL_DWF_LDS_KB")) * 1024 : DWF_LDS_BUDGET;
+    int maxc = (int)(lds_budget / per_c) / g.vec * g.vec;
     if (maxc < g.vec) maxc = g.vec;
     if (maxc > 256) maxc = 256;
     const int lanes = C / g.vec;
