@@ -178,6 +178,23 @@ PoolSrc make_pool_src(const uint8_t* argmax, const float* dp, int H, int W);
 int gap_fwd(const float* a, float* out, int N, int P, int C, hipStream_t st);
 int gap_bwd(const float* dout, float* da, int N, int P, int C, hipStream_t st);
 
+// ---------------------------------------------------------------- linear output heads (heads.hip)
+#define HEADS_MAX 4
+#define HEADS_MAX_OUT 8
+struct HeadSet {
+    int nheads;
+    int n[HEADS_MAX], off[HEADS_MAX];      // outputs of head h and its first column in lin
+    const float* w[HEADS_MAX];             // [K][n]
+    const float* b[HEADS_MAX];             // [n]
+    float* gw[HEADS_MAX];                  // gradients (null for inference-only heads)
+    float* gb[HEADS_MAX];
+};
+// lin[b][off_h + n] = b_h[n] + sum_k a[b][k] W_h[k][n]   (a: [B][lda], lin: [B][ldl])
+int heads_fwd(const float* a, int lda, const HeadSet& hs, float* lin, int ldl, int B, int K, hipStream_t st);
+// da[b][k] = sum_c dlin[b][c] W[k][c] (overwrite; da may be null), dW_h = a^T dlin_h, db_h = column sums of dlin_h
+int heads_bwd(const float* a, int lda, const HeadSet& hs, const float* dlin, int ldl, float* da, int ldda, int B, int K,
+              hipStream_t st);
+
 // ---------------------------------------------------------------- GRU (rnn.hip)
 // gates of step t: xp,hp [B][3u]; hprev [B][u]; saves z,r,hh; writes hnew
 int gru_gates_fwd(const float* xp, const float* hp, const float* hprev, float* z, float* r, float* hh, float* hnew,

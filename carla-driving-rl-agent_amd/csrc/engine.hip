@@ -1041,6 +1041,31 @@ void Learner::build_head(std::vector<Op>& ops, int model, const std::string& pre
     int L = 0;
     for (int i = 0; i < nheads; ++i) L += head_dims[i];
     lin = tens(B, L);
+    static const bool fused_heads = !(getenv("CDRL_FUSED_HEADS") && atoi(getenv("CDRL_FUSED_HEADS")) == 0);
+    if (fused_heads && nheads <= HEADS_MAX && L <= HEADS_MAX_OUT) {
+        // all linear heads of the branch in one launch per direction (heads.hip); same parameter names / order as add_dense
+        HeadSet hs{};
+        hs.nheads = nheads;
+        int off = 0;
+        for (int i = 0; i < nheads; ++i) {
+            PRef w = param(model, prefix + "." + head_names[i] + ".w", {c.head, head_dims[i]}, true);
+            PRef b = param(model, prefix + "." + head_names[i] + ".b", {head_dims[i]}, true);
+            hs.n[i] = head_dims[i];
+            hs.off[i] = off;
+            hs.w[i] = w.p;
+            hs.b[i] = b.p;
+            hs.gw[i] = w.g;
+            hs.gb[i] = b.g;
+            off += head_dims[i];
+        }
+        const int K = c.head;
+        Tens a1c = a1, linc = lin;
+        Op op;
+        op.fwd = [=](hipStream_t st, int) -> int { return heads_fwd(a1c.p, K, hs, linc.p, L, B, K, st); };
+        op.bwd = [=](hipStream_t st) -> int { return heads_bwd(a1c.p, K, hs, linc.g, L, a1c.g, K, B, K, st); };
+        ops.push_back(op);
+        return;
+    }
     int off = 0;
     for (int i = 0; i < nheads; ++i) {
         add_dense(ops, model, prefix + "." + head_names[i], a1.v(), B, c.head, head_dims[i], ACT_NONE, lin.v(off),
