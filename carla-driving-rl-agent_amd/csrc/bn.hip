@@ -192,6 +192,159 @@ int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* g
 }
 
 // ------------------------------------------------------------------------------------------
+// Single-group BatchNorm over a few hundred rows (the control branches' and the trunk's dense BNs: B x 320..512) as ONE
+// kernel per direction: statistics + finalize + apply (forward), sums + coefficients + apply (backward).  As three
+// launches each they were 15-19 us of pure dispatch latency per BatchNorm on the stretch between the trunk's forward and
+// backward.  block = (16 channel lanes, 16 row lanes); same arithmetic as bn_finalize / bn_bwd_finalize / the apply functors.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_small_fwd_kernel(View x, int M, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ mov_mean,
+                                                           float* __restrict__ mov_var, float* __restrict__ stats, View out) {
+    __shared__ double sm[2][16][16];
+    __shared__ float cf[2][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const bool ok = c < C;
+    const float* xp = x.p + x.coff + (ok ? c : 0);
+    double s = 0.0, q = 0.0;
+    for (int r0 = rl; r0 < M; r0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[(int64_t)min(r0 + 16 * u, M - 1) * x.ld];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r0 + 16 * u < M) {
+                s += (double)v[u];
+                q += (double)v[u] * (double)v[u];
+            }
+    }
+    sm[0][rl][cl] = s;
+    sm[1][rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) {
+            a += sm[0][y][cl];
+            b += sm[1][y][cl];
+        }
+        const double n = (double)M;
+        const double mean = a / n;
+        double var = b / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float meanf = (float)mean, varf = (float)var;
+        const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+        const float gm = gamma[c], bt = beta[c];
+        const float sc = gm * invstd, sh = bt - meanf * gm * invstd;
+        stats[0 * C + c] = meanf;
+        stats[1 * C + c] = invstd;
+        stats[2 * C + c] = sc;
+        stats[3 * C + c] = sh;
+        // Keras: moving -= (moving - value) * (1 - momentum); rank-2 inputs: no Bessel correction
+        mov_mean[c] = mov_mean[c] - (mov_mean[c] - meanf) * 0.01f;
+        mov_var[c] = mov_var[c] - (mov_var[c] - varf) * 0.01f;
+        cf[0][cl] = sc;
+        cf[1][cl] = sh;
+    }
+    __syncthreads();
+    if (!ok) return;
+    const float sc = cf[0][cl], sh = cf[1][cl];
+    float* op = out.p + out.coff + c;
+    for (int r0 = rl; r0 < M; r0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[(int64_t)min(r0 + 16 * u, M - 1) * x.ld];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r0 + 16 * u < M) op[(int64_t)(r0 + 16 * u) * out.ld] = fmaf(sc, v[u], sh);
+    }
+}
+
+int bn_small_fwd(View x, int M, int C, const float* gamma, const float* beta, float* mov_mean, float* mov_var, float* stats,
+                 View out, hipStream_t st) {
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, x, M, C, gamma, beta, mov_mean, mov_var, stats, out);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward: dz = dout (no activation), xhat from the raw input; dx = k1 * (dz - k2 - xhat * k3)
+__global__ void __launch_bounds__(256) bn_small_bwd_kernel(View dout, View x, int M, int C, const float* __restrict__ stats,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ coef, float* __restrict__ dx) {
+    __shared__ double sm[2][16][16];
+    __shared__ float cf[3][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const bool ok = c < C;
+    const float* xp = x.p + x.coff + (ok ? c : 0);
+    const float* dp = dout.p + dout.coff + (ok ? c : 0);
+    const float mean = ok ? stats[0 * C + c] : 0.0f, inv = ok ? stats[1 * C + c] : 0.0f;
+    double s = 0.0, q = 0.0;
+    for (int r0 = rl; r0 < M; r0 += 16 * 8) {
+        float v[8], d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t r = min(r0 + 16 * u, M - 1);
+            v[u] = xp[r * x.ld];
+            d[u] = dp[r * dout.ld];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r0 + 16 * u < M) {
+                const float xh = (v[u] - mean) * inv;
+                s += (double)d[u];
+                q += (double)d[u] * (double)xh;
+            }
+    }
+    sm[0][rl][cl] = s;
+    sm[1][rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) {
+            a += sm[0][y][cl];
+            b += sm[1][y][cl];
+        }
+        const double n = (double)M;
+        const float k1 = stats[2 * C + c], k2 = (float)(a / n), k3 = (float)(b / n);
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)b;
+        coef[0 * C + c] = k1;
+        coef[1 * C + c] = k2;
+        coef[2 * C + c] = k3;
+        cf[0][cl] = k1;
+        cf[1][cl] = k2;
+        cf[2][cl] = k3;
+    }
+    __syncthreads();
+    if (!ok) return;
+    const float k1 = cf[0][cl], k2 = cf[1][cl], k3 = cf[2][cl];
+    for (int r0 = rl; r0 < M; r0 += 16 * 8) {
+        float v[8], d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t r = min(r0 + 16 * u, M - 1);
+            v[u] = xp[r * x.ld];
+            d[u] = dp[r * dout.ld];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r0 + 16 * u < M) {
+                const float xh = (v[u] - mean) * inv;
+                dx[(int64_t)(r0 + 16 * u) * C + c] = k1 * (d[u] - k2 - xh * k3);
+            }
+    }
+}
+
+int bn_small_bwd(View dout, View x, int M, int C, const float* stats, float* dgamma, float* dbeta, float* coef, float* dx,
+                 hipStream_t st) {
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, dout, x, M, C, stats, dgamma, dbeta, coef, dx);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // forward apply
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float apply_act(float z, int act) {

@@ -20,6 +20,11 @@ int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* g
 // identity half of a ShuffleNet unit: concat + shuffle of both halves in one launch)
 int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
              hipStream_t st, const View* pass_src = nullptr, const View* pass_dst = nullptr);
+// single-group BatchNorm over few rows, one launch per direction (G = 1, no activation, no shuffle; training mode)
+int bn_small_fwd(View x, int M, int C, const float* gamma, const float* beta, float* mov_mean, float* mov_var, float* stats,
+                 View out, hipStream_t st);
+int bn_small_bwd(View dout, View x, int M, int C, const float* stats, float* dgamma, float* dbeta, float* coef, float* dx,
+                 hipStream_t st);
 // Gradient source "through a 3x3/s2 SAME max-pool": d(a)[n,iy,ix,c] = sum of dp over the windows whose
 // saved argmax points at (iy,ix).  Lets the stem BatchNorm backward read the pooled gradient directly
 // (the 255 MB pre-pool gradient tensor is never written or re-read).

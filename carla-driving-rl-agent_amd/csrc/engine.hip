@@ -357,7 +357,22 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     std::shared_ptr<bool> fused = rec.reduce_fused;
     const int bes = bessel ? 1 : 0;
     Scratch* sc = build_scr_;
+    // single-group BatchNorm over a few hundred rows (dense BNs of the trunk tail and the control branches): one launch per
+    // direction instead of three
+    static const bool small_env = !(getenv("CDRL_BN_SMALL") && atoi(getenv("CDRL_BN_SMALL")) == 0);
+    const bool small = small_env && G == 1 && Mg <= 2048 && !bessel && act == ACT_NONE && !out_shuffle && !dout_shuffle && dx &&
+                       !stats_nb && !defer_apply && !pass.fsrc.p && !pass.gsrc.p;
     Op op;
+    if (small) {
+        op.fwd = [=](hipStream_t st, int training) -> int {
+            if (training) return bn_small_fwd(x, Mg, C, gamma.p, beta.p, mm.p, mv.p, stats, out, st);
+            CDRL_TRY(bn_finalize(sc->part, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
+            return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st);
+        };
+        op.bwd = [=](hipStream_t st) -> int { return bn_small_bwd(dout, x, Mg, C, stats, gamma.g, beta.g, coef, dx, st); };
+        ops.push_back(op);
+        return rec;
+    }
     op.fwd = [=](hipStream_t st, int training) -> int {
         if (training && !stats_nb) CDRL_TRY(colstats(x, G, Mg, C, sc->part, st));
         CDRL_TRY(bn_finalize(sc->part, stats_nb ? stats_nb : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
