@@ -904,6 +904,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     // BN-backward apply as GEMM operand prologue (needs the filter-gradient GEMM's fixed column mapping)
                     // (not for N <= 32 outputs of the backward-data GEMM, i.e. the first unit's 24 input channels: the 128-row
                     //  variant of the prologue kernel runs at 248 us vs ~165 us for apply + plain GEMM)
+                    // (also for the wide stage-2 units: without the prologues there 19.55 vs 18.82 ms/update-step;
+                    //  CU-masking the side stream re-measured at v33: 224 / 192 / 128 CUs -> 21.2 / 21.2 / 23.5 vs 18.7 ms)
                     const bool bb1 = (fused_bb_ & 1) && gemm_tn_dpro_supported(mid) && (main_in > 32 || (fused_bb_ & 4));
                     const bool bb3 = (fused_bb_ & 2) && gemm_tn_dpro_supported(main_out);
                     float* stats1 = alloc((size_t)4 * T * mid);
