@@ -450,8 +450,133 @@ struct BnBwdReduceF {
     }
 };
 
+// Fast path of bn_bwd_reduce for the unit's last BatchNorm (dz gathered through the channel-shuffle map, ReLU6 mask,
+// optionally the identity half's gradient gathered + stored in the same pass): same partial layout as the generic
+// skeleton, but the per-channel columns / coefficients are computed once per thread and RU rows are loaded before any of
+// them is consumed (the generic functor re-derives everything per row and, with its pass-through store between the loads,
+// runs one row's round trip at a time; at 6-21 rows per thread the kernel was latency, not bandwidth).
+template <int VEC, bool PASS>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ctot, const float* __restrict__ y,
+                                                                 const float* __restrict__ stats, int GC, int C, int Mg, int rb,
+                                                                 View pgs, View pgd, double* __restrict__ part) {
+    extern __shared__ double sm[];   // [CY][VEC][CX]
+    constexpr int RU = 4;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int g = blockIdx.y, nb = gridDim.x;
+    const int r0 = blockIdx.x * rb, r1 = min(r0 + rb, Mg);
+    const int c0 = tx * VEC;
+    const bool on = c0 < C;
+    double acc[2][VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[0][i] = acc[1][i] = 0.0;
+    if (on) {
+        int dcol[VEC], pcol[VEC];
+        float mean[VEC], inv[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            dcol[i] = shuffle_dst(da.coff + c0 + i, ctot);
+            pcol[i] = PASS ? shuffle_dst(pgs.coff + c0 + i, ctot) : 0;
+            mean[i] = stats[0 * GC + g * C + c0 + i];
+            inv[i] = stats[1 * GC + g * C + c0 + i];
+            sc[i] = stats[2 * GC + g * C + c0 + i];
+            sh[i] = stats[3 * GC + g * C + c0 + i];
+        }
+        const int64_t gbase = (int64_t)g * Mg;
+        for (int rr = r0 + ty; rr < r1; rr += CY * RU) {
+            float dz[RU][VEC], pv[RU][VEC];
+            VecF<VEC> yv[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int64_t row = gbase + min(rr + u * CY, r1 - 1);          // clamped: unconditional loads
+                const float* dr = da.p + row * da.ld;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) dz[u][i] = dr[dcol[i]];
+                yv[u] = vload<VEC>(y + row * C + c0);
+                if (PASS) {
+                    const float* pr = pgs.p + row * pgs.ld;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) pv[u][i] = pr[pcol[i]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                if (rr + u * CY >= r1) break;
+                const int64_t row = gbase + rr + u * CY;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float v = yv[u].v[i];
+                    const float z = fmaf(sc[i], v, sh[i]);
+                    const float d = (z > 0.0f && z < 6.0f) ? dz[u][i] : 0.0f;
+                    const float xh = (v - mean[i]) * inv[i];
+                    acc[0][i] += (double)d;
+                    acc[1][i] += (double)d * (double)xh;
+                }
+                if (PASS) {
+                    VecF<VEC> o;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) o.v[i] = pv[u][i];
+                    vstore<VEC>(pgd.p + row * pgd.ld + pgd.coff + c0, o);
+                }
+            }
+        }
+    }
+    // block reduction over the row lanes, one quantity at a time (as vcolreduce_kernel)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (CY > 1) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) sm[(ty * VEC + i) * CX + tx] = acc[q][i];
+            __syncthreads();
+            if (ty == 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    double s = acc[q][i];
+                    for (int yy = 1; yy < CY; ++yy) s += sm[(yy * VEC + i) * CX + tx];
+                    acc[q][i] = s;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (ty == 0 && on) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) part[(((int64_t)g * nb + blockIdx.x) * 2 + q) * C + c0 + i] = acc[q][i];
+    }
+}
+
+template <int VEC>
+static void launch_bbr_shuf(const VColGeom& g, int G, hipStream_t st, View da, int ctot, const float* y, const float* stats, int C,
+                            int Mg, View pgs, View pgd, double* part) {
+    dim3 grid(g.nb, G), block(g.cx, g.cy);
+    const size_t sm = (size_t)g.cy * VEC * g.cx * sizeof(double);
+    if (pgs.p)
+        hipLaunchKernelGGL((bn_bwd_reduce_shuf_kernel<VEC, true>), grid, block, sm, st, da, ctot, y, stats, G * C, C, Mg, g.rb, pgs, pgd, part);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_shuf_kernel<VEC, false>), grid, block, sm, st, da, ctot, y, stats, G * C, C, Mg, g.rb, pgs, pgd, part);
+}
+
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
                   double* part, hipStream_t st, const PoolSrc* pool, const View* pass_gsrc, const View* pass_gdst) {
+    {
+        static const bool fast = !(getenv("CDRL_BBR_FAST") && atoi(getenv("CDRL_BBR_FAST")) == 0);
+        const VColGeom g = vcol_geom(Mg, C, NB_STATS);
+        View pgs{nullptr, 0, 0}, pgd{nullptr, 0, 0};
+        if (pass_gsrc && pass_gdst) {
+            pgs = *pass_gsrc;
+            pgd = *pass_gdst;
+        }
+        const bool ydense = y.ld == C && y.coff == 0 && view_aligned(y, g.vec);
+        const bool pok = !pgs.p || (pgd.p && view_aligned(pgd, g.vec));
+        if (fast && !pool && shuffle_ctot && act == ACT_RELU6 && g.nloop == 1 && ydense && pok && g.vec >= 2) {
+            if (g.vec == 4) launch_bbr_shuf<4>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
+            else launch_bbr_shuf<2>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
+            CDRL_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const int vec = vcol_geom(Mg, C).vec;
     PoolSrc ps{};
     if (pool) ps = *pool;
