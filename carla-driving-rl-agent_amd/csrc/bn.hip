@@ -389,8 +389,74 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(View y, int Mg, int C, in
     }
 }
 
+// Fast path of bn_apply for the unit output (concat + channel shuffle as a destination permutation, optionally with the
+// identity half): RU rows of loads are issued before the first store -- gfx9 counts loads and stores in one in-order
+// counter, so "load, store, load, use" (the generic loop) waits for a store round trip per row.
+template <int VEC, bool PASS>
+__global__ void __launch_bounds__(256) bn_apply_shuf_kernel(View y, int Mg, int C, int rb, int GC, const float* __restrict__ stats,
+                                                            int act, View dst, int ctot, View psrc, View pdst) {
+    constexpr int RU = 4;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CY = blockDim.y;
+    const int g = blockIdx.y;
+    const int r0 = blockIdx.x * rb, r1 = min(r0 + rb, Mg);
+    const int c0 = tx * VEC;
+    if (c0 >= C) return;
+    const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
+    int dcol[VEC], pcol[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        dcol[i] = shuffle_dst(dst.coff + c0 + i, ctot);
+        pcol[i] = PASS ? shuffle_dst(pdst.coff + c0 + i, ctot) : 0;
+    }
+    const int64_t gbase = (int64_t)g * Mg;
+    for (int rr = r0 + ty; rr < r1; rr += CY * RU) {
+        VecF<VEC> v[RU], pv[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int64_t row = gbase + min(rr + u * CY, r1 - 1);
+            v[u] = vload<VEC>(y.p + row * y.ld + y.coff + c0);
+            if (PASS) pv[u] = vload<VEC>(psrc.p + row * psrc.ld + psrc.coff + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            if (rr + u * CY >= r1) break;
+            const int64_t row = gbase + rr + u * CY;
+            float* dr = dst.p + row * dst.ld;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) dr[dcol[i]] = apply_act(fmaf(sc.v[i], v[u].v[i], sh.v[i]), act);
+            if (PASS) {
+                float* pr = pdst.p + row * pdst.ld;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) pr[pcol[i]] = pv[u].v[i];
+            }
+        }
+    }
+}
+
 int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
              hipStream_t st, const View* pass_src, const View* pass_dst) {
+    {
+        static const bool fast = !(getenv("CDRL_APPLY_FAST") && atoi(getenv("CDRL_APPLY_FAST")) == 0);
+        const VColGeom g = vcol_geom(Mg, C, 2048);
+        View ps{nullptr, 0, 0}, pd{nullptr, 0, 0};
+        if (pass_src && pass_dst) {
+            ps = *pass_src;
+            pd = *pass_dst;
+        }
+        if (fast && stats && shuffle_ctot && g.nloop == 1 && g.vec >= 2 && view_aligned(y, g.vec) && (!ps.p || view_aligned(ps, g.vec))) {
+            dim3 grid(g.nb, G), block(g.cx, g.cy);
+            if (g.vec == 4) {
+                if (ps.p) hipLaunchKernelGGL((bn_apply_shuf_kernel<4, true>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
+                else hipLaunchKernelGGL((bn_apply_shuf_kernel<4, false>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
+            } else {
+                if (ps.p) hipLaunchKernelGGL((bn_apply_shuf_kernel<2, true>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
+                else hipLaunchKernelGGL((bn_apply_shuf_kernel<2, false>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
+            }
+            CDRL_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     VColGeom g = vcol_geom(Mg, C, 2048);
     const bool ai = view_aligned(y, g.vec), ao = view_aligned(dst, g.vec);
     View ps{nullptr, 0, 0}, pd{nullptr, 0, 0};
