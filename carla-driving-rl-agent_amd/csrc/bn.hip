@@ -790,8 +790,110 @@ struct BnBwdApplyF {
     }
 };
 
+// Fast path of bn_bwd_apply (no pool source): RU rows of loads ahead of the stores, columns / coefficients once per thread;
+// same partial layout ([G][nb][C] column sums of dy) as the generic skeleton.
+template <int VEC>
+__global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int ctot, const float* __restrict__ y,
+                                                                const float* __restrict__ stats, const float* __restrict__ coef,
+                                                                int GC, int C, int Mg, int rb, int act, float* __restrict__ dy,
+                                                                double* __restrict__ part) {
+    extern __shared__ double sm[];   // [CY][VEC][CX]
+    constexpr int RU = 4;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int g = blockIdx.y, nb = gridDim.x;
+    const int r0 = blockIdx.x * rb, r1 = min(r0 + rb, Mg);
+    const int c0 = tx * VEC;
+    const bool on = c0 < C;
+    double acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.0;
+    if (on) {
+        int dcol[VEC];
+        float mean[VEC], inv[VEC], sc[VEC], sh[VEC], k1[VEC], k2[VEC], k3[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int cc = da.coff + c0 + i;
+            dcol[i] = ctot ? shuffle_dst(cc, ctot) : cc;
+            const int o = g * C + c0 + i;
+            mean[i] = stats[0 * GC + o];
+            inv[i] = stats[1 * GC + o];
+            sc[i] = stats[2 * GC + o];
+            sh[i] = stats[3 * GC + o];
+            k1[i] = coef[0 * GC + o];
+            k2[i] = coef[1 * GC + o];
+            k3[i] = coef[2 * GC + o];
+        }
+        const bool relu = act == ACT_RELU6;
+        const int64_t gbase = (int64_t)g * Mg;
+        for (int rr = r0 + ty; rr < r1; rr += CY * RU) {
+            float dz[RU][VEC];
+            VecF<VEC> yv[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int64_t row = gbase + min(rr + u * CY, r1 - 1);
+                const float* dr = da.p + row * da.ld;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) dz[u][i] = dr[dcol[i]];
+                yv[u] = vload<VEC>(y + row * C + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                if (rr + u * CY >= r1) break;
+                const int64_t row = gbase + rr + u * CY;
+                VecF<VEC> o;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float v = yv[u].v[i];
+                    float d = dz[u][i];
+                    if (relu) {
+                        const float z = fmaf(sc[i], v, sh[i]);
+                        d = (z > 0.0f && z < 6.0f) ? d : 0.0f;
+                    }
+                    const float xh = (v - mean[i]) * inv[i];
+                    o.v[i] = k1[i] * (d - k2[i] - xh * k3[i]);
+                    acc[i] += (double)o.v[i];
+                }
+                vstore<VEC>(dy + row * C + c0, o);
+            }
+        }
+    }
+    if (CY > 1) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) sm[(ty * VEC + i) * CX + tx] = acc[i];
+        __syncthreads();
+        if (ty == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                double s = acc[i];
+                for (int yy = 1; yy < CY; ++yy) s += sm[(yy * VEC + i) * CX + tx];
+                acc[i] = s;
+            }
+        }
+    }
+    if (ty == 0 && on) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) part[((int64_t)g * nb + blockIdx.x) * C + c0 + i] = acc[i];
+    }
+}
+
 int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, const float* coef,
                  int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool) {
+    {
+        static const bool fast = !(getenv("CDRL_BBA_FAST") && atoi(getenv("CDRL_BBA_FAST")) == 0);
+        const VColGeom g = vcol_geom(Mg, C, NB_STATS);
+        const bool ydense = y.ld == C && y.coff == 0 && view_aligned(y, g.vec);
+        if (fast && !pool && g.nloop == 1 && g.vec >= 2 && ydense && (reinterpret_cast<uintptr_t>(dy) % (4 * g.vec)) == 0) {
+            dim3 grid(g.nb, G), block(g.cx, g.cy);
+            const size_t sm = (size_t)g.cy * g.vec * g.cx * sizeof(double);
+            if (g.vec == 4)
+                hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<4>, grid, block, sm, st, da, shuffle_ctot, y.p, stats, coef, G * C, C, Mg, g.rb, act, dy, part2);
+            else
+                hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<2>, grid, block, sm, st, da, shuffle_ctot, y.p, stats, coef, G * C, C, Mg, g.rb, act, dy, part2);
+            CDRL_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const int vec = vcol_geom(Mg, C).vec;
     PoolSrc ps{};
     if (pool) ps = *pool;
