@@ -693,8 +693,106 @@ struct PoolBnReduceF {
     }
 };
 
+// Fast path of pool_bn_bwd_reduce (4 channels per thread): the scatter-form sums need two DEPENDENT round trips per pooled
+// element (argmax, then the gathered pre-pool value); the generic row loop paid them row by row (16 rows per thread).  Here
+// RU rows go through the two phases together: all pooled-gradient / argmax loads, then all 4*RU gathers, then the sums.
+__global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, const float* __restrict__ y,
+                                                                    const float* __restrict__ stats, int GC, int C, int Mg,
+                                                                    int rb, double* __restrict__ part) {
+    extern __shared__ double sm[];   // [CY][4][CX]
+    constexpr int RU = 4, VEC = 4;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int g = blockIdx.y, nb = gridDim.x;
+    const int r0 = blockIdx.x * rb, r1 = min(r0 + rb, Mg);
+    const int c0 = tx * VEC;
+    const bool on = c0 < C;
+    double acc[2][VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[0][i] = acc[1][i] = 0.0;
+    if (on) {
+        const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
+        const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
+        const int64_t gbase = (int64_t)g * Mg;
+        for (int rr = r0 + ty; rr < r1; rr += CY * RU) {
+            VecF<VEC> d[RU];
+            uint32_t am[RU];
+            int64_t ybase[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int64_t row = gbase + min(rr + u * CY, r1 - 1);          // clamped: unconditional loads
+                d[u] = vload<VEC>(ps.dp + row * C + c0);
+                am[u] = *reinterpret_cast<const uint32_t*>(ps.argmax + row * C + c0);
+                const int ox = (int)(row % ps.Wo);
+                const int64_t q = row / ps.Wo;
+                const int oy = (int)(q % ps.Ho);
+                const int64_t n = q / ps.Ho;
+                // element offset of the window's top-left input pixel (may lie in the padding: only used with the tap offset)
+                ybase[u] = ((n * ps.H + (2 * oy - ps.pt)) * ps.W + (2 * ox - ps.pl)) * C + c0;
+            }
+            float v[RU][VEC];
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const int k = (int)((am[u] >> (8 * i)) & 0xffu);
+                    const int ky = k / 3, kx = k - 3 * ky;
+                    v[u][i] = y[ybase[u] + ((int64_t)ky * ps.W + kx) * C + i];
+                }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                if (rr + u * CY >= r1) break;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float z = fmaf(sc.v[i], v[u][i], sh.v[i]);
+                    if (z > 0.0f && z < 6.0f) {
+                        const float xh = (v[u][i] - mean.v[i]) * invstd.v[i];
+                        acc[0][i] += (double)d[u].v[i];
+                        acc[1][i] += (double)d[u].v[i] * (double)xh;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (CY > 1) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) sm[(ty * VEC + i) * CX + tx] = acc[q][i];
+            __syncthreads();
+            if (ty == 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    double s = acc[q][i];
+                    for (int yy = 1; yy < CY; ++yy) s += sm[(yy * VEC + i) * CX + tx];
+                    acc[q][i] = s;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (ty == 0 && on) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) part[(((int64_t)g * nb + blockIdx.x) * 2 + q) * C + c0 + i] = acc[q][i];
+    }
+}
+
 int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_group, int C, const float* stats, double* part,
                        hipStream_t st) {
+    {
+        static const bool fast = !(getenv("CDRL_POOLRED_FAST") && atoi(getenv("CDRL_POOLRED_FAST")) == 0);
+        const int Mg = frames_per_group * ps.Ho * ps.Wo;
+        const VColGeom g = vcol_geom(Mg, C, NB_STATS);
+        if (fast && g.vec == 4 && g.nloop == 1) {
+            dim3 grid(g.nb, G), block(g.cx, g.cy);
+            const size_t smb = (size_t)g.cy * 4 * g.cx * sizeof(double);
+            hipLaunchKernelGGL(pool_bn_bwd_reduce_v4_kernel, grid, block, smb, st, ps, y, stats, G * C, C, Mg, g.rb, part);
+            CDRL_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     return launch_vcolreduce<2, PoolBnReduceF>(G, frames_per_group * ps.Ho * ps.Wo, C, part, st, NB_STATS, ps, y, stats, G * C, C);
 }
 
