@@ -328,12 +328,21 @@ __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restr
         }
         // patch tile: 32 rows x 28 (27 taps + ones column); the lane's 14 columns [14*half, 14*half+14), tap offsets are
         // compile-time constants
+        // (unconditional loads, select afterwards: with the loads inside `if (ok)` they were issued pair by pair, each pair
+        //  with its own s_waitcnt -- 7 round trips per slice; rows that do not exist read the first pixel of the image)
+        float pv[14];
 #pragma unroll
         for (int jj = 0; jj < 14; ++jj) {
-            const int64_t o0 = (int64_t)(jj / 9) * W * 3 + (jj % 9);
-            const int64_t o1 = (int64_t)((14 + jj) / 9) * W * 3 + ((14 + jj) % 9);
-            float val = 0.0f;
-            if (ok) val = (half && jj == 13) ? 1.0f : xp[half ? o1 : o0];
+            const int j1 = jj == 13 ? 12 : 14 + jj;        // column 27 is the ones column: no load (tap 26 is loaded twice)
+            const int o0 = (jj / 9) * W * 3 + (jj % 9);
+            const int o1 = (j1 / 9) * W * 3 + (j1 % 9);
+            pv[jj] = xp[half ? o1 : o0];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 14; ++jj) {
+            float val = pv[jj];
+            if (jj == 13 && half) val = 1.0f;
+            if (!ok) val = 0.0f;
             P[wave][r][half * 14 + jj] = val;
         }
         if (FUSED) {
