@@ -183,6 +183,14 @@ PoolSrc make_pool_src(const uint8_t* argmax, const float* dp, int H, int W);
 int gap_fwd(const float* a, float* out, int N, int P, int C, hipStream_t st);
 int gap_bwd(const float* dout, float* da, int N, int P, int C, hipStream_t st);
 
+// batched transposes W[cin][cout] -> WT[cout][cin] of many small matrices in one launch (gemm.hip)
+struct PwTranspose {
+    const float* w;
+    float* wt;
+    int cin, cout;
+};
+int transpose_many(const PwTranspose* tab_dev, int n, int max_dim, hipStream_t st);
+
 // ---------------------------------------------------------------- linear output heads (heads.hip)
 #define HEADS_MAX 4
 #define HEADS_MAX_OUT 8

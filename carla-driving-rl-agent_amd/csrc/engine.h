@@ -330,6 +330,13 @@ private:
     } seg_[3];
     void build_seg_tables();
     int upload_seg_tables();
+    // transposed copies of the pointwise-conv weights for the backward-data GEMMs: with W^T in memory the persistent GEMM
+    // loads its weight fragments coalesced (the strided fragment load of W cost ~7 us of TA time per CU and launch);
+    // refreshed by one batched transpose launch at the start of every trunk backward
+    std::vector<PwTranspose> h_pwt_;
+    std::map<std::string, float*> pwt_by_name_;
+    PwTranspose* d_pwt_ = nullptr;
+    float* pw_transposed(const std::string& name, const float* w, int cin, int cout);
     bool tables_uploaded_ = false;
 };
 

@@ -322,6 +322,15 @@ Learner::PRef Learner::param(int model, const std::string& name, std::initialize
     return r;
 }
 
+float* Learner::pw_transposed(const std::string& name, const float* w, int cin, int cout) {
+    auto it = pwt_by_name_.find(name);
+    if (it != pwt_by_name_.end()) return it->second;
+    float* wt = alloc((size_t)cin * cout);
+    pwt_by_name_[name] = wt;
+    h_pwt_.push_back(PwTranspose{w, wt, cin, cout});
+    return wt;
+}
+
 void Learner::note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn_f, size_t fpart_d) {
     if (part_d > max_part_) max_part_ = part_d;
     if (part2_d > max_part2_) max_part2_ = part2_d;
@@ -397,6 +406,10 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     PRef w = param(M_TRUNK, prefix + ".w", {1, 1, Cin, Cout}, true);
     PRef b = param(M_TRUNK, prefix + ".b", {Cout}, true);
     const int G = cfg_.T, Mg = rows / G;
+    static const bool wt_env = !(getenv("CDRL_PW_WT") && atoi(getenv("CDRL_PW_WT")) == 0);
+    const float* wt = (wt_env && fuse.bwd_pw) ? pw_transposed(prefix, w.p, Cin, Cout) : nullptr;
+    const float* wb = wt ? wt : w.p;                    // backward-data operand B(k = cout, n = cin)
+    const int wb_sk = wt ? Cin : 1, wb_sn = wt ? 1 : Cout;
     const int tn_groups = (fuse.pro_stats || fuse.bb) ? G : 1;
     note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin, tn_groups));
     if (fuse.epi_stats) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cout, Cin).nbpg * 2 * Cout, 0, 0, 0);
@@ -420,7 +433,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             CDRL_TRY(gemm_tn(in, dz, w.g, rows, Cout, Cin, tns_[slot_], 0, side, G, fuse.pro_stats, &tb));
             CDRL_TRY(done_side(side));
             PwBnBwd pb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act, part2s_[slot_]};
-            CDRL_TRY(pw_nn(dz, nullptr, w.p, 1, Cout, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
+            CDRL_TRY(pw_nn(dz, nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
                            fuse.bwd_epi_stats, scr_main_.part, st, &pb));
             // bias gradient = column sums of the (virtual) dy, reduced from the GEMM's partials: rides on the next fork
             double* p2 = part2s_[slot_];
@@ -435,7 +448,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         // main stream: the critical path to the previous layer
         if (din.p) {
             if (fuse.bwd_pw)
-                return pw_nn(make_view(dy, Cout), nullptr, w.p, 1, Cout, nullptr, din, din_acc, G, Mg, Cin, Cout,
+                return pw_nn(make_view(dy, Cout), nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout,
                              fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, scr_main_.part, st);
             CDRL_TRY(gemm_nn(make_view(dy, Cout), w.p, 1, Cout, nullptr, din, rows, Cin, Cout, din_acc, st));
         }
@@ -1112,7 +1125,10 @@ void Learner::build(bool dry) {
             fparts_[i] = alloc_d(max_fpart_);
         }
     }
+    h_pwt_.clear();
+    pwt_by_name_.clear();
     build_trunk(trunk_ops_);
+    d_pwt_ = reinterpret_cast<PwTranspose*>(alloc((h_pwt_.size() + 1) * sizeof(PwTranspose) / sizeof(float) + 4));
     const int A = cfg_.A;
     const int pdims[4] = {A, A, 1, 1};
     const char* const pnames[4] = {"alpha", "beta", "similarity", "speed"};
@@ -1180,6 +1196,8 @@ void Learner::build_seg_tables() {
 }
 
 int Learner::upload_seg_tables() {
+    if (!h_pwt_.empty())
+        CDRL_HIP(hipMemcpy(d_pwt_, h_pwt_.data(), h_pwt_.size() * sizeof(PwTranspose), hipMemcpyHostToDevice));
     for (int m = 1; m <= 2; ++m) {
         SegTable& s = seg_[m];
         CDRL_HIP(hipMemcpy(s.segs, s.h_segs.data(), s.h_segs.size() * sizeof(TensorSeg), hipMemcpyHostToDevice));
@@ -1336,6 +1354,7 @@ int Learner::policy_backward_impl(const PolicyBatch& b, float inv_world, hipStre
     a.inv_world = inv_world;
     CDRL_TRY(policy_loss(a, st));
     CDRL_TRY(run_bwd(policy_ops_, st));
+    CDRL_TRY(transpose_many(d_pwt_, (int)h_pwt_.size(), 256, st));      // W^T of the pointwise convs (weights of this pass)
     CDRL_TRY(run_bwd(trunk_ops_, st));
     return join_side(st);
 }
@@ -1396,6 +1415,7 @@ int Learner::value_forward_backward_impl(const ValueBatch& b, float inv_world, h
     a.inv_world = inv_world;
     CDRL_TRY(value_loss(a, st));
     CDRL_TRY(run_bwd(value_ops_, st));
+    CDRL_TRY(transpose_many(d_pwt_, (int)h_pwt_.size(), 256, st));
     CDRL_TRY(run_bwd(trunk_ops_, st));
     return join_side(st);
 }

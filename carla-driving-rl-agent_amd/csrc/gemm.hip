@@ -753,4 +753,29 @@ int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride
     return 0;
 }
 
+// one 32 x 32 tile per block through LDS; grid = (tiles of the largest matrix, matrices)
+__global__ void __launch_bounds__(256) transpose_many_kernel(const PwTranspose* __restrict__ tab) {
+    __shared__ float t[32][33];
+    const PwTranspose d = tab[blockIdx.y];
+    const int tk = (d.cin + 31) / 32, tn = (d.cout + 31) / 32;
+    if ((int)blockIdx.x >= tk * tn) return;
+    const int k0 = (blockIdx.x / tn) * 32, n0 = (blockIdx.x % tn) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        t[r][tx] = (k0 + r < d.cin && n0 + tx < d.cout) ? d.w[(int64_t)(k0 + r) * d.cout + n0 + tx] : 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (n0 + r < d.cout && k0 + tx < d.cin) d.wt[(int64_t)(n0 + r) * d.cin + k0 + tx] = t[tx][r];
+}
+
+int transpose_many(const PwTranspose* tab_dev, int n, int max_dim, hipStream_t st) {
+    if (n <= 0) return 0;
+    const int tiles = cdiv(max_dim, 32) * cdiv(max_dim, 32);
+    hipLaunchKernelGGL(transpose_many_kernel, dim3(tiles, n), dim3(256), 0, st, tab_dev);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace cdrl
