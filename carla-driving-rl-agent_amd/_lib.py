@@ -85,6 +85,10 @@ PROTOTYPES = {
     'cdrl_gemm_nn': (_i, [_fp, _i, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     'cdrl_gemm_tn_workspace_elems': (_i64, [_i, _i, _i]),
     'cdrl_gemm_tn': (_i, [_fp, _i, _i, _fp, _i, _i, _fp, _i, _i, _i, _fp, _i, _fp]),
+    'cdrl_bn_small_fwd': (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    'cdrl_bn_small_bwd': (_i, [_fp, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp]),
+    'cdrl_linear_heads_fwd': (_i, [_fp, _i, _fp, _fp, _fp, _fp, _i, _i, _fp]),
+    'cdrl_linear_heads_bwd': (_i, [_fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp]),
     'cdrl_stem_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),
     'cdrl_stem_bwd_workspace_doubles': (_i64, [_i, _i, _i, _i, _i]),
     'cdrl_stem_bwd_filter': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp]),

@@ -494,6 +494,55 @@ int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle
     return bn_bwd_apply(dv, shuffle_ctot, yv, G, Mg, C, stats, coef, act, dy, workspace, S(stream));
 }
 
+int cdrl_bn_small_fwd(const float* y, int M, int C, const float* gamma, const float* beta, float* moving_mean,
+                      float* moving_var, float* stats, float* out, void* stream) {
+    return bn_small_fwd(make_view(const_cast<float*>(y), C), M, C, gamma, beta, moving_mean, moving_var, stats, make_view(out, C),
+                        S(stream));
+}
+
+int cdrl_bn_small_bwd(const float* dout, const float* y, int M, int C, const float* stats, float* dgamma, float* dbeta,
+                      float* coef, float* dx, void* stream) {
+    return bn_small_bwd(make_view(const_cast<float*>(dout), C), make_view(const_cast<float*>(y), C), M, C, stats, dgamma, dbeta,
+                        coef, dx, S(stream));
+}
+
+static int make_head_set(HeadSet& hs, int nheads, const int* n, const float* const* w, const float* const* b, float* const* dw,
+                         float* const* db) {
+    if (nheads < 1 || nheads > HEADS_MAX) {
+        set_error("linear_heads: %d heads not supported", nheads);
+        return -1;
+    }
+    memset(&hs, 0, sizeof(hs));
+    hs.nheads = nheads;
+    int off = 0;
+    for (int h = 0; h < nheads; ++h) {
+        hs.n[h] = n[h];
+        hs.off[h] = off;
+        hs.w[h] = w[h];
+        hs.b[h] = b ? b[h] : nullptr;
+        hs.gw[h] = dw ? dw[h] : nullptr;
+        hs.gb[h] = db ? db[h] : nullptr;
+        off += n[h];
+    }
+    return off;
+}
+
+int cdrl_linear_heads_fwd(const float* a, int nheads, const int* n, const float* const* w, const float* const* b, float* lin,
+                          int B, int K, void* stream) {
+    HeadSet hs;
+    const int L = make_head_set(hs, nheads, n, w, b, nullptr, nullptr);
+    if (L < 0) return L;
+    return heads_fwd(a, K, hs, lin, L, B, K, S(stream));
+}
+
+int cdrl_linear_heads_bwd(const float* a, int nheads, const int* n, const float* const* w, const float* dlin, float* da,
+                          float* const* dw, float* const* db, int B, int K, void* stream) {
+    HeadSet hs;
+    const int L = make_head_set(hs, nheads, n, w, nullptr, dw, db);
+    if (L < 0) return L;
+    return heads_bwd(a, K, hs, dlin, L, da, K, B, K, S(stream));
+}
+
 int cdrl_maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax,
                         int N, int H, int W, int C, void* stream) {
     return maxpool_bn_fwd(y, stats, G, frames_per_group, p, argmax, N, H, W, C, S(stream));

@@ -29,7 +29,7 @@ __device__ __forceinline__ HeadCols head_cols(const HeadSet& hs) {
             hc.w[c] = hs.w[h] + n;
             hc.ws[c] = hs.n[h];
             hc.lc[c] = hs.off[h] + n;
-            hc.bias[c] = hs.b[h][n];
+            hc.bias[c] = hs.b[h] ? hs.b[h][n] : 0.0f;
         }
     }
     hc.L = c;

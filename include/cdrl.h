@@ -242,6 +242,20 @@ int cdrl_maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, i
 int cdrl_bn_train_fwd(const float* y, int G, int Mg, int C, const float* gamma, const float* beta, float* moving_mean,
                       float* moving_var, int bessel, int relu6, float* out, int out_ld, int out_coff, int shuffle_ctot,
                       float* stats, double* workspace, void* stream);
+/* Single-group BatchNorm over a few hundred rows (the dense BatchNorms of the trunk tail and of control_branch,
+ * core/networks.py:59-66, :53-54) as ONE launch per direction: statistics + moving-average update + apply (forward),
+ * sums + coefficients + apply (backward).  y / out / dout / dx dense [M][C]; stats 4*C, coef 3*C floats. */
+int cdrl_bn_small_fwd(const float* y, int M, int C, const float* gamma, const float* beta, float* moving_mean,
+                      float* moving_var, float* stats, float* out, void* stream);
+int cdrl_bn_small_bwd(const float* dout, const float* y, int M, int C, const float* stats, float* dgamma, float* dbeta,
+                      float* coef, float* dx, void* stream);
+/* The linear output heads of a control branch (core/networks.py:128-137, :267-275: up to 4 Dense(K -> n_h) layers on the
+ * same [B][K] activation, 8 outputs in total) as one launch per direction.  w[h]: [K][n[h]], b[h]: [n[h]];
+ * lin / dlin: [B][sum n]; backward: da [B][K] (overwritten), dw[h], db[h]. */
+int cdrl_linear_heads_fwd(const float* a, int nheads, const int* n, const float* const* w, const float* const* b, float* lin,
+                          int B, int K, void* stream);
+int cdrl_linear_heads_bwd(const float* a, int nheads, const int* n, const float* const* w, const float* dlin, float* da,
+                          float* const* dw, float* const* db, int B, int K, void* stream);
 int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, const float* y, int G, int Mg,
                       int C, const float* stats, int relu6, float* dgamma, float* dbeta, float* dy, float* coef,
                       double* workspace, void* stream);

@@ -454,6 +454,70 @@ def test_stem_block_bwd(lib, B, T, H, W):
     assert np.abs(db.cpu().numpy()).max() < 1e-4 * np.abs(dw.cpu().numpy()).max()
 
 
+@pytest.mark.parametrize('M,Cc', [(256, 512), (256, 320), (37, 352), (1024, 16), (5, 3)])
+def test_bn_small(lib, M, Cc):
+    """Single-group dense BatchNorm as one launch per direction (reference core/networks.py:59-66: BatchNormalization on
+    (B, C) activations, training mode) against fp64 numpy: outputs, moving statistics, dgamma / dbeta, input gradient."""
+    rng = np.random.default_rng(M + Cc)
+    y = (rng.standard_normal((M, Cc)) * rng.uniform(0.5, 2.0, Cc) + rng.uniform(-1, 1, Cc)).astype(np.float32)
+    gam, bet = rng.uniform(0.5, 1.5, Cc).astype(np.float32), rng.uniform(-1, 1, Cc).astype(np.float32)
+    mm0, mv0 = rng.standard_normal(Cc).astype(np.float32), rng.uniform(0.5, 2.0, Cc).astype(np.float32)
+    dout = rng.standard_normal((M, Cc)).astype(np.float32)
+    Y, G_, B_, MM, MV, DO = dev(y), dev(gam), dev(bet), dev(mm0), dev(mv0), dev(dout)
+    stats, out = torch.zeros(4 * Cc, device=DEV), torch.zeros((M, Cc), device=DEV)
+    _lib.check(lib.cdrl_bn_small_fwd(P(Y), M, Cc, P(G_), P(B_), P(MM), P(MV), P(stats), P(out), S()))
+    y64 = y.astype(np.float64)
+    mean, var = y64.mean(0), y64.var(0)
+    inv = 1.0 / np.sqrt(var + 1e-3)
+    xh = (y64 - mean) * inv
+    assert rel_err(out.cpu().numpy(), xh * gam + bet) < 1e-5
+    assert rel_err(MM.cpu().numpy(), mm0 - (mm0 - mean) * 0.01) < 1e-5
+    assert rel_err(MV.cpu().numpy(), mv0 - (mv0 - var) * 0.01) < 1e-5
+    dg, db, coef, dx = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(3 * Cc, device=DEV), torch.zeros((M, Cc), device=DEV)
+    _lib.check(lib.cdrl_bn_small_bwd(P(DO), P(Y), M, Cc, P(stats), P(dg), P(db), P(coef), P(dx), S()))
+    d64 = dout.astype(np.float64)
+    assert rel_err(db.cpu().numpy(), d64.sum(0)) < 2e-5
+    assert rel_err(dg.cpu().numpy(), (d64 * xh).sum(0)) < 2e-5
+    ref_dx = gam * inv * (d64 - d64.mean(0) - xh * (d64 * xh).mean(0))
+    assert rel_err(dx.cpu().numpy(), ref_dx) < 2e-5
+
+
+@pytest.mark.parametrize('B,K,dims', [(256, 320, (2, 2, 1, 1)), (256, 320, (1, 1, 1, 1)), (37, 64, (3, 3, 1, 1)), (1, 320, (2, 2, 1, 1)),
+                                      (300, 33, (2,))])
+def test_linear_heads(lib, B, K, dims):
+    """All linear output heads of a control branch in one launch per direction (core/networks.py:128-137, 267-275)
+    against fp64 numpy: outputs, input gradient, weight and bias gradients."""
+    rng = np.random.default_rng(B + K + sum(dims))
+    a = rng.standard_normal((B, K)).astype(np.float32)
+    ws = [(rng.standard_normal((K, n)) / np.sqrt(K)).astype(np.float32) for n in dims]
+    bs = [rng.standard_normal(n).astype(np.float32) for n in dims]
+    L = sum(dims)
+    dlin = rng.standard_normal((B, L)).astype(np.float32)
+    A_, DL = dev(a), dev(dlin)
+    Wd, Bd = [dev(w) for w in ws], [dev(b) for b in bs]
+    nh = len(dims)
+    n_arr = (C.c_int * nh)(*dims)
+    ptrs = lambda ts: (C.c_void_p * nh)(*[t.data_ptr() for t in ts])
+    lin = torch.zeros((B, L), device=DEV)
+    _lib.check(lib.cdrl_linear_heads_fwd(P(A_), nh, n_arr, ptrs(Wd), ptrs(Bd), P(lin), B, K, S()))
+    a64 = a.astype(np.float64)
+    ref = np.concatenate([a64 @ w.astype(np.float64) + b for w, b in zip(ws, bs)], axis=1)
+    assert rel_err(lin.cpu().numpy(), ref) < 1e-5
+    da = torch.full((B, K), 7.0, device=DEV)
+    dW, dB = [torch.zeros_like(w) for w in Wd], [torch.zeros_like(b) for b in Bd]
+    _lib.check(lib.cdrl_linear_heads_bwd(P(A_), nh, n_arr, ptrs(Wd), P(DL), P(da), ptrs(dW), ptrs(dB), B, K, S()))
+    d64 = dlin.astype(np.float64)
+    off = 0
+    ref_da = np.zeros((B, K))
+    for h, n in enumerate(dims):
+        dh = d64[:, off:off + n]
+        ref_da += dh @ ws[h].astype(np.float64).T
+        assert rel_err(dW[h].cpu().numpy(), a64.T @ dh) < 1e-5
+        assert rel_err(dB[h].cpu().numpy(), dh.sum(0)) < 1e-5
+        off += n
+    assert rel_err(da.cpu().numpy(), ref_da) < 1e-5
+
+
 @pytest.mark.parametrize('B,A,faithful', [(256, 2, True), (37, 3, False), (1024, 2, True)])
 def test_policy_loss(lib, B, A, faithful):
     rng = np.random.default_rng(B + A)
