@@ -243,7 +243,8 @@ private:
         double* part2 = nullptr;
         float* tn = nullptr;
     };
-    Scratch scr_main_, scr_aux_;
+    Scratch scr_main_, scr_aux_, scr_sc_;
+    hipEvent_t ev_sc_fork_[3] = {}, ev_sc_done_[3] = {};   // shortcut branch of the stride-2 units on the side stream (forward)
     Scratch* build_scr_ = &scr_main_;
     std::vector<Op> aux_ops_;
     hipEvent_t ev_aux_fork_ = nullptr, ev_aux_done_ = nullptr;

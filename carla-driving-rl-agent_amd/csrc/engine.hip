@@ -51,6 +51,10 @@ Learner::~Learner() {
     if (ev_out_) (void)hipEventDestroy(ev_out_);
     if (main_) (void)hipStreamDestroy(main_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
+    for (int i = 0; i < 3; ++i) {
+        if (ev_sc_fork_[i]) (void)hipEventDestroy(ev_sc_fork_[i]);
+        if (ev_sc_done_[i]) (void)hipEventDestroy(ev_sc_done_[i]);
+    }
     if (ev_aux_fork_) (void)hipEventDestroy(ev_aux_fork_);
     if (ev_aux_done_) (void)hipEventDestroy(ev_aux_done_);
     if (side_) (void)hipStreamDestroy(side_);
@@ -492,6 +496,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
     const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
     const int Mi = B * H * W, Mo = B * Ho * Wo;
     const bool pre = bn_pre != nullptr;
+    Scratch* sc = build_scr_;           // the shortcut branch of a stride-2 unit has its own partial buffers (it runs on the side stream)
     PRef g1, b1, mm1, mv1;
     float *stats1 = nullptr, *coef1 = nullptr;
     if (pre) {
@@ -522,12 +527,12 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
     if (pre) {      // BN1: statistics only in the forward; backward = finalize of the sums the depthwise op produced
         Op op;
         op.fwd = [=](hipStream_t st, int training) -> int {
-            if (training && !pre_stats_nb) CDRL_TRY(colstats(xv, G, Mi, C, scr_main_.part, st));
-            return bn_finalize(scr_main_.part, pre_stats_nb ? pre_stats_nb : nb_in, G, Mi, C, g1.p, b1.p, mm1.p, mv1.p, 1, training,
+            if (training && !pre_stats_nb) CDRL_TRY(colstats(xv, G, Mi, C, sc->part, st));
+            return bn_finalize(sc->part, pre_stats_nb ? pre_stats_nb : nb_in, G, Mi, C, g1.p, b1.p, mm1.p, mv1.p, 1, training,
                                stats1, st);
         };
         op.bwd = [=](hipStream_t st) -> int {
-            CDRL_TRY(bn_bwd_finalize(scr_main_.part, nbf, G, Mi, C, stats1, g1.g, b1.g, coef1, st));
+            CDRL_TRY(bn_bwd_finalize(sc->part, nbf, G, Mi, C, stats1, g1.g, b1.g, coef1, st));
             if (pre_defer_apply) return 0;                 // the 1x1 conv in front applies it on load (PwFuse::bb)
             const float* dz = dys_[slot_];                 // masked gradient left there by the depthwise op
             CDRL_TRY(next_slot(st));
@@ -539,13 +544,13 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
     {
         Op op;
         op.fwd = [=](hipStream_t st, int) -> int {
-            return dwf_fwd(x, stats1, w.p, b.p, y2, scr_main_.part, G, B, H, W, C, stride, st);
+            return dwf_fwd(x, stats1, w.p, b.p, y2, sc->part, G, B, H, W, C, stride, st);
         };
         op.bwd = [=](hipStream_t st) -> int {
             CDRL_TRY(next_slot(st));
             double* pw = fparts_[slot_];
             const View dx = pre ? make_view(dys_[slot_], C) : din;
-            CDRL_TRY(dwf_bwd(x, stats1, dout.p, y2, stats2, coef2, w.p, dx, scr_main_.part, pw, G, B, H, W, C, stride, st));
+            CDRL_TRY(dwf_bwd(x, stats1, dout.p, y2, stats2, coef2, w.p, dx, sc->part, pw, G, B, H, W, C, stride, st));
             return defer_side(st, [=](hipStream_t sd) -> int {
                 return reduce_partials2(pw, G * nbf, 9 * C, C, (int64_t)10 * C, w.g, b.g, 0, sd);
             });
@@ -555,13 +560,13 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
     {               // BN2: finalize + apply in the forward; backward = sums + coefficients only (applied by the dw op)
         Op op;
         op.fwd = [=](hipStream_t st, int training) -> int {
-            CDRL_TRY(bn_finalize(scr_main_.part, nbf, G, Mo, C, g2.p, b2.p, mm2.p, mv2.p, 1, training, stats2, st));
+            CDRL_TRY(bn_finalize(sc->part, nbf, G, Mo, C, g2.p, b2.p, mm2.p, mv2.p, 1, training, stats2, st));
             if (!post_apply) return 0;
             return bn_apply(y2v, G, Mo, C, stats2, ACT_NONE, out, 0, st);
         };
         op.bwd = [=](hipStream_t st) -> int {
-            if (!post_bwd_nb) CDRL_TRY(bn_bwd_reduce(dout, 0, y2v, G, Mo, C, stats2, ACT_NONE, scr_main_.part, st));
-            return bn_bwd_finalize(scr_main_.part, post_bwd_nb ? post_bwd_nb : nb_out, G, Mo, C, stats2, g2.g, b2.g, coef2, st);
+            if (!post_bwd_nb) CDRL_TRY(bn_bwd_reduce(dout, 0, y2v, G, Mo, C, stats2, ACT_NONE, sc->part, st));
+            return bn_bwd_finalize(sc->part, post_bwd_nb ? post_bwd_nb : nb_out, G, Mo, C, stats2, g2.g, b2.g, coef2, st);
         };
         ops.push_back(op);
     }
@@ -886,6 +891,22 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 const int Mg_in = B * curH * curW, Mg_out = B * Ho * Wo;
                 const std::string pre = "img.s" + std::to_string(s) + ".u" + std::to_string(u);
                 Tens out = tens(rows_out, C);
+                // stride-2 units: the shortcut branch (dw3x3/s2 -> BN -> 1x1 -> BN+ReLU6) only depends on the unit input; in the
+                // FORWARD pass (where the side stream is idle) it runs on the side stream next to the main branch
+                static const bool sc_overlap_env = !(getenv("CDRL_SC_OVERLAP") && atoi(getenv("CDRL_SC_OVERLAP")) == 0);
+                const bool sc_overlap = sc_overlap_env && stride == 2;
+                const int sc_ev = s;
+                if (sc_overlap) {
+                    Op fk;
+                    fk.fwd = [=](hipStream_t st, int) -> int {
+                        if (!side_enabled_) return 0;
+                        CDRL_HIP(hipEventRecord(ev_sc_fork_[sc_ev], st));
+                        CDRL_HIP(hipStreamWaitEvent(side_, ev_sc_fork_[sc_ev], 0));
+                        return 0;
+                    };
+                    fk.bwd = [](hipStream_t) -> int { return 0; };
+                    ops.push_back(fk);
+                }
                 Passthrough pass;
                 static const bool fuse_pass = !(getenv("CDRL_FUSED_PASS") && atoi(getenv("CDRL_FUSED_PASS")) == 0);
                 if (stride == 1 && fuse_pass && sc_c == C - sc_c) {
@@ -981,6 +1002,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                            nullptr, 0, false, pass);
                 }
                 if (stride == 2) {
+                    const size_t sc_begin = ops.size();
+                    if (sc_overlap) build_scr_ = &scr_sc_;
                     Tens ys1 = tens(rows_out, sc_c, false), b1 = tens(rows_out, sc_c);
                     if (fused_dw_) {
                         add_dw_block(ops, pre, nullptr, "sc_dw", "sc_bn1", X.p, curH, curW, sc_c, 2, ys1.p, b1.v(), b1.gv(),
@@ -994,6 +1017,22 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     add_pw(ops, pre + ".sc_pw", b1.v(), rows_out, sc_c, sc_c, ys2.p, b1.gv(), 0, bnrec(T, Mg_out, sc_c));
                     add_bn(ops, M_TRUNK, pre + ".sc_bn2", ys2.v(), T, Mg_out, sc_c, true, ACT_RELU6, out.v(0), C, out.gv(0),
                            C, nullptr);
+                    if (sc_overlap) {
+                        build_scr_ = &scr_main_;
+                        for (size_t i = sc_begin; i < ops.size(); ++i) {        // forward of the shortcut ops -> side stream
+                            auto f = ops[i].fwd;
+                            ops[i].fwd = [=](hipStream_t st, int training) -> int { return f(side_enabled_ ? side_ : st, training); };
+                        }
+                        Op jn;
+                        jn.fwd = [=](hipStream_t st, int) -> int {
+                            if (!side_enabled_) return 0;
+                            CDRL_HIP(hipEventRecord(ev_sc_done_[sc_ev], side_));
+                            CDRL_HIP(hipStreamWaitEvent(st, ev_sc_done_[sc_ev], 0));
+                            return 0;
+                        };
+                        jn.bwd = [](hipStream_t) -> int { return 0; };
+                        ops.push_back(jn);
+                    }
                 }
                 X = out;
                 curH = Ho;
@@ -1118,6 +1157,9 @@ void Learner::build(bool dry) {
         scr_aux_.part = alloc_d(max_part_);
         scr_aux_.part2 = alloc_d(max_part2_);
         scr_aux_.tn = alloc(max_tn_);
+        scr_sc_.part = alloc_d(max_part_);
+        scr_sc_.part2 = alloc_d(max_part2_);
+        scr_sc_.tn = scr_aux_.tn;           // (unused by the shortcut ops)
         for (int i = 0; i < NSLOT; ++i) {
             dys_[i] = alloc(max_dy_);
             part2s_[i] = alloc_d(max_part2_);
@@ -1165,6 +1207,7 @@ void Learner::build(bool dry) {
         // scratch goes first in the real layout; account for it here
         ws_off_ += 2 * (align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
                         align_up(max_tn_ * sizeof(float), 256)) +
+                   align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
                    NSLOT * (align_up(max_dy_ * sizeof(float), 256) + align_up(max_part2_ * sizeof(double), 256) +
                             align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256));
         ws_bytes_ = ws_off_ + 4096;
@@ -1251,6 +1294,10 @@ int Learner::bind(const Buffers& b) {
             CDRL_HIP(hipEventCreateWithFlags(&ev_side_[i], hipEventDisableTiming));
         }
         CDRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) {
+            CDRL_HIP(hipEventCreateWithFlags(&ev_sc_fork_[i], hipEventDisableTiming));
+            CDRL_HIP(hipEventCreateWithFlags(&ev_sc_done_[i], hipEventDisableTiming));
+        }
         CDRL_HIP(hipStreamCreateWithPriority(&aux_, hipStreamNonBlocking, prio_lo));
         CDRL_HIP(hipEventCreateWithFlags(&ev_aux_fork_, hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_aux_done_, hipEventDisableTiming));
