@@ -277,6 +277,16 @@ int cdrl_learner_get_buffer(const cdrl_learner* l, int which, float** ptr, int64
     return 0;
 }
 
+int cdrl_learner_named_buffer(const cdrl_learner* l, const char* name, void** ptr, int64_t* bytes) {
+    CHECK_L(l);
+    if (!name || !ptr || !bytes) return -1;
+    if (!l->impl->named_buffer(name, ptr, bytes)) {
+        cdrl::set_error("unknown named buffer %s (or learner not bound)", name);
+        return -1;
+    }
+    return 0;
+}
+
 int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double gamma, double lambda, float scale,
                      float* returns, float* returns_be, float* adv_raw, float* adv, double* scratch, void* stream) {
     if (!rewards || !values_be || !returns || !returns_be || !adv_raw || !adv || !scratch) {

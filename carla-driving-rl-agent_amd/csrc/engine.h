@@ -139,6 +139,15 @@ public:
     float* policy_lin() const { return lin_p_.p; }
     float* value_lin() const { return lin_v_.p; }
     DevHP* dev_hp() const { return hp_dev_; }
+    // Named internal tensors (parity tests: the raw BatchNorm inputs, statistics blocks, max-pool argmax codes and dense
+    // pre-activations from which the discrete ReLU6 / max-pool decisions of the last forward are reconstructed)
+    bool named_buffer(const std::string& name, void** p, int64_t* bytes) const {
+        auto it = named_.find(name);
+        if (it == named_.end()) return false;
+        *p = it->second.first;
+        *bytes = it->second.second;
+        return true;
+    }
 
 private:
     struct Tens {
@@ -339,6 +348,10 @@ private:
     PwTranspose* d_pwt_ = nullptr;
     float* pw_transposed(const std::string& name, const float* w, int cin, int cout);
     bool tables_uploaded_ = false;
+    std::map<std::string, std::pair<void*, int64_t>> named_;
+    void note_named(const std::string& name, const void* p, size_t bytes) {
+        if (!dry_) named_[name] = std::make_pair(const_cast<void*>(p), (int64_t)bytes);
+    }
 };
 
 }  // namespace cdrl

@@ -355,6 +355,8 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     PRef mv = param(model, prefix + ".moving_var", {C}, false);
     float* stats = alloc((size_t)4 * G * C);
     float* coef = alloc((size_t)3 * G * C);
+    note_named(prefix + ".stats", stats, (size_t)4 * G * C * sizeof(float));
+    if (x.ld == C && x.coff == 0) note_named(prefix + ".x", x.p, (size_t)G * Mg * C * sizeof(float));
     const int nb = vcol_geom(Mg, C).nb;
     note_scratch((size_t)G * std::max(nb, stats_nb) * 2 * C, (size_t)G * nb * C, 0, 0);
     BnRec rec;
@@ -507,6 +509,8 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
         mv1 = param(M_TRUNK, n1 + ".moving_var", {C}, false);
         stats1 = stats1_ext ? stats1_ext : alloc((size_t)4 * G * C);
         coef1 = coef1_ext ? coef1_ext : alloc((size_t)3 * G * C);
+        note_named(n1 + ".stats", stats1, (size_t)4 * G * C * sizeof(float));
+        note_named(n1 + ".x", x, (size_t)N * H * W * C * sizeof(float));
     }
     PRef w = param(M_TRUNK, unit + "." + dw + ".w", {3, 3, C, 1}, true);
     PRef b = param(M_TRUNK, unit + "." + dw + ".b", {C}, true);
@@ -581,6 +585,7 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
     if (act != ACT_NONE) {
         z = alloc((size_t)M * N);
         dz = alloc((size_t)M * N);
+        note_named(prefix + ".z", z, (size_t)M * N * sizeof(float));
     }
     note_scratch((size_t)vcol_geom(M, N).nb * N, (size_t)vcol_geom(M, N).nb * N, 0, (size_t)gemm_tn_part_elems(M, N, K));
     const int nb = vcol_geom(M, N).nb;
@@ -815,6 +820,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         const int Hp0 = same_out_h(Hs, 2), Wp0 = same_out_h(Ws, 2);
         Tens pool = tens(N * Hp0 * Wp0, c.stem);
         uint8_t* argmax = reinterpret_cast<uint8_t*>(alloc(((size_t)N * Hp0 * Wp0 * c.stem + 3) / 4));
+        note_named("img.stem.bn.stats", stem_stats, (size_t)4 * T * Cs * sizeof(float));
+        note_named("img.stem.bn.x", y.p, (size_t)N * Hs * Ws * Cs * sizeof(float));
+        note_named("img.stem.pool.argmax", argmax, (size_t)N * Hp0 * Wp0 * Cs);
         // one-pass form (stem_bwd.hip): BN sums and filter sums together, everything in the BN op's backward.  Opt-in
         // (CDRL_STEM_DIRECT=1): measured 747 us (three accumulator tiles, 64 KB LDS -> two workgroups per CU) against
         // 206 + 453 us for the two-pass form whose second pass overlaps on the side stream: 22.3 vs 22.0 ms/update-step.
@@ -1262,6 +1270,7 @@ int Learner::bind(const Buffers& b) {
         return -1;
     }
     drop_graphs();
+    named_.clear();
     buf_ = b;
     ws_base_ = reinterpret_cast<char*>(b.workspace);
     build(false);

@@ -151,6 +151,15 @@ class LearnerEngine:
         t = self.workspace[off: off + 4 * n.value].view(torch.float32)
         return t.view(shape) if shape is not None else t
 
+    def named_buffer(self, name: str, dtype=torch.float32, shape=None) -> torch.Tensor:
+        """Zero-copy view of a named internal tensor (cdrl_learner_named_buffer; parity tests)."""
+        p = C.c_void_p()
+        n = C.c_int64()
+        _lib.check(self.lib.cdrl_learner_named_buffer(self.h, name.encode(), C.byref(p), C.byref(n)), f'named_buffer({name})')
+        off = p.value - self.workspace.data_ptr()
+        t = self.workspace[off: off + n.value].view(dtype)
+        return t.view(shape) if shape is not None else t
+
     # ------------------------------------------------------------------ staging
     def stage(self, batch: dict, slot: str) -> dict:
         """Copies a (nested) batch into persistent device buffers owned by the engine and returns those.

@@ -151,6 +151,12 @@ enum {
     CDRL_BUF_SAMPLE = 8      /* (B, A) Beta sample drawn by ..._resample       */
 };
 int cdrl_learner_get_buffer(const cdrl_learner* l, int which, float** ptr, int64_t* elems);
+/* Named internal tensors of a bound learner, for parity tests: "<bn>.x" (raw BatchNorm input, dense NHWC rows with frames
+ * f = t*B + b), "<bn>.stats" ([4][T][C]: mean, invstd, scale, shift of the last training forward), "<dense>.z" (dense
+ * pre-activation), "img.stem.pool.argmax" (one byte ky*3+kx per pooled element).  The discrete decisions of the last forward
+ * (ReLU6 region = region of fmaf(scale, x, shift); max-pool argmax) are reconstructed from them, so that the float64 oracle
+ * can be evaluated on the SAME decisions (reference core/architectures.py:47,161 are the sites). */
+int cdrl_learner_named_buffer(const cdrl_learner* l, const char* name, void** ptr, int64_t* bytes);
 
 /* ---- rollout-buffer post-processing ---------------------------------------------------------
  * PPOMemory.compute_returns + compute_advantages (rl/agents/ppo.py:699-727), utils.gae /

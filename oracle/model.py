@@ -86,8 +86,61 @@ def same_pad(n: int, k: int, s: int):
     return total // 2, total - total // 2
 
 
+class Decisions:
+    """Record / replay of the DISCRETE decisions of a forward pass (ReLU6 regions, max-pool argmax).
+
+    Between two float32 implementations (or float32 and float64) an element within rounding distance of a
+    ReLU6 kink or of a max-pool tie takes a different branch, and the gradient changes by an O(1) amount per
+    flipped element.  A gradient comparison is only well defined when both sides took the same decisions:
+    `record` stores them during one forward, `replay` forces them onto another forward (e.g. the float64
+    oracle evaluated with the float32 decisions), which then is a smooth function of its inputs."""
+
+    def __init__(self):
+        self.mode = 'off'
+        self.items = []
+        self.cursor = 0
+
+    def start(self, mode):
+        assert mode in ('off', 'record', 'replay')
+        self.mode = mode
+        self.cursor = 0
+        if mode == 'record':
+            self.items = []
+        return self
+
+    def put(self, item):
+        self.items.append(item)
+
+    def get(self):
+        item = self.items[self.cursor]
+        self.cursor += 1
+        return item
+
+
+DEC = Decisions()
+
+
 def relu6(x):
-    return torch.clamp(x, 0.0, 6.0)      # ReLU(max_value=6), core/architectures.py:47
+    """ReLU(max_value=6), core/architectures.py:47 (gradient 1 strictly inside (0, 6))."""
+    if DEC.mode == 'replay':
+        mid, hi = DEC.get()
+        return x * mid.to(x.dtype) + 6.0 * hi.to(x.dtype)
+    if DEC.mode == 'record':
+        DEC.put(((x > 0.0) & (x < 6.0), x >= 6.0))
+    return torch.clamp(x, 0.0, 6.0)
+
+
+def max_pool_3x3_s2(xx):
+    """MaxPool2D(3, 2, 'same') on an input already padded with -inf (core/architectures.py:161)."""
+    if DEC.mode == 'replay':
+        idx = DEC.get()
+        flat = xx.reshape(xx.shape[0], xx.shape[1], -1)
+        return torch.gather(flat, 2, idx.reshape(idx.shape[0], idx.shape[1], -1)).reshape(idx.shape)
+    if DEC.mode == 'record':
+        y, idx = F.max_pool2d(xx, 3, 2, return_indices=True)
+        DEC.put(idx)
+        return y
+    return F.max_pool2d(xx, 3, 2)
 
 
 def swish6(x):
@@ -164,7 +217,7 @@ def shufflenet_v2(image, p, cfg: NetConfig, training: bool, taps: Optional[dict]
     ph = same_pad(x.shape[3], 3, 2)
     pw_ = same_pad(x.shape[4], 3, 2)
     xx = F.pad(_fold(x), (pw_[0], pw_[1], ph[0], ph[1]), value=float('-inf'))
-    x = _unfold(F.max_pool2d(xx, 3, 2), T)                                        # :161
+    x = _unfold(max_pool_3x3_s2(xx), T)                                        # :161
     if taps is not None:
         taps['pool'] = x
     for u in unit_plan(cfg):                                                      # :164-167

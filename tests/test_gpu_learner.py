@@ -25,7 +25,7 @@ def _group(name):
     return 'tower' if name.startswith('img.') else 'tail'
 
 
-def _compare(eng_views, ref32, ref64, tol, what, floor_frac=0.0, skip=lambda n: False, slack=3.0):
+def _compare(eng_views, ref32, ref64, tol, what, floor_frac=0.0, skip=lambda n: False, slack=2.0):
     """Engine vs the float64 oracle, with the float32 oracle as the noise yardstick.
 
     Two regimes (measured, see DESIGN.md "Parity methodology"):
@@ -35,7 +35,10 @@ def _compare(eng_views, ref32, ref64, tol, what, floor_frac=0.0, skip=lambda n: 
         float32 implementations and moves a channel's gradient by ~1/(rows per BN group).  The
         float32 oracle itself sits 1e-3..9e-2 from the float64 oracle there.  Flips are sparse
         random events, so the yardstick is the float32 oracle's WORST tensor of the group, not the
-        same tensor: bound = max(tol, slack * max_group |oracle32 - oracle64|)."""
+        same tensor: bound = max(tol, slack * max_group |oracle32 - oracle64|).
+    This UNPINNED comparison is a plausibility check only (a few-percent error in one tower tensor can hide under the
+    flip noise); the gate at north_star's 1e-4 is test_pinned_decisions_gradients_and_weights below, which evaluates the
+    float64 oracle on the engine's own decisions."""
     gmax = max(float(np.abs(_np(g)).max()) for g in ref64.values())
     errs, noise = {}, {'tower': 0.0, 'tail': 0.0}
     for name, g64 in ref64.items():
@@ -182,6 +185,146 @@ def test_policy_then_value_step(B, H, W, A, faithful):
         _compare(m_t, oracle.opt_trunk.m, o64.opt_trunk.m, TOL, 'adam m (t=2)', floor_frac=1e-3)
     finally:
         _dump_report(f'B{B}_{H}x{W}')
+
+
+def _adam_update(g, m0, v0, t, lr, b1=0.9, b2=0.999, eps=1e-7):
+    """Keras Adam parameter decrement for gradient g from moments (m0, v0), step t (float64, float32-rounded constants)."""
+    b1, b2, eps, lr = float(np.float32(b1)), float(np.float32(b2)), float(np.float32(eps)), float(np.float32(lr))
+    m = m0 + (g - m0) * (1.0 - b1)
+    v = v0 + (g * g - v0) * (1.0 - b2)
+    return lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t) * m / (np.sqrt(v) + eps)
+
+
+def _pinned_grad_check(eng_grads, g64, what, tol=TOL, floor_frac=1e-3, g32=None):
+    """Engine gradients vs the float64 oracle evaluated ON THE ENGINE'S OWN DISCRETE DECISIONS: a smooth function on both
+    sides, so north_star's 1e-4 (relative to each tensor's scale) applies with no noise allowance."""
+    gmax = max(float(np.abs(_np(g)).max()) for g in g64.values())
+    worst = {}
+    for name, g in g64.items():
+        r = _np(g).astype(np.float64)
+        scale = max(np.abs(r).max(), floor_frac * gmax, 1e-30)
+        e = float(np.abs(_np(eng_grads[name]).astype(np.float64) - r).max() / scale)
+        e32 = float(np.abs(_np(eng_grads[name]).astype(np.float64) - _np(g32[name]).astype(np.float64)).max() / scale) if g32 else None
+        grp = _group(name)
+        w = worst.setdefault(grp, dict(err=0.0, tensor='', errs=[], err_vs_oracle32=0.0))
+        w['errs'].append(e)
+        if e >= w['err']:
+            w['err'], w['tensor'] = e, name
+        if e32 is not None:
+            w['err_vs_oracle32'] = max(w['err_vs_oracle32'], e32)
+    for grp, w in worst.items():
+        REPORT.append(dict(what=f'{what} (decision-pinned float64 oracle)', group=grp, tensors=len(w['errs']),
+                           engine_worst_err=w['err'], tensor=w['tensor'], engine_median_err=float(np.median(w['errs'])),
+                           engine_vs_pinned_oracle32_worst=w['err_vs_oracle32'], bound=tol))
+    for grp, w in worst.items():
+        assert w['err'] <= tol, f"{what} [{grp}] {w['tensor']}: {w['err']:.3e} > {tol:.1e} (decisions pinned)"
+
+
+def _pinned_weight_check(views, w64, g64, m0, v0, t, lr, what, tol=TOL, floor_frac=1e-3):
+    """Updated weights after one Adam step.  Adam's decrement lr_t * m / (sqrt(v) + eps) is NOT Lipschitz in the gradient
+    around g = 0 (at t = 1 it is lr * sign(g)), so "updated weights within 1e-4" is only well defined through the gradient
+    tolerance: with every engine gradient element inside [g - d, g + d], d = tol * scale(tensor) (what _pinned_grad_check
+    asserts), the engine's weight must lie inside the image of that interval under the oracle's own Adam update.  Elements
+    with |g| >> d (the vast majority) are thereby held to ~1e-7 relative; elements with |g| <= d may move by up to 2 lr."""
+    gmax = max(float(np.abs(_np(g)).max()) for g in g64.values())
+    nsure = ntot = 0
+    worst_sure = 0.0
+    for name, g in g64.items():
+        if is_degenerate_bias(name):
+            continue
+        g = _np(g).astype(np.float64)
+        d = tol * max(np.abs(g).max(), floor_frac * gmax, 1e-30)
+        mm = _np(m0[name]).astype(np.float64) if m0 is not None else np.zeros_like(g)
+        vv = _np(v0[name]).astype(np.float64) if v0 is not None else np.zeros_like(g)
+        ref = _adam_update(g, mm, vv, t, lr)
+        dev = np.zeros_like(g)
+        for f in (-1.0, -0.5, 0.5, 1.0):
+            dev = np.maximum(dev, np.abs(_adam_update(g + f * d, mm, vv, t, lr) - ref))
+        w_ref = _np(w64[name]).astype(np.float64)
+        w_eng = _np(views[name]).astype(np.float64)
+        wscale = max(np.abs(w_ref).max(), 1e-30)
+        bound = 1.25 * dev + 2e-7 * wscale + 1e-9
+        bad = np.abs(w_eng - w_ref) > bound
+        assert not bad.any(), (what, name, float(np.abs(w_eng - w_ref).max()), float(bound[bad].max()), int(bad.sum()))
+        sure = dev < 1e-6 * wscale
+        nsure += int(sure.sum())
+        ntot += sure.size
+        if sure.any():
+            worst_sure = max(worst_sure, float((np.abs(w_eng - w_ref)[sure]).max() / wscale))
+    REPORT.append(dict(what=f'{what} (decision-pinned)', elements=ntot, elements_with_stable_update=nsure,
+                       worst_rel_err_on_stable_elements=worst_sure))
+    assert worst_sure <= tol
+
+
+@pytest.mark.parametrize('B,H,W,A,faithful', [(32, 48, 64, 2, True), (32, 41, 58, 3, False), (16, 90, 120, 2, True)])
+def test_pinned_decisions_gradients_and_weights(B, H, W, A, faithful):
+    """A11 at north_star's bar: gradients and updated weights within 1e-4 of the oracle, measured on a WELL-DEFINED
+    quantity.  ReLU6 regions and max-pool argmax are discrete decisions on float32 pre-activations; two implementations
+    that differ by one rounding flip an element and move a tower gradient by percents (the float32 oracle itself sits
+    1e-3..1e-1 from the float64 oracle, tests/test_gpu_learner.py::test_policy_then_value_step).  Here the float64 oracle is
+    evaluated with the decisions the ENGINE took (reconstructed from the engine's raw BatchNorm inputs, statistics and
+    argmax bytes: tests/util.py::engine_decisions), which makes both sides the same smooth function."""
+    from oracle import model as OM
+    from tests.util import engine_decisions
+    oracle, eng = make_pair(B, H, W, seed=3, A=A, with64=True)
+    o64 = oracle.o64
+    pol, val = make_batches(B, H, W, seed=3, A=A, faithful=faithful)
+    dpol, dval = to_dev(pol), to_dev(val)
+    del REPORT[:]
+    hp = oracle.hp
+
+    def pinned(fn64, fn32, batch):
+        OM.DEC.items = engine_decisions(eng, oracle.cfg)
+        try:
+            OM.DEC.start('replay')
+            r64 = fn64(batch)
+            assert OM.DEC.cursor == len(OM.DEC.items)
+            OM.DEC.start('replay')
+            r32 = fn32(batch)
+        finally:
+            OM.DEC.start('off')
+        return r64, r32
+
+    try:
+        # ---------------- policy pass (trunk Adam t = 1)
+        eng.policy_forward_backward(dpol)
+        (loss64, gp64, gt64, aux64), (loss32, gp32, gt32, aux32) = pinned(o64.policy_grads, oracle.policy_grads, oracle_batch(pol))
+        m = eng.metrics('policy')
+        assert abs(m['loss'] - float(loss64.detach())) < TOL * max(1.0, abs(float(loss64.detach())))
+        ax = eng.buffer(_lib.BUF_AUX_P, (B, 4, A)).cpu().numpy()
+        for i, k in enumerate(('alpha', 'beta', 'log_prob')):
+            assert rel_err(ax[:, i], _np(aux64[k])) < TOL, k
+        _pinned_grad_check(eng.grad_views('policy'), gp64, 'policy grad', g32=gp32)
+        _pinned_grad_check(eng.grad_views('trunk'), gt64, 'trunk grad (policy pass)', g32=gt32)
+        o64.policy_step(None, grads=(loss64, gp64, gt64, aux64))
+        eng.policy_apply()
+        _pinned_weight_check(eng.param_views('trunk'), o64.trunk, gt64, None, None, 1, hp['dynamics_lr'], 'updated trunk weights')
+        gpc = {n: OM.clip_by_norm(g, hp['clip_norm_policy']) for n, g in gp64.items()}
+        _pinned_weight_check(eng.param_views('policy'), o64.policy, gpc, None, None, 1, hp['policy_lr'], 'updated policy weights')
+        # BatchNorm moving statistics of the training forward are smooth: plain 1e-4
+        for name, t64 in o64.trunk.items():
+            if 'moving' in name:
+                assert rel_err(_np(eng.param_views('trunk')[name]), _np(t64)) < TOL, name
+
+        # ---------------- value pass from the common state (trunk Adam t = 2)
+        _sync_from_o64(oracle, eng)
+        m0 = {k: v.clone() for k, v in o64.opt_trunk.m.items()}
+        v0 = {k: v.clone() for k, v in o64.opt_trunk.v.items()}
+        eng.value_forward_backward(dval)
+        (loss64, gv64, gt64, aux64), (loss32, gv32, gt32, aux32) = pinned(o64.value_grads, oracle.value_grads, oracle_batch(val))
+        mv = eng.metrics('value')
+        assert abs(mv['loss'] - float(loss64.detach())) < TOL * max(1.0, abs(float(loss64.detach())))
+        vals = eng.buffer(_lib.BUF_AUX_V, (B, 2)).cpu().numpy()
+        assert rel_err(vals, _np(aux64['values'])) < TOL
+        _pinned_grad_check(eng.grad_views('value'), gv64, 'value grad', g32=gv32)
+        _pinned_grad_check(eng.grad_views('trunk'), gt64, 'trunk grad (value pass)', g32=gt32)
+        o64.value_step(None, grads=(loss64, gv64, gt64, aux64))
+        eng.value_apply()
+        _pinned_weight_check(eng.param_views('trunk'), o64.trunk, gt64, m0, v0, 2, hp['dynamics_lr'], 'updated trunk weights (t=2)')
+        gvc = {n: OM.clip_by_norm(g, hp['clip_norm_value']) for n, g in gv64.items()}
+        _pinned_weight_check(eng.param_views('value'), o64.value, gvc, None, None, 1, hp['value_lr'], 'updated value weights')
+    finally:
+        _dump_report(f'pinned_B{B}_{H}x{W}')
 
 
 @pytest.mark.parametrize('A', [2, 3])

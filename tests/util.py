@@ -91,3 +91,54 @@ def check3(got, ref32, ref64, tol=1e-4, slack=4.0, floor=0.0):
     err = float(np.abs(got - r64).max() / scale)
     noise = float(np.abs(r32 - r64).max() / scale)
     return err, max(tol, slack * noise)
+
+
+def engine_decisions(eng, ocfg):
+    """The discrete decisions (ReLU6 regions, stem max-pool argmax) the ENGINE took in its last training forward, as the
+    item list `oracle.model.Decisions` replays, in the oracle's call order (shufflenet_v2: stem ReLU6, max-pool, per unit
+    bn1 / bn3 (/ sc_bn2) ReLU6, head ReLU6; then the six feature-net ReLU6s).
+
+    ReLU6 region of a BatchNorm output = region of z = fmaf(scale, x, shift) -- the expression every engine kernel evaluates
+    (forward apply and backward mask alike).  The float64 product of two float32 numbers is exact, so rounding the float64
+    sum to float32 reproduces fmaf (up to double-rounding ties, probability ~2^-29 per element)."""
+    from oracle.spec import unit_plan
+    T, B = eng.cfg.T, eng.cfg.B
+
+    def bn_regions(prefix, h, w):
+        stats = eng.named_buffer(prefix + '.stats')
+        C = stats.numel() // (4 * T)
+        st = stats.view(4, T, C).double()
+        x = eng.named_buffer(prefix + '.x').view(T, B, h, w, C).double()
+        z = (x * st[2].view(T, 1, 1, 1, C) + st[3].view(T, 1, 1, 1, C)).float()
+        z = z.permute(0, 1, 4, 2, 3).cpu()                      # oracle layout (T, B, C, H, W)
+        return ((z > 0.0) & (z < 6.0)), (z >= 6.0)
+
+    def dense_regions(prefix, n):
+        z = eng.named_buffer(prefix + '.z').view(T, B, n).cpu()
+        return ((z > 0.0) & (z < 6.0)), (z >= 6.0)
+
+    H, W = ocfg.H, ocfg.W
+    hs, ws = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    items = [bn_regions('img.stem.bn', hs, ws)]
+    hp, wp = -(-hs // 2), -(-ws // 2)
+    code = eng.named_buffer('img.stem.pool.argmax', torch.uint8).view(T * B, hp, wp, ocfg.stem_channels).long()
+    pl = max((wp - 1) * 2 + 3 - ws, 0) // 2
+    wpad = ws + max((wp - 1) * 2 + 3 - ws, 0)
+    oy = torch.arange(hp, device=code.device).view(1, hp, 1, 1)
+    ox = torch.arange(wp, device=code.device).view(1, 1, wp, 1)
+    idx = (2 * oy + code // 3) * wpad + 2 * ox + code % 3       # index into the oracle's -inf padded plane
+    items.append(idx.permute(0, 3, 1, 2).contiguous().cpu())
+    h, w = hp, wp
+    for u in unit_plan(ocfg):
+        pre = f"img.s{u['stage']}.u{u['unit']}"
+        ho, wo = (-(-h // 2), -(-w // 2)) if u['stride'] == 2 else (h, w)
+        items.append(bn_regions(f'{pre}.bn1', h, w))
+        items.append(bn_regions(f'{pre}.bn3', ho, wo))
+        if u['stride'] == 2:
+            items.append(bn_regions(f'{pre}.sc_bn2', ho, wo))
+        h, w = ho, wo
+    items.append(bn_regions('img.head.bn', h, w))
+    for name in ('road', 'vehicle', 'navigation'):
+        for i in range(2):
+            items.append(dense_regions(f'{name}.fc{i}', ocfg.feat_units))
+    return items
