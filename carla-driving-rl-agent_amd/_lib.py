@@ -54,6 +54,7 @@ _L = C.c_void_p
 PROTOTYPES = {
     'cdrl_last_error': (C.c_char_p, []),
     'cdrl_version': (_i, []),
+    'cdrl_crc32c': (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     'cdrl_config_default': (None, [C.POINTER(Config)]),
     'cdrl_learner_create': (_i, [C.POINTER(Config), C.POINTER(_L)]),
     'cdrl_learner_destroy': (None, [_L]),

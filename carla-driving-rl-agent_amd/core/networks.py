@@ -152,21 +152,22 @@ class CARLANetwork(Network):
                     trunk=self.agent.dynamics_path + '.npz')
 
     def save_weights(self):
-        """Three files, like the reference's policy_net / value_net / dynamics_model checkpoints (npz
-        containers here; optimizer state is not saved, as in the reference)."""
+        """policy_net / value_net / dynamics_model as TensorFlow checkpoint-V2 files (`<name>.index` + two data shards), the
+        layout Keras' `save_weights` leaves in the reference (core/networks.py:297-300), keyed `layer_with_weights-N/<var>` in
+        Keras' layer order; optimizer state is not saved, as in the reference."""
+        from .. import tf_checkpoint
         for model, path in self._paths().items():
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            np.savez(path, **self.engine.export_params(model))
+            tf_checkpoint.save_from_engine(self.engine, model, path[:-4])
 
     def load_weights(self, full=True):
-        """Loads this package's .npz checkpoints, or -- when `<name>.index` exists -- the reference's own
-        TensorFlow checkpoint-V2 files (tf_checkpoint.py; tensors whose data shard is absent are skipped
+        """Loads TensorFlow checkpoint-V2 files (`<name>.index`: this package's own or the reference's shipped ones), or the
+        `.npz` containers earlier versions of this package wrote (tf_checkpoint.py; tensors whose data shard is absent are skipped
         with a warning, e.g. the trunk shards the reference repository does not ship)."""
         from .. import tf_checkpoint
         paths = self._paths()
         for model in (('policy', 'value', 'trunk') if full else ('trunk',)):
             prefix = paths[model][:-4]
-            if not os.path.exists(paths[model]) and os.path.exists(prefix + '.index'):
+            if os.path.exists(prefix + '.index'):
                 loaded = tf_checkpoint.load_into_engine(self.engine, model, prefix, strict=False)
                 n = len(self.engine.tables[model].entries)
                 if len(loaded) < n:

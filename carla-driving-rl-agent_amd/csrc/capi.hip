@@ -26,6 +26,37 @@ extern "C" {
 const char* cdrl_last_error(void) { return cdrl::last_error(); }
 int cdrl_version(void) { return CDRL_VERSION; }
 
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8 on the host: checksums of the TF-checkpoint-V2
+// writer (tf_checkpoint.py): every SSTable block and every tensor entry carries one
+uint32_t cdrl_crc32c(uint32_t crc, const void* data, size_t n) {
+    static uint32_t T[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xff];
+        ready = true;
+    }
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint32_t c = ~crc;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = T[7][lo & 0xff] ^ T[6][(lo >> 8) & 0xff] ^ T[5][(lo >> 16) & 0xff] ^ T[4][lo >> 24] ^ T[3][hi & 0xff] ^
+            T[2][(hi >> 8) & 0xff] ^ T[1][(hi >> 16) & 0xff] ^ T[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xff];
+    return ~c;
+}
+
 void cdrl_config_default(cdrl_config* c) {
     if (!c) return;
     Config d;

@@ -81,6 +81,9 @@ typedef struct cdrl_value_batch {
 
 const char* cdrl_last_error(void);
 int cdrl_version(void);
+/* CRC-32C (Castagnoli) of `n` host bytes continued from `crc` (0 to start): block and tensor checksums of the
+ * TensorFlow checkpoint-V2 files CARLANetwork.save_weights writes (reference core/networks.py:297-300). */
+uint32_t cdrl_crc32c(uint32_t crc, const void* data, size_t n);
 
 /* ---- learner object ------------------------------------------------------------------------
  * replaces CARLANetwork.__init__ / dynamics_model / value_network / PolicyNetwork construction

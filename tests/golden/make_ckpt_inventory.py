@@ -100,6 +100,35 @@ def read_index(path):
     return out
 
 
+def read_object_graph(prefix):
+    """{checkpoint key: variable full_name} from the _CHECKPOINTABLE_OBJECT_GRAPH string tensor (data-00000 shard)."""
+    data = open(prefix + '.index', 'rb').read()
+    footer = data[-48:]
+    pos = 0
+    _, pos = varint(footer, pos)
+    _, pos = varint(footer, pos)
+    ioff, pos = varint(footer, pos)
+    isize, pos = varint(footer, pos)
+    for _, handle in read_block(data, ioff, isize):
+        boff, p = varint(handle, 0)
+        bsize, p = varint(handle, p)
+        for key, val in read_block(data, boff, bsize):
+            if key != b'_CHECKPOINTABLE_OBJECT_GRAPH':
+                continue
+            e = parse_proto(val)
+            raw = open(prefix + '.data-%05d-of-00002' % e.get(3, [0])[0], 'rb').read()
+            raw = raw[e.get(4, [0])[0]:e.get(4, [0])[0] + e.get(5, [0])[0]]
+            n, q = varint(raw, 0)
+            out = {}
+            for node in parse_proto(raw[q + 4:q + 4 + n]).get(1, []):
+                for attr in parse_proto(node).get(2, []):
+                    a = parse_proto(attr)
+                    ck = a.get(3, [b''])[0].decode().replace('/.ATTRIBUTES/VARIABLE_VALUE', '')
+                    out[ck] = a.get(2, [b''])[0].decode()
+            return out
+    return {}
+
+
 def main():
     inv = {}
     for stage in sorted(os.listdir(REF)):
@@ -110,6 +139,8 @@ def main():
             ents = [e for e in read_index(idx) if e['dtype'] == 1]
             rec = dict(tensors=[[e['key'].replace('/.ATTRIBUTES/VARIABLE_VALUE', ''), e['shape']] for e in ents],
                        total=int(sum(int(np.prod(e['shape'])) if e['shape'] else 1 for e in ents)))
+            names = read_object_graph(os.path.join(REF, stage, model))
+            rec['names'] = [names.get(k, '') for k, _ in rec['tensors']]       # variable full names, same order as `tensors`
             shard = os.path.join(REF, stage, model + '.data-00001-of-00002')
             if os.path.exists(shard) and os.path.getsize(shard) > 1024:
                 raw = open(shard, 'rb').read()

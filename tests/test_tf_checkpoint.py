@@ -28,6 +28,91 @@ def test_keras_key_mapping_matches_reference_checkpoint_shapes(model, ckpt):
         assert shapes[mapping[key]] == tuple(shape), (key, mapping[key])
 
 
+def _expected_keras_names():
+    """engine layer prefix -> Keras auto-generated layer name, from the CREATION order of the layers in the reference's
+    graph builders (Keras numbers `conv2d`, `depthwise_conv2d`, `batch_normalization`, `dense`, `gru` per class in creation
+    order): stem conv + BN (core/architectures.py:159-160); per unit main branch pw1, BN, dw, BN, pw2, BN and THEN, for
+    stride 2, the shortcut dw, BN, pw, BN (:129-141); head conv + BN (:170-171); feature nets road, vehicle, navigation, each
+    [Dense, Dense] then [BN, BN] (:20-21; core/networks.py:41-43); GRUs image, road, vehicle, navigation (:47-50); the
+    concat BN and the named Dense 'dynamics-linear' (:24-30,55).  Heads: control-branch BN, Dense, BN, Dense continue the
+    process-wide counters (checked by relative order only), named heads carry their own names (core/networks.py:120-137,
+    260-275)."""
+    count = {}
+
+    def new(kind):
+        i = count.get(kind, 0)
+        count[kind] = i + 1
+        return kind if i == 0 else f'{kind}_{i}'
+    names = {'img.stem.conv': new('conv2d'), 'img.stem.bn': new('batch_normalization')}
+    for s, n in enumerate((4, 8, 4)):
+        for u in range(n):
+            pre = f'img.s{s}.u{u}'
+            for layer, kind in (('pw1', 'conv2d'), ('bn1', 'batch_normalization'), ('dw', 'depthwise_conv2d'),
+                                ('bn2', 'batch_normalization'), ('pw2', 'conv2d'), ('bn3', 'batch_normalization')):
+                names[f'{pre}.{layer}'] = new(kind)
+            if u == 0:
+                for layer, kind in (('sc_dw', 'depthwise_conv2d'), ('sc_bn1', 'batch_normalization'), ('sc_pw', 'conv2d'),
+                                    ('sc_bn2', 'batch_normalization')):
+                    names[f'{pre}.{layer}'] = new(kind)
+    names['img.head.conv'] = new('conv2d')
+    names['img.head.bn'] = new('batch_normalization')
+    for m in ('road', 'vehicle', 'navigation'):
+        names[f'{m}.fc0'], names[f'{m}.fc1'] = new('dense'), new('dense')
+        names[f'{m}.bn0'], names[f'{m}.bn1'] = new('batch_normalization'), new('batch_normalization')
+    for m in ('image', 'road', 'vehicle', 'navigation'):
+        names[f'gru_{m}'] = new('gru')
+    names['dyn.bn'] = new('batch_normalization')
+    names['dyn.fc'] = 'dynamics-linear'
+    return names
+
+
+def _layer_of(full_name):
+    """'conv2d_3_1/kernel' -> 'conv2d_3' (TF appends a second '_k' when a name is re-used by a later model instance),
+    'gru_1/gru_cell_1/kernel' -> 'gru_1', 'v-speed-0/bias' -> 'v-speed-0'."""
+    import re
+    layer = full_name.split('/')[0]
+    m = re.match(r'^(conv2d|depthwise_conv2d|batch_normalization|dense|gru)(_\d+)?(_\d+)?$', layer)
+    return (m.group(1) + (m.group(2) or '')) if m else layer
+
+
+def test_keras_key_mapping_matches_reference_variable_names():
+    """Pins WHICH layer every `layer_with_weights-N` slot holds, through the variable full names recorded in the shipped
+    checkpoints' object graphs -- shapes alone cannot tell same-shape layers apart (the two 1x1 convs / depthwise convs / BNs
+    of the stage-1/2 stride-2 units, the three feature nets, v-speed vs v-similarity)."""
+    inv = json.load(open(os.path.join(HERE, 'golden', 'ref_ckpt_inventory.json')))['full']
+    expected = _expected_keras_names()
+    mapping = tfc.key_map('trunk')
+    seen = 0
+    for (key, _), full in zip(inv['dynamics_model']['tensors'], inv['dynamics_model']['names']):
+        prefix = mapping[key].rsplit('.', 1)[0]
+        assert _layer_of(full) == expected[prefix], (key, full, prefix, expected[prefix])
+        seen += 1
+    assert seen == 390
+    head_names = dict(policy={'pi.alpha': 'alpha-0', 'pi.beta': 'beta-0', 'pi.similarity': 'pi-similarity-0', 'pi.speed': 'pi-speed-0'},
+                      value={'v.base': 'v-base-0', 'v.exp': 'v-exp-0', 'v.similarity': 'v-similarity-0', 'v.speed': 'v-speed-0'})
+    for model, ckpt in (('policy', 'policy_net'), ('value', 'value_net')):
+        mapping = tfc.key_map(model)
+        order = {}
+        for (key, _), full in zip(inv[ckpt]['tensors'], inv[ckpt]['names']):
+            prefix = mapping[key].rsplit('.', 1)[0]
+            if prefix in head_names[model]:
+                assert _layer_of(full) == head_names[model][prefix], (key, full, prefix)
+            else:
+                order[prefix] = _layer_of(full)
+        p = 'pi' if model == 'policy' else 'v'
+        num = lambda n: int(n.rsplit('_', 1)[1])
+        assert order[f'{p}.bn0'].startswith('batch_normalization_') and order[f'{p}.fc0'].startswith('dense_')
+        assert num(order[f'{p}.bn1']) == num(order[f'{p}.bn0']) + 1 and num(order[f'{p}.fc1']) == num(order[f'{p}.fc0']) + 1
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present on this machine')
+def test_object_graph_reader_matches_inventory():
+    inv = json.load(open(os.path.join(HERE, 'golden', 'ref_ckpt_inventory.json')))['full']
+    for ckpt in ('policy_net', 'value_net', 'dynamics_model'):
+        og = tfc.read_object_graph(os.path.join(REF, ckpt))
+        assert [og[k] for k, _ in inv[ckpt]['tensors']] == inv[ckpt]['names']
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present on this machine')
 def test_reads_reference_policy_and_value_shards():
     stats = json.load(open(os.path.join(HERE, 'golden', 'ref_ckpt_inventory.json')))['full']
@@ -40,3 +125,62 @@ def test_reads_reference_policy_and_value_shards():
             assert abs(t[k].mean() - mean) < 1e-6 + 1e-5 * abs(mean) and abs(t[k].max() - mx) < 1e-6
     # the trunk's data shard is not shipped (.MISSING_LARGE_BLOBS): the reader must not invent tensors
     assert tfc.load_checkpoint(os.path.join(REF, 'dynamics_model')) == {}
+
+
+# ------------------------------------------------------------------------------------------------
+# writer (reference core/networks.py:297-300: Keras save_weights, TF format)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('model,ckpt', [('trunk', 'dynamics_model'), ('policy', 'policy_net'), ('value', 'value_net')])
+def test_writer_round_trip_and_reference_key_set(model, ckpt, tmp_path):
+    """save_checkpoint -> load_checkpoint is bit-exact, the written index holds exactly the reference checkpoint's key set and
+    shapes, and the generated object graph names every variable like the reference's does."""
+    inv = json.load(open(os.path.join(HERE, 'golden', 'ref_ckpt_inventory.json')))['full'][ckpt]
+    eng = LearnerEngine(1, device=None)
+    shapes = {e['name']: tuple(e['shape']) for e in eng.tables[model].entries}
+    mapping = tfc.key_map(model)
+    rng = np.random.default_rng(5)
+    tensors = {k: rng.standard_normal(shapes[name]).astype(np.float32) for k, name in mapping.items()}
+    names = tfc.keras_full_names(model)
+    prefix = str(tmp_path / ckpt)
+    tfc.save_checkpoint(prefix, tensors, names)
+    back = tfc.load_checkpoint(prefix)
+    assert sorted(back) == sorted(tensors) == sorted(k for k, _ in inv['tensors'])
+    for k, v in tensors.items():
+        assert back[k].shape == v.shape and np.array_equal(back[k], v), k
+    written = {e['key']: tuple(e['shape']) for e in tfc.read_index(prefix + '.index')}
+    assert written == {k: tuple(sh) for k, sh in inv['tensors']}
+    og = tfc.read_object_graph(prefix)
+    assert og == names
+    ref_names = dict(zip((k for k, _ in inv['tensors']), inv['names']))
+    for k, full in names.items():
+        if model == 'trunk' or '-' in full.split('/')[0]:          # trunk layers and named heads: same layer name as the reference
+            assert _layer_of(full) == _layer_of(ref_names[k]) and full.split('/')[-1] == ref_names[k].split('/')[-1], (k, full, ref_names[k])
+        else:                                                       # control-branch layers: process-wide counters, same class + variable
+            strip = lambda n: n.split('/')[0].rstrip('0123456789').rstrip('_') + '/' + n.split('/')[-1]
+            assert strip(full) == strip(ref_names[k]), (k, full, ref_names[k])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present on this machine')
+@pytest.mark.parametrize('ckpt', ['policy_net', 'value_net'])
+def test_writer_reproduces_reference_files_byte_for_byte(ckpt, tmp_path):
+    """Decode the shipped checkpoint, re-encode it with save_checkpoint: `.index` (SSTable blocks, prefix compression, restart
+    arrays, masked CRC-32C of every block and tensor), the object-graph shard and the tensor shard are byte-identical to the
+    files Keras / TensorFlow 2.3 wrote."""
+    src = os.path.join(REF, ckpt)
+    tensors = tfc.load_checkpoint(src)
+    raw = open(src + '.data-00000-of-00002', 'rb').read()
+    n, pos = tfc._varint(raw, 0)
+    order = [e['key'] for e in sorted(tfc.read_index(src + '.index'), key=lambda e: e['offset'])]
+    assert order == list(tfc.key_map('policy' if ckpt == 'policy_net' else 'value'))       # layout order = layer order
+    dst = str(tmp_path / ckpt)
+    tfc.save_checkpoint(dst, tensors, object_graph=raw[pos + 4:pos + 4 + n], order=order)
+    for suffix in ('.index', '.data-00000-of-00002', '.data-00001-of-00002'):
+        assert open(src + suffix, 'rb').read() == open(dst + suffix, 'rb').read(), suffix
+
+
+def test_crc32c_known_answers():
+    """RFC 3720 B.4 test vectors for CRC-32C."""
+    assert tfc._crc32c(bytes(32)) == 0x8a9136aa
+    assert tfc._crc32c(bytes([0xff] * 32)) == 0x62a8ab43
+    assert tfc._crc32c(bytes(range(32))) == 0x46dd794e
+    assert tfc._crc32c(b'123456789') == 0xe3069283
