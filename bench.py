@@ -45,11 +45,12 @@ def pmc_traffic(B, T, H, W):
     return best
 
 
-def kernel_rooflines(B, T):
+def kernel_rooflines(B, T, nsets=8):
     """Isolated roofline points of the three kernel families that carry the tower (stage-1 shapes of the benchmark
     workload: B*T frames of 6x8 pixels, 116 channels per branch), timed with HIP events on the launch stream through the
-    C ABI.  achieved = algorithmic bytes of the launch / average duration (back-to-back launches of the same call, so
-    the figure includes the ~3 us launch gap; inputs are L2/MALL-warm, i.e. an upper bound of what the step sees)."""
+    C ABI.  achieved = algorithmic bytes of the launch / average duration of back-to-back launches (includes the launch
+    gap).  The launches ROTATE over `nsets` disjoint buffer sets (8 x 45.6 MB = 365 MB > the 256 MB Infinity Cache), so every
+    launch streams its operands from HBM: these are HBM figures, not cache-resident ones."""
     import ctypes as C
     import torch
     from carla_driving_rl_agent_amd import _lib
@@ -58,13 +59,13 @@ def kernel_rooflines(B, T):
     S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 
-    def timeit(fn, iters=30):
-        for _ in range(3):
-            fn()
+    def timeit(fn, iters=32):
+        for k in range(nsets):
+            fn(k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            fn()
+        for k in range(iters):
+            fn(k % nsets)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters * 1e-3
@@ -73,43 +74,52 @@ def kernel_rooflines(B, T):
     G, px, Cc = T, 48, 116
     Mg = B * px
     M = G * Mg
-    a = torch.randn(M, Cc, device=dev)
+    a = [torch.randn(M, Cc, device=dev) for _ in range(nsets)]
+    y = [torch.empty(M, Cc, device=dev) for _ in range(nsets)]
     w = torch.randn(Cc, Cc, device=dev)
     bias = torch.randn(Cc, device=dev)
-    y = torch.empty(M, Cc, device=dev)
     nb = int(lib.cdrl_pwconv_fused_partial_rows(G, Mg, Cc, Cc))
     part = torch.zeros(G * nb * 2 * Cc, dtype=torch.float64, device=dev)
-    t = timeit(lambda: lib.cdrl_pwconv_fused(P(a), Cc, 0, None, P(w), Cc, 1, P(bias), P(y), Cc, 0, 0, G, Mg, Cc, Cc, 1, None, None,
-                                             P(part), S()))
+    cold = f'cold: launches rotate over {nsets} buffer sets ({nsets * 2 * M * Cc * 4 / 1e6:.0f} MB > 256 MB Infinity Cache)'
+    t = timeit(lambda k: lib.cdrl_pwconv_fused(P(a[k]), Cc, 0, None, P(w), Cc, 1, P(bias), P(y[k]), Cc, 0, 0, G, Mg, Cc, Cc, 1, None,
+                                               None, P(part), S()))
     by = 4.0 * M * 2 * Cc
     out.append(dict(kernel='pw_nn_kernel<64,4,0,1> (1x1 conv + BN statistics epilogue)', shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1),
-                    algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1), frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4)))
+                    algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1), frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
+                    cache_state=cold))
     dw = torch.empty(Cc, Cc, device=dev)
     ws = torch.empty(int(lib.cdrl_gemm_tn_workspace_elems(M, Cc, Cc)), device=dev)
-    t = timeit(lambda: lib.cdrl_gemm_tn(P(a), Cc, 0, P(y), Cc, 0, P(dw), M, Cc, Cc, P(ws), 0, S()))
+    t = timeit(lambda k: lib.cdrl_gemm_tn(P(a[k]), Cc, 0, P(y[k]), Cc, 0, P(dw), M, Cc, Cc, P(ws), 0, S()))
     out.append(dict(kernel='tn_direct_kernel<4> + tn_reduce (filter gradient)', shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1),
-                    algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1), frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4)))
+                    algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1), frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
+                    cache_state=cold))
     N, Hh, Ww = G * B, 6, 8
-    x = torch.randn(N, Hh, Ww, Cc, device=dev)
     wd = torch.randn(3, 3, Cc, 1, device=dev)
-    yd = torch.empty(N, Hh, Ww, Cc, device=dev)
     st = torch.rand(4 * G * Cc, device=dev) + 0.5
     pst = torch.zeros(4 * G * Cc, device=dev)
     ones, zeros = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
     mm, mv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
     wsd = torch.zeros(int(lib.cdrl_dwconv_bn_workspace_doubles(G, B, Hh, Ww, Cc, 1)), dtype=torch.float64, device=dev)
-    t = timeit(lambda: lib.cdrl_dwconv_bn_fwd(P(x), P(st), P(wd), P(bias), P(yd), G, B, Hh, Ww, Cc, 1, P(ones), P(zeros), P(mm), P(mv), 1,
-                                              P(pst), P(wsd), S()))
-    byd = 4.0 * 2 * x.numel()
+    t = timeit(lambda k: lib.cdrl_dwconv_bn_fwd(P(a[k]), P(st), P(wd), P(bias), P(y[k]), G, B, Hh, Ww, Cc, 1, P(ones), P(zeros), P(mm),
+                                                P(mv), 1, P(pst), P(wsd), S()))
+    byd = 4.0 * 2 * N * Hh * Ww * Cc
     out.append(dict(kernel='dwf_fwd_kernel<1,4,true> + bn_finalize (BN+ReLU6 -> dw3x3 -> BN statistics)', shape=f'{N}x{Hh}x{Ww}x{Cc}',
                     us=round(t * 1e6, 1), algorithmic_bytes=byd, achieved_GBs=round(byd / t / 1e9, 1),
-                    frac=round(byd / t / 1e9 / HBM_PEAK_GBS, 4)))
+                    frac=round(byd / t / 1e9 / HBM_PEAK_GBS, 4), cache_state=cold))
     return out
 
 
-def cpu_baseline(B_sample, T, H, W, threads, seed=42):
-    """Oracle (PyTorch-CPU restatement of the reference TF path) timed on the host cores on a bounded
-    sample: update-steps at minibatch B_sample, scaled to 256-sample update-steps/s."""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown CPU'
+
+
+def _oracle_timer(B_sample, T, H, W, threads, warmup, steps, budget_s, seed=42):
     import torch
     from oracle import model as OM
     from oracle.spec import NetConfig, trunk_spec, policy_spec, value_spec
@@ -119,24 +129,42 @@ def cpu_baseline(B_sample, T, H, W, threads, seed=42):
     cfg = NetConfig(T=T, H=H, W=W)
     learner = OM.OracleLearner(cfg, OM.init_params(trunk_spec(cfg), 1, False), OM.init_params(policy_spec(cfg), 2, False),
                                OM.init_params(value_spec(cfg), 3, False), synthetic.DEFAULT_HP)
-    pol, val = make_batches(B_sample, H, W, seed=seed, faithful=False)
+    pol, val = make_batches(B_sample, H, W, seed=seed, faithful=True)       # injected sample + Jacobians = the re-sampled loss
     pol, val = oracle_batch(pol), oracle_batch(val)
-    learner.policy_step(pol)          # warm-up
-    learner.value_step(val)
+    t_start = time.time()
+    for _ in range(warmup):
+        learner.policy_step(pol)
+        learner.value_step(val)
     times = []
-    t_budget = time.time()
-    while len(times) < 3 and (time.time() - t_budget) < 25.0:
+    while len(times) < steps and (not times or (time.time() - t_start) < budget_s):
         t0 = time.time()
         learner.policy_step(pol)
         learner.value_step(val)
         times.append(time.time() - t0)
-    best = min(times)
-    return dict(value=(B_sample / 256.0) / best, unit='update-steps/s (256-sample equivalents)', cores=threads, kind='port',
-                sample=f'{len(times)} update-steps of the PyTorch-CPU oracle at minibatch {B_sample} (T={T}, {H}x{W}x3), '
-                       f'best {best:.3f} s/step, scaled by {B_sample}/256; host has {os.cpu_count()} logical cores')
+    return times
 
 
-def run_cpu_baseline_child(B_sample, T, H, W, threads, timeout=240):
+def cpu_baseline(B_sample, T, H, W, threads, one_thread_batch=32):
+    """Oracle (PyTorch-CPU restatement of the reference TF-CPU path: same per-slice BatchNorm, same two-phase update) timed
+    on the host cores, SURVEY.md section 8(d): the benchmark's own minibatch (B_sample = 256 by default), 2 warm-ups, then
+    >= 5 timed update-steps (bounded by a wall-clock budget), median and min, at the best thread count; plus a bounded
+    1-thread figure (one update-step at a smaller minibatch, scaled)."""
+    import statistics
+    times = _oracle_timer(B_sample, T, H, W, threads, warmup=2, steps=5, budget_s=150.0)
+    med, best = statistics.median(times), min(times)
+    one = _oracle_timer(one_thread_batch, T, H, W, 1, warmup=0, steps=1, budget_s=1.0)[0]
+    scale = B_sample / 256.0
+    return dict(value=scale / med, unit='update-steps/s (256-sample update-steps)', cores=threads, kind='port',
+                median_s_per_step=round(med, 3), min_s_per_step=round(best, 3), timed_steps=len(times), warmup_steps=2,
+                one_thread=dict(value=(one_thread_batch / 256.0) / one, s_per_step=round(one, 3), minibatch=one_thread_batch,
+                                note=f'1 update-step at minibatch {one_thread_batch} on 1 thread, scaled by {one_thread_batch}/256'),
+                sample=f'{len(times)} timed update-steps (after 2 warm-ups) of the PyTorch-CPU oracle at minibatch {B_sample} '
+                       f'(T={T}, {H}x{W}x3, re-sampled policy loss with injected sample), {threads} intra-op threads '
+                       f'(fastest measured setting on this host class), median {med:.3f} s, min {best:.3f} s per update-step; '
+                       f'host: {_cpu_model()}, {os.cpu_count()} logical cores; TensorFlow itself is not installable here')
+
+
+def run_cpu_baseline_child(B_sample, T, H, W, threads, timeout=420):
     """The oracle runs in a CHILD process (plain subprocess, never exec from the GPU-initialised
     process) with a hard wall-clock limit, so the default bench always finishes within minutes."""
     import subprocess
@@ -153,6 +181,23 @@ def run_cpu_baseline_child(B_sample, T, H, W, threads, timeout=240):
         return dict(value=None, unit='update-steps/s', cores=threads, kind='port', sample=f'timed out after {timeout}s')
 
 
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` started as a plain process: start the N ranks as CHILDREN through torch.distributed.run (one
+    process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, relay their output and
+    exit with their status.  (The driver's own `python -m torch.distributed.run ... bench.py --gpus N` form sets
+    WORLD_SIZE and never comes through here.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -162,15 +207,19 @@ def main():
     ap.add_argument('--height', type=int, default=90)
     ap.add_argument('--width', type=int, default=120)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-batch', type=int, default=128)
+    ap.add_argument('--cpu-sample-batch', type=int, default=256)
     ap.add_argument('--cpu-threads', type=int, default=min(16, os.cpu_count() or 1),
                     help='oracle intra-op threads; measured on the 2x64-core EPYC GPU host: 16 threads is the '
                          'fastest setting (32: 2.2x slower, 64: 5.8x slower, 256: does not finish)')
     ap.add_argument('--cpu-baseline-only', action='store_true')
+    ap.add_argument('--stored-actions', action='store_true',
+                    help='time the textbook-PPO loss on the stored rollout actions instead of the reference-faithful re-sampled loss')
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.cpu_sample_batch, 4, args.height, args.width, args.cpu_threads)))
         return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -182,9 +231,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        if rank == 0:
-            print(f'[bench] WORLD_SIZE={world} != --gpus {args.gpus}; launch with torchrun for N>1', file=sys.stderr)
-        args.gpus = world
+        raise SystemExit(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}: start one rank per GPU')
     torch.cuda.set_device(local_rank)
     dev = f'cuda:{local_rank}'
     use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('CDRL_FORCE_COLLECTIVES') == '1')
@@ -227,14 +274,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the policy loss is the reference's: evaluated on a fresh Beta sample of the NEW policy drawn on the device with pathwise
+    # gradients (core/networks.py:96-110); Philox stream = (seed, rank-disjoint offset per step)
+    step_no = [0]
+
+    def one_step():
+        step_no[0] += 1
+        dp.update_step(pol, val, resample=None if args.stored_actions else (42, step_no[0] * world + rank))
+
     for _ in range(args.warmup):
-        dp.update_step(pol, val)
+        one_step()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.time()
     ev0.record()
     for _ in range(args.steps):
-        dp.update_step(pol, val)
+        one_step()
     ev1.record()
     barrier()
     elapsed = time.time() - t0
@@ -262,9 +317,10 @@ def main():
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'configs[1]: synthetic rollout buffer {B}x{T}-frame {H}x{W}x3 obs per GPU, full '
-                                        f'CARLANetwork fwd/bwd + PPO/value loss + clip + Adam, fp32',
+                                        f'CARLANetwork fwd/bwd + PPO (re-sampled Beta, pathwise) / value loss + clip + Adam, fp32',
                                per_gpu_batch=B, global_batch=B * world, time_horizon=T, image=[H, W, 3],
-                               parallelism=f'dp{world}', passes_per_step=2),
+                               parallelism=f'dp{world}', passes_per_step=2,
+                               policy_loss='stored-actions' if args.stored_actions else 'resampled (reference-faithful)'),
                    roofline=roof, kernel_rooflines=kernel_rooflines(B, T) if world == 1 else None, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3),
                    final_losses=dict(policy=loss_p, value=loss_v))
         if world == 1 and not args.no_cpu_baseline:

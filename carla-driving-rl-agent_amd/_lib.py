@@ -67,11 +67,13 @@ PROTOTYPES = {
     'cdrl_learner_workspace_bytes': (_sz, [_L]),
     'cdrl_learner_bind': (_i, [_L, _fp, _fp, _fp, _fp, _fp, _sz]),
     'cdrl_learner_set_hparams': (_i, [_L, C.POINTER(HParams), _fp]),
+    'cdrl_learner_share_hparams': (_i, [_L, _L]),
     'cdrl_learner_reset_optimizer_steps': (_i, [_L, _fp]),
     'cdrl_learner_policy_forward_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
     'cdrl_learner_policy_forward': (_i, [_L, _fp, _fp, _fp, _fp, _fp]),
     'cdrl_learner_policy_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
     'cdrl_learner_policy_forward_backward_resample': (_i, [_L, C.POINTER(PolicyBatch), C.c_uint64, C.c_uint64, _f, _fp]),
+    'cdrl_beta_sample_logp': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp]),
     'cdrl_beta_sample': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp, _fp]),
     'cdrl_gamma_implicit_grad': (_i, [_fp, _fp, _i, _fp, _fp]),
     'cdrl_learner_policy_apply': (_i, [_L, _fp]),

@@ -91,10 +91,11 @@ class CARLAgent(PPOAgent):
                             dynamics=dict(units=512))
 
     def __init__(self, *args, aug_intensity=1.0, clip_norm=(1.0, 1.0, 1.0), name='carla', load_full=True, eta=0.0,
-                 dynamics_lr=1e-3, update_dynamics=True, delta=0.0, aux=1.0, resample_actions=False, **kwargs):
-        """`resample_actions=True` evaluates the policy loss on a fresh Beta sample of the NEW policy
-        with pathwise gradients, as the reference's PolicyNetwork.call does; the default
-        uses the stored rollout actions (deterministic, same cost)."""
+                 dynamics_lr=1e-3, update_dynamics=True, delta=0.0, aux=1.0, resample_actions=True, **kwargs):
+        """`resample_actions=True` (default, the reference's behaviour): the policy loss is evaluated on a fresh Beta sample of
+        the NEW policy with pathwise gradients, as PolicyNetwork.call does (reference core/networks.py:96-110, SURVEY.md F8);
+        the sample is drawn on the device.  `False` is the textbook-PPO variant on the stored rollout actions
+        (rl/agents/ppo.py:322-325 semantics; deterministic, same cost)."""
         assert aug_intensity >= 0.0
         if not update_dynamics:
             raise NotImplementedError('update_dynamics=False (frozen trunk) is not implemented natively')
@@ -156,7 +157,7 @@ class CARLAgent(PPOAgent):
 
     def get_policy_gradients(self, batch):
         states, advantages, actions, log_probabilities, speed, similarity = batch
-        eng = self.network.engine
+        eng = self._step_engine = self.network.engine_for(advantages.shape[0])
         b = dict(states={k: states[k] for k in ('state_image', 'state_road', 'state_vehicle', 'state_navigation')},
                  advantages=advantages, old_log_prob=log_probabilities, speed=speed, similarity=similarity, u=actions)
         b = eng.stage(b, 'policy')           # fixed addresses -> the captured hipGraph of the step is replayed
@@ -168,22 +169,22 @@ class CARLAgent(PPOAgent):
                                                  offset=self._sample_offset)
         else:
             eng.policy_forward_backward(b)
-        return eng.buffer(2)[0], 'policy'         # device scalar (CDRL_BUF_METRICS_P[0]); gradients stay in the arena
+        return eng.buffer(2)[0].clone(), 'policy'  # device scalar (copy of CDRL_BUF_METRICS_P[0]); gradients stay in the arena
 
     def apply_policy_gradients(self, gradients):
-        self.network.engine.policy_apply()        # trunk Adam -> clip -> old_policy <- policy -> policy Adam
+        self._step_engine.policy_apply()          # trunk Adam -> clip -> old_policy <- policy -> policy Adam
         return gradients
 
     def get_value_gradients(self, batch):
         states, returns, speed, similarity = batch
-        eng = self.network.engine
+        eng = self._step_engine = self.network.engine_for(returns.shape[0])
         b = dict(states={k: states[k] for k in ('state_image', 'state_road', 'state_vehicle', 'state_navigation')},
                  returns=returns, speed=speed, similarity=similarity)
         eng.value_forward_backward(eng.stage(b, 'value'))
-        return eng.buffer(3)[0], 'value'
+        return eng.buffer(3)[0].clone(), 'value'
 
     def apply_value_gradients(self, gradients):
-        self.network.engine.value_apply()
+        self._step_engine.value_apply()
         return gradients
 
     # -- rollout helpers ------------------------------------------------------------------------------

@@ -83,11 +83,30 @@ class CARLANetwork(Network):
                         head=p_branch['units'], exp_scale=self.exp_scale)
         self.device = agent.device
         self.engine = LearnerEngine(agent.batch_size, device=self.device, **self.cfg)          # learner minibatches
-        self.rollout = LearnerEngine(1, device=self.device, share_with=self.engine, **self.cfg)  # B = 1 inference
+        self._rollouts = {}                # number of environments E -> inference engine over the same arenas
+        self.rollout = self.rollout_for(1)                                                       # B = 1 inference
+        self._ragged = {}                  # minibatch rows -> engine for a ragged last minibatch (shares arenas + optimizer)
         init_engine_parameters(self.engine, seed=agent.seed if agent.seed is not None else 0)
         self.last_value = torch.zeros((1, 2), dtype=torch.float32, device=self.device)   # (base, exp) at terminal states
-        self.action_index = 0
+        self.action_index = 0              # Philox offset of the rollout sampler: one stream per predict() call
+        self.sample_seed = (agent.seed if agent.seed is not None else 0) + 0x5eed
         self.update_dynamics = update_dynamics
+
+    def rollout_for(self, envs: int) -> LearnerEngine:
+        """Inference engine for `envs` environments stepped together (one batched forward + one sampling launch per step)."""
+        if envs not in self._rollouts:
+            self._rollouts[envs] = LearnerEngine(envs, device=self.device, share_with=self.engine, **self.cfg)
+        return self._rollouts[envs]
+
+    def engine_for(self, rows: int) -> LearnerEngine:
+        """The learner engine for a minibatch of `rows` samples: the main engine, or -- for the ragged last minibatch the
+        reference's `batch(drop_remainder=False)` pipeline yields (rl/utils.py:388) -- an engine planned for that size over the
+        SAME parameter / gradient / Adam arenas and optimizer counters (built on first use, kept)."""
+        if rows == self.engine.cfg.B:
+            return self.engine
+        if rows not in self._ragged:
+            self._ragged[rows] = LearnerEngine(rows, device=self.device, share_with=self.engine, **self.cfg)
+        return self._ragged[rows]
 
     # -- hyper-parameters -----------------------------------------------------------------------
     def set_hparams(self, **kw):
@@ -99,17 +118,27 @@ class CARLANetwork(Network):
                 for k in ('state_image', 'state_road', 'state_vehicle', 'state_navigation')}
 
     def predict(self, inputs: dict):
-        """-> (action sample, mean, std, log_prob of the clipped sample, value (base, exp)); uses old_policy
-        and BatchNorm moving statistics, like the reference's rollout forward."""
-        out = self.rollout.predict(self._pick(inputs))
-        dist = torch.distributions.Beta(out['alpha'], out['beta'])
-        action = dist.sample()
-        log_prob = dist.log_prob(torch.clamp(action, utils.EPSILON, 1.0 - utils.EPSILON))
+        """-> (action sample, mean, std, log_prob of the clipped sample, value (base, exp)); uses old_policy and BatchNorm
+        moving statistics, like the reference's rollout forward (core/networks.py:181-193).  The leading axis of the inputs
+        is the number of environments E stepped together (1 in the reference's loop); the Beta sample and its log-density
+        come from one cdrl_beta_sample_logp launch on the (alpha, beta) the forward left on the device -- no host round trip.
+        Returned tensors are fresh (not views of the engine's persistent output buffers)."""
+        st = self._pick(inputs)
+        E = st['state_image'].shape[0]
+        out = self.rollout_for(E).predict(st)
+        A = out['alpha'].shape[1]
+        action = torch.empty((E, A), dtype=torch.float32, device=self.device)
+        log_prob = torch.empty((E, A), dtype=torch.float32, device=self.device)
         self.action_index += 1
-        return action, out['mean'], out['std'], log_prob, out['value'].clone()
+        alpha, beta = out['alpha'], out['beta']              # views of the persistent (E, 4, A) block: row stride 4A
+        _lib.check(self.engine.lib.cdrl_beta_sample_logp(_lib.ptr(alpha), _lib.ptr(beta), E, A, 4 * A, int(self.sample_seed),
+                                                         int(self.action_index), _lib.ptr(action), _lib.ptr(log_prob),
+                                                         self.engine._stream()), 'cdrl_beta_sample_logp')
+        return action, out['mean'].clone(), out['std'].clone(), log_prob, out['value'].clone()
 
     def dynamics_predict(self, inputs: dict):
-        return self.rollout.predict(self._pick(inputs))['dynamics']
+        st = self._pick(inputs)
+        return self.rollout_for(st['state_image'].shape[0]).predict(st)['dynamics'].clone()
 
     def dynamics_predict_train(self, inputs: dict):
         return self.engine.trunk_forward_train(self._pick(inputs))
@@ -120,15 +149,16 @@ class CARLANetwork(Network):
     def predict_last_value(self, state, is_terminal: bool, **kwargs):
         if is_terminal:
             return self.last_value
-        return self.rollout.predict(self._pick(state))['value'].clone()
+        st = self._pick(state)
+        return self.rollout_for(st['state_image'].shape[0]).predict(st)['value'].clone()
 
     def value_predict(self, inputs):
-        return self.rollout.predict(self._pick(inputs))['value']
+        st = self._pick(inputs)
+        return self.rollout_for(st['state_image'].shape[0]).predict(st)['value'].clone()
 
     # -- weights ----------------------------------------------------------------------------------
     def reset(self):
         super().reset()
-        self.action_index = 0
 
     def update_old_policy(self, weights=None):
         if weights:

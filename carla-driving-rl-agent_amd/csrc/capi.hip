@@ -189,6 +189,16 @@ int cdrl_learner_set_hparams(cdrl_learner* l, const cdrl_hparams* hp, void* stre
     return l->impl->upload_hp(S(stream));
 }
 
+int cdrl_learner_share_hparams(cdrl_learner* l, const cdrl_learner* owner) {
+    CHECK_L(l);
+    if (!owner || !owner->impl || !owner->impl->dev_hp() || !l->impl->dev_hp()) {
+        cdrl::set_error("cdrl_learner_share_hparams: both learners must be bound");
+        return -1;
+    }
+    l->impl->share_hp(*owner->impl);
+    return 0;
+}
+
 int cdrl_learner_reset_optimizer_steps(cdrl_learner* l, void* stream) {
     CHECK_L(l);
     return l->impl->reset_counters(S(stream));
@@ -235,6 +245,15 @@ int cdrl_learner_policy_forward_backward_resample(cdrl_learner* l, const cdrl_po
         return -1;
     }
     return l->impl->policy_forward_backward_resample(pb, seed, offset, grad_scale, S(stream));
+}
+
+int cdrl_beta_sample_logp(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,
+                          float* u, float* log_prob, void* stream) {
+    if (!alpha || !beta || !u || !log_prob) {
+        cdrl::set_error("cdrl_beta_sample_logp: null argument");
+        return -1;
+    }
+    return beta_sample(alpha, beta, rows, A, ld, seed, offset, u, nullptr, nullptr, S(stream), log_prob);
 }
 
 int cdrl_beta_sample(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,

@@ -139,6 +139,9 @@ public:
     float* policy_lin() const { return lin_p_.p; }
     float* value_lin() const { return lin_v_.p; }
     DevHP* dev_hp() const { return hp_dev_; }
+    // Use another (bound) learner's device hyper-parameter block -- learning rates, clip, AND the Adam step counters -- so
+    // that engines built for different minibatch sizes over the same parameter arenas behave as one optimizer.
+    void share_hp(const Learner& owner) { hp_dev_ = owner.hp_dev_; }
     // Named internal tensors (parity tests: the raw BatchNorm inputs, statistics blocks, max-pool argmax codes and dense
     // pre-activations from which the discrete ReLU6 / max-pool decisions of the last forward are reconstructed)
     bool named_buffer(const std::string& name, void** p, int64_t* bytes) const {

@@ -64,7 +64,7 @@ __device__ double gamma_grad(double a, double g) {
 // element i = (row, col): alpha[row*ld + col], beta[row*ld + col]; outputs are dense [rows][A]
 __global__ void beta_sample_kernel(const float* __restrict__ alpha, const float* __restrict__ beta, int n, int A, int ld,
                                    uint64_t seed, uint64_t offset, float* __restrict__ u, float* __restrict__ du_da,
-                                   float* __restrict__ du_db) {
+                                   float* __restrict__ du_db, float* __restrict__ logp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int row = i / A, col = i - row * A;
@@ -75,14 +75,19 @@ __global__ void beta_sample_kernel(const float* __restrict__ alpha, const float*
     u[i] = (float)(g1 / s);
     if (du_da) du_da[i] = (float)(gamma_grad(a, g1) * g2 / (s * s));
     if (du_db) du_db[i] = (float)(-gamma_grad(b, g2) * g1 / (s * s));
+    if (logp) {     // log-density of the CLIPPED sample, as PolicyNetwork.call evaluates it (core/networks.py:100-103,139-144)
+        const float eps = 1.1920929e-07f;
+        const double x = (double)fminf(fmaxf((float)(g1 / s), eps), 1.0f - eps);
+        logp[i] = (float)((a - 1.0) * log(x) + (b - 1.0) * log1p(-x) - (lgamma(a) + lgamma(b) - lgamma(a + b)));
+    }
 }
 
 int beta_sample(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset, float* u,
-                float* du_da, float* du_db, hipStream_t st) {
+                float* du_da, float* du_db, hipStream_t st, float* logp) {
     const int n = rows * A;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(beta_sample_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, alpha, beta, n, A, ld, seed, offset, u, du_da,
-                       du_db);
+                       du_db, logp);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

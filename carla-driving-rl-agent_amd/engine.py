@@ -81,7 +81,14 @@ class LearnerEngine:
         _lib.check(self.lib.cdrl_learner_bind(h, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
                                               _lib.ptr(self.adam_v), _lib.ptr(self.workspace), self.workspace_bytes),
                    'cdrl_learner_bind')
-        self.set_hparams()
+        if share_with is not None and share_with.device is not None:
+            # one optimizer: learning rates, clip and the Adam step counters live in the owner's device block
+            _lib.check(self.lib.cdrl_learner_share_hparams(h, share_with.h), 'cdrl_learner_share_hparams')
+            self.hp = share_with.hp
+            self._hp_owner = share_with
+        else:
+            self._hp_owner = None
+            self.set_hparams()
 
     def __del__(self):
         try:
@@ -128,6 +135,8 @@ class LearnerEngine:
         return {k: v.detach().cpu().numpy().copy() for k, v in self.param_views(model).items()}
 
     def set_hparams(self, **kw):
+        if getattr(self, '_hp_owner', None) is not None:
+            return self._hp_owner.set_hparams(**kw)
         self.hp.update(kw)
         hp = _lib.HParams()
         for k in ('policy_lr', 'value_lr', 'dynamics_lr', 'clip_ratio', 'entropy_coef', 'beta1', 'beta2', 'eps'):

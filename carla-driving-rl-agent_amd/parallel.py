@@ -25,11 +25,14 @@ class DataParallelLearner:
         assert p_off == 0 and t_off == p_n and v_off == p_n + t_n, 'gradient arena must be [policy|trunk|value]'
         self._policy_slice = (0, p_n + t_n)
         self._value_slice = (t_off, t_off + t_n + v_n)
+        # BatchNorm moving statistics = everything the replicated Adam update does not touch:
+        # [policy_state | trunk_state | value_state] (contiguous) and the old policy's copy of the policy-head statistics.
+        # The old-policy WEIGHTS are identical on every rank by construction (policy_apply copies the replicated policy) and
+        # are NOT reduced: SUM x 1/world would only reproduce them exactly for power-of-two world sizes.
         s0, _ = engine.region('policy', False)
-        # [policy_state | trunk_state | value_state | old_policy (weights + state)]: everything that is
-        # not touched by the replicated Adam update; world_size is a power of two, so averaging the
-        # (identical) old-policy weights is exact
-        self._state_slice = (s0, engine.params_total)
+        v0, vn = engine.region('value', False)
+        o0, on = engine.region('old_policy', False)
+        self._state_slices = [(s0, v0 + vn), (o0, o0 + on)]
 
     def _allreduce(self, flat, lo, hi, scale=None):
         if self.world == 1 and not self.force:
@@ -45,9 +48,14 @@ class DataParallelLearner:
             dist.broadcast(self.engine.adam_m, src=src, group=self.group)
             dist.broadcast(self.engine.adam_v, src=src, group=self.group)
 
-    def policy_step(self, batch):
+    def policy_step(self, batch, resample=None):
+        """resample=(seed, offset): the reference-faithful loss on a fresh Beta sample of the new policy drawn on the device
+        (each rank passes its own Philox offset); None: stored-action loss (batch['u'])."""
         e = self.engine
-        e.policy_forward_backward(batch, grad_scale=1.0 / self.world)
+        if resample is not None:
+            e.policy_forward_backward_resample(batch, seed=resample[0], offset=resample[1], grad_scale=1.0 / self.world)
+        else:
+            e.policy_forward_backward(batch, grad_scale=1.0 / self.world)
         self._allreduce(e.grads, *self._policy_slice)
         e.policy_apply()
 
@@ -59,11 +67,12 @@ class DataParallelLearner:
 
     def sync_moving_statistics(self):
         if self.sync_bn_stats and (self.world > 1 or self.force):
-            self._allreduce(self.engine.params, *self._state_slice, scale=1.0 / self.world)
+            for lo, hi in self._state_slices:
+                self._allreduce(self.engine.params, lo, hi, scale=1.0 / self.world)
 
-    def update_step(self, policy_batch, value_batch):
+    def update_step(self, policy_batch, value_batch, resample=None):
         """One PPO update-step = one policy minibatch step + one value minibatch step
         (reference rl/agents/ppo.py:199-224)."""
-        self.policy_step(policy_batch)
+        self.policy_step(policy_batch, resample)
         self.value_step(value_batch)
         self.sync_moving_statistics()

@@ -106,6 +106,10 @@ size_t cdrl_learner_workspace_bytes(const cdrl_learner* l);
 int cdrl_learner_bind(cdrl_learner* l, float* params, float* grads, float* adam_m, float* adam_v, void* workspace,
                       size_t workspace_bytes);
 int cdrl_learner_set_hparams(cdrl_learner* l, const cdrl_hparams* hp, void* stream);
+/* Makes `l` read its hyper-parameters and Adam step counters from `owner`'s device block (both bound, sharing the same
+ * parameter / Adam arenas): a second learner built for the ragged LAST minibatch of an update (the reference's tf.data
+ * pipeline keeps it unless drop_remainder is set, rl/utils.py:365-393) then advances the same optimizer. */
+int cdrl_learner_share_hparams(cdrl_learner* l, const cdrl_learner* owner);
 int cdrl_learner_reset_optimizer_steps(cdrl_learner* l, void* stream);
 
 /* CARLAgent.get_policy_gradients (core/carla_agent.py:351-373): train-mode trunk forward,
@@ -174,6 +178,10 @@ int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double
  * du/dbeta by implicit differentiation of the Gamma CDF.  Element (row, col) reads alpha[row*ld + col]. */
 int cdrl_beta_sample(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,
                      float* u, float* du_dalpha, float* du_dbeta, void* stream);
+/* Rollout form (CARLANetwork.predict, core/networks.py:181-193 -> PolicyNetwork.call :96-103): the sample and the
+ * log-density of the sample clipped to [eps, 1 - eps], no Jacobians. */
+int cdrl_beta_sample_logp(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,
+                          float* u, float* log_prob, void* stream);
 int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* out, void* stream);
 
 /* Minibatch assembly: utils.data_to_batches' tf.data gather of the shuffled rollout rows

@@ -129,3 +129,66 @@ def test_two_rank_data_parallel_equals_averaged_gradients(tmp_path):
     # the value-head region was not part of the policy all-reduce slice and must be untouched (zeros)
     voff, vn = lay.region('value', True)
     assert float(g0[voff:voff + vn].abs().max()) == 0.0
+
+
+def _worker_sync(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from carla_driving_rl_agent_amd.parallel import DataParallelLearner
+    from carla_driving_rl_agent_amd.engine import LearnerEngine
+
+    class Arena:         # the arenas + layout DataParallelLearner's broadcast / statistics sync touch
+        def __init__(self):
+            self.layout = LearnerEngine(B, device=None, H=H, W=W)
+            g = torch.Generator().manual_seed(100 + rank)
+            self.params_total = self.layout.params_total
+            self.params = torch.randn(self.layout.params_total, generator=g)
+            self.grads = torch.zeros(self.layout.grads_total)
+            self.adam_m = torch.randn(self.layout.grads_total, generator=g)
+            self.adam_v = torch.rand(self.layout.grads_total, generator=g)
+
+        def region(self, model, trainable):
+            return self.layout.region(model, trainable)
+
+    eng = Arena()
+    dp = DataParallelLearner(eng, sync_bn_stats=True)
+    mine = eng.params.clone()
+    dp.broadcast_parameters(src=0)
+    torch.save(dict(params=eng.params.clone(), m=eng.adam_m.clone(), v=eng.adam_v.clone(), before=mine),
+               os.path.join(out, f'bcast{rank}.pt'))
+    # rank-local BatchNorm moving statistics (every non-trainable region), identical weights
+    for model in ('policy', 'trunk', 'value', 'old_policy'):
+        off, n = eng.region(model, False)
+        eng.params[off:off + n] = float(rank + 1) + torch.arange(n, dtype=torch.float32) * 1e-3
+    dp.sync_moving_statistics()
+    torch.save(eng.params.clone(), os.path.join(out, f'sync{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_broadcast_parameters_and_moving_statistics_sync(tmp_path):
+    """broadcast_parameters: every rank ends on rank 0's weights AND Adam moments; sync_moving_statistics: the BatchNorm
+    moving statistics of policy / trunk / value and the old policy's copy become the rank average, while every trainable
+    region -- incl. the old-policy WEIGHTS, identical by construction -- is left bit-for-bit alone."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_sync, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    b0, b1 = torch.load(tmp_path / 'bcast0.pt'), torch.load(tmp_path / 'bcast1.pt')
+    assert not torch.equal(b0['before'], b1['before'])
+    for k in ('params', 'm', 'v'):
+        assert torch.equal(b0[k], b1[k]), k
+    assert torch.equal(b0['params'], b0['before'])                      # source rank unchanged
+    s0, s1 = torch.load(tmp_path / 'sync0.pt'), torch.load(tmp_path / 'sync1.pt')
+    assert torch.equal(s0, s1)
+    from carla_driving_rl_agent_amd.engine import LearnerEngine
+    lay = LearnerEngine(B, device=None, H=H, W=W)
+    for model in ('policy', 'trunk', 'value', 'old_policy'):
+        off, n = lay.region(model, False)
+        expect = 1.5 + torch.arange(n, dtype=torch.float32) * 1e-3          # mean of (1 + x, 2 + x)
+        assert torch.allclose(s0[off:off + n], expect, rtol=0, atol=1e-6), model
+        toff, tn = lay.region(model, True)
+        assert torch.equal(s0[toff:toff + tn], b0['params'][toff:toff + tn]), model
