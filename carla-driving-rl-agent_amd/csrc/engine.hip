@@ -1194,7 +1194,11 @@ void Learner::build(bool dry) {
     sample_u_ = alloc((size_t)cfg_.B * A);
     sample_da_ = alloc((size_t)cfg_.B * A);
     sample_db_ = alloc((size_t)cfg_.B * A);
+    note_named("sample.u", sample_u_, (size_t)cfg_.B * A * sizeof(float));
+    note_named("sample.du_dalpha", sample_da_, (size_t)cfg_.B * A * sizeof(float));
+    note_named("sample.du_dbeta", sample_db_, (size_t)cfg_.B * A * sizeof(float));
     hp_dev_ = reinterpret_cast<DevHP*>(alloc(sizeof(DevHP) / sizeof(float) + 4));
+    note_named("hparams", hp_dev_, sizeof(DevHP));      // 10 floats (lr x3, clip, entropy, clip norms x2, beta1, beta2, eps), 3 int step counters
     // optimiser tables
     for (int m = 1; m <= 2; ++m) {
         SegTable& s = seg_[m];
