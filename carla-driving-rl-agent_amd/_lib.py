@@ -73,6 +73,8 @@ PROTOTYPES = {
     'cdrl_learner_policy_forward': (_i, [_L, _fp, _fp, _fp, _fp, _fp]),
     'cdrl_learner_policy_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
     'cdrl_learner_policy_forward_backward_resample': (_i, [_L, C.POINTER(PolicyBatch), C.c_uint64, C.c_uint64, _f, _fp]),
+    'cdrl_gru_step_fwd': (_i, [_fp] * 9 + [_i, _i, _fp]),
+    'cdrl_gru_step_bwd': (_i, [_fp, _i] + [_fp] * 9 + [_i, _i, _fp]),
     'cdrl_beta_sample_logp': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp]),
     'cdrl_beta_sample': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp, _fp]),
     'cdrl_gamma_implicit_grad': (_i, [_fp, _fp, _i, _fp, _fp]),
@@ -133,6 +135,10 @@ def load():
         raise ImportError(
             f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(hipcc --offload-arch=gfx950). There is no CPU fallback for the learner hot path.')
+    # torch first: it brings its own HIP runtime (libamdhip64 under torch/lib).  libcdrl_hip.so must resolve its HIP symbols to
+    # THAT runtime -- loaded the other way round the process ends up with two runtimes, and device memory / streams handed over
+    # from torch are unknown to the one this library would have bound to.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported

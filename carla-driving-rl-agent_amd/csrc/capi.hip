@@ -346,6 +346,24 @@ int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double
     return gae_returns(rewards, values_be, N, gamma, lambda, scale, returns, returns_be, adv_raw, adv, scratch, S(stream));
 }
 
+int cdrl_gru_step_fwd(const float* xp, const float* hprev, const float* R, const float* b1, float* z, float* r, float* hh,
+                      float* hp, float* hnew, int B, int u, void* stream) {
+    if (!xp || !hprev || !R || !b1 || !z || !r || !hh || !hp || !hnew) {
+        cdrl::set_error("cdrl_gru_step_fwd: null argument");
+        return -1;
+    }
+    return gru_step_fwd(xp, hprev, R, b1, z, r, hh, hp, hnew, View{nullptr, 0, 0}, B, u, S(stream));
+}
+
+int cdrl_gru_step_bwd(const float* dh, int ld_dh, const float* z, const float* r, const float* hh, const float* hp,
+                      const float* hprev, const float* RT, float* dxp, float* dhp, float* dhprev, int B, int u, void* stream) {
+    if (!dh || !z || !r || !hh || !hp || !hprev || !RT || !dxp || !dhp) {
+        cdrl::set_error("cdrl_gru_step_bwd: null argument");
+        return -1;
+    }
+    return gru_step_bwd(make_view(const_cast<float*>(dh), ld_dh), z, r, hh, hp, hprev, RT, dxp, dhp, dhprev, B, u, S(stream));
+}
+
 int cdrl_gather_rows(const float* src, const int32_t* idx, float* dst, int nrows, int64_t row_elems, void* stream) {
     if (!src || !idx || !dst) {
         cdrl::set_error("cdrl_gather_rows: null argument");

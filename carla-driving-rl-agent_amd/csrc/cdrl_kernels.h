@@ -189,7 +189,8 @@ struct PwTranspose {
     float* wt;
     int cin, cout;
 };
-int transpose_many(const PwTranspose* tab_dev, int n, int max_dim, hipStream_t st);
+// one launch: grid = (tiles, n) with tiles >= max over the entries of ceil(cin/32) * ceil(cout/32)
+int transpose_many(const PwTranspose* tab_dev, int n, int tiles, hipStream_t st);
 
 // ---------------------------------------------------------------- linear output heads (heads.hip)
 #define HEADS_MAX 4
@@ -210,10 +211,13 @@ int heads_bwd(const float* a, int lda, const HeadSet& hs, const float* dlin, int
 
 // ---------------------------------------------------------------- GRU (rnn.hip)
 // gates of step t: xp,hp [B][3u]; hprev [B][u]; saves z,r,hh; writes hnew
-int gru_gates_fwd(const float* xp, const float* hp, const float* hprev, float* z, float* r, float* hh, float* hnew,
-                  int B, int u, hipStream_t st);
-int gru_gates_bwd(const float* dh, const float* z, const float* r, const float* hh, const float* hp,
-                  const float* hprev, float* dxp, float* dhp, float* dhprev, int B, int u, hipStream_t st);
+// one fused kernel per GRU time step and direction (rnn.hip): recurrent product + gate math / gate derivatives + product
+// against R^T; `out` (optional) is a second destination of h_new, `dh` a strided view, dhprev == null for the first step
+bool gru_step_supported(int u);
+int gru_step_fwd(const float* xp, const float* hprev, const float* R, const float* b1, float* z, float* r, float* hh, float* hp,
+                 float* hnew, View out, int B, int u, hipStream_t st);
+int gru_step_bwd(View dh, const float* z, const float* r, const float* hh, const float* hp, const float* hprev, const float* RT,
+                 float* dxp, float* dhp, float* dhprev, int B, int u, hipStream_t st);
 
 // ---------------------------------------------------------------- losses (loss.hip)
 struct PolicyLossArgs {

@@ -349,6 +349,8 @@ private:
     std::vector<PwTranspose> h_pwt_;
     std::map<std::string, float*> pwt_by_name_;
     PwTranspose* d_pwt_ = nullptr;
+    int pwt_tiles_ = 0;
+    std::vector<std::pair<void*, size_t>> zero_once_;    // workspace regions that must read as zero and are never written
     float* pw_transposed(const std::string& name, const float* w, int cin, int cout);
     bool tables_uploaded_ = false;
     std::map<std::string, std::pair<void*, int64_t>> named_;

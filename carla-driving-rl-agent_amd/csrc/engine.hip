@@ -332,6 +332,7 @@ float* Learner::pw_transposed(const std::string& name, const float* w, int cin, 
     float* wt = alloc((size_t)cin * cout);
     pwt_by_name_[name] = wt;
     h_pwt_.push_back(PwTranspose{w, wt, cin, cout});
+    pwt_tiles_ = std::max(pwt_tiles_, ((cin + 31) / 32) * ((cout + 31) / 32));
     return wt;
 }
 
@@ -632,50 +633,43 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
     float* Z = alloc((size_t)T * B * u);
     float* R = alloc((size_t)T * B * u);
     float* HH = alloc((size_t)T * B * u);
-    float* Hs = alloc((size_t)(T + 1) * B * u);
+    float* Hs = alloc((size_t)(T + 1) * B * u);         // Hs[0] = h_{-1} = 0: zeroed once at bind, never written
     float* dXP = alloc((size_t)T * B * U3);
     float* dHP = alloc((size_t)T * B * U3);
     float* dHa = alloc((size_t)B * u);
     float* dHb = alloc((size_t)B * u);
+    if (!dry_) zero_once_.push_back(std::make_pair(Hs, (size_t)B * u * sizeof(float)));
+    if (!gru_step_supported(u)) set_error("GRU units %d unsupported by the fused step kernels", u);
+    const float* RT = pw_transposed(name + ".recurrent", Rp.p, u, U3);        // [3u][u], refreshed with the conv W^T copies
     note_scratch((size_t)vcol_geom(T * B, U3).nb * U3, (size_t)vcol_geom(T * B, U3).nb * U3, 0,
                  (size_t)std::max(gemm_tn_part_elems(T * B, U3, In), gemm_tn_part_elems(T * B, U3, u)));
     const int nbc = vcol_geom(T * B, U3).nb;
     View xv = x.v();
     View xg = x.gv();
     Scratch* sc = build_scr_;
-    // split-K scratch for the projections (small M = B or T*B, K = In / u / 3u): own buffer per GRU, the GRUs of different
+    // split-K scratch for the input projections (M = T*B, K = In / 3u): own buffer per GRU, the GRUs of different
     // modalities run on different streams
     size_t skn = 0;
-    for (int64_t e : {gemm_nn_splitk_elems(T * B, U3, In), gemm_nn_splitk_elems(B, U3, u), gemm_nn_splitk_elems(B, u, U3),
-                      gemm_nn_splitk_elems(T * B, In, U3)})
-        skn = std::max(skn, (size_t)e);
+    for (int64_t e : {gemm_nn_splitk_elems(T * B, U3, In), gemm_nn_splitk_elems(T * B, In, U3)}) skn = std::max(skn, (size_t)e);
     float* sk = skn ? alloc(skn) : nullptr;
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
-        CDRL_TRY(fill(Hs, (int64_t)B * u, 0.0f, st));
         CDRL_TRY(gemm_nn(xv, Kp.p, U3, 1, bp.p, make_view(XP, U3), T * B, U3, In, 0, st, sk));
-        for (int t = 0; t < T; ++t) {
-            float* h = Hs + (size_t)t * B * u;
-            float* hp = HP + (size_t)t * B * U3;
-            CDRL_TRY(gemm_nn(make_view(h, u), Rp.p, U3, 1, bp.p + U3, make_view(hp, U3), B, U3, u, 0, st, sk));
-            CDRL_TRY(gru_gates_fwd(XP + (size_t)t * B * U3, hp, h, Z + (size_t)t * B * u, R + (size_t)t * B * u,
-                                   HH + (size_t)t * B * u, Hs + (size_t)(t + 1) * B * u, B, u, st));
-        }
-        return bn_apply(make_view(Hs + (size_t)T * B * u, u), 1, B, u, nullptr, ACT_NONE, out, 0, st);
+        for (int t = 0; t < T; ++t)         // one fused kernel per step: h R + b1, gates, saved tensors, (last step) the concat slot
+            CDRL_TRY(gru_step_fwd(XP + (size_t)t * B * U3, Hs + (size_t)t * B * u, Rp.p, bp.p + U3, Z + (size_t)t * B * u,
+                                  R + (size_t)t * B * u, HH + (size_t)t * B * u, HP + (size_t)t * B * U3,
+                                  Hs + (size_t)(t + 1) * B * u, t == T - 1 ? out : View{nullptr, 0, 0}, B, u, st));
+        return 0;
     };
     op.bwd = [=](hipStream_t st) -> int {
-        CDRL_TRY(gather_view(dout, 0, B, u, make_view(dHa, u), 0, st));
-        float* cur = dHa;
-        float* nxt = dHb;
+        View cur = dout;                    // the gradient enters through the last hidden state only
+        float* nxt = dHa;
         for (int t = T - 1; t >= 0; --t) {
-            float* dhp = dHP + (size_t)t * B * U3;
-            CDRL_TRY(gru_gates_bwd(cur, Z + (size_t)t * B * u, R + (size_t)t * B * u, HH + (size_t)t * B * u,
-                                   HP + (size_t)t * B * U3, Hs + (size_t)t * B * u, dXP + (size_t)t * B * U3, dhp, nxt, B,
-                                   u, st));
-            CDRL_TRY(gemm_nn(make_view(dhp, U3), Rp.p, 1, U3, nullptr, make_view(nxt, u), B, u, U3, 1, st, sk));
-            float* tmp = cur;
-            cur = nxt;
-            nxt = tmp;
+            CDRL_TRY(gru_step_bwd(cur, Z + (size_t)t * B * u, R + (size_t)t * B * u, HH + (size_t)t * B * u,
+                                  HP + (size_t)t * B * U3, Hs + (size_t)t * B * u, RT, dXP + (size_t)t * B * U3,
+                                  dHP + (size_t)t * B * U3, t > 0 ? nxt : nullptr, B, u, st));
+            cur = make_view(nxt, u);
+            nxt = nxt == dHa ? dHb : dHa;
         }
         // critical path first: the gradient w.r.t. the GRU input
         if (need_dx) CDRL_TRY(gemm_nn(make_view(dXP, U3), Kp.p, 1, U3, nullptr, xg, T * B, In, U3, 0, st, sk));
@@ -1177,6 +1171,8 @@ void Learner::build(bool dry) {
     }
     h_pwt_.clear();
     pwt_by_name_.clear();
+    pwt_tiles_ = 0;
+    zero_once_.clear();
     build_trunk(trunk_ops_);
     d_pwt_ = reinterpret_cast<PwTranspose*>(alloc((h_pwt_.size() + 1) * sizeof(PwTranspose) / sizeof(float) + 4));
     const int A = cfg_.A;
@@ -1283,6 +1279,7 @@ int Learner::bind(const Buffers& b) {
         return -1;
     }
     CDRL_TRY(upload_seg_tables());
+    for (auto& z : zero_once_) CDRL_HIP(hipMemset(z.first, 0, z.second));
     if (!side_) {
         const char* env = getenv("CDRL_SIDE_STREAM");
         side_enabled_ = !(env && atoi(env) == 0);
@@ -1414,7 +1411,7 @@ int Learner::policy_backward_impl(const PolicyBatch& b, float inv_world, hipStre
     a.inv_world = inv_world;
     CDRL_TRY(policy_loss(a, st));
     CDRL_TRY(run_bwd(policy_ops_, st));
-    CDRL_TRY(transpose_many(d_pwt_, (int)h_pwt_.size(), 256, st));      // W^T of the pointwise convs (weights of this pass)
+    CDRL_TRY(transpose_many(d_pwt_, (int)h_pwt_.size(), pwt_tiles_, st));      // W^T of the pointwise convs (weights of this pass)
     CDRL_TRY(run_bwd(trunk_ops_, st));
     return join_side(st);
 }
@@ -1475,7 +1472,7 @@ int Learner::value_forward_backward_impl(const ValueBatch& b, float inv_world, h
     a.inv_world = inv_world;
     CDRL_TRY(value_loss(a, st));
     CDRL_TRY(run_bwd(value_ops_, st));
-    CDRL_TRY(transpose_many(d_pwt_, (int)h_pwt_.size(), 256, st));
+    CDRL_TRY(transpose_many(d_pwt_, (int)h_pwt_.size(), pwt_tiles_, st));
     CDRL_TRY(run_bwd(trunk_ops_, st));
     return join_side(st);
 }

@@ -770,9 +770,8 @@ __global__ void __launch_bounds__(256) transpose_many_kernel(const PwTranspose* 
         if (n0 + r < d.cout && k0 + tx < d.cin) d.wt[(int64_t)(n0 + r) * d.cin + k0 + tx] = t[tx][r];
 }
 
-int transpose_many(const PwTranspose* tab_dev, int n, int max_dim, hipStream_t st) {
-    if (n <= 0) return 0;
-    const int tiles = cdiv(max_dim, 32) * cdiv(max_dim, 32);
+int transpose_many(const PwTranspose* tab_dev, int n, int tiles, hipStream_t st) {
+    if (n <= 0 || tiles <= 0) return 0;
     hipLaunchKernelGGL(transpose_many_kernel, dim3(tiles, n), dim3(256), 0, st, tab_dev);
     CDRL_LAUNCH_CHECK();
     return 0;

@@ -1,69 +1,217 @@
-// GRU gate kernels (gfx950).  Keras GRU v2 cell, reset_after=True, gate order z, r, h
-// (reference core/networks.py:47-50):
-//   z = sig(xz + hz); r = sig(xr + hr); hh = tanh(xh + r * hh_p); h' = z*h + (1-z)*hh
-// The projections xp = x K + b0 and hp = h R + b1 are MFMA GEMMs (gemm.hip); these kernels are
-// the fused elementwise gate math and its BPTT counterpart.
+// GRU time step as ONE kernel per direction (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// Keras GRU v2 cell, reset_after=True, gate order z, r, h (reference core/networks.py:47-50):
+//   hp = h R + b1;  z = sig(xz + hz); r = sig(xr + hr); hh = tanh(xh + r * hp_h); h' = z*h + (1-z)*hh
+// with xp = x K + b0 precomputed for all T steps by one batched GEMM (gemm.hip).
+//
+// The recurrence couples only the columns of one batch row, so a workgroup owns a 32-row x 32-unit tile of the step:
+//   forward : the recurrent product for its three gate column tiles (z, r, h) from an LDS-staged copy of h[rows, :]
+//             (K = u split over the four waves, fixed-order fold through LDS), then the gate math and all saved tensors;
+//   backward: the gate derivatives of its 32 rows for ALL 3u pre-activations into LDS (that is the A operand of
+//             dh_prev = dhp R^T; the column-tile-0 workgroups also write dxp / dhp for the weight gradients), the product
+//             against R^T (K = 3u split over the waves), plus the direct term dh * z.
+// Before: recurrent GEMM + split-K reduce + gate kernel = 3 launches per step and direction on the critical stream.
 #include "cdrl_kernels.h"
 
 namespace cdrl {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ void gru_gates_fwd_kernel(const float* __restrict__ xp, const float* __restrict__ hp,
-                                     const float* __restrict__ hprev, float* __restrict__ z, float* __restrict__ r,
-                                     float* __restrict__ hh, float* __restrict__ hnew, int B, int u) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * u) return;
-    const int b = i / u, j = i % u;
-    const float* x = xp + (int64_t)b * 3 * u;
-    const float* h = hp + (int64_t)b * 3 * u;
-    const float zz = sigm(x[j] + h[j]);
-    const float rr = sigm(x[u + j] + h[u + j]);
-    const float cand = tanhf(x[2 * u + j] + rr * h[2 * u + j]);
-    z[i] = zz;
-    r[i] = rr;
-    hh[i] = cand;
-    hnew[i] = zz * hprev[i] + (1.0f - zz) * cand;
+struct GruFwdArgs {
+    const float* xp;      // [B][3u]
+    const float* hprev;   // [B][u]
+    const float* R;       // [u][3u]
+    const float* b1;      // [3u]
+    float *z, *r, *hh, *hp, *hnew;
+    View out;             // optional second destination of hnew (the concat view after the last step)
+    int B, u;
+};
+
+// C/D fragment of a 32x32 tile: lane l, register i -> (row, col)
+__device__ __forceinline__ int frag_row(int lane, int i) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+__global__ void __launch_bounds__(256) gru_step_fwd_kernel(GruFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int u = a.u, U3 = 3 * u, LDA = u + 1;
+    float* As = smem;                               // [32][u + 1]
+    float* red = smem + 32 * LDA;                   // [4 waves][3 gates][32][33]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int i = tid; i < 32 * u; i += 256) {
+        const int r = i / u, k = i - r * u;
+        As[r * LDA + k] = (r0 + r < a.B) ? a.hprev[(int64_t)(r0 + r) * u + k] : 0.0f;
+    }
+    __syncthreads();
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int KW = u >> 2, k0 = wave * KW;          // this wave's slice of K
+    f32x16 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][i] = 0.0f;
+    const float* Rb = a.R + c0 + lrow;
+#pragma unroll 4
+    for (int s = 0; s < KW / 2; ++s) {
+        const int k = k0 + 2 * s + lk;
+        const float av = As[lrow * LDA + k];
+        const float* rk = Rb + (int64_t)k * U3;
+        const float b0 = rk[0], b1 = rk[u], b2 = rk[2 * u];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b2, acc[2], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[((wave * 3 + g) * 32 + frag_row(lane, i)) * 33 + lrow] = acc[g][i];
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        const int row = r0 + r, j = c0 + c;
+        if (row >= a.B) continue;
+        float hpv[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            float s = red[((0 * 3 + g) * 32 + r) * 33 + c];
+            s += red[((1 * 3 + g) * 32 + r) * 33 + c];
+            s += red[((2 * 3 + g) * 32 + r) * 33 + c];
+            s += red[((3 * 3 + g) * 32 + r) * 33 + c];
+            hpv[g] = s + a.b1[g * u + j];
+        }
+        const float* x = a.xp + (int64_t)row * U3;
+        const float zz = sigm(x[j] + hpv[0]);
+        const float rr = sigm(x[u + j] + hpv[1]);
+        const float cand = tanhf(x[2 * u + j] + rr * hpv[2]);
+        const float hn = zz * As[r * LDA + j] + (1.0f - zz) * cand;
+        const int64_t o = (int64_t)row * u + j;
+        a.z[o] = zz;
+        a.r[o] = rr;
+        a.hh[o] = cand;
+        float* hpo = a.hp + (int64_t)row * U3;
+        hpo[j] = hpv[0];
+        hpo[u + j] = hpv[1];
+        hpo[2 * u + j] = hpv[2];
+        a.hnew[o] = hn;
+        if (a.out.p) a.out.p[(int64_t)row * a.out.ld + a.out.coff + j] = hn;
+    }
 }
 
-int gru_gates_fwd(const float* xp, const float* hp, const float* hprev, float* z, float* r, float* hh, float* hnew,
-                  int B, int u, hipStream_t st) {
-    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(cdiv(B * u, 256)), dim3(256), 0, st, xp, hp, hprev, z, r, hh, hnew, B, u);
+bool gru_step_supported(int u) { return u >= 32 && u % 32 == 0 && (size_t)(32 * (3 * u + 1) + 4 * 32 * 33) * 4 <= 160 * 1024; }
+
+int gru_step_fwd(const float* xp, const float* hprev, const float* R, const float* b1, float* z, float* r, float* hh, float* hp,
+                 float* hnew, View out, int B, int u, hipStream_t st) {
+    if (!gru_step_supported(u)) {
+        set_error("gru_step_fwd: units %d unsupported (multiple of 32, <= 416)", u);
+        return -1;
+    }
+    GruFwdArgs a{xp, hprev, R, b1, z, r, hh, hp, hnew, out, B, u};
+    const size_t lds = (size_t)(32 * (u + 1) + 4 * 3 * 32 * 33) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(cdiv(B, 32), u / 32), dim3(256), lds, st, a);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
 
-__global__ void gru_gates_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ z,
-                                     const float* __restrict__ r, const float* __restrict__ hh,
-                                     const float* __restrict__ hp, const float* __restrict__ hprev,
-                                     float* __restrict__ dxp, float* __restrict__ dhp, float* __restrict__ dhprev, int B,
-                                     int u) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * u) return;
-    const int b = i / u, j = i % u;
-    const float g = dh[i], zz = z[i], rr = r[i], cand = hh[i];
-    const float hhp = hp[(int64_t)b * 3 * u + 2 * u + j];
-    const float dcand = g * (1.0f - zz);
-    const float dz = g * (hprev[i] - cand);
-    const float dpre_h = dcand * (1.0f - cand * cand);
-    const float dr = dpre_h * hhp;
-    const float dpre_z = dz * zz * (1.0f - zz);
-    const float dpre_r = dr * rr * (1.0f - rr);
-    float* dx = dxp + (int64_t)b * 3 * u;
-    float* dhh = dhp + (int64_t)b * 3 * u;
-    dx[j] = dpre_z;
-    dx[u + j] = dpre_r;
-    dx[2 * u + j] = dpre_h;
-    dhh[j] = dpre_z;
-    dhh[u + j] = dpre_r;
-    dhh[2 * u + j] = dpre_h * rr;
-    dhprev[i] = g * zz;
+struct GruBwdArgs {
+    View dh;              // gradient w.r.t. h_t: element (row, j) at dh.p[row * dh.ld + dh.coff + j]
+    const float *z, *r, *hh, *hp, *hprev;
+    const float* RT;      // [3u][u] = R^T
+    float *dxp, *dhp;     // [B][3u]
+    float* dhprev;        // [B][u] (may be null: first time step)
+    int B, u;
+};
+
+__global__ void __launch_bounds__(256) gru_step_bwd_kernel(GruBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int u = a.u, U3 = 3 * u, LDD = U3 + 1;
+    float* Ds = smem;                               // [32][3u + 1]: dhp of the workgroup's rows
+    float* red = smem + 32 * LDD;                   // [4][32][33]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const bool writer = blockIdx.y == 0;
+    for (int i = tid; i < 32 * u; i += 256) {
+        const int r = i / u, j = i - r * u;
+        const int row = r0 + r;
+        float pz = 0.0f, pr = 0.0f, ph = 0.0f, rr = 0.0f;
+        if (row < a.B) {
+            const int64_t o = (int64_t)row * u + j;
+            const float g = a.dh.p[(int64_t)row * a.dh.ld + a.dh.coff + j];
+            const float zz = a.z[o], cand = a.hh[o];
+            rr = a.r[o];
+            const float hhp = a.hp[(int64_t)row * U3 + 2 * u + j];
+            const float dcand = g * (1.0f - zz);
+            const float dz = g * (a.hprev[o] - cand);
+            ph = dcand * (1.0f - cand * cand);
+            const float dr = ph * hhp;
+            pz = dz * zz * (1.0f - zz);
+            pr = dr * rr * (1.0f - rr);
+            if (writer) {
+                float* dx = a.dxp + (int64_t)row * U3;
+                float* dhh = a.dhp + (int64_t)row * U3;
+                dx[j] = pz;
+                dx[u + j] = pr;
+                dx[2 * u + j] = ph;
+                dhh[j] = pz;
+                dhh[u + j] = pr;
+                dhh[2 * u + j] = ph * rr;
+            }
+        }
+        Ds[r * LDD + j] = pz;
+        Ds[r * LDD + u + j] = pr;
+        Ds[r * LDD + 2 * u + j] = ph * rr;
+    }
+    if (!a.dhprev) return;
+    __syncthreads();
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int KW = U3 >> 2, k0 = wave * KW;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const float* Tb = a.RT + c0 + lrow;
+#pragma unroll 8
+    for (int s = 0; s < KW / 2; ++s) {
+        const int k = k0 + 2 * s + lk;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[lrow * LDD + k], Tb[(int64_t)k * u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[(wave * 32 + frag_row(lane, i)) * 33 + lrow] = acc[i];
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        const int row = r0 + r, j = c0 + c;
+        if (row >= a.B) continue;
+        float s = red[(0 * 32 + r) * 33 + c];
+        s += red[(1 * 32 + r) * 33 + c];
+        s += red[(2 * 32 + r) * 33 + c];
+        s += red[(3 * 32 + r) * 33 + c];
+        const int64_t o = (int64_t)row * u + j;
+        a.dhprev[o] = a.dh.p[(int64_t)row * a.dh.ld + a.dh.coff + j] * a.z[o] + s;
+    }
 }
 
-int gru_gates_bwd(const float* dh, const float* z, const float* r, const float* hh, const float* hp,
-                  const float* hprev, float* dxp, float* dhp, float* dhprev, int B, int u, hipStream_t st) {
-    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(cdiv(B * u, 256)), dim3(256), 0, st, dh, z, r, hh, hp, hprev, dxp, dhp,
-                       dhprev, B, u);
+int gru_step_bwd(View dh, const float* z, const float* r, const float* hh, const float* hp, const float* hprev, const float* RT,
+                 float* dxp, float* dhp, float* dhprev, int B, int u, hipStream_t st) {
+    if (!gru_step_supported(u)) {
+        set_error("gru_step_bwd: units %d unsupported (multiple of 32, <= 416)", u);
+        return -1;
+    }
+    GruBwdArgs a{dh, z, r, hh, hp, hprev, RT, dxp, dhp, dhprev, B, u};
+    const size_t lds = (size_t)(32 * (3 * u + 1) + 4 * 32 * 33) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        attr = true;
+    }
+    // first time step: no dh_prev consumer -> only the gate derivatives (one column of workgroups)
+    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(cdiv(B, 32), dhprev ? u / 32 : 1), dim3(256), lds, st, a);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

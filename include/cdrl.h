@@ -184,6 +184,15 @@ int cdrl_beta_sample_logp(const float* alpha, const float* beta, int rows, int A
                           float* u, float* log_prob, void* stream);
 int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* out, void* stream);
 
+/* One time step of the Keras GRU v2 cell (reset_after=True, gates z, r, h; reference core/networks.py:47-50 ->
+ * keras.layers.GRU(unroll=True)) as ONE kernel per direction.  xp = x K + b0 of the step [B][3u], hprev [B][u], R [u][3u],
+ * b1 [3u]; saved for the backward: z, r, hh [B][u] and hp = hprev R + b1 [B][3u].  Backward: dh [B][ld_dh] gradient w.r.t.
+ * the step's output, RT = R^T [3u][u]; outputs dxp (gradient w.r.t. xp), dhp (gradient w.r.t. hp), dhprev (may be null). */
+int cdrl_gru_step_fwd(const float* xp, const float* hprev, const float* R, const float* b1, float* z, float* r, float* hh,
+                      float* hp, float* hnew, int B, int u, void* stream);
+int cdrl_gru_step_bwd(const float* dh, int ld_dh, const float* z, const float* r, const float* hh, const float* hp,
+                      const float* hprev, const float* RT, float* dxp, float* dhp, float* dhprev, int B, int u, void* stream);
+
 /* Minibatch assembly: utils.data_to_batches' tf.data gather of the shuffled rollout rows
  * (rl/utils.py:365-393); dst[i, :] = src[idx[i], :], idx = int32 device array of row numbers. */
 int cdrl_gather_rows(const float* src, const int32_t* idx, float* dst, int nrows, int64_t row_elems, void* stream);

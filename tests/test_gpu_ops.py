@@ -587,3 +587,48 @@ def test_value_loss(lib):
     _lib.check(lib.cdrl_value_loss(*[P(k) for k in keep], B, 6.0, 1.0, P(dlin), P(metrics), P(vals), S()))
     assert abs(metrics.cpu().numpy()[0] - total.item()) < 1e-6 * max(1.0, abs(total.item()))
     assert rel_err(dlin.cpu().numpy(), lt.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('B,In,u,T', [(256, 768, 256, 4), (37, 16, 32, 4), (1, 16, 32, 3), (64, 40, 96, 2)])
+def test_gru_steps_vs_fp64_autograd(lib, B, In, u, T):
+    """Fused GRU time-step kernels (cdrl_gru_step_fwd / _bwd) composed into a T-step GRU against float64 autograd of the
+    oracle's Keras-GRU restatement (oracle/model.py::gru_last): last hidden state, every saved gate tensor, and the
+    gradients w.r.t. the input projection, the recurrent pre-activations (-> dK, dR, db) and the input."""
+    rng = np.random.default_rng(B + In + u)
+    x = rng.standard_normal((T, B, In))
+    p64 = {'g.kernel': torch.tensor(rng.standard_normal((In, 3 * u)) / np.sqrt(In), requires_grad=True),
+           'g.recurrent': torch.tensor(rng.standard_normal((u, 3 * u)) / np.sqrt(u), requires_grad=True),
+           'g.bias': torch.tensor(rng.standard_normal((2, 3 * u)) * 0.1, requires_grad=True)}
+    x64 = torch.tensor(x, requires_grad=True)
+    h_ref = OM.gru_last(x64, p64, 'g')
+    gout = rng.standard_normal((B, u))
+    h_ref.backward(torch.tensor(gout))
+    K, R, b = (p64[k].detach().float().to(DEV).contiguous() for k in ('g.kernel', 'g.recurrent', 'g.bias'))
+    xd = dev(x.astype(np.float32))
+    XP = (xd.reshape(T * B, In) @ K + b[0]).reshape(T, B, 3 * u).contiguous()      # input projection: one batched GEMM in the engine
+    Hs = torch.zeros((T + 1, B, u), device=DEV)
+    Z, Rg, HH = (torch.empty((T, B, u), device=DEV) for _ in range(3))
+    HP = torch.empty((T, B, 3 * u), device=DEV)
+    b1 = b[1].contiguous()
+    for t in range(T):
+        _lib.check(lib.cdrl_gru_step_fwd(P(XP[t]), P(Hs[t]), P(R), P(b1), P(Z[t]), P(Rg[t]), P(HH[t]), P(HP[t]), P(Hs[t + 1]), B, u, S()))
+    assert rel_err(Hs[T].cpu().numpy(), h_ref.detach().numpy()) < 1e-5
+    RT = R.t().contiguous()
+    dXP = torch.zeros((T, B, 3 * u), device=DEV)
+    dHP = torch.zeros((T, B, 3 * u), device=DEV)
+    dh = [torch.empty((B, u + 3), device=DEV), torch.empty((B, u), device=DEV), torch.empty((B, u), device=DEV)]
+    dh[0][:, :u] = dev(gout.astype(np.float32))                                     # strided first gradient (the concat slot)
+    cur, ld = dh[0], u + 3
+    for t in range(T - 1, -1, -1):
+        nxt = dh[1] if cur is not dh[1] else dh[2]
+        _lib.check(lib.cdrl_gru_step_bwd(P(cur), ld, P(Z[t]), P(Rg[t]), P(HH[t]), P(HP[t]), P(Hs[t]), P(RT), P(dXP[t]), P(dHP[t]),
+                                         P(nxt) if t > 0 else None, B, u, S()))
+        cur, ld = nxt, u
+    dXPf, dHPf = dXP.reshape(T * B, 3 * u).double(), dHP.reshape(T * B, 3 * u).double()
+    got = {'g.kernel': xd.reshape(T * B, In).double().t() @ dXPf,
+           'g.recurrent': Hs[:T].reshape(T * B, u).double().t() @ dHPf,
+           'g.bias': torch.stack([dXPf.sum(0), dHPf.sum(0)])}
+    for k, g in got.items():
+        assert rel_err(g.cpu().numpy(), p64[k].grad.numpy()) < 3e-5, k
+    dx = (dXPf @ K.double().t()).reshape(T, B, In)
+    assert rel_err(dx.cpu().numpy(), x64.grad.numpy()) < 3e-5
