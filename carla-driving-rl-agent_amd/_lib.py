@@ -68,6 +68,7 @@ PROTOTYPES = {
     'cdrl_learner_bind': (_i, [_L, _fp, _fp, _fp, _fp, _fp, _sz]),
     'cdrl_learner_set_hparams': (_i, [_L, C.POINTER(HParams), _fp]),
     'cdrl_learner_share_hparams': (_i, [_L, _L]),
+    'cdrl_learner_set_comm_stream': (_i, [_L, _fp]),
     'cdrl_learner_reset_optimizer_steps': (_i, [_L, _fp]),
     'cdrl_learner_policy_forward_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
     'cdrl_learner_policy_forward': (_i, [_L, _fp, _fp, _fp, _fp, _fp]),

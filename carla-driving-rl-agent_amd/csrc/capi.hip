@@ -199,6 +199,12 @@ int cdrl_learner_share_hparams(cdrl_learner* l, const cdrl_learner* owner) {
     return 0;
 }
 
+int cdrl_learner_set_comm_stream(cdrl_learner* l, void* stream) {
+    CHECK_L(l);
+    l->impl->set_comm_stream(S(stream));
+    return 0;
+}
+
 int cdrl_learner_reset_optimizer_steps(cdrl_learner* l, void* stream) {
     CHECK_L(l);
     return l->impl->reset_counters(S(stream));

@@ -142,6 +142,10 @@ public:
     // Use another (bound) learner's device hyper-parameter block -- learning rates, clip, AND the Adam step counters -- so
     // that engines built for different minibatch sizes over the same parameter arenas behave as one optimizer.
     void share_hp(const Learner& owner) { hp_dev_ = owner.hp_dev_; }
+    // Data-parallel overlap: `s` (a caller-owned stream, or null) is made to wait, in the middle of every backward pass, for
+    // the point where the gradients of the heads and of the trunk tail (GRUs, feature nets, concat BN + Dense) are final --
+    // a collective enqueued on `s` after the pass has been enqueued then runs UNDER the tower's backward.
+    void set_comm_stream(hipStream_t s) { comm_ = s; }
     // Named internal tensors (parity tests: the raw BatchNorm inputs, statistics blocks, max-pool argmax codes and dense
     // pre-activations from which the discrete ReLU6 / max-pool decisions of the last forward are reconstructed)
     bool named_buffer(const std::string& name, void** p, int64_t* bytes) const {
@@ -350,6 +354,8 @@ private:
     std::map<std::string, float*> pwt_by_name_;
     PwTranspose* d_pwt_ = nullptr;
     int pwt_tiles_ = 0;
+    hipStream_t comm_ = nullptr;
+    hipEvent_t ev_tail_main_ = nullptr, ev_tail_side_ = nullptr;
     std::vector<std::pair<void*, size_t>> zero_once_;    // workspace regions that must read as zero and are never written
     float* pw_transposed(const std::string& name, const float* w, int cin, int cout);
     bool tables_uploaded_ = false;

@@ -51,6 +51,8 @@ Learner::~Learner() {
     if (ev_out_) (void)hipEventDestroy(ev_out_);
     if (main_) (void)hipStreamDestroy(main_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (ev_tail_main_) (void)hipEventDestroy(ev_tail_main_);
+    if (ev_tail_side_) (void)hipEventDestroy(ev_tail_side_);
     for (int i = 0; i < 3; ++i) {
         if (ev_sc_fork_[i]) (void)hipEventDestroy(ev_sc_fork_[i]);
         if (ev_sc_done_[i]) (void)hipEventDestroy(ev_sc_done_[i]);
@@ -1087,6 +1089,26 @@ void Learner::build_trunk(std::vector<Op>& ops) {
     // ---- GRUs + concat + BN + Dense (core/networks.py:44-56)
     const int catC = c.rnn_image + 3 * c.rnn_small;
     Tens cat = tens(B, catC);
+    {   // backward: everything behind this point of the (reversed) op list -- heads, concat BN + Dense, the small-modality
+        // nets on the aux stream, the image GRU -- has its gradient work enqueued: hand the "tail gradients final" point to
+        // the caller's communication stream (DataParallelLearner: early all-reduce bucket under the tower's backward)
+        Op mark;
+        mark.fwd = [](hipStream_t, int) -> int { return 0; };
+        mark.bwd = [=](hipStream_t st) -> int {
+            if (!comm_) return 0;
+            CDRL_TRY(aux_wait());
+            CDRL_HIP(hipEventRecord(ev_tail_main_, st));
+            CDRL_HIP(hipStreamWaitEvent(comm_, ev_tail_main_, 0));
+            if (side_enabled_) {
+                flush_deferred();
+                CDRL_HIP(hipEventRecord(ev_tail_side_, side_));
+                CDRL_HIP(hipStreamWaitEvent(comm_, ev_tail_side_, 0));
+                if (aux_pending_) CDRL_HIP(hipStreamWaitEvent(comm_, ev_aux_done_, 0));
+            }
+            return 0;
+        };
+        ops.push_back(mark);
+    }
     add_gru(ops, "gru_image", feat_, c.last, c.rnn_image, cat.v(0), cat.gv(0), true);
     build_scr_ = &scr_aux_;
     for (int i = 0; i < 3; ++i)
@@ -1304,6 +1326,8 @@ int Learner::bind(const Buffers& b) {
             CDRL_HIP(hipEventCreateWithFlags(&ev_side_[i], hipEventDisableTiming));
         }
         CDRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_tail_main_, hipEventDisableTiming));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_tail_side_, hipEventDisableTiming));
         for (int i = 0; i < 3; ++i) {
             CDRL_HIP(hipEventCreateWithFlags(&ev_sc_fork_[i], hipEventDisableTiming));
             CDRL_HIP(hipEventCreateWithFlags(&ev_sc_done_[i], hipEventDisableTiming));

@@ -145,6 +145,12 @@ class LearnerEngine:
         hp.clip_norm_value = float(self.hp['clip_norm_value'] or 0.0)
         _lib.check(self.lib.cdrl_learner_set_hparams(self.h, C.byref(hp), self._stream()), 'set_hparams')
 
+    def set_comm_stream(self, stream: Optional['torch.cuda.Stream']):
+        """See cdrl_learner_set_comm_stream (data-parallel overlap); None switches it off."""
+        self._comm_stream = stream      # keep it alive: the engine holds the raw handle
+        _lib.check(self.lib.cdrl_learner_set_comm_stream(self.h, C.c_void_p(stream.cuda_stream) if stream is not None else None),
+                   'set_comm_stream')
+
     def reset_optimizer(self):
         self.adam_m.zero_()
         self.adam_v.zero_()

@@ -110,6 +110,11 @@ int cdrl_learner_set_hparams(cdrl_learner* l, const cdrl_hparams* hp, void* stre
  * parameter / Adam arenas): a second learner built for the ragged LAST minibatch of an update (the reference's tf.data
  * pipeline keeps it unless drop_remainder is set, rl/utils.py:365-393) then advances the same optimizer. */
 int cdrl_learner_share_hparams(cdrl_learner* l, const cdrl_learner* owner);
+/* Data-parallel overlap: `stream` (caller-owned, or NULL to switch off) is made to wait inside every
+ * following *_forward_backward call for the point of the backward pass at which the gradients of the head and of the trunk
+ * tail (every trunk tensor behind the image tower) are final.  A collective enqueued on that stream after the call has
+ * returned runs concurrently with the tower's backward; the tower's gradients are final when the call's own stream is. */
+int cdrl_learner_set_comm_stream(cdrl_learner* l, void* stream);
 int cdrl_learner_reset_optimizer_steps(cdrl_learner* l, void* stream);
 
 /* CARLAgent.get_policy_gradients (core/carla_agent.py:351-373): train-mode trunk forward,
