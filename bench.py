@@ -87,6 +87,19 @@ def kernel_rooflines(B, T, nsets=8):
     out.append(dict(kernel='pw_nn_kernel<64,4,0,1> (1x1 conv + BN statistics epilogue)', shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1),
                     algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1), frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
                     cache_state=cold))
+    # bf16 path (configuration 3), kernel level: the same conv with bf16 activations + bf16 MFMA (half the bytes)
+    ab = [x.to(torch.bfloat16) for x in a]
+    yb = [torch.empty(M, Cc, dtype=torch.bfloat16, device=dev) for _ in range(nsets)]
+    nbb = int(lib.cdrl_pwconv_bf16_partial_rows(G, Mg, Cc, Cc))
+    partb = torch.zeros(G * nbb * 2 * Cc, dtype=torch.float64, device=dev)
+    t = timeit(lambda k: lib.cdrl_pwconv_bf16(P(ab[k]), Cc, 0, None, P(w), P(bias), P(yb[k]), Cc, 0, G, Mg, Cc, Cc, P(partb), S()))
+    byb = 2.0 * M * 2 * Cc
+    out.append(dict(kernel='pw_bf16_kernel<128,4,false,true> (bf16 activations, v_mfma_f32_32x32x16_bf16, BN statistics epilogue)',
+                    shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1), algorithmic_bytes=byb, achieved_GBs=round(byb / t / 1e9, 1),
+                    frac=round(byb / t / 1e9 / HBM_PEAK_GBS, 4), dtype='bf16',
+                    cache_state=f'cold: {nsets} buffer sets ({nsets * byb / 1e6:.0f} MB, above the 256 MB Infinity Cache only from '
+                                f'B = 1024; at this size partly cache-resident)'))
+    del ab, yb
     dw = torch.empty(Cc, Cc, device=dev)
     ws = torch.empty(int(lib.cdrl_gemm_tn_workspace_elems(M, Cc, Cc)), device=dev)
     t = timeit(lambda k: lib.cdrl_gemm_tn(P(a[k]), Cc, 0, P(y[k]), Cc, 0, P(dw), M, Cc, Cc, P(ws), 0, S()))

@@ -352,6 +352,27 @@ int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double
     return gae_returns(rewards, values_be, N, gamma, lambda, scale, returns, returns_be, adv_raw, adv, scratch, S(stream));
 }
 
+int cdrl_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+    if (!x || !y) return -1;
+    return f32_to_bf16(x, y, n, S(stream));
+}
+
+int cdrl_bf16_to_f32(const void* x, float* y, int64_t n, void* stream) {
+    if (!x || !y) return -1;
+    return bf16_to_f32(x, y, n, S(stream));
+}
+
+int cdrl_pwconv_bf16_partial_rows(int G, int Mg, int N, int K) { return pw_bf16_partial_rows(G, Mg, N, K); }
+
+int cdrl_pwconv_bf16(const void* A, int lda, int a_coff, const float* pro_stats, const float* W, const float* bias, void* C,
+                     int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream) {
+    if (!A || !W || !C) {
+        cdrl::set_error("cdrl_pwconv_bf16: null argument");
+        return -1;
+    }
+    return pw_bf16(A, lda, a_coff, pro_stats, W, bias, C, ldc, c_coff, G, Mg, N, K, part, S(stream));
+}
+
 int cdrl_gru_step_fwd(const float* xp, const float* hprev, const float* R, const float* b1, float* z, float* r, float* hh,
                       float* hp, float* hnew, int B, int u, void* stream) {
     if (!xp || !hprev || !R || !b1 || !z || !r || !hh || !hp || !hnew) {

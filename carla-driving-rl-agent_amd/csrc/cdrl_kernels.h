@@ -192,6 +192,16 @@ struct PwTranspose {
 // one launch: grid = (tiles, n) with tiles >= max over the entries of ceil(cin/32) * ceil(cout/32)
 int transpose_many(const PwTranspose* tab_dev, int n, int tiles, hipStream_t st);
 
+// ---------------------------------------------------------------- bf16 pointwise conv (gemm_pw_bf16.hip)
+// bf16 activations (A, C), float32 master weights / bias / BatchNorm blocks, bf16 MFMA with float32 accumulate; optional
+// BN-apply prologue (pro_stats [4][G][K]) and statistics epilogue (part [G][nbpg][2][N], nbpg = pw_bf16_partial_rows)
+bool pw_bf16_supported(int lda, int a_coff, int N, int K);
+int pw_bf16_partial_rows(int G, int Mg, int N, int K);
+int pw_bf16(const void* A, int lda, int a_coff, const float* pro_stats, const float* W, const float* bias, void* C, int ldc,
+            int c_coff, int G, int Mg, int N, int K, double* part, hipStream_t st);
+int f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t st);
+int bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t st);
+
 // ---------------------------------------------------------------- linear output heads (heads.hip)
 #define HEADS_MAX 4
 #define HEADS_MAX_OUT 8

@@ -189,6 +189,17 @@ int cdrl_beta_sample_logp(const float* alpha, const float* beta, int rows, int A
                           float* u, float* log_prob, void* stream);
 int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* out, void* stream);
 
+/* bf16 path (BASELINE.json configuration 3), first kernel: the unit's 1x1 convolution (core/architectures.py:130,140) with
+ * bf16 activations in HBM, float32 master weights / bias, v_mfma_f32_32x32x16_bf16 with float32 accumulate.  A [G*Mg][lda]
+ * bf16 (+ a_coff), C [G*Mg][ldc] bf16; pro_stats ([4][G][K] float32 or NULL): BatchNorm-apply of the previous layer on load;
+ * part ([G][rows][2][N] double or NULL, rows = cdrl_pwconv_bf16_partial_rows): (sum, sum of squares) of the ROUNDED outputs
+ * per channel for the following BatchNorm.  K, N <= 128; K, lda, a_coff multiples of 4. */
+int cdrl_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+int cdrl_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
+int cdrl_pwconv_bf16_partial_rows(int G, int Mg, int N, int K);
+int cdrl_pwconv_bf16(const void* A, int lda, int a_coff, const float* pro_stats, const float* W, const float* bias, void* C,
+                     int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream);
+
 /* One time step of the Keras GRU v2 cell (reset_after=True, gates z, r, h; reference core/networks.py:47-50 ->
  * keras.layers.GRU(unroll=True)) as ONE kernel per direction.  xp = x K + b0 of the step [B][3u], hprev [B][u], R [u][3u],
  * b1 [3u]; saved for the backward: z, r, hh [B][u] and hp = hprev R + b1 [B][3u].  Backward: dh [B][ld_dh] gradient w.r.t.

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Per-kernel and per-update-step MFMA utilisation from the `rocprofv3 --pmc` passes of tools/pmc_mfma.sh.
 
-MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)   (the gfx94x derived-metric formula; ROCm 7.2
-ships no gfx950 section, MI355X_MICROARCH.md "rocprofv3 PMC slots").  GRBM_GUI_ACTIVE of a dispatch = its busy cycles at the
-clock it ran at, so the ratio is clock-independent.  SQ_INSTS_VALU_MFMA_MOPS_F32 counts fp32 matrix operations in units of
-512 FLOP-pairs... recorded raw; the FLOP figure used for TFLOP/s is the algorithmic one."""
+MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs)   (the gfx94x derived-metric formula;
+ROCm 7.2 ships no gfx950 section, MI355X_MICROARCH.md "rocprofv3 PMC slots").  As collected here SQ_VALU_MFMA_BUSY_CYCLES is
+summed over all 1024 SIMDs (it equals 64 cycles x SQ_INSTS_VALU_MFMA_F32 for v_mfma_f32_32x32x2_f32, checked on every kernel)
+and GRBM_GUI_ACTIVE is summed over the 8 XCDs (8 x the dispatch's busy cycles), so the ratio is clock-independent.
+SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 = FLOPs issued to the matrix pipe, padding included (1 fp32 32x32x2 MFMA = 8 MOPS)."""
 import json
 import sys
 import os
@@ -40,11 +41,12 @@ for k, v in a.items():
     tot_mops += mops
     if busy > 0:
         kern.append(dict(kernel=k, calls=calls, mfma_busy_cycles=busy, gui_active_cycles=act,
-                         mfma_util=round(busy / (act * 1024.0), 4) if act else None, mfma_mops_f32=mops, mfma_insts_f32=insts))
+                         mfma_util=round(busy / (act / 8.0 * 1024.0), 4) if act else None, mfma_flops_issued=mops * 512.0, mfma_insts_f32=insts))
 kern.sort(key=lambda r: -r['mfma_busy_cycles'])
 print(json.dumps(dict(method='rocprofv3 --kernel-trace --pmc <counters> in separate passes over bench.py --steps 2 --warmup 1 '
-                             '(3 update-steps); MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs), summed over '
+                             '(3 update-steps); MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), summed over '
                              'the libcdrl kernels; kernels of the two streams overlap in time, so the step figure is a lower bound '
                              'of the utilisation while an MFMA kernel is resident',
-                      bench_args=sys.argv[2:], mfma_util_all_kernels=round(tot_busy / (tot_active * 1024.0), 4) if tot_active else None,
+                      bench_args=sys.argv[2:], mfma_util_all_kernels=round(tot_busy / (tot_active / 8.0 * 1024.0), 4) if tot_active else None,
+                      mfma_flops_issued_per_update_step=tot_mops * 512.0 / 3.0,
                       mfma_busy_cycles=tot_busy, gui_active_cycles=tot_active, mfma_mops_f32=tot_mops, kernels=kern[:25]), indent=1))
