@@ -92,7 +92,9 @@ def kernel_rooflines(B, T, nsets=8):
     yb = [torch.empty(M, Cc, dtype=torch.bfloat16, device=dev) for _ in range(nsets)]
     nbb = int(lib.cdrl_pwconv_bf16_partial_rows(G, Mg, Cc, Cc))
     partb = torch.zeros(G * nbb * 2 * Cc, dtype=torch.float64, device=dev)
-    t = timeit(lambda k: lib.cdrl_pwconv_bf16(P(ab[k]), Cc, 0, None, P(w), P(bias), P(yb[k]), Cc, 0, G, Mg, Cc, Cc, P(partb), S()))
+    wp = torch.zeros(int(lib.cdrl_pwconv_bf16_packed_elems(Cc)), dtype=torch.bfloat16, device=dev)
+    lib.cdrl_pwconv_bf16_pack(P(w), Cc, Cc, P(wp), S())
+    t = timeit(lambda k: lib.cdrl_pwconv_bf16(P(ab[k]), Cc, 0, None, None, P(wp), P(bias), P(yb[k]), Cc, 0, G, Mg, Cc, Cc, P(partb), S()))
     byb = 2.0 * M * 2 * Cc
     out.append(dict(kernel='pw_bf16_kernel<128,4,false,true> (bf16 activations, v_mfma_f32_32x32x16_bf16, BN statistics epilogue)',
                     shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1), algorithmic_bytes=byb, achieved_GBs=round(byb / t / 1e9, 1),

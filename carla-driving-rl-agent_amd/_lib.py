@@ -77,7 +77,9 @@ PROTOTYPES = {
     'cdrl_f32_to_bf16': (_i, [_fp, _fp, _i64, _fp]),
     'cdrl_bf16_to_f32': (_i, [_fp, _fp, _i64, _fp]),
     'cdrl_pwconv_bf16_partial_rows': (_i, [_i, _i, _i, _i]),
-    'cdrl_pwconv_bf16': (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp]),
+    'cdrl_pwconv_bf16_packed_elems': (_i64, [_i]),
+    'cdrl_pwconv_bf16_pack': (_i, [_fp, _i, _i, _fp, _fp]),
+    'cdrl_pwconv_bf16': (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp]),
     'cdrl_gru_step_fwd': (_i, [_fp] * 9 + [_i, _i, _fp]),
     'cdrl_gru_step_bwd': (_i, [_fp, _i] + [_fp] * 9 + [_i, _i, _fp]),
     'cdrl_beta_sample_logp': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp]),

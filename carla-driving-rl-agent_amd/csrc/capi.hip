@@ -364,13 +364,20 @@ int cdrl_bf16_to_f32(const void* x, float* y, int64_t n, void* stream) {
 
 int cdrl_pwconv_bf16_partial_rows(int G, int Mg, int N, int K) { return pw_bf16_partial_rows(G, Mg, N, K); }
 
-int cdrl_pwconv_bf16(const void* A, int lda, int a_coff, const float* pro_stats, const float* W, const float* bias, void* C,
-                     int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream) {
-    if (!A || !W || !C) {
+int64_t cdrl_pwconv_bf16_packed_elems(int K) { return pw_bf16_packed_elems(K); }
+
+int cdrl_pwconv_bf16_pack(const float* W, int K, int N, void* packed, void* stream) {
+    if (!W || !packed) return -1;
+    return pw_bf16_pack(W, K, N, packed, S(stream));
+}
+
+int cdrl_pwconv_bf16(const void* A, int lda, int a_coff, const float* pro_stats, const float* W, const void* W_packed,
+                     const float* bias, void* C, int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream) {
+    if (!A || (!W && !W_packed) || !C) {
         cdrl::set_error("cdrl_pwconv_bf16: null argument");
         return -1;
     }
-    return pw_bf16(A, lda, a_coff, pro_stats, W, bias, C, ldc, c_coff, G, Mg, N, K, part, S(stream));
+    return pw_bf16(A, lda, a_coff, pro_stats, W, bias, C, ldc, c_coff, G, Mg, N, K, part, S(stream), W_packed);
 }
 
 int cdrl_gru_step_fwd(const float* xp, const float* hprev, const float* R, const float* b1, float* z, float* r, float* hh,

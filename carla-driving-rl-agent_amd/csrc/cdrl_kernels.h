@@ -110,9 +110,18 @@ struct PwBnBwd {
 };
 bool pw_nn_supported(View A, int N, int K);
 PwPlan pw_nn_plan(int G, int Mg, int N, int K);
+// Wp (optional): B pre-packed in MFMA fragment order by pw_pack_many (pw_packed_elems(N, K) floats)
 int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, const float* bias, View C, int accumulate, int G,
           int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st,
-          const PwBnBwd* bnbwd = nullptr);
+          const PwBnBwd* bnbwd = nullptr, const float* Wp = nullptr);
+struct PwPack {             // one operand to pack: B(k, n) = w[k * sbk + n * sbn], K x N
+    const float* w;
+    float* wp;
+    int K, N, sbk, sbn, ksm, ntiles;
+};
+int64_t pw_packed_elems(int N, int K);
+PwPack pw_pack_entry(const float* w, float* wp, int K, int N, int sbk, int sbn);
+int pw_pack_many(const PwPack* tab_dev, int n, hipStream_t st);
 // out[i] (+)= sum_p part[p*stride + i] for float partials (double accumulation, fixed order)
 int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride, float* out, int accumulate,
                         hipStream_t st);
@@ -197,8 +206,11 @@ int transpose_many(const PwTranspose* tab_dev, int n, int tiles, hipStream_t st)
 // BN-apply prologue (pro_stats [4][G][K]) and statistics epilogue (part [G][nbpg][2][N], nbpg = pw_bf16_partial_rows)
 bool pw_bf16_supported(int lda, int a_coff, int N, int K);
 int pw_bf16_partial_rows(int G, int Mg, int N, int K);
+// Wp (optional): the weights pre-packed as bf16 MFMA fragments by pw_bf16_pack (pw_bf16_packed_elems(K) bf16 elements)
 int pw_bf16(const void* A, int lda, int a_coff, const float* pro_stats, const float* W, const float* bias, void* C, int ldc,
-            int c_coff, int G, int Mg, int N, int K, double* part, hipStream_t st);
+            int c_coff, int G, int Mg, int N, int K, double* part, hipStream_t st, const void* Wp = nullptr);
+int64_t pw_bf16_packed_elems(int K);
+int pw_bf16_pack(const float* W, int K, int N, void* Wp, hipStream_t st);
 int f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t st);
 int bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t st);
 

@@ -354,6 +354,12 @@ private:
     std::map<std::string, float*> pwt_by_name_;
     PwTranspose* d_pwt_ = nullptr;
     int pwt_tiles_ = 0;
+    // pointwise-conv weights in MFMA fragment order (forward operand W, backward-data operand W^T), re-packed by ONE launch
+    // at the start of every trunk forward: the per-workgroup weight prologue of the persistent GEMM becomes KSM/4 16-byte loads
+    std::vector<PwPack> h_pack_;
+    PwPack* d_pack_ = nullptr;
+    float* pw_packed(const float* w, int K, int N, int sbk, int sbn);
+    int run_trunk_fwd(hipStream_t st, int training);
     hipStream_t comm_ = nullptr;
     hipEvent_t ev_tail_main_ = nullptr, ev_tail_side_ = nullptr;
     std::vector<std::pair<void*, size_t>> zero_once_;    // workspace regions that must read as zero and are never written

@@ -338,6 +338,17 @@ float* Learner::pw_transposed(const std::string& name, const float* w, int cin, 
     return wt;
 }
 
+float* Learner::pw_packed(const float* w, int K, int N, int sbk, int sbn) {
+    float* wp = alloc((size_t)pw_packed_elems(N, K));
+    h_pack_.push_back(pw_pack_entry(w, wp, K, N, sbk, sbn));
+    return wp;
+}
+
+int Learner::run_trunk_fwd(hipStream_t st, int training) {
+    CDRL_TRY(pw_pack_many(d_pack_, (int)h_pack_.size(), st));       // this pass's weights in fragment order (fwd + bwd-data)
+    return run_fwd(trunk_ops_, st, training);
+}
+
 void Learner::note_scratch(size_t part_d, size_t part2_d, size_t dy_f, size_t tn_f, size_t fpart_d) {
     if (part_d > max_part_) max_part_ = part_d;
     if (part2_d > max_part2_) max_part2_ = part2_d;
@@ -415,10 +426,13 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     PRef w = param(M_TRUNK, prefix + ".w", {1, 1, Cin, Cout}, true);
     PRef b = param(M_TRUNK, prefix + ".b", {Cout}, true);
     const int G = cfg_.T, Mg = rows / G;
+    static const bool pack_env = !(getenv("CDRL_PW_PACK") && atoi(getenv("CDRL_PW_PACK")) == 0);
     static const bool wt_env = !(getenv("CDRL_PW_WT") && atoi(getenv("CDRL_PW_WT")) == 0);
-    const float* wt = (wt_env && fuse.bwd_pw) ? pw_transposed(prefix, w.p, Cin, Cout) : nullptr;
+    const float* wt = (wt_env && !pack_env && fuse.bwd_pw) ? pw_transposed(prefix, w.p, Cin, Cout) : nullptr;
     const float* wb = wt ? wt : w.p;                    // backward-data operand B(k = cout, n = cin)
     const int wb_sk = wt ? Cin : 1, wb_sn = wt ? 1 : Cout;
+    const float* wpf = (pack_env && fuse.fwd_pw) ? pw_packed(w.p, Cin, Cout, Cout, 1) : nullptr;      // forward: B(k = cin, n = cout)
+    const float* wpb = (pack_env && fuse.bwd_pw) ? pw_packed(w.p, Cout, Cin, 1, Cout) : nullptr;      // backward-data: W^T
     const int tn_groups = (fuse.pro_stats || fuse.bb) ? G : 1;
     note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin, tn_groups));
     if (fuse.epi_stats) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cout, Cin).nbpg * 2 * Cout, 0, 0, 0);
@@ -427,7 +441,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     op.fwd = [=](hipStream_t st, int) -> int {
         if (fuse.fwd_pw)
             return pw_nn(in, fuse.pro_stats, w.p, Cout, 1, b.p, make_view(y, Cout), 0, G, Mg, Cout, Cin, fuse.epi_stats ? 1 : 0,
-                         nullptr, nullptr, scr_main_.part, st);
+                         nullptr, nullptr, scr_main_.part, st, nullptr, wpf);
         return gemm_nn(in, w.p, Cout, 1, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
     };
     const int nbp_bwd = fuse.bb ? pw_nn_plan(G, Mg, Cin, Cout).nbpg : 0;
@@ -443,7 +457,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             CDRL_TRY(done_side(side));
             PwBnBwd pb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act, part2s_[slot_]};
             CDRL_TRY(pw_nn(dz, nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
-                           fuse.bwd_epi_stats, scr_main_.part, st, &pb));
+                           fuse.bwd_epi_stats, scr_main_.part, st, &pb, wpb));
             // bias gradient = column sums of the (virtual) dy, reduced from the GEMM's partials: rides on the next fork
             double* p2 = part2s_[slot_];
             return defer_side(st, [=](hipStream_t sd) -> int { return reduce_partials(p2, G * nbp_bwd, Cout, Cout, b.g, 0, sd); });
@@ -458,7 +472,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         if (din.p) {
             if (fuse.bwd_pw)
                 return pw_nn(make_view(dy, Cout), nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout,
-                             fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, scr_main_.part, st);
+                             fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, scr_main_.part, st, nullptr, wpb);
             CDRL_TRY(gemm_nn(make_view(dy, Cout), w.p, 1, Cout, nullptr, din, rows, Cin, Cout, din_acc, st));
         }
         return 0;
@@ -1195,7 +1209,9 @@ void Learner::build(bool dry) {
     pwt_by_name_.clear();
     pwt_tiles_ = 0;
     zero_once_.clear();
+    h_pack_.clear();
     build_trunk(trunk_ops_);
+    d_pack_ = reinterpret_cast<PwPack*>(alloc((h_pack_.size() + 1) * sizeof(PwPack) / sizeof(float) + 4));
     d_pwt_ = reinterpret_cast<PwTranspose*>(alloc((h_pwt_.size() + 1) * sizeof(PwTranspose) / sizeof(float) + 4));
     const int A = cfg_.A;
     const int pdims[4] = {A, A, 1, 1};
@@ -1271,6 +1287,8 @@ void Learner::build_seg_tables() {
 int Learner::upload_seg_tables() {
     if (!h_pwt_.empty())
         CDRL_HIP(hipMemcpy(d_pwt_, h_pwt_.data(), h_pwt_.size() * sizeof(PwTranspose), hipMemcpyHostToDevice));
+    if (!h_pack_.empty())
+        CDRL_HIP(hipMemcpy(d_pack_, h_pack_.data(), h_pack_.size() * sizeof(PwPack), hipMemcpyHostToDevice));
     for (int m = 1; m <= 2; ++m) {
         SegTable& s = seg_[m];
         CDRL_HIP(hipMemcpy(s.segs, s.h_segs.data(), s.h_segs.size() * sizeof(TensorSeg), hipMemcpyHostToDevice));
@@ -1394,7 +1412,7 @@ int Learner::trunk_forward_train(const float* image, const float* road, const fl
                                  hipStream_t caller) {
     return launch(caller, {}, false, [&](hipStream_t st) -> int {
         CDRL_TRY(set_inputs(image, road, vehicle, navigation));
-        return run_fwd(trunk_ops_, st, 1);
+        return run_trunk_fwd(st, 1);
     });
 }
 
@@ -1406,7 +1424,7 @@ int Learner::policy_forward(const float* image, const float* road, const float* 
 int Learner::policy_forward_impl(const float* image, const float* road, const float* vehicle, const float* navigation,
                                  hipStream_t st) {
     CDRL_TRY(set_inputs(image, road, vehicle, navigation));
-    CDRL_TRY(run_fwd(trunk_ops_, st, 1));
+    CDRL_TRY(run_trunk_fwd(st, 1));
     CDRL_TRY(run_fwd(policy_ops_, st, 1));
     // alpha, beta (+ mean, std) of the CURRENT policy for the Beta re-sampling
     return policy_dist(lin_p_.p, aux_p_, cfg_.B, cfg_.A, st);
@@ -1467,7 +1485,7 @@ int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipS
                                  K(b.similarity), K(b.u), K(b.du_da), K(b.du_db), Kf(inv_world)};
     return launch(caller, key, true, [&](hipStream_t st) -> int {
         CDRL_TRY(set_inputs(b.image, b.road, b.vehicle, b.navigation));
-        CDRL_TRY(run_fwd(trunk_ops_, st, 1));
+        CDRL_TRY(run_trunk_fwd(st, 1));
         CDRL_TRY(run_fwd(policy_ops_, st, 1));
         return policy_backward_impl(b, inv_world, st);
     });
@@ -1481,7 +1499,7 @@ int Learner::value_forward_backward(const ValueBatch& b, float inv_world, hipStr
 
 int Learner::value_forward_backward_impl(const ValueBatch& b, float inv_world, hipStream_t st) {
     CDRL_TRY(set_inputs(b.image, b.road, b.vehicle, b.navigation));
-    CDRL_TRY(run_fwd(trunk_ops_, st, 1));
+    CDRL_TRY(run_trunk_fwd(st, 1));
     CDRL_TRY(run_fwd(value_ops_, st, 1));
     ValueLossArgs a;
     a.lin = lin_v_.p;
@@ -1562,7 +1580,7 @@ int Learner::predict(const float* image, const float* road, const float* vehicle
 int Learner::predict_impl(const float* image, const float* road, const float* vehicle, const float* navigation,
                           float* dist_out, float* value_out, float* dyn_out, hipStream_t st) {
     CDRL_TRY(set_inputs(image, road, vehicle, navigation));
-    CDRL_TRY(run_fwd(trunk_ops_, st, 0));
+    CDRL_TRY(run_trunk_fwd(st, 0));
     CDRL_TRY(run_fwd(old_policy_ops_, st, 0));
     CDRL_TRY(policy_dist(lin_old_.p, dist_out, cfg_.B, cfg_.A, st));
     CDRL_TRY(run_fwd(value_ops_, st, 0));

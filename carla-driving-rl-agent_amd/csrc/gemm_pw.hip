@@ -37,6 +37,7 @@ struct PwArgs {
     const float* pro_stats;     // [4][G][K]
     const float* W;
     int sbk, sbn;
+    const float* Wp;            // optional: W in fragment order [ceil(N/32)][2][32][KSM] (pw_pack_many): 16-byte loads
     const float* bias;
     View C;
     int accumulate;
@@ -77,13 +78,30 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
 
     // ---- W fragments -> registers (once)
     float breg[NTW][KSM];
+    if (a.Wp) {
+        // pre-packed once per weight version: the lane's KSM fragment values are contiguous -> KSM/4 16-byte loads instead of
+        // KSM dependent 4-byte loads (the strided form was ~9 us of every launch: isolated 1x1 conv 24.8 -> see DESIGN.md)
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        const int n = nb0 + (wc + j * WC) * 32 + lrow;
+        for (int j = 0; j < NTW; ++j) {
+            const float* wp = a.Wp + ((int64_t)(((nb0 >> 5) + wc + j * WC) * 2 + lk) * 32 + lrow) * KSM;
 #pragma unroll
-        for (int s = 0; s < KSM; ++s) {
-            const int k = 2 * s + lk;
-            breg[j][s] = (k < K && n < N) ? a.W[(int64_t)k * a.sbk + (int64_t)n * a.sbn] : 0.0f;
+            for (int s = 0; s < KSM; s += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(wp + s);
+                breg[j][s] = v.x;
+                breg[j][s + 1] = v.y;
+                breg[j][s + 2] = v.z;
+                breg[j][s + 3] = v.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = nb0 + (wc + j * WC) * 32 + lrow;
+#pragma unroll
+            for (int s = 0; s < KSM; ++s) {
+                const int k = 2 * s + lk;
+                breg[j][s] = (k < K && n < N) ? a.W[(int64_t)k * a.sbk + (int64_t)n * a.sbn] : 0.0f;
+            }
         }
     }
     float bv[NTW], emean[NTW], einv[NTW];
@@ -359,6 +377,40 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
 // ------------------------------------------------------------------------------------------
 static int pw_ksm(int K) { return K <= 32 ? 16 : (K <= 64 ? 32 : (K <= 128 ? 64 : 128)); }
 
+// B(k, n) = w[k * sbk + n * sbn] -> fragment order [ct = n / 32][lk = k & 1][n & 31][s = k >> 1] (zero padded to KSM, 32):
+// what lane (lrow = n & 31, lk) of the wave that owns column tile ct keeps in registers.  One launch for all convs of a pass.
+__global__ void __launch_bounds__(256) pw_pack_many_kernel(const PwPack* __restrict__ tab) {
+    const PwPack d = tab[blockIdx.y];
+    const int total = d.ntiles * 2 * 32 * d.ksm;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int s = i % d.ksm, lrow = (i / d.ksm) % 32, lk = (i / (d.ksm * 32)) % 2, ct = i / (d.ksm * 64);
+        const int k = 2 * s + lk, n = ct * 32 + lrow;
+        d.wp[i] = (k < d.K && n < d.N) ? d.w[(int64_t)k * d.sbk + (int64_t)n * d.sbn] : 0.0f;
+    }
+}
+
+int64_t pw_packed_elems(int N, int K) { return (int64_t)cdiv(N, 32) * 2 * 32 * pw_ksm(K); }
+
+PwPack pw_pack_entry(const float* w, float* wp, int K, int N, int sbk, int sbn) {
+    PwPack e;
+    e.w = w;
+    e.wp = wp;
+    e.K = K;
+    e.N = N;
+    e.sbk = sbk;
+    e.sbn = sbn;
+    e.ksm = pw_ksm(K);
+    e.ntiles = cdiv(N, 32);
+    return e;
+}
+
+int pw_pack_many(const PwPack* tab_dev, int n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pw_pack_many_kernel, dim3(16, n), dim3(256), 0, st, tab_dev);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
 bool pw_nn_supported(View A, int N, int K) {
     if (K > 256 || N > 256 || (K & 1) || N < 1) return false;
     const int nt = N > 128 ? 4 : cdiv(N, 32), ksm = pw_ksm(K);
@@ -426,7 +478,7 @@ static int launch_pw_nt(int nt, int pro, int epi, const PwArgs& a, hipStream_t s
 
 int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, const float* bias, View C, int accumulate, int G,
           int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st,
-          const PwBnBwd* bb) {
+          const PwBnBwd* bb, const float* Wp) {
     if (!pw_nn_supported(bb ? make_view(const_cast<float*>(bb->y), K) : A, N, K)) {
         set_error("pw_nn: shape K=%d N=%d / alignment not supported", K, N);
         return -1;
@@ -452,6 +504,7 @@ int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, cons
     a.W = W;
     a.sbk = sbk;
     a.sbn = sbn;
+    a.Wp = Wp;
     a.bias = bias;
     a.C = C;
     a.accumulate = accumulate;

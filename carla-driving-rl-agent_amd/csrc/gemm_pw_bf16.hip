@@ -9,6 +9,8 @@
 // registers for the whole kernel, A staged through LDS, optional BN-apply of the previous layer on load (PRO) and statistics
 // partials of the next BatchNorm in the epilogue (EPI).  At K = N = 116 the float32 kernel spends 58 MFMA steps of 64 cycles
 // per 32x32 tile (36 % MfmaUtil measured, profiles/r02_pmc_mfma.json); here it is 8 steps of 32 cycles.
+#include <stdlib.h>
+
 #include "cdrl_kernels.h"
 
 namespace cdrl {
@@ -21,7 +23,8 @@ struct PwBf16Args {
     const __bf16* A;            // [G*Mg][lda] (+ a_coff)
     int lda, a_coff;
     const float* pro_stats;     // [4][G][K] or null: a = scale * a + shift on load
-    const float* W;             // [K][N] float32 master weights
+    const float* W;             // [K][N] float32 master weights (used when Wp == null)
+    const __bf16* Wp;           // packed bf16 fragments [KP/16][2][128][8] (pw_bf16_pack) or null
     const float* bias;          // [N] or null
     __bf16* C;                  // [G*Mg][ldc] (+ c_coff)
     int ldc, c_coff;
@@ -51,13 +54,18 @@ __global__ void __launch_bounds__(256) pw_bf16_kernel(PwBf16Args a) {
     // ---- W fragments -> registers: B[k = 16 s + 8 lk + e][n], rounded to bf16 once
     const int n = wc * 32 + lrow;
     bf16x8 breg[KS];
+    if (a.Wp) {                 // pre-packed in fragment order: one 16-byte load per k step instead of eight strided float loads
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < KS; ++s) breg[s] = *reinterpret_cast<const bf16x8*>(a.Wp + ((int64_t)(s * 2 + lk) * 128 + n) * 8);
+    } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 16 * s + 8 * lk + e;
-            breg[s][e] = (__bf16)((k < K && n < N) ? a.W[(int64_t)k * N + n] : 0.0f);
-        }
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * s + 8 * lk + e;
+                breg[s][e] = (__bf16)((k < K && n < N) ? a.W[(int64_t)k * N + n] : 0.0f);
+            }
+    }
     const float bv = (a.bias && n < N) ? a.bias[n] : 0.0f;
     if (PRO) {
         const int GK = a.G * K;
@@ -138,8 +146,11 @@ __global__ void __launch_bounds__(256) pw_bf16_kernel(PwBf16Args a) {
     }
     if (EPI && a.part) {
         // lanes lk = 0, 1 hold different rows of the same column; wave rows wr likewise: fold in a fixed order
-        red[0][wave][lrow] = s1 + __shfl_down(s1, 32);
-        red[1][wave][lrow] = s2 + __shfl_down(s2, 32);
+        const double f1 = s1 + __shfl_down(s1, 32), f2 = s2 + __shfl_down(s2, 32);
+        if (lk == 0) {
+            red[0][wave][lrow] = f1;
+            red[1][wave][lrow] = f2;
+        }
         __syncthreads();
         if (wr == 0 && lk == 0 && n < N) {
             double u1 = 0.0, u2 = 0.0;
@@ -155,6 +166,22 @@ __global__ void __launch_bounds__(256) pw_bf16_kernel(PwBf16Args a) {
     }
 }
 
+// W [K][N] float32 -> bf16 MFMA B fragments [KP/16][2][128][8]: element e of lane (lk, n) at k step s is W[16 s + 8 lk + e][n]
+// (zero beyond K, N).  Run once per weight version (like the W^T copies of the float32 path), 8 KB .. 32 KB per conv.
+__global__ void pw_bf16_pack_kernel(const float* __restrict__ W, int K, int N, int KP, __bf16* __restrict__ Wp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;         // (s, lk, n)
+    const int total = (KP / 16) * 2 * 128;
+    if (i >= total) return;
+    const int n = i % 128, lk = (i / 128) % 2, s = i / 256;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 16 * s + 8 * lk + e;
+        v[e] = (__bf16)((k < K && n < N) ? W[(int64_t)k * N + n] : 0.0f);
+    }
+    *reinterpret_cast<bf16x8*>(Wp + (int64_t)i * 8) = v;
+}
+
 static int pw_bf16_nbpg(int G, int Mg, int BM, int occ) {
     const int tiles = cdiv(Mg, BM);
     int nb = 256 * occ / G;
@@ -168,7 +195,25 @@ static inline int pw_bf16_nt(int N) { return N <= 32 ? 1 : (N <= 64 ? 2 : 4); }
 
 bool pw_bf16_supported(int lda, int a_coff, int N, int K) { return K >= 4 && K <= 128 && N >= 1 && N <= 128 && lda % 4 == 0 && a_coff % 4 == 0 && K % 4 == 0; }
 
-int pw_bf16_partial_rows(int G, int Mg, int N, int K) { return pw_bf16_nbpg(G, Mg, 32 * (4 / pw_bf16_nt(N)), 4); }
+static int pw_bf16_occ() {
+    static const int v = getenv("CDRL_PWB_OCC") ? atoi(getenv("CDRL_PWB_OCC")) : 2;
+    return v < 1 ? 1 : (v > 8 ? 8 : v);
+}
+
+int pw_bf16_partial_rows(int G, int Mg, int N, int K) { return pw_bf16_nbpg(G, Mg, 32 * (4 / pw_bf16_nt(N)), pw_bf16_occ()); }
+
+int64_t pw_bf16_packed_elems(int K) { return (int64_t)(pw_bf16_kp(K) / 16) * 2 * 128 * 8; }
+
+int pw_bf16_pack(const float* W, int K, int N, void* Wp, hipStream_t st) {
+    if (K < 1 || K > 128 || N < 1 || N > 128) {
+        set_error("pw_bf16_pack: K, N <= 128");
+        return -1;
+    }
+    const int kp = pw_bf16_kp(K), total = (kp / 16) * 2 * 128;
+    hipLaunchKernelGGL(pw_bf16_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, W, K, N, kp, reinterpret_cast<__bf16*>(Wp));
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
 
 template <int KP, int NT>
 static void pw_bf16_launch(const PwBf16Args& a, bool pro, bool epi, hipStream_t st) {
@@ -180,7 +225,7 @@ static void pw_bf16_launch(const PwBf16Args& a, bool pro, bool epi, hipStream_t 
 }
 
 int pw_bf16(const void* A, int lda, int a_coff, const float* pro_stats, const float* W, const float* bias, void* C, int ldc,
-            int c_coff, int G, int Mg, int N, int K, double* part, hipStream_t st) {
+            int c_coff, int G, int Mg, int N, int K, double* part, hipStream_t st, const void* Wp) {
     if (!pw_bf16_supported(lda, a_coff, N, K)) {
         set_error("pw_bf16: unsupported shape K=%d N=%d lda=%d coff=%d (K, N <= 128; K, lda, coff multiples of 4)", K, N, lda, a_coff);
         return -1;
@@ -195,6 +240,7 @@ int pw_bf16(const void* A, int lda, int a_coff, const float* pro_stats, const fl
     a.a_coff = a_coff;
     a.pro_stats = pro_stats;
     a.W = W;
+    a.Wp = reinterpret_cast<const __bf16*>(Wp);
     a.bias = bias;
     a.C = reinterpret_cast<__bf16*>(C);
     a.ldc = ldc;

@@ -193,12 +193,16 @@ int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* ou
  * bf16 activations in HBM, float32 master weights / bias, v_mfma_f32_32x32x16_bf16 with float32 accumulate.  A [G*Mg][lda]
  * bf16 (+ a_coff), C [G*Mg][ldc] bf16; pro_stats ([4][G][K] float32 or NULL): BatchNorm-apply of the previous layer on load;
  * part ([G][rows][2][N] double or NULL, rows = cdrl_pwconv_bf16_partial_rows): (sum, sum of squares) of the ROUNDED outputs
- * per channel for the following BatchNorm.  K, N <= 128; K, lda, a_coff multiples of 4. */
+ * per channel for the following BatchNorm.  K, N <= 128; K, lda, a_coff multiples of 4.
+ * W_packed (optional): the weights as bf16 MFMA fragments, written once per weight version by cdrl_pwconv_bf16_pack
+ * (cdrl_pwconv_bf16_packed_elems(K) bf16 elements); with it a workgroup's weight prologue is 8 x 16-byte loads per lane. */
 int cdrl_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 int cdrl_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
 int cdrl_pwconv_bf16_partial_rows(int G, int Mg, int N, int K);
-int cdrl_pwconv_bf16(const void* A, int lda, int a_coff, const float* pro_stats, const float* W, const float* bias, void* C,
-                     int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream);
+int64_t cdrl_pwconv_bf16_packed_elems(int K);
+int cdrl_pwconv_bf16_pack(const float* W, int K, int N, void* packed, void* stream);
+int cdrl_pwconv_bf16(const void* A, int lda, int a_coff, const float* pro_stats, const float* W, const void* W_packed,
+                     const float* bias, void* C, int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream);
 
 /* One time step of the Keras GRU v2 cell (reset_after=True, gates z, r, h; reference core/networks.py:47-50 ->
  * keras.layers.GRU(unroll=True)) as ONE kernel per direction.  xp = x K + b0 of the step [B][3u], hprev [B][u], R [u][3u],

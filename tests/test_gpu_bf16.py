@@ -36,7 +36,8 @@ def test_bf16_round_trip_matches_torch(lib):
 
 @pytest.mark.parametrize('G,Mg,K,N,pro', [(4, 1000, 116, 116, True), (4, 777, 116, 116, False), (2, 515, 24, 56, True), (1, 4100, 60, 92, False),
                                           (4, 333, 116, 120, True), (3, 64, 28, 28, False), (4, 49152, 116, 116, True)])
-def test_pwconv_bf16(lib, G, Mg, K, N, pro):
+@pytest.mark.parametrize('packed', [False, True])
+def test_pwconv_bf16(lib, G, Mg, K, N, pro, packed):
     rng = np.random.default_rng(G + Mg + K + N)
     M = G * Mg
     lda, a_coff, ldc, c_coff = K + 12, 4, N + 8, 4
@@ -50,11 +51,17 @@ def test_pwconv_bf16(lib, G, Mg, K, N, pro):
     c = torch.full((M, ldc), 7.0, dtype=torch.bfloat16, device=DEV)
     nb = int(lib.cdrl_pwconv_bf16_partial_rows(G, Mg, N, K))
     part = torch.zeros((G, nb, 2, N), dtype=torch.float64, device=DEV)
-    _lib.check(lib.cdrl_pwconv_bf16(P(a), lda, a_coff, P(stats), P(w), P(bias), P(c), ldc, c_coff, G, Mg, N, K, P(part), S()))
+    wp = None
+    if packed:
+        wp = torch.zeros(int(lib.cdrl_pwconv_bf16_packed_elems(K)), dtype=torch.bfloat16, device=DEV)
+        _lib.check(lib.cdrl_pwconv_bf16_pack(P(w), K, N, P(wp), S()))
+    _lib.check(lib.cdrl_pwconv_bf16(P(a), lda, a_coff, P(stats), None if packed else P(w), P(wp), P(bias), P(c), ldc, c_coff, G, Mg,
+                                    N, K, P(part), S()))
     # reference on the operands the kernel's MFMA sees: bf16 A (after the float32 BN-apply, re-rounded to bf16), bf16 W
     av = a[:, a_coff:a_coff + K].float().view(G, Mg, K)
     if pro:
-        av = torch.addcmul(stats[3].view(G, 1, K), stats[2].view(G, 1, K), av).to(torch.bfloat16).float()   # fmaf = exact product + 1 rounding
+        # fmaf = exact product + sum, ONE rounding to float32 (float64 evaluates it exactly), then the bf16 rounding of the MFMA operand
+        av = (stats[2].view(G, 1, K).double() * av.double() + stats[3].view(G, 1, K).double()).float().to(torch.bfloat16).float()
     ref = av.double().view(M, K) @ w.to(torch.bfloat16).double() + bias.double()
     got = c[:, c_coff:c_coff + N].double()
     err = (got - ref).abs()
