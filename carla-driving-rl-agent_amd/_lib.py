@@ -74,6 +74,10 @@ PROTOTYPES = {
     'cdrl_learner_policy_forward': (_i, [_L, _fp, _fp, _fp, _fp, _fp]),
     'cdrl_learner_policy_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
     'cdrl_learner_policy_forward_backward_resample': (_i, [_L, C.POINTER(PolicyBatch), C.c_uint64, C.c_uint64, _f, _fp]),
+    'cdrl_pwconv_x3_packed_bytes': (_i64, [_i]),
+    'cdrl_pwconv_x3_partial_rows': (_i, [_i, _i, _i, _i]),
+    'cdrl_pwconv_x3_pack': (_i, [_fp, _i, _i, _i, _i, _fp, _fp]),
+    'cdrl_pwconv_x3': (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp]),
     'cdrl_f32_to_bf16': (_i, [_fp, _fp, _i64, _fp]),
     'cdrl_bf16_to_f32': (_i, [_fp, _fp, _i64, _fp]),
     'cdrl_pwconv_bf16_partial_rows': (_i, [_i, _i, _i, _i]),

@@ -352,6 +352,31 @@ int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double
     return gae_returns(rewards, values_be, N, gamma, lambda, scale, returns, returns_be, adv_raw, adv, scratch, S(stream));
 }
 
+int64_t cdrl_pwconv_x3_packed_bytes(int K) { return pw_x3_packed_bytes(K); }
+int cdrl_pwconv_x3_partial_rows(int G, int Mg, int N, int K) { return pw_x3_partial_rows(G, Mg, N, K); }
+
+int cdrl_pwconv_x3_pack(const float* W, int K, int N, int sbk, int sbn, void* packed, void* stream) {
+    if (!W || !packed) return -1;
+    // one-entry table through a temporary device copy (test / tooling entry point; the engine packs all layers in one launch)
+    PwX3Pack e = pw_x3_pack_entry(W, packed, K, N, sbk, sbn);
+    PwX3Pack* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(e)) != hipSuccess) return -2;
+    int rc = hipMemcpy(d, &e, sizeof(e), hipMemcpyHostToDevice) == hipSuccess ? pw_x3_pack_many(d, 1, S(stream)) : -2;
+    (void)hipStreamSynchronize(S(stream));
+    (void)hipFree(d);
+    return rc;
+}
+
+int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, const void* W_packed, const float* bias, float* C,
+                   int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream) {
+    if (!A || !W_packed || !C) {
+        cdrl::set_error("cdrl_pwconv_x3: null argument");
+        return -1;
+    }
+    return pw_x3(make_view(const_cast<float*>(A), lda, a_coff), pro_stats, W_packed, bias, make_view(C, ldc, c_coff), G, Mg, N, K,
+                 part, S(stream));
+}
+
 int cdrl_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
     if (!x || !y) return -1;
     return f32_to_bf16(x, y, n, S(stream));

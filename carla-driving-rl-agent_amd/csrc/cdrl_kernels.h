@@ -201,6 +201,22 @@ struct PwTranspose {
 // one launch: grid = (tiles, n) with tiles >= max over the entries of ceil(cin/32) * ceil(cout/32)
 int transpose_many(const PwTranspose* tab_dev, int n, int tiles, hipStream_t st);
 
+// ---------------------------------------------------------------- float32 pointwise conv on the bf16 matrix pipe (gemm_pw_x3.hip)
+// exact 3-way bf16 split of both operands, six bf16 MFMAs per K = 16 step, float32 in / out; W packed by pw_x3_pack_many
+struct PwX3Pack {
+    const float* w;
+    __bf16* wp;
+    int K, N, sbk, sbn, kp;
+};
+bool pw_x3_supported(View A, int N, int K);
+int pw_x3_partial_rows(int G, int Mg, int N, int K);
+int64_t pw_x3_packed_bytes(int K);
+PwX3Pack pw_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, int sbn);
+int pw_x3_pack_many(const PwX3Pack* tab_dev, int n, hipStream_t st);
+// nbpg > 0: workgroups (= partial rows) per group chosen by the caller (the engine keeps pw_nn_plan's count)
+int pw_x3(View A, const float* pro_stats, const void* Wp, const float* bias, View C, int G, int Mg, int N, int K, double* part,
+          hipStream_t st, int nbpg = 0);
+
 // ---------------------------------------------------------------- bf16 pointwise conv (gemm_pw_bf16.hip)
 // bf16 activations (A, C), float32 master weights / bias / BatchNorm blocks, bf16 MFMA with float32 accumulate; optional
 // BN-apply prologue (pro_stats [4][G][K]) and statistics epilogue (part [G][nbpg][2][N], nbpg = pw_bf16_partial_rows)

@@ -344,8 +344,15 @@ float* Learner::pw_packed(const float* w, int K, int N, int sbk, int sbn) {
     return wp;
 }
 
+const void* Learner::pw_x3_packed(const float* w, int K, int N, int sbk, int sbn) {
+    void* wp = alloc((size_t)pw_x3_packed_bytes(K) / sizeof(float));
+    h_pack3_.push_back(pw_x3_pack_entry(w, wp, K, N, sbk, sbn));
+    return wp;
+}
+
 int Learner::run_trunk_fwd(hipStream_t st, int training) {
     CDRL_TRY(pw_pack_many(d_pack_, (int)h_pack_.size(), st));       // this pass's weights in fragment order (fwd + bwd-data)
+    CDRL_TRY(pw_x3_pack_many(d_pack3_, (int)h_pack3_.size(), st));
     return run_fwd(trunk_ops_, st, training);
 }
 
@@ -431,7 +438,11 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     const float* wt = (wt_env && !pack_env && fuse.bwd_pw) ? pw_transposed(prefix, w.p, Cin, Cout) : nullptr;
     const float* wb = wt ? wt : w.p;                    // backward-data operand B(k = cout, n = cin)
     const int wb_sk = wt ? Cin : 1, wb_sn = wt ? 1 : Cout;
-    const float* wpf = (pack_env && fuse.fwd_pw) ? pw_packed(w.p, Cin, Cout, Cout, 1) : nullptr;      // forward: B(k = cin, n = cout)
+    // forward on the bf16 matrix pipe (exact three-way operand split, gemm_pw_x3.hip) where the shape allows it
+    static const bool x3_env = !(getenv("CDRL_PW_X3") && atoi(getenv("CDRL_PW_X3")) == 0);
+    const void* w3f = (x3_env && fuse.fwd_pw && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
+    const int nb_fwd = pw_nn_plan(G, Mg, Cout, Cin).nbpg;
+    const float* wpf = (pack_env && fuse.fwd_pw && !w3f) ? pw_packed(w.p, Cin, Cout, Cout, 1) : nullptr;      // forward: B(k = cin, n = cout)
     const float* wpb = (pack_env && fuse.bwd_pw) ? pw_packed(w.p, Cout, Cin, 1, Cout) : nullptr;      // backward-data: W^T
     const int tn_groups = (fuse.pro_stats || fuse.bb) ? G : 1;
     note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin, tn_groups));
@@ -439,6 +450,9 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     if (fuse.bwd_ey) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cin, Cout).nbpg * 2 * Cin, 0, 0, 0);
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
+        if (w3f)
+            return pw_x3(in, fuse.pro_stats, w3f, b.p, make_view(y, Cout), G, Mg, Cout, Cin, fuse.epi_stats ? scr_main_.part : nullptr, st,
+                         nb_fwd);
         if (fuse.fwd_pw)
             return pw_nn(in, fuse.pro_stats, w.p, Cout, 1, b.p, make_view(y, Cout), 0, G, Mg, Cout, Cin, fuse.epi_stats ? 1 : 0,
                          nullptr, nullptr, scr_main_.part, st, nullptr, wpf);
@@ -1210,8 +1224,10 @@ void Learner::build(bool dry) {
     pwt_tiles_ = 0;
     zero_once_.clear();
     h_pack_.clear();
+    h_pack3_.clear();
     build_trunk(trunk_ops_);
     d_pack_ = reinterpret_cast<PwPack*>(alloc((h_pack_.size() + 1) * sizeof(PwPack) / sizeof(float) + 4));
+    d_pack3_ = reinterpret_cast<PwX3Pack*>(alloc((h_pack3_.size() + 1) * sizeof(PwX3Pack) / sizeof(float) + 4));
     d_pwt_ = reinterpret_cast<PwTranspose*>(alloc((h_pwt_.size() + 1) * sizeof(PwTranspose) / sizeof(float) + 4));
     const int A = cfg_.A;
     const int pdims[4] = {A, A, 1, 1};
@@ -1289,6 +1305,8 @@ int Learner::upload_seg_tables() {
         CDRL_HIP(hipMemcpy(d_pwt_, h_pwt_.data(), h_pwt_.size() * sizeof(PwTranspose), hipMemcpyHostToDevice));
     if (!h_pack_.empty())
         CDRL_HIP(hipMemcpy(d_pack_, h_pack_.data(), h_pack_.size() * sizeof(PwPack), hipMemcpyHostToDevice));
+    if (!h_pack3_.empty())
+        CDRL_HIP(hipMemcpy(d_pack3_, h_pack3_.data(), h_pack3_.size() * sizeof(PwX3Pack), hipMemcpyHostToDevice));
     for (int m = 1; m <= 2; ++m) {
         SegTable& s = seg_[m];
         CDRL_HIP(hipMemcpy(s.segs, s.h_segs.data(), s.h_segs.size() * sizeof(TensorSeg), hipMemcpyHostToDevice));

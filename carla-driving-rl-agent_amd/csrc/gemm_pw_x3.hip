@@ -1,0 +1,265 @@
+// Float32 pointwise (1x1) convolution on the bf16 matrix pipe by exact operand splitting (gfx950, v_mfma_f32_32x32x16_bf16).
+//
+// Reference: core/architectures.py:130,140 (Conv2D(k=1)).  The float32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16
+// rate, and the persistent float32 kernel of gemm_pw.hip is measurably matrix-bound (MfmaUtil 0.36 at K = N = 116,
+// profiles/r02_pmc_mfma.json).  A float32 number is the exact sum of three bf16 numbers (3 x 8 significand bits):
+//     a = a1 + a2 + a3,   b = b1 + b2 + b3
+// and  a b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) + O(2^-24 |a b|):  six bf16 products accumulated in float32 carry
+// the product to float32 accuracy (the dropped terms are below half an ulp of the product).  Six K=16 steps of 32 cycles replace
+// eight K=2 steps of 64 cycles: 2.7x less matrix-pipe time for the same float32 inputs, outputs and HBM traffic.
+// The result is NOT bit-identical to a k-ordered fmaf chain (it is at least as accurate: every product is exact to 2^-24 and the
+// accumulation is float32 either way); parity is asserted against the float64 reference at 1e-5 (tests/test_gpu_ops.py).
+// Same skeleton as gemm_pw.hip: persistent workgroups over the row tiles of one BatchNorm group, W (three bf16 planes, packed
+// once per weight version) in registers, A split on its way into LDS, BN-apply prologue, statistics epilogue.
+#include <stdlib.h>
+
+#include "cdrl_kernels.h"
+
+namespace cdrl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct PwX3Args {
+    View A;
+    const float* pro_stats;     // [4][G][K] or null
+    const __bf16* Wp;           // [3][KP/16][2][128][8]
+    const float* bias;
+    View C;
+    double* part;               // [G][nbpg][2][N] or null
+    int N, K, G, Mg, nbpg;
+};
+
+__device__ __forceinline__ void split3(float x, __bf16& h1, __bf16& h2, __bf16& h3) {
+    h1 = (__bf16)x;
+    const float r1 = x - (float)h1;             // exact
+    h2 = (__bf16)r1;
+    h3 = (__bf16)(r1 - (float)h2);              // exact difference, final rounding below 2^-24 |x|
+}
+
+template <int KP, int NT, bool PRO, bool EPI>
+__global__ void __launch_bounds__(256) pw_x3_kernel(PwX3Args a) {
+    constexpr int WC = NT, WR = 4 / WC, BM = 32 * WR, KS = KP / 16;
+    constexpr int LDA = KP + 8;
+    constexpr int CPR = KP / 4;                      // 16-byte chunks (4 floats) per row
+    constexpr int NCH = BM * CPR / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * LDA];
+    __shared__ float pc[2][KP];
+    __shared__ double red[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WR, wc = wave / WR;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int g = blockIdx.x / a.nbpg, b = blockIdx.x % a.nbpg;
+    const int K = a.K, N = a.N;
+    const int64_t mbeg = (int64_t)g * a.Mg, mend = mbeg + a.Mg;
+    const int tiles_g = (a.Mg + BM - 1) / BM;
+    const int t0 = (int)((int64_t)b * tiles_g / a.nbpg), t1 = (int)((int64_t)(b + 1) * tiles_g / a.nbpg);
+    const int n = wc * 32 + lrow;
+    bf16x8 breg[3][KS];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            breg[p][s] = *reinterpret_cast<const bf16x8*>(a.Wp + (((int64_t)(p * KS + s) * 2 + lk) * 128 + n) * 8);
+    const float bv = (a.bias && n < N) ? a.bias[n] : 0.0f;
+    if (PRO) {
+        const int GK = a.G * K;
+        for (int k = tid; k < KP; k += 256) {
+            pc[0][k] = k < K ? a.pro_stats[2 * GK + g * K + k] : 0.0f;
+            pc[1][k] = k < K ? a.pro_stats[3 * GK + g * K + k] : 0.0f;
+        }
+        __syncthreads();
+    }
+    double s1 = 0.0, s2 = 0.0;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const uint32_t OOR = 0x80000000u;
+    const int64_t Mtot = (int64_t)a.G * a.Mg;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a.A.p, 0, (int)(Mtot * a.A.ld * 4), 0x00020000);
+    u32x4_t ra[NCH];
+    auto load_tile = [&](int t) {
+        const int64_t m0 = mbeg + (int64_t)t * BM;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, r = c / CPR, k4 = 4 * (c % CPR);
+            const bool ok = (m0 + r < mend) && (k4 < K);
+            const uint32_t off = (uint32_t)(((m0 + r) * a.A.ld + a.A.coff + k4) * 4);
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : OOR, 0, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, r = c / CPR, k4 = 4 * (c % CPR);
+            bf16x4 h[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = __uint_as_float(ra[i][e]);
+                if (PRO) x = (k4 + e < K) ? fmaf(pc[0][k4 + e], x, pc[1][k4 + e]) : 0.0f;
+                __bf16 h1, h2, h3;
+                split3(x, h1, h2, h3);
+                h[0][e] = h1;
+                h[1][e] = h2;
+                h[2][e] = h3;
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(&As[p][r * LDA + k4]) = h[p];
+        }
+    };
+    auto compute_tile = [&](int t) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const int ao = (wr * 32 + lrow) * LDA + 8 * lk;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[0][ao + 16 * s]);
+            const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&As[1][ao + 16 * s]);
+            const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&As[2][ao + 16 * s]);
+            // smallest terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, breg[0][s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[2][s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[1][s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[0][s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[1][s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[0][s], acc, 0, 0, 0);
+        }
+        if (n >= N) return;
+        const int64_t m0 = mbeg + (int64_t)t * BM + wr * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < mend) {
+                const float v = acc[r] + bv;
+                if (EPI) {
+                    s1 += (double)v;
+                    s2 += (double)v * (double)v;
+                }
+                a.C.p[m * a.C.ld + a.C.coff + n] = v;
+            }
+        }
+    };
+    if (t0 < t1) load_tile(t0);
+    for (int t = t0; t < t1; ++t) {
+        store_tile();
+        __syncthreads();
+        if (t + 1 < t1) load_tile(t + 1);
+        compute_tile(t);
+        __syncthreads();
+    }
+    if (EPI && a.part) {
+        const double f1 = s1 + __shfl_down(s1, 32), f2 = s2 + __shfl_down(s2, 32);
+        if (lk == 0) {
+            red[0][wave][lrow] = f1;
+            red[1][wave][lrow] = f2;
+        }
+        __syncthreads();
+        if (wr == 0 && lk == 0 && n < N) {
+            double u1 = 0.0, u2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < WR; ++w) {
+                u1 += red[0][wc * WR + w][lrow];
+                u2 += red[1][wc * WR + w][lrow];
+            }
+            double* p = a.part + ((int64_t)g * a.nbpg + b) * 2 * N;
+            p[n] = u1;
+            p[N + n] = u2;
+        }
+    }
+}
+
+static inline int x3_kp(int K) { return K <= 32 ? 32 : (K <= 64 ? 64 : 128); }
+static inline int x3_nt(int N) { return N <= 32 ? 1 : (N <= 64 ? 2 : 4); }
+
+// B(k, n) = w[k * sbk + n * sbn] -> three bf16 planes of MFMA B fragments [3][KP/16][2][128][8]
+__global__ void pw_x3_pack_many_kernel(const PwX3Pack* __restrict__ tab) {
+    const PwX3Pack d = tab[blockIdx.y];
+    const int ks = d.kp / 16, total = ks * 2 * 128;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int n = i % 128, lk = (i / 128) % 2, s = i / 256;
+        bf16x8 v[3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * s + 8 * lk + e;
+            const float x = (k < d.K && n < d.N) ? d.w[(int64_t)k * d.sbk + (int64_t)n * d.sbn] : 0.0f;
+            __bf16 h1, h2, h3;
+            split3(x, h1, h2, h3);
+            v[0][e] = h1;
+            v[1][e] = h2;
+            v[2][e] = h3;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(d.wp + ((int64_t)p * total + i) * 8) = v[p];
+    }
+}
+
+int64_t pw_x3_packed_bytes(int K) { return (int64_t)3 * (x3_kp(K) / 16) * 2 * 128 * 8 * 2; }
+
+PwX3Pack pw_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, int sbn) {
+    PwX3Pack e;
+    e.w = w;
+    e.wp = reinterpret_cast<__bf16*>(wp);
+    e.K = K;
+    e.N = N;
+    e.sbk = sbk;
+    e.sbn = sbn;
+    e.kp = x3_kp(K);
+    return e;
+}
+
+int pw_x3_pack_many(const PwX3Pack* tab_dev, int n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pw_x3_pack_many_kernel, dim3(8, n), dim3(256), 0, st, tab_dev);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+bool pw_x3_supported(View A, int N, int K) {
+    return K >= 4 && K <= 128 && N >= 1 && N <= 128 && K % 4 == 0 && A.ld % 4 == 0 && A.coff % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(A.p) & 15) == 0;
+}
+
+static int x3_occ() {
+    static const int v = getenv("CDRL_X3_OCC") ? atoi(getenv("CDRL_X3_OCC")) : 2;
+    return v < 1 ? 1 : (v > 8 ? 8 : v);
+}
+
+int pw_x3_partial_rows(int G, int Mg, int N, int K) {
+    const int bm = 32 * (4 / x3_nt(N)), tiles = cdiv(Mg, bm);
+    int nb = 256 * x3_occ() / G;
+    if (nb < 1) nb = 1;
+    return nb > tiles ? tiles : nb;
+}
+
+template <int KP, int NT>
+static void pw_x3_launch(const PwX3Args& a, bool pro, bool epi, hipStream_t st) {
+    const dim3 grid(a.G * a.nbpg), block(256);
+    if (pro && epi) hipLaunchKernelGGL((pw_x3_kernel<KP, NT, true, true>), grid, block, 0, st, a);
+    else if (pro) hipLaunchKernelGGL((pw_x3_kernel<KP, NT, true, false>), grid, block, 0, st, a);
+    else if (epi) hipLaunchKernelGGL((pw_x3_kernel<KP, NT, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_x3_kernel<KP, NT, false, false>), grid, block, 0, st, a);
+}
+
+int pw_x3(View A, const float* pro_stats, const void* Wp, const float* bias, View C, int G, int Mg, int N, int K, double* part,
+          hipStream_t st, int nbpg) {
+    if (!pw_x3_supported(A, N, K) || !Wp) {
+        set_error("pw_x3: unsupported shape / alignment K=%d N=%d ld=%d coff=%d", K, N, A.ld, A.coff);
+        return -1;
+    }
+    if ((int64_t)G * Mg * A.ld * 4 >= (int64_t)1 << 31) {
+        set_error("pw_x3: operand of 2 GB or more");
+        return -1;
+    }
+    PwX3Args a{A, pro_stats, reinterpret_cast<const __bf16*>(Wp), bias, C, part, N, K, G, Mg, nbpg > 0 ? nbpg : pw_x3_partial_rows(G, Mg, N, K)};
+    const int kp = x3_kp(K), nt = x3_nt(N);
+    const bool pro = pro_stats != nullptr, epi = part != nullptr;
+#define CDRL_X3(KPV, NTV) pw_x3_launch<KPV, NTV>(a, pro, epi, st)
+    if (kp == 32) { if (nt == 1) CDRL_X3(32, 1); else if (nt == 2) CDRL_X3(32, 2); else CDRL_X3(32, 4); }
+    else if (kp == 64) { if (nt == 1) CDRL_X3(64, 1); else if (nt == 2) CDRL_X3(64, 2); else CDRL_X3(64, 4); }
+    else { if (nt == 1) CDRL_X3(128, 1); else if (nt == 2) CDRL_X3(128, 2); else CDRL_X3(128, 4); }
+#undef CDRL_X3
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cdrl

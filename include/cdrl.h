@@ -189,6 +189,17 @@ int cdrl_beta_sample_logp(const float* alpha, const float* beta, int rows, int A
                           float* u, float* log_prob, void* stream);
 int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* out, void* stream);
 
+/* Float32 1x1 convolution on the bf16 matrix pipe (exact three-way bf16 split of both operands, six bf16 MFMAs per K = 16
+ * step; float32 in / out, float32-accurate, not bit-identical to an fmaf chain).  W_packed: cdrl_pwconv_x3_packed_bytes(K)
+ * bytes written by cdrl_pwconv_x3_pack from B(k, n) = W[k * sbk + n * sbn].  Same prologue / epilogue contract as
+ * cdrl_pwconv_fused (pro_stats: BN-apply on load; part: statistics partials, cdrl_pwconv_x3_partial_rows rows per group).
+ * K, N <= 128; K, lda, a_coff multiples of 4. */
+int64_t cdrl_pwconv_x3_packed_bytes(int K);
+int cdrl_pwconv_x3_partial_rows(int G, int Mg, int N, int K);
+int cdrl_pwconv_x3_pack(const float* W, int K, int N, int sbk, int sbn, void* packed, void* stream);
+int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, const void* W_packed, const float* bias, float* C,
+                   int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream);
+
 /* bf16 path (BASELINE.json configuration 3), first kernel: the unit's 1x1 convolution (core/architectures.py:130,140) with
  * bf16 activations in HBM, float32 master weights / bias, v_mfma_f32_32x32x16_bf16 with float32 accumulate.  A [G*Mg][lda]
  * bf16 (+ a_coff), C [G*Mg][ldc] bf16; pro_stats ([4][G][K] float32 or NULL): BatchNorm-apply of the previous layer on load;

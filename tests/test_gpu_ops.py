@@ -632,3 +632,44 @@ def test_gru_steps_vs_fp64_autograd(lib, B, In, u, T):
         assert rel_err(g.cpu().numpy(), p64[k].grad.numpy()) < 3e-5, k
     dx = (dXPf @ K.double().t()).reshape(T, B, In)
     assert rel_err(dx.cpu().numpy(), x64.grad.numpy()) < 3e-5
+
+
+@pytest.mark.parametrize('G,Mg,K,N,pro', [(4, 1000, 116, 116, True), (4, 777, 116, 116, False), (2, 515, 24, 56, True), (1, 4100, 60, 92, False),
+                                          (3, 64, 28, 28, False), (4, 12288, 116, 116, True)])
+def test_pwconv_x3_split(lib, G, Mg, K, N, pro):
+    """Float32 1x1 conv on the bf16 matrix pipe (exact 3-way bf16 split of both operands, six MFMAs per K = 16 step): float32
+    accuracy against the float64 reference (same bar as the float32-MFMA kernel), statistics epilogue, untouched padding."""
+    rng = np.random.default_rng(G + Mg + K + N)
+    M = G * Mg
+    lda, a_coff, ldc, c_coff = K + 12, 4, N + 8, 4
+    a = dev(rng.standard_normal((M, lda)).astype(np.float32))
+    w = dev((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32))
+    bias = dev((rng.standard_normal(N) * 0.1).astype(np.float32))
+    stats = None
+    if pro:
+        stats = dev(rng.uniform(0.5, 1.5, (4, G, K)).astype(np.float32))
+        stats[3] = dev(rng.uniform(-0.3, 0.3, (G, K)).astype(np.float32))
+    wp = torch.zeros(int(lib.cdrl_pwconv_x3_packed_bytes(K)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cdrl_pwconv_x3_pack(P(w), K, N, N, 1, P(wp), S()))
+    c = torch.full((M, ldc), 7.0, device=DEV)
+    nb = int(lib.cdrl_pwconv_x3_partial_rows(G, Mg, N, K))
+    part = torch.zeros((G, nb, 2, N), dtype=torch.float64, device=DEV)
+    _lib.check(lib.cdrl_pwconv_x3(P(a), lda, a_coff, P(stats), P(wp), P(bias), P(c), ldc, c_coff, G, Mg, N, K, P(part), S()))
+    av = a[:, a_coff:a_coff + K].double().view(G, Mg, K)
+    if pro:
+        av = (stats[2].view(G, 1, K).double() * av + stats[3].view(G, 1, K).double()).float().double()     # fmaf, one float32 rounding
+    ref = (av.view(M, K) @ w.double() + bias.double()).cpu().numpy()
+    got = c[:, c_coff:c_coff + N]
+    assert rel_err(got.cpu().numpy(), ref) < 1e-5
+    assert bool((c[:, :c_coff] == 7.0).all()) and bool((c[:, c_coff + N:] == 7.0).all())
+    sums = part.sum(dim=1)
+    g64 = got.double().view(G, Mg, N)
+    assert torch.allclose(sums[:, 0], g64.sum(1), rtol=1e-9, atol=1e-6) and torch.allclose(sums[:, 1], (g64 * g64).sum(1), rtol=1e-9, atol=1e-6)
+    # transposed operand (backward-data orientation): B(k, n) = W[n][k]
+    wp2 = torch.zeros(int(lib.cdrl_pwconv_x3_packed_bytes(N)), dtype=torch.uint8, device=DEV)
+    if N % 4 == 0:
+        _lib.check(lib.cdrl_pwconv_x3_pack(P(w), N, K, 1, N, P(wp2), S()))
+        d = torch.zeros((M, K), device=DEV)
+        gc = got.contiguous()
+        _lib.check(lib.cdrl_pwconv_x3(P(gc), N, 0, None, P(wp2), None, P(d), K, 0, G, Mg, K, N, None, S()))
+        assert rel_err(d.cpu().numpy(), (gc.double() @ w.double().t()).cpu().numpy()) < 1e-5
