@@ -27,16 +27,41 @@ def _run(path, **env):
     return torch.load(path)
 
 
-def test_fused_and_unfused_paths_agree_at_full_size(tmp_path):
-    a = _run(str(tmp_path / 'fused.pt'))
-    b = _run(str(tmp_path / 'plain.pt'), CDRL_FUSED_DW=0, CDRL_FUSED_PW=0, CDRL_FUSED_STEM=0, CDRL_FUSED_PASS=0, CDRL_FUSED_BB=0,
-             CDRL_SIDE_STREAM=0)
-    assert abs(a['loss'].item() - b['loss'].item()) <= 1e-6 * max(1.0, abs(b['loss'].item()))
+def _worst(a, b):
     worst = {}
     for k in a:
         if k == 'loss' or is_degenerate_bias(k.split('/', 1)[-1]):
             continue
         x, y = a[k].double(), b[k].double()
         worst[k] = (x - y).abs().max().item() / (y.abs().max().item() + 1e-30)
-    bad = {k: v for k, v in worst.items() if v > 1e-5}
+    return worst
+
+
+def test_fused_and_unfused_paths_agree_at_full_size(tmp_path):
+    """(a0) every fusion on, float32-MFMA GEMMs  vs  (b) everything off: same arithmetic (k-ordered fmaf chains, double
+    reductions), different kernels -> 1e-5 on every tensor, in practice bit for bit."""
+    a0 = _run(str(tmp_path / 'fused.pt'), CDRL_PW_X3=0)
+    b = _run(str(tmp_path / 'plain.pt'), CDRL_FUSED_DW=0, CDRL_FUSED_PW=0, CDRL_FUSED_STEM=0, CDRL_FUSED_PASS=0, CDRL_FUSED_BB=0,
+             CDRL_SIDE_STREAM=0, CDRL_PW_X3=0)
+    assert abs(a0['loss'].item() - b['loss'].item()) <= 1e-6 * max(1.0, abs(b['loss'].item()))
+    bad = {k: v for k, v in _worst(a0, b).items() if v > 1e-5}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
+def test_split_precision_convs_agree_with_float32_mfma_at_full_size(tmp_path):
+    """Default engine (stage-1 forward 1x1 convs on the bf16 matrix pipe by exact three-way operand splitting,
+    gemm_pw_x3.hip) vs the same engine on float32 MFMA.  The split product is float32-accurate but not bit-identical, so
+    at B x T x pixels ~ 10^7 activations a handful of ReLU6 / max-pool decisions flip (any two float32 implementations do
+    this): the SMOOTH quantities -- loss, trunk output, BatchNorm moving statistics, head and tail
+    gradients -- must agree to 1e-5 / 1e-4, the tower gradients to flip noise (median 1e-4, no tensor beyond 5e-2).  The
+    1e-4 gate on tower gradients with decisions pinned is tests/test_gpu_learner.py::test_pinned_decisions_*."""
+    a = _run(str(tmp_path / 'x3.pt'))
+    a0 = _run(str(tmp_path / 'f32.pt'), CDRL_PW_X3=0)
+    assert abs(a['loss'].item() - a0['loss'].item()) <= 1e-6 * max(1.0, abs(a0['loss'].item()))
+    w = _worst(a, a0)
+    assert w['dyn'] < 1e-5
+    assert max(v for k, v in w.items() if k.startswith('mv/')) < 1e-5
+    tail = {k: v for k, v in w.items() if not k.startswith('trunk/img.') and not k.startswith('mv/') and k != 'dyn'}
+    assert max(tail.values()) < 1e-4, sorted(tail.items(), key=lambda kv: -kv[1])[:4]
+    tower = sorted(v for k, v in w.items() if k.startswith('trunk/img.'))
+    assert tower[len(tower) // 2] < 1e-4 and tower[-1] < 5e-2, (tower[len(tower) // 2], tower[-1])
