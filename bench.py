@@ -45,6 +45,52 @@ def pmc_traffic(B, T, H, W):
     return best
 
 
+def pmc_mfma(ms_per_step):
+    """MFMA figures of the committed PMC run (profiles/*_pmc_mfma.json, tools/pmc_mfma.sh): utilisation of the float32 GEMM
+    kernels and the float32 matrix-pipe rate over the update-step against the 157.3 TFLOP/s peak."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_mfma.json')))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    utils = [k['mfma_util'] for k in d['kernels'] if k.get('mfma_util')]
+    flops = d.get('mfma_flops_issued_per_update_step')
+    return dict(source=os.path.relpath(files[-1], ROOT), mfma_util_all_kernel_time=d.get('mfma_util_all_kernels'),
+                mfma_util_gemm_kernels=[min(utils), max(utils)] if utils else None, f32_flops_issued_per_update_step=flops,
+                f32_mfma_tflops=round(flops / (ms_per_step * 1e-3) / 1e12, 2) if flops else None, f32_mfma_peak_tflops=157.3)
+
+
+def dominant_kernel(B, T, H, W):
+    """The kernel with the largest total time in the committed kernel trace of the benchmark workload
+    (profiles/*_kernel_trace_summary.md): name, average duration, algorithmic bytes per launch, fraction of the HBM peak.
+    Algorithmic bytes of the filter-gradient GEMM = 4 (M K + M N) per call (its two operands once), averaged over the
+    (M, K, N) shapes the variant is launched with in one pass."""
+    import glob
+    import re
+    if (B, T, H, W) != (256, 4, 90, 120):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_kernel_trace_summary.md')), key=os.path.getmtime)
+    if not files:
+        return None
+    for line in open(files[-1]):
+        m = re.match(r'\| (\S.*?) \| (\d+) \| ([\d.]+) \| ([\d.]+) \|', line)
+        if m and not m.group(1).startswith('kernel'):
+            name, avg_us = m.group(1), float(m.group(4))
+            break
+    else:
+        return None
+    out = dict(source=os.path.relpath(files[-1], ROOT), kernel=name, avg_us=avg_us)
+    if name.startswith('tn_direct_tr_kernel<4'):
+        # pw1 / pw2 filter gradients of the stage-1 (8 units: M = 49152, K = N = 116) and stage-2 (3 stride-1 units: M = 12288,
+        # K = N = 232 runs in two 128-column blocks) units: 12 launches per pass
+        shapes = [(49152, 116, 116)] * 8 + [(12288, 232, 232)] * 4
+        by = sum(4.0 * m_ * (k + n) for m_, k, n in shapes) / len(shapes)
+        out.update(algorithmic_bytes_per_launch=by, achieved_GBs=round(by / (avg_us * 1e-6) / 1e9, 1),
+                   frac=round(by / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                   note='side-stream kernel: its duration in the step includes sharing the CUs with the critical stream')
+    return out
+
+
 def kernel_rooflines(B, T, nsets=8):
     """Isolated roofline points of the three kernel families that carry the tower (stage-1 shapes of the benchmark
     workload: B*T frames of 6x8 pixels, 116 channels per branch), timed with HIP events on the launch stream through the
@@ -336,7 +382,7 @@ def main():
                                per_gpu_batch=B, global_batch=B * world, time_horizon=T, image=[H, W, 3],
                                parallelism=f'dp{world}', passes_per_step=2,
                                policy_loss='stored-actions' if args.stored_actions else 'resampled (reference-faithful)'),
-                   roofline=roof, kernel_rooflines=kernel_rooflines(B, T) if world == 1 else None, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3),
+                   roofline=roof, mfma=pmc_mfma(ms_per_step), dominant_kernel=dominant_kernel(B, T, H, W), kernel_rooflines=kernel_rooflines(B, T) if world == 1 else None, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3),
                    final_losses=dict(policy=loss_p, value=loss_v))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = run_cpu_baseline_child(args.cpu_sample_batch, T, H, W, args.cpu_threads)
