@@ -39,7 +39,7 @@ __device__ __forceinline__ void split3(float x, __bf16& h1, __bf16& h2, __bf16& 
 }
 
 template <int KP, int NT, bool PRO, bool EPI>
-__global__ void __launch_bounds__(256) pw_x3_kernel(PwX3Args a) {
+__global__ void __launch_bounds__(256, 2) pw_x3_kernel(PwX3Args a) {
     constexpr int WC = NT, WR = 4 / WC, BM = 32 * WR, KS = KP / 16;
     constexpr int LDA = KP + 8;
     constexpr int CPR = KP / 4;                      // 16-byte chunks (4 floats) per row

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from carla_driving_rl_agent_amd import _lib
-from tests.util import make_pair, make_batches, oracle_batch, to_dev, rel_err, is_degenerate_bias, check3
+from tests.util import make_pair, make_batches, oracle_batch, to_dev, rel_err, is_degenerate_bias, is_zero_gradient, check3
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -220,9 +220,9 @@ def _pinned_grad_check(eng_grads, g64, what, tol=TOL, floor_frac=1e-3, g32=None)
     worst = {}
     zero_noise = 0.0
     for name, g in g64.items():
-        if is_degenerate_bias(name):
-            # analytically ZERO gradient (a bias in front of a train-mode BatchNorm): what any implementation computes is the
-            # rounding residue of a cancelling sum over up to 1e6 rows; it must be negligible next to the real gradients
+        if is_zero_gradient(name):
+            # analytically ZERO gradient (a bias / beta in front of a train-mode BatchNorm): what any implementation computes is
+            # the rounding residue of a cancelling sum over up to 1e6 rows; it must be negligible next to the real gradients
             zero_noise = max(zero_noise, float(np.abs(_np(eng_grads[name])).max()) / gmax)
             assert float(np.abs(_np(g)).max()) <= 1e-9 * gmax, name
             continue

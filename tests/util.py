@@ -17,6 +17,13 @@ def is_degenerate_bias(name: str) -> bool:
     return name.startswith('img.') and name.endswith('.b')
 
 
+def is_zero_gradient(name: str) -> bool:
+    """Parameters whose gradient is ANALYTICALLY zero: the biases above, and the beta of a BatchNorm whose output goes through a
+    linear layer straight into another train-mode BatchNorm (unit bn2 -> pw2 -> bn3, sc_bn1 -> sc_pw -> sc_bn2, dyn.bn -> dyn.fc
+    -> the heads' bn0): a per-channel constant added there is removed by the next mean subtraction."""
+    return is_degenerate_bias(name) or name.endswith('.bn2.beta') or name.endswith('.sc_bn1.beta') or name == 'dyn.bn.beta'
+
+
 def make_pair(B, H, W, seed=0, device='cuda:0', A=2, hp=None, with64=False, **cfg):
     ocfg = NetConfig(H=H, W=W, A=A, **cfg)
     tp = OM.init_params(trunk_spec(ocfg), seed + 1)
