@@ -8,6 +8,8 @@ applies the identical clip + Adam update (parameters and Adam state stay replica
 BatchNorm statistics are local to a rank's minibatch (N independent reference agents sharing
 weights); the moving statistics are averaged with a second, tiny all-reduce.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -38,6 +40,8 @@ class DataParallelLearner:
         self._policy_early = [(0, p_n), (t_off + tower_n, t_off + t_n)]
         self._value_early = [(t_off + tower_n, t_off + t_n + v_n)]
         self._comm = None
+        if os.environ.get('CDRL_DP_OVERLAP', '1') == '0':       # one fused all-reduce per pass after the backward (round 1 form)
+            overlap = False
         if overlap and (self.world > 1 or self.force) and getattr(engine, 'device', None) and hasattr(engine, 'set_comm_stream') \
                 and engine.grads.is_cuda:
             self._comm = torch.cuda.Stream(device=engine.grads.device)
