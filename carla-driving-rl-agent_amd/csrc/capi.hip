@@ -377,6 +377,29 @@ int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, 
                  part, S(stream));
 }
 
+int64_t cdrl_gemm_x3_packed_bytes(int N, int K) { return gemm_x3_packed_bytes(N, K); }
+
+int cdrl_gemm_x3_pack(const float* B, int K, int N, int sbk, int sbn, void* packed, void* stream) {
+    if (!B || !packed) return -1;
+    GemmX3Pack e = gemm_x3_pack_entry(B, packed, K, N, sbk, sbn);
+    GemmX3Pack* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(e)) != hipSuccess) return -2;      // tooling entry point; the engine packs in one launch
+    int rc = hipMemcpy(d, &e, sizeof(e), hipMemcpyHostToDevice) == hipSuccess ? gemm_x3_pack_many(d, 1, S(stream)) : -2;
+    (void)hipStreamSynchronize(S(stream));
+    (void)hipFree(d);
+    return rc;
+}
+
+int cdrl_gemm_x3(const float* A, int lda, int a_coff, const void* B_packed, const float* bias, float* C, int ldc, int c_coff, int M,
+                 int N, int K, int accumulate, void* stream) {
+    if (!A || !B_packed || !C) {
+        cdrl::set_error("cdrl_gemm_x3: null argument");
+        return -1;
+    }
+    return gemm_x3(make_view(const_cast<float*>(A), lda, a_coff), B_packed, bias, make_view(C, ldc, c_coff), M, N, K, accumulate,
+                   S(stream));
+}
+
 int cdrl_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
     if (!x || !y) return -1;
     return f32_to_bf16(x, y, n, S(stream));

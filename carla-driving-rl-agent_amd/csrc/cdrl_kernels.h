@@ -217,6 +217,18 @@ int pw_x3_pack_many(const PwX3Pack* tab_dev, int n, hipStream_t st);
 int pw_x3(View A, const float* pro_stats, const void* Wp, const float* bias, View C, int G, int Mg, int N, int K, double* part,
           hipStream_t st, int nbpg = 0);
 
+// general form (gemm_x3.hip): any K (multiple of 4), any N; B packed once per pass by gemm_x3_pack_many into [3][K/16][2][Npad][8]
+struct GemmX3Pack {
+    const float* w;
+    __bf16* wp;
+    int K, N, sbk, sbn, KS, NP;
+};
+bool gemm_x3_supported(View A, int K);
+int64_t gemm_x3_packed_bytes(int N, int K);
+GemmX3Pack gemm_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, int sbn);
+int gemm_x3_pack_many(const GemmX3Pack* tab_dev, int n, hipStream_t st);
+int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st);
+
 // ---------------------------------------------------------------- bf16 pointwise conv (gemm_pw_bf16.hip)
 // bf16 activations (A, C), float32 master weights / bias / BatchNorm blocks, bf16 MFMA with float32 accumulate; optional
 // BN-apply prologue (pro_stats [4][G][K]) and statistics epilogue (part [G][nbpg][2][N], nbpg = pw_bf16_partial_rows)

@@ -362,6 +362,9 @@ private:
     std::vector<PwX3Pack> h_pack3_;         // three-plane bf16 fragments of the convs that run on the bf16 matrix pipe (gemm_pw_x3.hip)
     PwX3Pack* d_pack3_ = nullptr;
     const void* pw_x3_packed(const float* w, int K, int N, int sbk, int sbn);
+    std::vector<GemmX3Pack> h_gpack_;       // general split-precision GEMM operands (head conv, wide shortcut convs: gemm_x3.hip)
+    GemmX3Pack* d_gpack_ = nullptr;
+    const void* gemm_x3_packed(const float* w, int K, int N, int sbk, int sbn);
     int run_trunk_fwd(hipStream_t st, int training);
     hipStream_t comm_ = nullptr;
     hipEvent_t ev_tail_main_ = nullptr, ev_tail_side_ = nullptr;

@@ -350,7 +350,14 @@ const void* Learner::pw_x3_packed(const float* w, int K, int N, int sbk, int sbn
     return wp;
 }
 
+const void* Learner::gemm_x3_packed(const float* w, int K, int N, int sbk, int sbn) {
+    void* wp = alloc((size_t)gemm_x3_packed_bytes(N, K) / sizeof(float));
+    h_gpack_.push_back(gemm_x3_pack_entry(w, wp, K, N, sbk, sbn));
+    return wp;
+}
+
 int Learner::run_trunk_fwd(hipStream_t st, int training) {
+    CDRL_TRY(gemm_x3_pack_many(d_gpack_, (int)h_gpack_.size(), st));
     CDRL_TRY(pw_pack_many(d_pack_, (int)h_pack_.size(), st));       // this pass's weights in fragment order (fwd + bwd-data)
     CDRL_TRY(pw_x3_pack_many(d_pack3_, (int)h_pack3_.size(), st));
     return run_fwd(trunk_ops_, st, training);
@@ -442,6 +449,10 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     static const bool x3_env = !(getenv("CDRL_PW_X3") && atoi(getenv("CDRL_PW_X3")) == 0);
     const void* w3f = (x3_env && fuse.fwd_pw && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
     const int nb_fwd = pw_nn_plan(G, Mg, Cout, Cin).nbpg;
+    // plain (unfused) wide convs -- the 464 -> 768 head conv, the 232-wide shortcut conv -- on the bf16 matrix pipe too (gemm_x3.hip)
+    const bool wide = Cin >= 128 || Cout > 128;
+    const void* g3f = (x3_env && !fuse.fwd_pw && wide && gemm_x3_supported(in, Cin)) ? gemm_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
+    const void* g3b = (x3_env && !fuse.bwd_pw && !fuse.bb && wide && Cout % 4 == 0) ? gemm_x3_packed(w.p, Cout, Cin, 1, Cout) : nullptr;
     const float* wpf = (pack_env && fuse.fwd_pw && !w3f) ? pw_packed(w.p, Cin, Cout, Cout, 1) : nullptr;      // forward: B(k = cin, n = cout)
     const float* wpb = (pack_env && fuse.bwd_pw) ? pw_packed(w.p, Cout, Cin, 1, Cout) : nullptr;      // backward-data: W^T
     const int tn_groups = (fuse.pro_stats || fuse.bb) ? G : 1;
@@ -456,6 +467,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         if (fuse.fwd_pw)
             return pw_nn(in, fuse.pro_stats, w.p, Cout, 1, b.p, make_view(y, Cout), 0, G, Mg, Cout, Cin, fuse.epi_stats ? 1 : 0,
                          nullptr, nullptr, scr_main_.part, st, nullptr, wpf);
+        if (g3f) return gemm_x3(in, g3f, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
         return gemm_nn(in, w.p, Cout, 1, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
     };
     const int nbp_bwd = fuse.bb ? pw_nn_plan(G, Mg, Cin, Cout).nbpg : 0;
@@ -487,6 +499,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             if (fuse.bwd_pw)
                 return pw_nn(make_view(dy, Cout), nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout,
                              fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, scr_main_.part, st, nullptr, wpb);
+            if (g3b) return gemm_x3(make_view(dy, Cout), g3b, nullptr, din, rows, Cin, Cout, din_acc, st);
             CDRL_TRY(gemm_nn(make_view(dy, Cout), w.p, 1, Cout, nullptr, din, rows, Cin, Cout, din_acc, st));
         }
         return 0;
@@ -1225,9 +1238,11 @@ void Learner::build(bool dry) {
     zero_once_.clear();
     h_pack_.clear();
     h_pack3_.clear();
+    h_gpack_.clear();
     build_trunk(trunk_ops_);
     d_pack_ = reinterpret_cast<PwPack*>(alloc((h_pack_.size() + 1) * sizeof(PwPack) / sizeof(float) + 4));
     d_pack3_ = reinterpret_cast<PwX3Pack*>(alloc((h_pack3_.size() + 1) * sizeof(PwX3Pack) / sizeof(float) + 4));
+    d_gpack_ = reinterpret_cast<GemmX3Pack*>(alloc((h_gpack_.size() + 1) * sizeof(GemmX3Pack) / sizeof(float) + 4));
     d_pwt_ = reinterpret_cast<PwTranspose*>(alloc((h_pwt_.size() + 1) * sizeof(PwTranspose) / sizeof(float) + 4));
     const int A = cfg_.A;
     const int pdims[4] = {A, A, 1, 1};
@@ -1307,6 +1322,8 @@ int Learner::upload_seg_tables() {
         CDRL_HIP(hipMemcpy(d_pack_, h_pack_.data(), h_pack_.size() * sizeof(PwPack), hipMemcpyHostToDevice));
     if (!h_pack3_.empty())
         CDRL_HIP(hipMemcpy(d_pack3_, h_pack3_.data(), h_pack3_.size() * sizeof(PwX3Pack), hipMemcpyHostToDevice));
+    if (!h_gpack_.empty())
+        CDRL_HIP(hipMemcpy(d_gpack_, h_gpack_.data(), h_gpack_.size() * sizeof(GemmX3Pack), hipMemcpyHostToDevice));
     for (int m = 1; m <= 2; ++m) {
         SegTable& s = seg_[m];
         CDRL_HIP(hipMemcpy(s.segs, s.h_segs.data(), s.h_segs.size() * sizeof(TensorSeg), hipMemcpyHostToDevice));

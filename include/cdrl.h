@@ -200,6 +200,14 @@ int cdrl_pwconv_x3_pack(const float* W, int K, int N, int sbk, int sbn, void* pa
 int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, const void* W_packed, const float* bias, float* C,
                    int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream);
 
+/* General float32 GEMM C (+)= A B + bias on the bf16 matrix pipe (three-way operand split; the 464 -> 768 head conv of
+ * core/architectures.py:170 and its backward-data product).  B_packed: cdrl_gemm_x3_packed_bytes(N, K) bytes written by
+ * cdrl_gemm_x3_pack from B(k, n) = B[k * sbk + n * sbn].  K, lda, a_coff multiples of 4, A 16-byte aligned. */
+int64_t cdrl_gemm_x3_packed_bytes(int N, int K);
+int cdrl_gemm_x3_pack(const float* B, int K, int N, int sbk, int sbn, void* packed, void* stream);
+int cdrl_gemm_x3(const float* A, int lda, int a_coff, const void* B_packed, const float* bias, float* C, int ldc, int c_coff, int M,
+                 int N, int K, int accumulate, void* stream);
+
 /* bf16 path (BASELINE.json configuration 3), first kernel: the unit's 1x1 convolution (core/architectures.py:130,140) with
  * bf16 activations in HBM, float32 master weights / bias, v_mfma_f32_32x32x16_bf16 with float32 accumulate.  A [G*Mg][lda]
  * bf16 (+ a_coff), C [G*Mg][ldc] bf16; pro_stats ([4][G][K] float32 or NULL): BatchNorm-apply of the previous layer on load;

@@ -673,3 +673,29 @@ def test_pwconv_x3_split(lib, G, Mg, K, N, pro):
         gc = got.contiguous()
         _lib.check(lib.cdrl_pwconv_x3(P(gc), N, 0, None, P(wp2), None, P(d), K, 0, G, Mg, K, N, None, S()))
         assert rel_err(d.cpu().numpy(), (gc.double() @ w.double().t()).cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('M,K,N', [(12288, 464, 768), (12288, 768, 464), (1000, 232, 232), (130, 464, 768), (4099, 60, 92), (257, 16, 8)])
+def test_gemm_x3_split(lib, M, K, N):
+    """General split-precision GEMM (head conv shapes, forward and backward-data orientation, ragged edges): float32 accuracy
+    vs float64, bias, accumulate into a strided view."""
+    rng = np.random.default_rng(M + K + N)
+    lda, a_coff = K + 8, 4
+    a = dev(rng.standard_normal((M, lda)).astype(np.float32))
+    b = dev((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32))
+    bias = dev(rng.standard_normal(N).astype(np.float32))
+    bp = torch.zeros(int(lib.cdrl_gemm_x3_packed_bytes(N, K)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cdrl_gemm_x3_pack(P(b), K, N, N, 1, P(bp), S()))
+    c = torch.full((M, N + 5), 3.0, device=DEV)
+    _lib.check(lib.cdrl_gemm_x3(P(a), lda, a_coff, P(bp), P(bias), P(c), N + 5, 2, M, N, K, 0, S()))
+    ref = a[:, a_coff:a_coff + K].double() @ b.double() + bias.double()
+    assert rel_err(c[:, 2:2 + N].cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert bool((c[:, :2] == 3.0).all()) and bool((c[:, 2 + N:] == 3.0).all())
+    # transposed operand + accumulate: d += c_block @ b^T
+    if N % 4 == 0:
+        bt = torch.zeros(int(lib.cdrl_gemm_x3_packed_bytes(K, N)), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.cdrl_gemm_x3_pack(P(b), N, K, 1, N, P(bt), S()))
+        g = dev(rng.standard_normal((M, N)).astype(np.float32))
+        d = torch.ones((M, K), device=DEV)
+        _lib.check(lib.cdrl_gemm_x3(P(g), N, 0, P(bt), None, P(d), K, 0, M, K, N, 1, S()))
+        assert rel_err(d.cpu().numpy(), (g.double() @ b.double().t() + 1.0).cpu().numpy()) < 1e-5
