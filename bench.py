@@ -267,6 +267,9 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--height', type=int, default=90)
     ap.add_argument('--width', type=int, default=120)
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help="bf16: configuration 3's compute mode (bf16 MFMA operands in the tower's 1x1 convolutions, float32 storage "
+                         "and accumulation); quote it with --batch 1024")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=256)
     ap.add_argument('--cpu-threads', type=int, default=min(16, os.cpu_count() or 1),
@@ -302,7 +305,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
 
     B, T, H, W = args.batch, 4, args.height, args.width
-    eng = LearnerEngine(B, device=dev, T=T, H=H, W=W)
+    eng = LearnerEngine(B, device=dev, T=T, H=H, W=W, compute=args.dtype)
     # random-init weights of the reference architecture, identical on every rank
     from carla_driving_rl_agent_amd.init import init_engine_parameters
     init_engine_parameters(eng, seed=42)
@@ -352,6 +355,7 @@ def main():
     for _ in range(args.steps):
         one_step()
     ev1.record()
+    host_ms = (time.time() - t0) / args.steps * 1e3       # host time to ENQUEUE one update-step (no sync inside the loop)
     barrier()
     elapsed = time.time() - t0
     dev_ms = ev0.elapsed_time(ev1)
@@ -376,13 +380,14 @@ def main():
                         algorithmic_bytes_per_launch=alg)
         out = dict(metric='PPO update-steps/sec (batch=256, 4x90x120x3 obs)', value=round(value, 3), unit='update-steps/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype='f32' if args.dtype == 'f32' else 'bf16 MFMA operands in the 1x1 convolutions (fwd, bwd-data), f32 storage/accumulate', data='synthetic',
                    config=dict(workload=f'configs[1]: synthetic rollout buffer {B}x{T}-frame {H}x{W}x3 obs per GPU, full '
-                                        f'CARLANetwork fwd/bwd + PPO (re-sampled Beta, pathwise) / value loss + clip + Adam, fp32',
+                                        f'CARLANetwork fwd/bwd + PPO (re-sampled Beta, pathwise) / value loss + clip + Adam, ' + ('fp32' if args.dtype == 'f32' else 'bf16-operand compute mode (configs[2])'),
                                per_gpu_batch=B, global_batch=B * world, time_horizon=T, image=[H, W, 3],
                                parallelism=f'dp{world}', passes_per_step=2,
                                policy_loss='stored-actions' if args.stored_actions else 'resampled (reference-faithful)'),
-                   roofline=roof, mfma=pmc_mfma(ms_per_step), dominant_kernel=dominant_kernel(B, T, H, W), kernel_rooflines=kernel_rooflines(B, T) if world == 1 else None, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3),
+                   roofline=roof, mfma=pmc_mfma(ms_per_step), dominant_kernel=dominant_kernel(B, T, H, W), kernel_rooflines=kernel_rooflines(B, T) if world == 1 else None, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3), host_enqueue_ms_per_step=round(host_ms, 3),
                    final_losses=dict(policy=loss_p, value=loss_v))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = run_cpu_baseline_child(args.cpu_sample_batch, T, H, W, args.cpu_threads)

@@ -18,7 +18,10 @@ class Config(C.Structure):
                 ('road', C.c_int32), ('vehicle', C.c_int32), ('navigation', C.c_int32), ('A', C.c_int32),
                 ('stem', C.c_int32), ('stage_c', C.c_int32 * 3), ('stage_n', C.c_int32 * 3), ('last', C.c_int32),
                 ('feat', C.c_int32), ('rnn_image', C.c_int32), ('rnn_small', C.c_int32), ('dyn', C.c_int32),
-                ('head', C.c_int32), ('exp_scale', C.c_float)]
+                ('head', C.c_int32), ('exp_scale', C.c_float), ('compute', C.c_int32)]
+
+
+COMPUTE_F32, COMPUTE_BF16_OPERANDS = 0, 1
 
 
 class ParamInfo(C.Structure):
@@ -122,6 +125,10 @@ PROTOTYPES = {
     'cdrl_stem_block_bwd': (_i, [_fp] * 5 + [_i] * 5 + [_fp] * 7),
     'cdrl_pwconv_fused_partial_rows': (_i, [_i, _i, _i, _i]),
     'cdrl_pwconv_fused': (_i, [_fp, _i, _i, _fp, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp]),
+    'cdrl_pwconv_pack_elems': (_i64, [_i, _i]),
+    'cdrl_pwconv_pack': (_i, [_fp, _i, _i, _i, _i, _fp, _i, _fp]),
+    'cdrl_pwconv_fused_packed': (_i, [_fp, _i, _i, _fp, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _fp]),
+    'cdrl_pwconv_bn_bwd_packed': (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _fp]),
     'cdrl_pwconv_bn_bwd_workspace_bytes': (_i64, [_i, _i, _i, _i]),
     'cdrl_pwconv_bn_bwd': (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp]),
     'cdrl_dwconv_bn_workspace_doubles': (_i64, [_i] * 6),

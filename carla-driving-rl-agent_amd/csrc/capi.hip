@@ -66,6 +66,7 @@ void cdrl_config_default(cdrl_config* c) {
     for (int i = 0; i < 3; ++i) { c->stage_c[i] = d.stage_c[i]; c->stage_n[i] = d.stage_n[i]; }
     c->last = d.last; c->feat = d.feat; c->rnn_image = d.rnn_image; c->rnn_small = d.rnn_small;
     c->dyn = d.dyn; c->head = d.head; c->exp_scale = d.exp_scale;
+    c->compute = d.compute;
 }
 
 int cdrl_learner_create(const cdrl_config* c, cdrl_learner** out) {
@@ -89,12 +90,23 @@ int cdrl_learner_create(const cdrl_config* c, cdrl_learner** out) {
     for (int i = 0; i < 3; ++i) { d.stage_c[i] = c->stage_c[i]; d.stage_n[i] = c->stage_n[i]; }
     d.last = c->last; d.feat = c->feat; d.rnn_image = c->rnn_image; d.rnn_small = c->rnn_small;
     d.dyn = c->dyn; d.head = c->head; d.exp_scale = c->exp_scale;
+    if (c->compute != CDRL_COMPUTE_F32 && c->compute != CDRL_COMPUTE_BF16_OPERANDS) {
+        cdrl::set_error("cdrl_learner_create: unknown compute mode %d", c->compute);
+        return -1;
+    }
+    d.compute = c->compute;
     cdrl_learner* l = new (std::nothrow) cdrl_learner;
     if (!l) return -3;
     l->impl = new (std::nothrow) Learner(d);
     if (!l->impl) {
         delete l;
         return -3;
+    }
+    if (!l->impl->build_error().empty()) {
+        cdrl::set_error("cdrl_learner_create: %s", l->impl->build_error().c_str());
+        delete l->impl;
+        delete l;
+        return -1;
     }
     *out = l;
     return 0;
@@ -549,6 +561,32 @@ int cdrl_pwconv_fused(const float* a, int lda, int a_coff, const float* pro_stat
                  accumulate, G, Mg, N, K, epilogue, epi_y, epi_stats, part, S(stream));
 }
 
+int64_t cdrl_pwconv_pack_elems(int N, int K) { return pw_packed_elems(N, K); }
+
+int cdrl_pwconv_pack(const float* W, int K, int N, int sbk, int sbn, float* packed, int bf16, void* stream) {
+    if (!W || !packed) return -1;
+    // one-entry table through a temporary device copy (test / tooling entry point; the engine packs all layers in one launch)
+    PwPack e = pw_pack_entry(W, packed, K, N, sbk, sbn, bf16 != 0);
+    PwPack* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(e)) != hipSuccess) return -2;
+    int rc = hipMemcpy(d, &e, sizeof(e), hipMemcpyHostToDevice) == hipSuccess ? pw_pack_many(d, 1, S(stream)) : -2;
+    (void)hipStreamSynchronize(S(stream));
+    (void)hipFree(d);
+    return rc;
+}
+
+int cdrl_pwconv_fused_packed(const float* a, int lda, int a_coff, const float* pro_stats, const float* w, int sbk, int sbn,
+                             const float* bias, float* c, int ldc, int c_coff, int accumulate, int G, int Mg, int N, int K,
+                             int epilogue, const float* epi_y, const float* epi_stats, double* part, const float* w_packed,
+                             int packed_bf16, void* stream) {
+    if (!w_packed) {
+        cdrl::set_error("cdrl_pwconv_fused_packed: null packed weights");
+        return -1;
+    }
+    return pw_nn(make_view(const_cast<float*>(a), lda, a_coff), pro_stats, w, sbk, sbn, bias, make_view(c, ldc, c_coff),
+                 accumulate, G, Mg, N, K, epilogue, epi_y, epi_stats, part, S(stream), nullptr, w_packed, packed_bf16 != 0);
+}
+
 static int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 
 int64_t cdrl_pwconv_bn_bwd_workspace_bytes(int G, int Mg, int N, int K) {
@@ -556,10 +594,11 @@ int64_t cdrl_pwconv_bn_bwd_workspace_bytes(int G, int Mg, int N, int K) {
     return al256((int64_t)G * nbr * 2 * N * 8) + al256((int64_t)G * nbp * N * 8) + al256(gemm_tn_part_elems(G * Mg, N, K, G) * 4);
 }
 
-int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
-                       const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
-                       int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
-                       int dx_coff, int accumulate, float* dw, float* db, void* workspace, void* stream) {
+static int pwconv_bn_bwd_impl(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
+                              const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
+                              int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
+                              int dx_coff, int accumulate, float* dw, float* db, void* workspace, const float* wt_packed,
+                              int packed_bf16, void* stream) {
     hipStream_t st = S(stream);
     const int act = relu6 ? ACT_RELU6 : ACT_NONE;
     const int nbr = vcol_geom(Mg, N).nb, nbp = pw_nn_plan(G, Mg, K, N).nbpg;
@@ -576,10 +615,31 @@ int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffl
     PwBnBwd bb{y, stats, coef, shuffle_ctot, act, part2};
     // dx[m,k] = sum_n dy[m,n] W[k,n]: GEMM with "K" = N (reduction over the conv outputs) and "N" = K
     CDRL_TRY(pw_nn(vd, nullptr, w, 1, N, nullptr, make_view(dx, dx_ld, dx_coff), accumulate, G, Mg, K, N, 0, nullptr, nullptr, nullptr,
-                   st, &bb));
+                   st, &bb, wt_packed, packed_bf16 != 0));
     CDRL_TRY(reduce_partials(part2, G * nbp, N, N, db, 0, st));
     TnBnBwd tb{y, stats, coef, shuffle_ctot, act};
     return gemm_tn(vx, vd, dw, G * Mg, N, K, tn, 0, st, G, x_pro_stats, &tb);
+}
+
+int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
+                       const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
+                       int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
+                       int dx_coff, int accumulate, float* dw, float* db, void* workspace, void* stream) {
+    return pwconv_bn_bwd_impl(dout, dout_ld, dout_coff, shuffle_ctot, relu6, y, stats, x, x_ld, x_coff, x_pro_stats, w, G, Mg, N, K,
+                              dgamma, dbeta, coef, dx, dx_ld, dx_coff, accumulate, dw, db, workspace, nullptr, 0, stream);
+}
+
+int cdrl_pwconv_bn_bwd_packed(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
+                              const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
+                              int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
+                              int dx_coff, int accumulate, float* dw, float* db, void* workspace, const float* wt_packed,
+                              int packed_bf16, void* stream) {
+    if (!wt_packed) {
+        cdrl::set_error("cdrl_pwconv_bn_bwd_packed: null packed weights");
+        return -1;
+    }
+    return pwconv_bn_bwd_impl(dout, dout_ld, dout_coff, shuffle_ctot, relu6, y, stats, x, x_ld, x_coff, x_pro_stats, w, G, Mg, N, K,
+                              dgamma, dbeta, coef, dx, dx_ld, dx_coff, accumulate, dw, db, workspace, wt_packed, packed_bf16, stream);
 }
 
 int64_t cdrl_dwconv_bn_workspace_doubles(int G, int B, int H, int W, int C, int stride) {

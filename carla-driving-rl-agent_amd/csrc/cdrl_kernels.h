@@ -111,16 +111,19 @@ struct PwBnBwd {
 bool pw_nn_supported(View A, int N, int K);
 PwPlan pw_nn_plan(int G, int Mg, int N, int K);
 // Wp (optional): B pre-packed in MFMA fragment order by pw_pack_many (pw_packed_elems(N, K) floats)
+// wp_bf16: Wp holds bf16 fragments (PwPack::bf16) -> bf16-operand variant (both MFMA operands rounded to bf16, float32
+// tensors / accumulation / statistics: the compute mode of configuration 3)
 int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, const float* bias, View C, int accumulate, int G,
           int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st,
-          const PwBnBwd* bnbwd = nullptr, const float* Wp = nullptr);
+          const PwBnBwd* bnbwd = nullptr, const float* Wp = nullptr, bool wp_bf16 = false);
 struct PwPack {             // one operand to pack: B(k, n) = w[k * sbk + n * sbn], K x N
     const float* w;
     float* wp;
     int K, N, sbk, sbn, ksm, ntiles;
+    int bf16;               // 1: bf16 fragments of the bf16-operand variant (same element count, half the bytes)
 };
 int64_t pw_packed_elems(int N, int K);
-PwPack pw_pack_entry(const float* w, float* wp, int K, int N, int sbk, int sbn);
+PwPack pw_pack_entry(const float* w, float* wp, int K, int N, int sbk, int sbn, bool bf16 = false);
 int pw_pack_many(const PwPack* tab_dev, int n, hipStream_t st);
 // out[i] (+)= sum_p part[p*stride + i] for float partials (double accumulation, fixed order)
 int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride, float* out, int accumulate,
@@ -227,7 +230,9 @@ bool gemm_x3_supported(View A, int K);
 int64_t gemm_x3_packed_bytes(int N, int K);
 GemmX3Pack gemm_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, int sbn);
 int gemm_x3_pack_many(const GemmX3Pack* tab_dev, int n, hipStream_t st);
-int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st);
+// bf16_operands: one product per step on the first plane only (operands rounded to bf16: configuration 3's compute mode)
+int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st,
+            bool bf16_operands = false);
 
 // ---------------------------------------------------------------- bf16 pointwise conv (gemm_pw_bf16.hip)
 // bf16 activations (A, C), float32 master weights / bias / BatchNorm blocks, bf16 MFMA with float32 accumulate; optional

@@ -27,6 +27,7 @@ struct Config {
     int dyn = 512;
     int head = 320;
     float exp_scale = 6.0f;
+    int compute = 0;        // 0: float32 products; 1: bf16 MFMA operands in the tower's 1x1 convolutions (configuration 3)
 };
 
 enum Model : int { M_TRUNK = 0, M_POLICY = 1, M_VALUE = 2, M_OLD_POLICY = 3 };
@@ -91,6 +92,7 @@ struct PwFuse {
 
 class Learner {
 public:
+    const std::string& build_error() const { return build_err_; }
     explicit Learner(const Config& cfg);
     ~Learner();
 
@@ -356,9 +358,11 @@ private:
     int pwt_tiles_ = 0;
     // pointwise-conv weights in MFMA fragment order (forward operand W, backward-data operand W^T), re-packed by ONE launch
     // at the start of every trunk forward: the per-workgroup weight prologue of the persistent GEMM becomes KSM/4 16-byte loads
+    std::string build_err_;                 // first configuration error met while the op lists were built (reported by create)
+    void build_fail(const char* fmt, ...);
     std::vector<PwPack> h_pack_;
     PwPack* d_pack_ = nullptr;
-    float* pw_packed(const float* w, int K, int N, int sbk, int sbn);
+    float* pw_packed(const float* w, int K, int N, int sbk, int sbn, bool bf16 = false);
     std::vector<PwX3Pack> h_pack3_;         // three-plane bf16 fragments of the convs that run on the bf16 matrix pipe (gemm_pw_x3.hip)
     PwX3Pack* d_pack3_ = nullptr;
     const void* pw_x3_packed(const float* w, int K, int N, int sbk, int sbn);

@@ -10,6 +10,9 @@
 // Frames are ordered f = t*B + b, so each per-time-slice BatchNorm group is a contiguous row
 // range (F6); split / concat / channel_shuffle never materialise on their own: they are views
 // (ld, channel offset) plus a destination-index permutation in the BN-apply store (F7).
+#include <cstdarg>
+#include <cstdio>
+
 #include "engine.h"
 
 #include <stdlib.h>
@@ -338,9 +341,18 @@ float* Learner::pw_transposed(const std::string& name, const float* w, int cin, 
     return wt;
 }
 
-float* Learner::pw_packed(const float* w, int K, int N, int sbk, int sbn) {
+void Learner::build_fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (build_err_.empty()) build_err_ = buf;
+}
+
+float* Learner::pw_packed(const float* w, int K, int N, int sbk, int sbn, bool bf16) {
     float* wp = alloc((size_t)pw_packed_elems(N, K));
-    h_pack_.push_back(pw_pack_entry(w, wp, K, N, sbk, sbn));
+    h_pack_.push_back(pw_pack_entry(w, wp, K, N, sbk, sbn, bf16));
     return wp;
 }
 
@@ -445,16 +457,27 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     const float* wt = (wt_env && !pack_env && fuse.bwd_pw) ? pw_transposed(prefix, w.p, Cin, Cout) : nullptr;
     const float* wb = wt ? wt : w.p;                    // backward-data operand B(k = cout, n = cin)
     const int wb_sk = wt ? Cin : 1, wb_sn = wt ? 1 : Cout;
+    // compute mode 1 (configuration 3): every 1x1 convolution of the tower multiplies bf16-rounded operands (forward and
+    // backward-data; the filter gradients stay float32) -- the fused kernels in their BF variant, the plain wide ones through
+    // gemm_x3's single-plane form
+    const bool bfc = cfg_.compute == 1;
     // forward on the bf16 matrix pipe (exact three-way operand split, gemm_pw_x3.hip) where the shape allows it
     static const bool x3_env = !(getenv("CDRL_PW_X3") && atoi(getenv("CDRL_PW_X3")) == 0);
-    const void* w3f = (x3_env && fuse.fwd_pw && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
+    const void* w3f = (!bfc && x3_env && fuse.fwd_pw && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
     const int nb_fwd = pw_nn_plan(G, Mg, Cout, Cin).nbpg;
     // plain (unfused) wide convs -- the 464 -> 768 head conv, the 232-wide shortcut conv -- on the bf16 matrix pipe too (gemm_x3.hip)
     const bool wide = Cin >= 128 || Cout > 128;
-    const void* g3f = (x3_env && !fuse.fwd_pw && wide && gemm_x3_supported(in, Cin)) ? gemm_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
-    const void* g3b = (x3_env && !fuse.bwd_pw && !fuse.bb && wide && Cout % 4 == 0) ? gemm_x3_packed(w.p, Cout, Cin, 1, Cout) : nullptr;
-    const float* wpf = (pack_env && fuse.fwd_pw && !w3f) ? pw_packed(w.p, Cin, Cout, Cout, 1) : nullptr;      // forward: B(k = cin, n = cout)
-    const float* wpb = (pack_env && fuse.bwd_pw) ? pw_packed(w.p, Cout, Cin, 1, Cout) : nullptr;      // backward-data: W^T
+    const bool g3 = bfc || (x3_env && wide);
+    const bool use_g3f = g3 && !fuse.fwd_pw && gemm_x3_supported(in, Cin);
+    const bool use_g3b = g3 && !fuse.bwd_pw && !fuse.bb && Cout % 4 == 0;
+    const void* g3f = use_g3f ? gemm_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
+    const void* g3b = use_g3b ? gemm_x3_packed(w.p, Cout, Cin, 1, Cout) : nullptr;
+    if (bfc && ((!fuse.fwd_pw && !use_g3f) || (!fuse.bwd_pw && !fuse.bb && !use_g3b) || (fuse.bb && !fuse.bwd_pw)))
+        build_fail("bf16-operand mode: 1x1 convolution %s (%d -> %d, fwd %d bwd %d bb %d; input ld %d coff %d) has no bf16 kernel",
+                   prefix.c_str(), Cin, Cout, (int)fuse.fwd_pw, (int)fuse.bwd_pw, (int)fuse.bb, in.ld, in.coff);
+    if (bfc && !pack_env) build_fail("bf16-operand mode needs the packed-weight path (CDRL_PW_PACK=0 is set)");
+    const float* wpf = (pack_env && fuse.fwd_pw && !w3f) ? pw_packed(w.p, Cin, Cout, Cout, 1, bfc) : nullptr;      // forward: B(k = cin, n = cout)
+    const float* wpb = (pack_env && fuse.bwd_pw) ? pw_packed(w.p, Cout, Cin, 1, Cout, bfc) : nullptr;      // backward-data: W^T
     const int tn_groups = (fuse.pro_stats || fuse.bb) ? G : 1;
     note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin, tn_groups));
     if (fuse.epi_stats) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cout, Cin).nbpg * 2 * Cout, 0, 0, 0);
@@ -466,8 +489,8 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
                          nb_fwd);
         if (fuse.fwd_pw)
             return pw_nn(in, fuse.pro_stats, w.p, Cout, 1, b.p, make_view(y, Cout), 0, G, Mg, Cout, Cin, fuse.epi_stats ? 1 : 0,
-                         nullptr, nullptr, scr_main_.part, st, nullptr, wpf);
-        if (g3f) return gemm_x3(in, g3f, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
+                         nullptr, nullptr, scr_main_.part, st, nullptr, wpf, bfc);
+        if (g3f) return gemm_x3(in, g3f, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st, bfc);
         return gemm_nn(in, w.p, Cout, 1, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
     };
     const int nbp_bwd = fuse.bb ? pw_nn_plan(G, Mg, Cin, Cout).nbpg : 0;
@@ -483,7 +506,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             CDRL_TRY(done_side(side));
             PwBnBwd pb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act, part2s_[slot_]};
             CDRL_TRY(pw_nn(dz, nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
-                           fuse.bwd_epi_stats, scr_main_.part, st, &pb, wpb));
+                           fuse.bwd_epi_stats, scr_main_.part, st, &pb, wpb, bfc));
             // bias gradient = column sums of the (virtual) dy, reduced from the GEMM's partials: rides on the next fork
             double* p2 = part2s_[slot_];
             return defer_side(st, [=](hipStream_t sd) -> int { return reduce_partials(p2, G * nbp_bwd, Cout, Cout, b.g, 0, sd); });
@@ -498,8 +521,8 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         if (din.p) {
             if (fuse.bwd_pw)
                 return pw_nn(make_view(dy, Cout), nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout,
-                             fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, scr_main_.part, st, nullptr, wpb);
-            if (g3b) return gemm_x3(make_view(dy, Cout), g3b, nullptr, din, rows, Cin, Cout, din_acc, st);
+                             fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, scr_main_.part, st, nullptr, wpb, bfc);
+            if (g3b) return gemm_x3(make_view(dy, Cout), g3b, nullptr, din, rows, Cin, Cout, din_acc, st, bfc);
             CDRL_TRY(gemm_nn(make_view(dy, Cout), w.p, 1, Cout, nullptr, din, rows, Cin, Cout, din_acc, st));
         }
         return 0;
@@ -682,7 +705,7 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
     float* dHa = alloc((size_t)B * u);
     float* dHb = alloc((size_t)B * u);
     if (!dry_) zero_once_.push_back(std::make_pair(Hs, (size_t)B * u * sizeof(float)));
-    if (!gru_step_supported(u)) set_error("GRU units %d unsupported by the fused step kernels", u);
+    if (!gru_step_supported(u)) build_fail("GRU units %d unsupported by the fused step kernels", u);
     const float* RT = pw_transposed(name + ".recurrent", Rp.p, u, U3);        // [3u][u], refreshed with the conv W^T copies
     note_scratch((size_t)vcol_geom(T * B, U3).nb * U3, (size_t)vcol_geom(T * B, U3).nb * U3, 0,
                  (size_t)std::max(gemm_tn_part_elems(T * B, U3, In), gemm_tn_part_elems(T * B, U3, u)));

@@ -26,6 +26,8 @@
 namespace cdrl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 struct PwArgs {
     View A;                     // PRO_BNBWD: gradient w.r.t. the BN output (the dz source)
@@ -38,6 +40,7 @@ struct PwArgs {
     const float* W;
     int sbk, sbn;
     const float* Wp;            // optional: W in fragment order [ceil(N/32)][2][32][KSM] (pw_pack_many): 16-byte loads
+                                // BF variant: bf16 fragments [ceil(N/32)][KSM/8][2][32][8] (pw_pack_many with PwPack::bf16)
     const float* bias;
     View C;
     int accumulate;
@@ -45,6 +48,7 @@ struct PwArgs {
     const float* epi_stats;     // EPI_BNRED: [4][G][N]
     double* part;               // [G][nbpg][2][N]
     int N, K, G, Mg, nbpg, tpb;
+    int bf;                     // host dispatch only: Wp holds bf16 fragments -> BF variant
 };
 
 // register budget: W fragments (NTW*KSM) + accumulators + one prefetched A tile; the K > 64 and 3-column-tile variants
@@ -54,13 +58,19 @@ constexpr int pw_occ(int ksm, int nt) { return ((ksm == 32 && nt == 3) || (ksm =
 // the W fragments then cost only KSM VGPRs per wave and 2+ workgroups fit a CU even at K = 128
 constexpr int pw_wc(int nt) { return nt == 3 ? 1 : nt; }
 
-template <int KSM, int NT, int PRO, int EPI>
+// BF (bf16-operand compute mode, configuration 3): same skeleton, same float32 tensors in HBM, float32 accumulation, statistics
+// and epilogues, but both MFMA operands are rounded to bf16 (round-to-nearest-even) -- A on its way into LDS (after the
+// prologue), W when it is packed -- and the product runs as v_mfma_f32_32x32x16_bf16: 1/8 of the float32 matrix-pipe time and
+// half the W registers / LDS tile.
+template <int KSM, int NT, int PRO, int EPI, bool BF>
 __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a) {
     constexpr int WC = pw_wc(NT);                   // wave columns
     constexpr int WR = 4 / WC;                      // wave rows
     constexpr int NTW = NT / WC;                    // column tiles per wave
     constexpr int BM = 32 * WR;
     constexpr int LDA = 2 * KSM + 2;
+    constexpr int KS16 = KSM / 8;                   // BF: K = 16 steps
+    constexpr int LDB = 2 * KSM + 8;                // BF: bf16 elements per LDS row (16-byte fragment reads, conflict-free)
     constexpr int NA2 = BM * KSM / 256;             // float2 loads per thread per tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                               // [BM][LDA]
@@ -77,8 +87,18 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
     const int t0 = (int)((int64_t)b * tiles_g / a.nbpg), t1 = (int)((int64_t)(b + 1) * tiles_g / a.nbpg);
 
     // ---- W fragments -> registers (once)
-    float breg[NTW][KSM];
-    if (a.Wp) {
+    float breg[BF ? 1 : NTW][BF ? 1 : KSM];
+    bf16x8 bregb[BF ? NTW : 1][BF ? KS16 : 1];
+    if (BF) {
+        const __bf16* wb = reinterpret_cast<const __bf16*>(a.Wp);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int ct = (nb0 >> 5) + wc + j * WC;
+#pragma unroll
+            for (int s = 0; s < KS16; ++s)
+                bregb[j][s] = *reinterpret_cast<const bf16x8*>(wb + ((((int64_t)ct * KS16 + s) * 2 + lk) * 32 + lrow) * 8);
+        }
+    } else if (a.Wp) {
         // pre-packed once per weight version: the lane's KSM fragment values are contiguous -> KSM/4 16-byte loads instead of
         // KSM dependent 4-byte loads (the strided form was ~9 us of every launch: isolated 1x1 conv 24.8 -> see DESIGN.md)
 #pragma unroll
@@ -247,7 +267,14 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
                         v.y = qr[4][1] * (v.y - qr[5][1] - xh1 * qr[6][1]);
                         cs0 += (double)v.x;
                         cs1 += (double)v.y;
-                        *reinterpret_cast<float2*>(&As[r * LDA + 2 * kk_t]) = v;
+                        if (BF) {
+                            bf16x2 h;
+                            h[0] = (__bf16)v.x;
+                            h[1] = (__bf16)v.y;
+                            *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(As) + r * LDB + 2 * kk_t) = h;
+                        } else {
+                            *reinterpret_cast<float2*>(&As[r * LDA + 2 * kk_t]) = v;
+                        }
                         continue;
                     }
                     const float* q0 = qc + 2 * kk_t;
@@ -264,7 +291,14 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
                     cs1 += (double)v.y;
                 }
             }
-            *reinterpret_cast<float2*>(&As[r * LDA + 2 * kk_t]) = v;
+            if (BF) {
+                bf16x2 h;
+                h[0] = (__bf16)v.x;
+                h[1] = (__bf16)v.y;
+                *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(As) + r * LDB + 2 * kk_t) = h;
+            } else {
+                *reinterpret_cast<float2*>(&As[r * LDA + 2 * kk_t]) = v;
+            }
         }
     };
     auto compute_tile = [&](int t) {
@@ -288,14 +322,24 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
                 }
             }
         }
-        const float* arow = &As[(wr * 32 + lrow) * LDA + lk];
+        if (BF) {
+            const __bf16* arow = reinterpret_cast<const __bf16*>(As) + (wr * 32 + lrow) * LDB + 8 * lk;
 #pragma unroll
-        for (int s = 0; s < KSM; ++s) {
-            // keep the scheduler from hoisting all KSM fragment reads above the MFMA chain (64 extra live VGPRs)
-            if (KSM > 16 && (s % 16) == 0) __builtin_amdgcn_sched_barrier(0);
-            const float av = arow[2 * s];
+            for (int s = 0; s < KS16; ++s) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + 16 * s);
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[j][s], acc[j], 0, 0, 0);
+                for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bregb[j][s], acc[j], 0, 0, 0);
+            }
+        } else {
+            const float* arow = &As[(wr * 32 + lrow) * LDA + lk];
+#pragma unroll
+            for (int s = 0; s < KSM; ++s) {
+                // keep the scheduler from hoisting all KSM fragment reads above the MFMA chain (64 extra live VGPRs)
+                if (KSM > 16 && (s % 16) == 0) __builtin_amdgcn_sched_barrier(0);
+                const float av = arow[2 * s];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[j][s], acc[j], 0, 0, 0);
+            }
         }
         // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         const int64_t m0 = mbeg + (int64_t)t * BM + wr * 32;
@@ -382,6 +426,17 @@ static int pw_ksm(int K) { return K <= 32 ? 16 : (K <= 64 ? 32 : (K <= 128 ? 64 
 __global__ void __launch_bounds__(256) pw_pack_many_kernel(const PwPack* __restrict__ tab) {
     const PwPack d = tab[blockIdx.y];
     const int total = d.ntiles * 2 * 32 * d.ksm;
+    if (d.bf16) {
+        // bf16 fragments of the BF variant: [ct][s = k / 16][lk][lrow][8], element e <-> k = 16 s + 8 lk + e (round-to-nearest-even)
+        __bf16* wb = reinterpret_cast<__bf16*>(d.wp);
+        const int ks = d.ksm / 8;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+            const int e = i % 8, lrow = (i / 8) % 32, lk = (i / 256) % 2, s = (i / 512) % ks, ct = i / (512 * ks);
+            const int k = 16 * s + 8 * lk + e, n = ct * 32 + lrow;
+            wb[i] = (__bf16)((k < d.K && n < d.N) ? d.w[(int64_t)k * d.sbk + (int64_t)n * d.sbn] : 0.0f);
+        }
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int s = i % d.ksm, lrow = (i / d.ksm) % 32, lk = (i / (d.ksm * 32)) % 2, ct = i / (d.ksm * 64);
         const int k = 2 * s + lk, n = ct * 32 + lrow;
@@ -391,8 +446,9 @@ __global__ void __launch_bounds__(256) pw_pack_many_kernel(const PwPack* __restr
 
 int64_t pw_packed_elems(int N, int K) { return (int64_t)cdiv(N, 32) * 2 * 32 * pw_ksm(K); }
 
-PwPack pw_pack_entry(const float* w, float* wp, int K, int N, int sbk, int sbn) {
+PwPack pw_pack_entry(const float* w, float* wp, int K, int N, int sbk, int sbn, bool bf16) {
     PwPack e;
+    e.bf16 = bf16 ? 1 : 0;
     e.w = w;
     e.wp = wp;
     e.K = K;
@@ -434,19 +490,24 @@ PwPlan pw_nn_plan(int G, int Mg, int N, int K) {
     return p;
 }
 
-template <int KSM, int NT, int PRO, int EPI>
-static int launch_pw(const PwArgs& a, hipStream_t st) {
+template <int KSM, int NT, int PRO, int EPI, bool BF>
+static int launch_pw_bf(const PwArgs& a, hipStream_t st) {
     constexpr int WR = 4 / pw_wc(NT);
     constexpr int BM = 32 * WR;
     size_t lds = (size_t)(BM * (2 * KSM + 2) + (PRO == 2 ? 14 * KSM : 0)) * sizeof(float);
     const size_t red = (size_t)WR * 2 * 32 * NT * sizeof(double);
     if (lds < red) lds = red;
     if (lds < (size_t)512 * sizeof(double)) lds = (size_t)512 * sizeof(double);      // PRO_BNBWD column-sum scratch
-    auto kern = pw_nn_kernel<KSM, NT, PRO, EPI>;
+    auto kern = pw_nn_kernel<KSM, NT, PRO, EPI, BF>;
     if (lds > 64 * 1024) CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg, cdiv(a.N, 128)), dim3(256), lds, st, a);
     CDRL_LAUNCH_CHECK();
     return 0;
+}
+
+template <int KSM, int NT, int PRO, int EPI>
+static int launch_pw(const PwArgs& a, hipStream_t st) {
+    return a.bf ? launch_pw_bf<KSM, NT, PRO, EPI, true>(a, st) : launch_pw_bf<KSM, NT, PRO, EPI, false>(a, st);
 }
 
 template <int KSM, int NT>
@@ -478,7 +539,7 @@ static int launch_pw_nt(int nt, int pro, int epi, const PwArgs& a, hipStream_t s
 
 int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, const float* bias, View C, int accumulate, int G,
           int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st,
-          const PwBnBwd* bb, const float* Wp) {
+          const PwBnBwd* bb, const float* Wp, bool wp_bf16) {
     if (!pw_nn_supported(bb ? make_view(const_cast<float*>(bb->y), K) : A, N, K)) {
         set_error("pw_nn: shape K=%d N=%d / alignment not supported", K, N);
         return -1;
@@ -505,6 +566,7 @@ int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, cons
     a.sbk = sbk;
     a.sbn = sbn;
     a.Wp = Wp;
+    a.bf = (wp_bf16 && Wp) ? 1 : 0;
     a.bias = bias;
     a.C = C;
     a.accumulate = accumulate;

@@ -34,9 +34,12 @@ __device__ __forceinline__ void gx3_split(float x, __bf16& h1, __bf16& h2, __bf1
     h3 = (__bf16)(r1 - (float)h2);
 }
 
+// NS = 3: exact three-way split (float32-accurate product).  NS = 1: the bf16-operand compute mode of configuration 3 -- both
+// operands rounded once to bf16 (plane 0 of the split = round-to-nearest-even), one MFMA per K = 16 step.
+template <int NS>
 __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
     constexpr int BM = 128, BK = 32, LDA = BK + 8;          // bf16 elements per LDS row (+16 bytes)
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BM * LDA];
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][BM * LDA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 1, wc = wave >> 1;
     const int lrow = lane & 31, lk = lane >> 5;
@@ -71,7 +74,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
                 h[2][e] = h3;
             }
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(&As[buf][p][(cr + 32 * i) * LDA + ck]) = h[p];
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<bf16x4*>(&As[buf][p][(cr + 32 * i) * LDA + ck]) = h[p];
         }
     };
     f32x16 acc[2][2];
@@ -83,19 +86,19 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     // B fragments of one K = 16 step for this wave's two column tiles: [plane][column tile]
     const int64_t plane = (int64_t)a.KS * 2 * a.NP * 8;
-    auto load_b = [&](int ks, bf16x8 (&bf)[3][2]) {
+    auto load_b = [&](int ks, bf16x8 (&bf)[NS][2]) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NS; ++p)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wc * 64 + j * 32 + lrow;
                 bf[p][j] = *reinterpret_cast<const bf16x8*>(a.Bp + p * plane + (((int64_t)ks * 2 + lk) * a.NP + n) * 8);
             }
     };
-    auto mma = [&](int buf, int kk, const bf16x8 (&bf)[3][2]) {
-        bf16x8 af[3][2];
+    auto mma = [&](int buf, int kk, const bf16x8 (&bf)[NS][2]) {
+        bf16x8 af[NS][2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NS; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 af[p][i] = *reinterpret_cast<const bf16x8*>(&As[buf][p][(wr * 64 + i * 32 + lrow) * LDA + 16 * kk + 8 * lk]);
@@ -104,18 +107,20 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x16 c = acc[i][j];           // smallest terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);
+                if constexpr (NS == 3) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], c, 0, 0, 0);
                 acc[i][j] = c;
             }
     };
     // B fragments (L2) are fetched one K = 16 step ahead; A stages (HBM, ~2 us under load) TWO stages ahead in two register
     // sets -- one stage is only ~1500 matrix-pipe cycles and left every stage waiting on its loads (91 us for 24 us of MFMA)
-    bf16x8 b0[3][2], b1[3][2];
+    bf16x8 b0[NS][2], b1[NS][2];
     u32x4_t raA[4], raB[4];
     load_stage(0, raA);
     load_b(0, b0);
@@ -209,7 +214,7 @@ bool gemm_x3_supported(View A, int K) {
     return K >= 4 && K % 4 == 0 && A.ld % 4 == 0 && A.coff % 4 == 0 && (reinterpret_cast<uintptr_t>(A.p) & 15) == 0;
 }
 
-int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st) {
+int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st, bool bf16_operands) {
     if (M <= 0 || N <= 0) return 0;
     if (!gemm_x3_supported(A, K) || !Bp) {
         set_error("gemm_x3: unsupported alignment K=%d ld=%d coff=%d", K, A.ld, A.coff);
@@ -220,7 +225,8 @@ int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int
         return -1;
     }
     GemmX3Args a{A, reinterpret_cast<const __bf16*>(Bp), bias, C, accumulate, M, N, K, cdiv(K, 16), cdiv(N, 128) * 128};
-    hipLaunchKernelGGL(gemm_x3_kernel, dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
+    if (bf16_operands) hipLaunchKernelGGL(gemm_x3_kernel<1>, dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemm_x3_kernel<3>, dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

@@ -37,7 +37,13 @@ typedef struct cdrl_config {
     int32_t last;                          /* 768                                               */
     int32_t feat, rnn_image, rnn_small, dyn, head; /* 16, 256, 32, 512, 320                     */
     float exp_scale;                       /* 6.0 (core/networks.py:169)                        */
+    int32_t compute;                       /* CDRL_COMPUTE_*: arithmetic of the tower's 1x1 convolutions (default float32) */
 } cdrl_config;
+
+/* CDRL_COMPUTE_BF16_OPERANDS (BASELINE.json configs[2]): the 1x1 convolutions of the image tower (core/architectures.py:130,140,
+ * 170) multiply bf16-rounded operands on v_mfma_f32_32x32x16_bf16 -- forward and backward-data; float32 accumulation, float32
+ * tensors in HBM, float32 BatchNorm statistics, filter gradients, optimizer and master weights. */
+enum { CDRL_COMPUTE_F32 = 0, CDRL_COMPUTE_BF16_OPERANDS = 1 };
 
 enum { CDRL_TRUNK = 0, CDRL_POLICY = 1, CDRL_VALUE = 2, CDRL_OLD_POLICY = 3 };
 
@@ -268,6 +274,18 @@ int cdrl_pwconv_fused_partial_rows(int G, int Mg, int N, int K);
 int cdrl_pwconv_fused(const float* a, int lda, int a_coff, const float* pro_stats, const float* w, int sbk, int sbn,
                       const float* bias, float* c, int ldc, int c_coff, int accumulate, int G, int Mg, int N, int K,
                       int epilogue, const float* epi_y, const float* epi_stats, double* part, void* stream);
+/* Same operator with the weights pre-packed in MFMA fragment order (cdrl_pwconv_pack: cdrl_pwconv_pack_elems(N, K) floats of
+ * space, written once per weight version from B(k, n) = W[k * sbk + n * sbn]).  packed_bf16 = 0: float32 fragments, results
+ * bit-identical to cdrl_pwconv_fused.  packed_bf16 = 1 (cdrl_pwconv_pack(..., bf16 = 1)): the bf16-OPERAND compute mode of
+ * configuration 3 (BASELINE.json configs[2]) -- both MFMA operands are rounded to bf16 (round-to-nearest-even: A after the
+ * prologue on its way into LDS, W at pack time), the product runs as v_mfma_f32_32x32x16_bf16 with float32 accumulation;
+ * tensors in HBM, bias, statistics and epilogues stay float32.  Reference layer: core/architectures.py:130,140. */
+int64_t cdrl_pwconv_pack_elems(int N, int K);
+int cdrl_pwconv_pack(const float* W, int K, int N, int sbk, int sbn, float* packed, int bf16, void* stream);
+int cdrl_pwconv_fused_packed(const float* a, int lda, int a_coff, const float* pro_stats, const float* w, int sbk, int sbn,
+                             const float* bias, float* c, int ldc, int c_coff, int accumulate, int G, int Mg, int N, int K,
+                             int epilogue, const float* epi_y, const float* epi_stats, double* part, const float* w_packed,
+                             int packed_bf16, void* stream);
 /* Backward of [Conv2D(k=1) -> BatchNormalization(training, per time slice) (+ReLU6) (+channel_shuffle on the store)]
  * (core/architectures.py:130-131,140-145) without materialising the gradient w.r.t. the conv output: the BN-backward
  * "apply" runs as the operand prologue of the two GEMMs.  dout: gradient w.r.t. the BN output (view ld/coff, read through
@@ -280,6 +298,14 @@ int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffl
                        const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
                        int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
                        int dx_coff, int accumulate, float* dw, float* db, void* workspace, void* stream);
+/* ... with the backward-data operand W^T pre-packed: cdrl_pwconv_pack(W, N, K, 1, N, wt_packed, bf16) packs
+ * B(k = n_out, n = k_in) = W[k_in * N + n_out]; packed_bf16 = 1 runs the backward-data GEMM in the bf16-operand mode
+ * (dz rounded to bf16 after the BatchNorm-backward prologue); the filter gradient stays float32. */
+int cdrl_pwconv_bn_bwd_packed(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
+                              const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
+                              int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
+                              int dx_coff, int accumulate, float* dw, float* db, void* workspace, const float* wt_packed,
+                              int packed_bf16, void* stream);
 /* Fused depthwise block of the ShuffleNet unit: [BatchNormalization + ReLU6 of the previous 1x1 conv, applied on
  * load] -> DepthwiseConv2D(3, stride, 'same') -> statistics of the BatchNormalization that follows
  * (core/architectures.py:130-139; per-time-slice BN :44-57).  Whole frames are staged in LDS; the normalised

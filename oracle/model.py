@@ -176,9 +176,39 @@ def _unfold(x, T):
     return x.reshape((T, x.shape[0] // T) + tuple(x.shape[1:]))
 
 
+def _bf16_round(t):
+    """Round-to-nearest-even to bf16, kept in t's dtype (float64 inputs pass through float32 first, as the engine's operands
+    are float32 numbers)."""
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _PwBf16Operands(torch.autograd.Function):
+    """1x1 convolution in the engine's bf16-OPERAND compute mode (include/cdrl.h CDRL_COMPUTE_BF16_OPERANDS; BASELINE.json
+    configs[2]): forward y = bf(x) bf(W) + b, backward-data dx = bf(dy) bf(W)^T, both accumulated in the working dtype; the
+    filter and bias gradients use the unrounded x and dy (the engine keeps those products in float32)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):           # x (N,Cin,H,W), w (Cin,Cout), b (Cout)
+        ctx.save_for_backward(x, w)
+        return torch.einsum('nchw,cd->ndhw', _bf16_round(x), _bf16_round(w)) + b.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = torch.einsum('ndhw,cd->nchw', _bf16_round(dy), _bf16_round(w))
+        dw = torch.einsum('nchw,ndhw->cd', x, dy)
+        return dx, dw, dy.sum(dim=(0, 2, 3))
+
+
+PW_BF16_OPERANDS = False        # set by the bf16-mode parity tests (tests/test_gpu_bf16.py); module state like DEC
+
+
 def conv_pw(x, p, prefix):
     """Conv2D(k=1) (core/architectures.py:130,134,140,170); kernel (1,1,Cin,Cout)."""
     T = x.shape[0]
+    if PW_BF16_OPERANDS:
+        w2 = p[f'{prefix}.w']
+        return _unfold(_PwBf16Operands.apply(_fold(x), w2.reshape(w2.shape[2], w2.shape[3]), p[f'{prefix}.b']), T)
     w = p[f'{prefix}.w'].permute(3, 2, 0, 1)
     return _unfold(F.conv2d(_fold(x), w, p[f'{prefix}.b']), T)
 

@@ -24,7 +24,7 @@ def is_zero_gradient(name: str) -> bool:
     return is_degenerate_bias(name) or name.endswith('.bn2.beta') or name.endswith('.sc_bn1.beta') or name == 'dyn.bn.beta'
 
 
-def make_pair(B, H, W, seed=0, device='cuda:0', A=2, hp=None, with64=False, **cfg):
+def make_pair(B, H, W, seed=0, device='cuda:0', A=2, hp=None, with64=False, compute='f32', **cfg):
     ocfg = NetConfig(H=H, W=W, A=A, **cfg)
     tp = OM.init_params(trunk_spec(ocfg), seed + 1)
     pp = OM.init_params(policy_spec(ocfg), seed + 2)
@@ -33,7 +33,7 @@ def make_pair(B, H, W, seed=0, device='cuda:0', A=2, hp=None, with64=False, **cf
     oracle = OM.OracleLearner(ocfg, tp, pp, vp, hp)
     if with64:
         oracle.o64 = OM.OracleLearner(ocfg, tp, pp, vp, hp, dtype=torch.float64)
-    eng = LearnerEngine(B, device=device, H=H, W=W, A=A, **cfg)
+    eng = LearnerEngine(B, device=device, H=H, W=W, A=A, compute=compute, **cfg)
     eng.load_params('trunk', tp)
     eng.load_params('policy', pp)
     eng.load_params('value', vp)
