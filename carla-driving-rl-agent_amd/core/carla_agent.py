@@ -91,11 +91,12 @@ class CARLAgent(PPOAgent):
                             dynamics=dict(units=512))
 
     def __init__(self, *args, aug_intensity=1.0, clip_norm=(1.0, 1.0, 1.0), name='carla', load_full=True, eta=0.0,
-                 dynamics_lr=1e-3, update_dynamics=True, delta=0.0, aux=1.0, resample_actions=True, **kwargs):
+                 dynamics_lr=1e-3, update_dynamics=True, delta=0.0, aux=1.0, resample_actions=True, compute='f32', **kwargs):
         """`resample_actions=True` (default, the reference's behaviour): the policy loss is evaluated on a fresh Beta sample of
         the NEW policy with pathwise gradients, as PolicyNetwork.call does (reference core/networks.py:96-110, SURVEY.md F8);
         the sample is drawn on the device.  `False` is the textbook-PPO variant on the stored rollout actions
-        (rl/agents/ppo.py:322-325 semantics; deterministic, same cost)."""
+        (rl/agents/ppo.py:322-325 semantics; deterministic, same cost).
+        `compute='bf16'`: the engine's bf16-operand mode (not in the reference; CARLANetwork docstring)."""
         assert aug_intensity >= 0.0
         if not update_dynamics:
             raise NotImplementedError('update_dynamics=False (frozen trunk) is not implemented natively')
@@ -104,6 +105,7 @@ class CARLAgent(PPOAgent):
         network_spec.setdefault('control_policy', self.DEFAULT_CONTROL)
         network_spec.setdefault('control_value', self.DEFAULT_CONTROL_VALUE)
         network_spec.setdefault('dynamics', self.DEFAULT_DYNAMICS)
+        network_spec.setdefault('compute', compute)
         self.should_update_dynamics = update_dynamics
         self.dynamics_path = os.path.join(kwargs.get('weights_dir', 'weights'), name, 'dynamics_model')
         self.load_full = load_full

@@ -57,7 +57,9 @@ class PolicyNetwork:
 
 
 class CARLANetwork(Network):
-    def __init__(self, agent, control_policy: dict, control_value: dict, dynamics: dict, update_dynamics=False):
+    def __init__(self, agent, control_policy: dict, control_value: dict, dynamics: dict, update_dynamics=False, compute='f32'):
+        """compute: 'f32' (the reference's arithmetic) or 'bf16' -- bf16 MFMA operands in the tower's 1x1 convolutions
+        (include/cdrl.h CDRL_COMPUTE_BF16_OPERANDS, BASELINE.json configs[2]; see DESIGN.md section 7 for what it costs numerically)."""
         super().__init__(agent)
         env = agent.env
         T = env.time_horizon
@@ -80,7 +82,7 @@ class CARLANetwork(Network):
                         stem=img['stem'], stage_c=img['stage_c'], stage_n=img['stage_n'], last=img['last'],
                         feat=self.dynamics_spec['features']['road']['units'], rnn_image=self.dynamics_spec['rnn']['image'],
                         rnn_small=self.dynamics_spec['rnn']['road'], dyn=self.dynamics_spec['units'],
-                        head=p_branch['units'], exp_scale=self.exp_scale)
+                        head=p_branch['units'], exp_scale=self.exp_scale, compute=compute)
         self.device = agent.device
         self.engine = LearnerEngine(agent.batch_size, device=self.device, **self.cfg)          # learner minibatches
         self._rollouts = {}                # number of environments E -> inference engine over the same arenas

@@ -56,3 +56,20 @@ def test_update_guard_small_memory(capsys):
     agent.learn(episodes=1, timesteps=5, close=False)       # 5 < 32: update() must refuse and reset the info buffer
     assert '[Not updated] memory too small!' in capsys.readouterr().out
     assert agent.env.info_buffer == dict(speed=[], similarity=[])
+
+
+def test_learn_cycle_bf16_compute_mode(tmp_path):
+    """CARLAgent(compute='bf16') -- the engine's bf16-operand mode behind the reference's agent API: a learn cycle with a ragged
+    last minibatch (17 timesteps, minibatch 8 -> the shared-arena remainder engine inherits the mode) trains finite weights."""
+    env = _env()
+    agent = CARLAgent(env, batch_size=8, log_mode=None, seed=3, skip_data=1, shuffle=True, policy_lr=3e-4, value_lr=3e-4,
+                      dynamics_lr=3e-4, aug_intensity=0.0, weights_dir=str(tmp_path), name='t16', optimization_steps=(1, 1),
+                      compute='bf16')
+    assert agent.network.engine.cfg.compute == 1 and agent.network.rollout.cfg.compute == 1
+    before = agent.network.engine.params.clone()
+    agent.learn(episodes=1, timesteps=17, save_every='end', close=False)
+    after = agent.network.engine.params
+    assert torch.isfinite(after).all() and not torch.equal(before, after)
+    assert np.isfinite(agent.network.engine.metrics('policy')['loss'])
+    with pytest.raises(Exception):
+        CARLAgent(_env(), batch_size=8, log_mode=None, compute='fp8')
