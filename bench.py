@@ -49,15 +49,20 @@ def pmc_mfma(ms_per_step):
     """MFMA figures of the committed PMC run (profiles/*_pmc_mfma.json, tools/pmc_mfma.sh): utilisation of the float32 GEMM
     kernels and the float32 matrix-pipe rate over the update-step against the 157.3 TFLOP/s peak."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_mfma.json')))
+    import re
+    # profiles/rNN_pmc_mfma.json of the benchmark workload only (the configuration-3 runs are named r02_c3_*)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_mfma.json')) if re.fullmatch(r'r\d+_pmc_mfma\.json', os.path.basename(f)))
     if not files:
         return None
     d = json.load(open(files[-1]))
     utils = [k['mfma_util'] for k in d['kernels'] if k.get('mfma_util')]
     flops = d.get('mfma_flops_issued_per_update_step')
+    flops16 = d.get('mfma_bf16_flops_issued_per_update_step')      # split-precision kernels: 6 bf16 products per float32 product
     return dict(source=os.path.relpath(files[-1], ROOT), mfma_util_all_kernel_time=d.get('mfma_util_all_kernels'),
                 mfma_util_gemm_kernels=[min(utils), max(utils)] if utils else None, f32_flops_issued_per_update_step=flops,
-                f32_mfma_tflops=round(flops / (ms_per_step * 1e-3) / 1e12, 2) if flops else None, f32_mfma_peak_tflops=157.3)
+                f32_mfma_tflops=round(flops / (ms_per_step * 1e-3) / 1e12, 2) if flops else None, f32_mfma_peak_tflops=157.3,
+                bf16_flops_issued_per_update_step=flops16,
+                bf16_mfma_tflops=round(flops16 / (ms_per_step * 1e-3) / 1e12, 2) if flops16 else None, bf16_mfma_peak_tflops=2500.0)
 
 
 def dominant_kernel(B, T, H, W):
@@ -69,7 +74,9 @@ def dominant_kernel(B, T, H, W):
     import re
     if (B, T, H, W) != (256, 4, 90, 120):
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_kernel_trace_summary.md')), key=os.path.getmtime)
+    # profiles/rNN_kernel_trace_summary.md = the trace of THIS workload at the round's final commit (other traces carry a tag)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_kernel_trace_summary.md'))
+                   if re.fullmatch(r'r\d+_kernel_trace_summary\.md', os.path.basename(f)))
     if not files:
         return None
     for line in open(files[-1]):
@@ -81,9 +88,10 @@ def dominant_kernel(B, T, H, W):
         return None
     out = dict(source=os.path.relpath(files[-1], ROOT), kernel=name, avg_us=avg_us)
     if name.startswith('tn_direct_tr_kernel<4'):
-        # pw1 / pw2 filter gradients of the stage-1 (8 units: M = 49152, K = N = 116) and stage-2 (3 stride-1 units: M = 12288,
-        # K = N = 232 runs in two 128-column blocks) units: 12 launches per pass
-        shapes = [(49152, 116, 116)] * 8 + [(12288, 232, 232)] * 4
+        # pw1 filter gradients (A = the unit's input, D = dz of BN1 recomputed in the operand prologue) of the stage-1 units
+        # (K = N = 116: 7 stride-1 units at M = B*T*48 rows and the stride-2 unit, whose pw1 runs at the INPUT resolution: B*T*180 rows)
+        # and of the stage-2 units (K = N = 232, two 128-column blocks: 3 stride-1 units at B*T*12 rows + the stride-2 unit at B*T*48)
+        shapes = [(184320, 116, 116)] + [(49152, 116, 116)] * 7 + [(49152, 232, 232)] + [(12288, 232, 232)] * 3
         by = sum(4.0 * m_ * (k + n) for m_, k, n in shapes) / len(shapes)
         out.update(algorithmic_bytes_per_launch=by, achieved_GBs=round(by / (avg_us * 1e-6) / 1e9, 1),
                    frac=round(by / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
