@@ -618,7 +618,7 @@ static int pwconv_bn_bwd_impl(const float* dout, int dout_ld, int dout_coff, int
                    st, &bb, wt_packed, packed_bf16 != 0));
     CDRL_TRY(reduce_partials(part2, G * nbp, N, N, db, 0, st));
     TnBnBwd tb{y, stats, coef, shuffle_ctot, act};
-    return gemm_tn(vx, vd, dw, G * Mg, N, K, tn, 0, st, G, x_pro_stats, &tb);
+    return gemm_tn(vx, vd, dw, G * Mg, N, K, tn, 0, st, G, x_pro_stats, &tb, wt_packed && packed_bf16 != 0);
 }
 
 int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,

@@ -87,8 +87,9 @@ struct TnBnBwd {
 };
 bool gemm_tn_dpro_supported(int N);
 int64_t gemm_tn_part_elems(int M, int N, int K, int G = 1);
+// bf16_operands: both operands rounded to bf16 AFTER their prologues, v_mfma_f32_32x32x16_bf16 over 16-row steps (configuration 3)
 int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G = 1,
-            const float* pro_stats = nullptr, const TnBnBwd* dpro = nullptr);
+            const float* pro_stats = nullptr, const TnBnBwd* dpro = nullptr, bool bf16_operands = false);
 
 // ---------------------------------------------------------------- fused pointwise conv (gemm_pw.hip)
 // Persistent skinny GEMM for K, N <= 128: C[m,n] (+)= sum_k pro(A[m,k]) W(k,n) + bias[n] over G groups of Mg rows.

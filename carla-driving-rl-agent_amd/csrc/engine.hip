@@ -457,9 +457,9 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     const float* wt = (wt_env && !pack_env && fuse.bwd_pw) ? pw_transposed(prefix, w.p, Cin, Cout) : nullptr;
     const float* wb = wt ? wt : w.p;                    // backward-data operand B(k = cout, n = cin)
     const int wb_sk = wt ? Cin : 1, wb_sn = wt ? 1 : Cout;
-    // compute mode 1 (configuration 3): every 1x1 convolution of the tower multiplies bf16-rounded operands (forward and
-    // backward-data; the filter gradients stay float32) -- the fused kernels in their BF variant, the plain wide ones through
-    // gemm_x3's single-plane form
+    // compute mode 1 (configuration 3): every 1x1 convolution of the tower multiplies bf16-rounded operands -- forward,
+    // backward-data and filter gradient: the fused kernels in their BF variant, the plain wide ones through gemm_x3's
+    // single-plane form, the filter gradients through tn_direct's BF variant
     const bool bfc = cfg_.compute == 1;
     // forward on the bf16 matrix pipe (exact three-way operand split, gemm_pw_x3.hip) where the shape allows it
     static const bool x3_env = !(getenv("CDRL_PW_X3") && atoi(getenv("CDRL_PW_X3")) == 0);
@@ -502,7 +502,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             const View dz = fuse.bb_dz.p ? fuse.bb_dz : make_view(dys_[slot_], Cout);
             hipStream_t side = fork_side(st);
             TnBnBwd tb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act};
-            CDRL_TRY(gemm_tn(in, dz, w.g, rows, Cout, Cin, tns_[slot_], 0, side, G, fuse.pro_stats, &tb));
+            CDRL_TRY(gemm_tn(in, dz, w.g, rows, Cout, Cin, tns_[slot_], 0, side, G, fuse.pro_stats, &tb, bfc));
             CDRL_TRY(done_side(side));
             PwBnBwd pb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act, part2s_[slot_]};
             CDRL_TRY(pw_nn(dz, nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
@@ -515,7 +515,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         // side stream: bias gradient (column sums of dy, reduced per block by bn_bwd_apply) + filter gradient
         hipStream_t side = fork_side(st);
         CDRL_TRY(reduce_partials(part2s_[slot_], bn_after.G * bn_after.nb, Cout, Cout, b.g, 0, side));
-        CDRL_TRY(gemm_tn(in, make_view(dy, Cout), w.g, rows, Cout, Cin, tns_[slot_], 0, side, tn_groups, fuse.pro_stats));
+        CDRL_TRY(gemm_tn(in, make_view(dy, Cout), w.g, rows, Cout, Cin, tns_[slot_], 0, side, tn_groups, fuse.pro_stats, nullptr, bfc));
         CDRL_TRY(done_side(side));
         // main stream: the critical path to the previous layer
         if (din.p) {

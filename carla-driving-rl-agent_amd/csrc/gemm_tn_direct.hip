@@ -17,6 +17,10 @@
 //   A <- scale[g][k]*A + shift[g][k]                    (BatchNorm apply of the layer that produced A's raw values)
 //   D <- k1*(dz - k2 - xhat*k3), dz = D (shuffle-gathered, ReLU6-masked), xhat from the BN's raw input y
 // (both need the row splits aligned to the G BatchNorm groups, which the plan guarantees).
+// BF variants (bf16-operand compute mode, configuration 3): the contraction runs over the ROWS, so one v_mfma_f32_32x32x16_bf16
+// step consumes 16 rows: lane (column = lane%32, h = lane/32) holds rows m0 + 8h .. m0 + 8h + 7 of its column -- the same
+// 2-rows-per-load-instruction access pattern with the second half-wave 8 rows (instead of 1 row) further down, the same
+// operand prologues in float32, then one round-to-nearest-even pack of 8 values per operand and 1/16 of the matrix-pipe time.
 #include <stdlib.h>
 
 #include "cdrl_kernels.h"
@@ -24,6 +28,7 @@
 namespace cdrl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct TnDirectArgs {
     View A, D;
@@ -39,8 +44,10 @@ struct TnDirectArgs {
 };
 
 
-template <int NJW, bool APRO, bool DPRO, int U>
+template <int NJW, bool APRO, bool DPRO, int U, bool BF>
 __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
+    static_assert(!BF || U == 8, "BF: one batch = one K = 16 MFMA step (8 rows per half-wave)");
+    constexpr int LHR = BF ? 8 : 1;             // rows between the two half-waves of a load
     extern __shared__ float tnd_red[];          // RS2 == 2: [4 waves][NJW][16][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = (tid >> 6) & 3, half = tid >> 8;
@@ -116,12 +123,12 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D.p), 0, (int)((int64_t)a.M * a.D.ld * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(DPRO ? a.db.y : a.D.p), 0, (int)((int64_t)a.M * (DPRO ? N : a.D.ld) * 4), 0x00020000);
-    const uint32_t voA = kon ? (uint32_t)(lh * a.A.ld + a.A.coff + k) * 4u : OOR;
+    const uint32_t voA = kon ? (uint32_t)(LHR * lh * a.A.ld + a.A.coff + k) * 4u : OOR;
     uint32_t voD[NJW], voY[NJW];
 #pragma unroll
     for (int j = 0; j < NJW; ++j) {
-        voD[j] = non[j] ? (uint32_t)(lh * a.D.ld + dcol[j]) * 4u : OOR;
-        voY[j] = non[j] ? (uint32_t)(lh * N + ncol[j]) * 4u : OOR;
+        voD[j] = non[j] ? (uint32_t)(LHR * lh * a.D.ld + dcol[j]) * 4u : OOR;
+        voY[j] = non[j] ? (uint32_t)(LHR * lh * N + ncol[j]) * 4u : OOR;
     }
     const uint32_t sA = (uint32_t)a.A.ld * 4u, sD = (uint32_t)a.D.ld * 4u, sY = (uint32_t)N * 4u;      // row strides in bytes
     float av0[U], dv0[U][NJW], yv0[DPRO ? U : 1][DPRO ? NJW : 1];
@@ -132,9 +139,9 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
     auto load_batch = [&](int m0, bool tail, float* av, float (*dv)[NJW], float (*yv)[DPRO ? NJW : 1]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t r = (uint32_t)(m0 + 2 * u);
+            const uint32_t r = (uint32_t)(BF ? m0 + u : m0 + 2 * u);
             uint32_t msk = 0u;
-            if (tail) msk = (m0 + 2 * u + lh) < me ? 0u : OOR;
+            if (tail) msk = (BF ? m0 + u + 8 * lh : m0 + 2 * u + lh) < me ? 0u : OOR;
             av[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, voA | msk, r * sA, 0));
 #pragma unroll
             for (int j = 0; j < NJW; ++j) {
@@ -151,11 +158,13 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
     // `if (row and column exist)` every batch started with s_waitcnt vmcnt(0): the loads of the NEXT batch, already in
     // flight, were waited for as well.
     auto mma_batch = [&](int m0, bool tail, const float* av, const float (*dv)[NJW], const float (*yv)[DPRO ? NJW : 1]) {
+        bf16x8 xb, db[BF ? NJW : 1];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float keep = (!tail || (m0 + 2 * u + lh) < me) ? 1.0f : 0.0f;
+            const float keep = (!tail || (BF ? m0 + u + 8 * lh : m0 + 2 * u + lh) < me) ? 1.0f : 0.0f;
             float x = av[u];
             if (APRO) x = fmaf(asc, x, ash);          // rows past the end: x = ash, but their d is 0
+            if (BF) xb[u & 7] = (__bf16)x;
 #pragma unroll
             for (int j = 0; j < NJW; ++j) {
                 float d = dv[u][j];
@@ -168,8 +177,13 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
                     const float xh = (y - qm[j]) * qi[j];
                     d = keep * (qk1[j] * (d - qk2[j] - xh * qk3[j]));
                 }
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, d, acc[j], 0, 0, 0);
+                if (BF) db[BF ? j : 0][u & 7] = (__bf16)d;
+                else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, d, acc[j], 0, 0, 0);
             }
+        }
+        if (BF) {
+#pragma unroll
+            for (int j = 0; j < NJW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, db[BF ? j : 0], acc[j], 0, 0, 0);
         }
     };
     // steady state: two register sets, the loads of batch i+1 are in flight while the MFMAs of batch i run
@@ -228,8 +242,10 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
 // BatchNorm-backward transform of a D element (2 loads + ~10 VALU) is computed once per workgroup instead of once per
 // k-tile wave (4x), and a row pair costs NJW + 2 loads instead of 2*NJW + 1.  The cheap side (A, at most one fma) is the
 // one that is re-read by the 4 waves.  Same partial layout and reduction as tn_direct_kernel.
-template <int NJW, bool APRO, bool DPRO, int U>
+template <int NJW, bool APRO, bool DPRO, int U, bool BF>
 __global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
+    static_assert(!BF || U == 8, "BF: one batch = one K = 16 MFMA step (8 rows per half-wave)");
+    constexpr int LHR = BF ? 8 : 1;
     extern __shared__ float tnd_red[];          // RS2 == 2: [4 waves][NJW][16][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = (tid >> 6) & 3, half = tid >> 8;
@@ -300,20 +316,20 @@ __global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D.p), 0, (int)((int64_t)a.M * a.D.ld * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(DPRO ? a.db.y : a.D.p), 0, (int)((int64_t)a.M * (DPRO ? N : a.D.ld) * 4), 0x00020000);
-    const uint32_t voD = non ? (uint32_t)(lh * a.D.ld + dcol) * 4u : OOR;
-    const uint32_t voY = non ? (uint32_t)(lh * N + n) * 4u : OOR;
+    const uint32_t voD = non ? (uint32_t)(LHR * lh * a.D.ld + dcol) * 4u : OOR;
+    const uint32_t voY = non ? (uint32_t)(LHR * lh * N + n) * 4u : OOR;
     uint32_t voA[NJW];
 #pragma unroll
-    for (int j = 0; j < NJW; ++j) voA[j] = kon[j] ? (uint32_t)(lh * a.A.ld + a.A.coff + kcol[j]) * 4u : OOR;
+    for (int j = 0; j < NJW; ++j) voA[j] = kon[j] ? (uint32_t)(LHR * lh * a.A.ld + a.A.coff + kcol[j]) * 4u : OOR;
     const uint32_t sA = (uint32_t)a.A.ld * 4u, sD = (uint32_t)a.D.ld * 4u, sY = (uint32_t)N * 4u;
     const int mb = __builtin_amdgcn_readfirstlane((int)mbeg), me = __builtin_amdgcn_readfirstlane((int)mend);
     float av0[U][NJW], dv0[U], yv0[U], av1[U][NJW], dv1[U], yv1[U];
     auto load_batch = [&](int m0, bool tail, float (*av)[NJW], float* dv, float* yv) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t r = (uint32_t)(m0 + 2 * u);
+            const uint32_t r = (uint32_t)(BF ? m0 + u : m0 + 2 * u);
             uint32_t msk = 0u;
-            if (tail) msk = (m0 + 2 * u + lh) < me ? 0u : OOR;
+            if (tail) msk = (BF ? m0 + u + 8 * lh : m0 + 2 * u + lh) < me ? 0u : OOR;
             dv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rD, voD | msk, r * sD, 0));
             if (DPRO) yv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rY, voY | msk, r * sY, 0));
 #pragma unroll
@@ -322,9 +338,10 @@ __global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     };
     auto mma_batch = [&](int m0, bool tail, const float (*av)[NJW], const float* dv, const float* yv) {
+        bf16x8 db, xb[BF ? NJW : 1];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float keep = (!tail || (m0 + 2 * u + lh) < me) ? 1.0f : 0.0f;      // branch-free (see tn_direct_kernel)
+            const float keep = (!tail || (BF ? m0 + u + 8 * lh : m0 + 2 * u + lh) < me) ? 1.0f : 0.0f;      // branch-free (see tn_direct_kernel)
             float d = dv[u];
             if (DPRO) {
                 const float y = yv[u];
@@ -335,12 +352,18 @@ __global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
                 const float xh = (y - qm) * qi;
                 d = keep * (qk1 * (d - qk2 - xh * qk3));
             }
+            if (BF) db[u & 7] = (__bf16)d;
 #pragma unroll
             for (int j = 0; j < NJW; ++j) {
                 float x = av[u][j];
                 if (APRO) x = fmaf(asc[j], x, ash[j]);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, d, acc[j], 0, 0, 0);
+                if (BF) xb[BF ? j : 0][u & 7] = (__bf16)x;
+                else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, d, acc[j], 0, 0, 0);
             }
+        }
+        if (BF) {
+#pragma unroll
+            for (int j = 0; j < NJW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[BF ? j : 0], db, acc[j], 0, 0, 0);
         }
     };
     int m0 = mb;
@@ -443,33 +466,37 @@ int64_t gemm_tn_part_elems(int M, int N, int K, int G) {
 
 bool gemm_tn_dpro_supported(int) { return true; }
 
-template <int NJW, int U>
+template <int NJW, int U, bool BF>
 static void launch_tnd_u(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a) {
     const dim3 blk(256 * a.RS2);
     const size_t lds = a.RS2 == 2 ? (size_t)4 * NJW * 16 * 64 * sizeof(float) : 0;     // <= 64 KB
     if (a.TR) {         // (planned only with a D prologue)
-        if (apro) hipLaunchKernelGGL((tn_direct_tr_kernel<NJW, true, true, U>), grid, blk, lds, st, a);
-        else hipLaunchKernelGGL((tn_direct_tr_kernel<NJW, false, true, U>), grid, blk, lds, st, a);
+        if (apro) hipLaunchKernelGGL((tn_direct_tr_kernel<NJW, true, true, U, BF>), grid, blk, lds, st, a);
+        else hipLaunchKernelGGL((tn_direct_tr_kernel<NJW, false, true, U, BF>), grid, blk, lds, st, a);
         return;
     }
-    if (apro && dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, true, U>), grid, blk, lds, st, a);
-    else if (apro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, false, U>), grid, blk, lds, st, a);
-    else if (dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, false, true, U>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((tn_direct_kernel<NJW, false, false, U>), grid, blk, lds, st, a);
+    if (apro && dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, true, U, BF>), grid, blk, lds, st, a);
+    else if (apro) hipLaunchKernelGGL((tn_direct_kernel<NJW, true, false, U, BF>), grid, blk, lds, st, a);
+    else if (dpro) hipLaunchKernelGGL((tn_direct_kernel<NJW, false, true, U, BF>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((tn_direct_kernel<NJW, false, false, U, BF>), grid, blk, lds, st, a);
 }
 
 template <int NJW>
-static void launch_tnd(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a) {
+static void launch_tnd(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a, bool bf) {
+    if (bf) {           // bf16 operands: a batch is one 16-row MFMA step
+        launch_tnd_u<NJW, 8, true>(apro, dpro, grid, st, a);
+        return;
+    }
     static const int u = getenv("CDRL_TN_U") ? atoi(getenv("CDRL_TN_U")) : 4;
     static const int ud = getenv("CDRL_TN_UD") ? atoi(getenv("CDRL_TN_UD")) : 8;      // D prologue (transposed mapping: 200 VGPRs at U = 8; 19.6 -> 19.2 ms/update-step over U = 4)
     const int uu = dpro ? ud : u;
-    if (uu >= 16 && !dpro) launch_tnd_u<NJW, 16>(apro, dpro, grid, st, a);
-    else if (uu >= 8) launch_tnd_u<NJW, 8>(apro, dpro, grid, st, a);
-    else launch_tnd_u<NJW, 4>(apro, dpro, grid, st, a);
+    if (uu >= 16 && !dpro) launch_tnd_u<NJW, 16, false>(apro, dpro, grid, st, a);
+    else if (uu >= 8) launch_tnd_u<NJW, 8, false>(apro, dpro, grid, st, a);
+    else launch_tnd_u<NJW, 4, false>(apro, dpro, grid, st, a);
 }
 
 int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G,
-            const float* pro_stats, const TnBnBwd* dpro) {
+            const float* pro_stats, const TnBnBwd* dpro, bool bf16_operands) {
     if (G < 1 || M % G != 0) {
         set_error("gemm_tn: M=%d is not a multiple of G=%d", M, G);
         return -1;
@@ -504,9 +531,9 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     if (dpro) a.db = *dpro;
     dim3 grid(p.nsplit, p.gy, p.gz);
     switch (p.NJW) {
-        case 1: launch_tnd<1>(pro_stats != nullptr, dpro != nullptr, grid, st, a); break;
-        case 2: launch_tnd<2>(pro_stats != nullptr, dpro != nullptr, grid, st, a); break;
-        default: launch_tnd<4>(pro_stats != nullptr, dpro != nullptr, grid, st, a); break;
+        case 1: launch_tnd<1>(pro_stats != nullptr, dpro != nullptr, grid, st, a, bf16_operands); break;
+        case 2: launch_tnd<2>(pro_stats != nullptr, dpro != nullptr, grid, st, a, bf16_operands); break;
+        default: launch_tnd<4>(pro_stats != nullptr, dpro != nullptr, grid, st, a, bf16_operands); break;
     }
     CDRL_LAUNCH_CHECK();
     const int64_t n = (int64_t)K * N;

@@ -41,8 +41,8 @@ typedef struct cdrl_config {
 } cdrl_config;
 
 /* CDRL_COMPUTE_BF16_OPERANDS (BASELINE.json configs[2]): the 1x1 convolutions of the image tower (core/architectures.py:130,140,
- * 170) multiply bf16-rounded operands on v_mfma_f32_32x32x16_bf16 -- forward and backward-data; float32 accumulation, float32
- * tensors in HBM, float32 BatchNorm statistics, filter gradients, optimizer and master weights. */
+ * 170) multiply bf16-rounded operands on v_mfma_f32_32x32x16_bf16 -- forward, backward-data and filter gradient; float32
+ * accumulation, float32 tensors in HBM, float32 BatchNorm statistics, bias gradients, optimizer and master weights. */
 enum { CDRL_COMPUTE_F32 = 0, CDRL_COMPUTE_BF16_OPERANDS = 1 };
 
 enum { CDRL_TRUNK = 0, CDRL_POLICY = 1, CDRL_VALUE = 2, CDRL_OLD_POLICY = 3 };
@@ -299,8 +299,9 @@ int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffl
                        int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
                        int dx_coff, int accumulate, float* dw, float* db, void* workspace, void* stream);
 /* ... with the backward-data operand W^T pre-packed: cdrl_pwconv_pack(W, N, K, 1, N, wt_packed, bf16) packs
- * B(k = n_out, n = k_in) = W[k_in * N + n_out]; packed_bf16 = 1 runs the backward-data GEMM in the bf16-operand mode
- * (dz rounded to bf16 after the BatchNorm-backward prologue); the filter gradient stays float32. */
+ * B(k = n_out, n = k_in) = W[k_in * N + n_out]; packed_bf16 = 1 runs the backward-data GEMM AND the filter-gradient GEMM in the
+ * bf16-operand mode (dz rounded to bf16 after the BatchNorm-backward prologue, x after its BatchNorm-apply prologue); db,
+ * dgamma, dbeta are float32 reductions. */
 int cdrl_pwconv_bn_bwd_packed(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
                               const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
                               int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,

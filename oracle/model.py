@@ -184,8 +184,8 @@ def _bf16_round(t):
 
 class _PwBf16Operands(torch.autograd.Function):
     """1x1 convolution in the engine's bf16-OPERAND compute mode (include/cdrl.h CDRL_COMPUTE_BF16_OPERANDS; BASELINE.json
-    configs[2]): forward y = bf(x) bf(W) + b, backward-data dx = bf(dy) bf(W)^T, both accumulated in the working dtype; the
-    filter and bias gradients use the unrounded x and dy (the engine keeps those products in float32)."""
+    configs[2]): forward y = bf(x) bf(W) + b, backward-data dx = bf(dy) bf(W)^T, filter gradient dW = bf(x)^T bf(dy), all
+    accumulated in the working dtype; the bias gradient is the plain sum of dy (a float32 reduction in the engine)."""
 
     @staticmethod
     def forward(ctx, x, w, b):           # x (N,Cin,H,W), w (Cin,Cout), b (Cout)
@@ -196,7 +196,7 @@ class _PwBf16Operands(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = torch.einsum('ndhw,cd->nchw', _bf16_round(dy), _bf16_round(w))
-        dw = torch.einsum('nchw,ndhw->cd', x, dy)
+        dw = torch.einsum('nchw,ndhw->cd', _bf16_round(x), _bf16_round(dy))
         return dx, dw, dy.sum(dim=(0, 2, 3))
 
 

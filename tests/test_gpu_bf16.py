@@ -79,7 +79,7 @@ def test_pwconv_bf16(lib, G, Mg, K, N, pro, packed):
 # ------------------------------------------------------------------------------------------
 # bf16-OPERAND compute mode of the float32 engine kernels (float32 tensors, bf16 MFMA operands): cdrl_pwconv_fused_packed /
 # cdrl_pwconv_bn_bwd_packed with packed_bf16 = 1.  Forward: against float64 on the operands the MFMA sees (A after the float32
-# prologue, rounded to bf16 like torch's .bfloat16(); W rounded to bf16) -> float32-accumulation accuracy (1e-5).  Backward-data:
+# prologue, rounded to bf16 like torch's .bfloat16(); W rounded to bf16) -> float32-accumulation accuracy (1e-5).  Backward-data and filter gradient:
 # against float64 autograd of the UNROUNDED layer -> the stated bf16-operand tolerance 6e-3 (and > 1e-4: the bf16 pipe was used).
 # ------------------------------------------------------------------------------------------
 def _rel(a, b):
@@ -206,7 +206,8 @@ def test_pwconv_bn_bwd_packed(lib, G, Mg, K, N, relu, shuffle, xpro, bf16):
             assert np.array_equal(u, v)
         return
     assert _rel(dg, p['b.gamma'].grad.numpy()) < 2e-5 and _rel(dbt, p['b.beta'].grad.numpy()) < 2e-5      # float32 reductions
-    assert _rel(dw, wt.grad.numpy()) < 3e-5                                                              # float32 filter gradient
+    ew = _rel(dw, wt.grad.numpy())
+    assert 1e-5 < ew < 6e-3, ew                                  # filter gradient from bf16 operands as well (sum over G*Mg rows)
     ref_dxin = (xt.grad.reshape(M, K).numpy() / xst[2].astype(np.float64).repeat(Mg, axis=0)) if xpro else xt.grad.reshape(M, K).numpy()
     e = _rel(dx[:, 2:2 + K] - 2.0, ref_dxin)
     assert 1e-4 < e < 6e-3, e
