@@ -62,7 +62,8 @@ constexpr int pw_wc(int nt) { return nt == 3 ? 1 : nt; }
 // and epilogues, but both MFMA operands are rounded to bf16 (round-to-nearest-even) -- A on its way into LDS (after the
 // prologue), W when it is packed -- and the product runs as v_mfma_f32_32x32x16_bf16: 1/8 of the float32 matrix-pipe time and
 // half the W registers / LDS tile.
-template <int KSM, int NT, int PRO, int EPI, bool BF>
+// ACC (instantiated for EPI == 0 only): C += product with the old values of the tile prefetched before the MFMA chain.
+template <int KSM, int NT, int PRO, int EPI, bool BF, bool ACC>
 __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a) {
     constexpr int WC = pw_wc(NT);                   // wave columns
     constexpr int WR = 4 / WC;                      // wave rows
@@ -322,6 +323,23 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
                 }
             }
         }
+        // accumulate (the stride-2 units' first conv adds its input gradient to the shortcut branch's): the old values of the
+        // output tile are fetched BEFORE the MFMA chain as well -- read in the epilogue they were 16 dependent scalar round trips
+        // per tile with nothing to hide behind: 124 vs 56 us for the 24-channel backward-data conv of the first unit (isolated)
+        constexpr bool ACC_PF = ACC && NTW == 1;      // (three column tiles per wave: 48 more VGPRs would spill -> plain read-modify-write)
+        float cold[ACC_PF ? NTW : 1][ACC_PF ? 16 : 1];
+        if (ACC_PF) {
+            const int64_t mc0 = mbeg + (int64_t)t * BM + wr * 32;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int n = nb0 + (wc + j * WC) * 32 + lrow;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = mc0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    cold[ACC_PF ? j : 0][ACC_PF ? r : 0] = (n < N && m < mend) ? a.C.p[m * a.C.ld + a.C.coff + n] : 0.0f;
+                }
+            }
+        }
         if (BF) {
             const __bf16* arow = reinterpret_cast<const __bf16*>(As) + (wr * 32 + lrow) * LDB + 8 * lk;
 #pragma unroll
@@ -361,7 +379,8 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
                         s1[j] += (double)v;
                         s2[j] += (double)v * (double)xh;
                     }
-                    if (a.accumulate) v += *c;
+                    if (ACC_PF) v += cold[ACC_PF ? j : 0][ACC_PF ? r : 0];
+                    else if (a.accumulate) v += *c;
                     *c = v;
                 }
             }
@@ -490,7 +509,7 @@ PwPlan pw_nn_plan(int G, int Mg, int N, int K) {
     return p;
 }
 
-template <int KSM, int NT, int PRO, int EPI, bool BF>
+template <int KSM, int NT, int PRO, int EPI, bool BF, bool ACC>
 static int launch_pw_bf(const PwArgs& a, hipStream_t st) {
     constexpr int WR = 4 / pw_wc(NT);
     constexpr int BM = 32 * WR;
@@ -498,7 +517,7 @@ static int launch_pw_bf(const PwArgs& a, hipStream_t st) {
     const size_t red = (size_t)WR * 2 * 32 * NT * sizeof(double);
     if (lds < red) lds = red;
     if (lds < (size_t)512 * sizeof(double)) lds = (size_t)512 * sizeof(double);      // PRO_BNBWD column-sum scratch
-    auto kern = pw_nn_kernel<KSM, NT, PRO, EPI, BF>;
+    auto kern = pw_nn_kernel<KSM, NT, PRO, EPI, BF, ACC>;
     if (lds > 64 * 1024) CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg, cdiv(a.N, 128)), dim3(256), lds, st, a);
     CDRL_LAUNCH_CHECK();
@@ -507,7 +526,10 @@ static int launch_pw_bf(const PwArgs& a, hipStream_t st) {
 
 template <int KSM, int NT, int PRO, int EPI>
 static int launch_pw(const PwArgs& a, hipStream_t st) {
-    return a.bf ? launch_pw_bf<KSM, NT, PRO, EPI, true>(a, st) : launch_pw_bf<KSM, NT, PRO, EPI, false>(a, st);
+    if constexpr (EPI == 0) {
+        if (a.accumulate) return a.bf ? launch_pw_bf<KSM, NT, PRO, EPI, true, true>(a, st) : launch_pw_bf<KSM, NT, PRO, EPI, false, true>(a, st);
+    }
+    return a.bf ? launch_pw_bf<KSM, NT, PRO, EPI, true, false>(a, st) : launch_pw_bf<KSM, NT, PRO, EPI, false, false>(a, st);
 }
 
 template <int KSM, int NT>
