@@ -17,15 +17,20 @@ DEV = 'cuda:0'
 S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for (px, K, N) in [(180, 58, 58), (48, 116, 116), (12, 232, 232)]:
+SHAPES = [(165, 58, 58), (48, 116, 116), (12, 232, 232)]
+if len(sys.argv) > 2:
+    SHAPES = [SHAPES[int(a)] for a in sys.argv[2:]]
+for (px, K, N) in SHAPES:
     G, Mg = 4, B * px
     M = G * Mg
     ctot = 2 * N
-    x = torch.randn(M, K, device=DEV)
+    R = 5                                            # rotating operand sets: cold reads
+    xs = [torch.randn(M, K, device=DEV) for _ in range(R)]
     w = torch.randn(K, N, device=DEV) / K ** 0.5
-    y = torch.randn(M, N, device=DEV)
-    dout = torch.randn(M, ctot, device=DEV)
-    xs = torch.rand(4, G, K, device=DEV) + 0.5
+    ys = [torch.randn(M, N, device=DEV) for _ in range(R)]
+    douts = [torch.randn(M, ctot, device=DEV) for _ in range(R)]
+    y = ys[0]
+    xst = torch.rand(4, G, K, device=DEV) + 0.5
     stats = torch.zeros(4 * G * N, device=DEV)
     tmp = torch.zeros(M, N, device=DEV)
     ws0 = torch.zeros(G * 256 * 2 * N, dtype=torch.float64, device=DEV)
@@ -34,10 +39,10 @@ for (px, K, N) in [(180, 58, 58), (48, 116, 116), (12, 232, 232)]:
     _lib.check(lib.cdrl_bn_train_fwd(P(y), G, Mg, N, P(gam), P(bet), P(mm), P(mv), 1, 1, P(tmp), N, 0, 0, P(stats), P(ws0), S()))
     ws = torch.zeros(int(lib.cdrl_pwconv_bn_bwd_workspace_bytes(G, Mg, N, K)), dtype=torch.uint8, device=DEV)
     dg, dbt, coef = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV), torch.zeros(3 * G * N, device=DEV)
-    dx = torch.zeros(M, K, device=DEV)
+    dxs = [torch.zeros(M, K, device=DEV) for _ in range(R)]
     dw, db = torch.zeros(K, N, device=DEV), torch.zeros(N, device=DEV)
-    for _ in range(6):
-        _lib.check(lib.cdrl_pwconv_bn_bwd(P(dout), ctot, N, ctot, 1, P(y), P(stats), P(x), K, 0, P(xs), P(w), G, Mg, N, K, P(dg), P(dbt),
-                                          P(coef), P(dx), K, 0, 0, P(dw), P(db), P(ws), S()))
+    for it in range(2 * R):
+        _lib.check(lib.cdrl_pwconv_bn_bwd(P(douts[it % R]), ctot, N, ctot, 1, P(ys[it % R]), P(stats), P(xs[it % R]), K, 0, P(xst), P(w), G, Mg,
+                                          N, K, P(dg), P(dbt), P(coef), P(dxs[it % R]), K, 0, 0, P(dw), P(db), P(ws), S()))
     torch.cuda.synchronize()
 print('done')
