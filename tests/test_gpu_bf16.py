@@ -320,3 +320,23 @@ def test_bf16_operand_training_tracks_float32():
         assert np.abs(h16[:, j] - h32[:, j]).max() <= 0.15 * scale, (j, h16[:, j], h32[:, j])
     assert h32[-1, 1] < h32[0, 1] and h16[-1, 1] < h16[0, 1]          # the value loss goes down on both
     assert h16[-1, 0] < 0.2 * h16[0, 0]                                # and the bf16 run minimises the policy objective as well
+
+
+def test_bf16_operand_mode_is_deterministic():
+    """Same inputs, same weights -> bit-identical losses and gradient arenas (fixed-order reductions in every BF kernel)."""
+    from tests.util import make_pair, make_batches, to_dev
+    B, H, W = 16, 90, 120
+    pol, val = make_batches(B, H, W, seed=11)
+    dpol, dval = to_dev(pol), to_dev(val)
+    outs = []
+    for _ in range(2):
+        _, e = make_pair(B, H, W, seed=11, compute='bf16')
+        e.policy_forward_backward(dpol)
+        lp = e.metrics('policy')['loss']
+        gp = e.grads.clone()
+        e.policy_apply()
+        e.value_forward_backward(dval)
+        outs.append((lp, e.metrics('value')['loss'], gp, e.grads.clone(), e.params.clone()))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    for a, b in zip(outs[0][2:], outs[1][2:]):
+        assert torch.equal(a, b)
