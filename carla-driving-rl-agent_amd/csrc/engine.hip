@@ -1387,12 +1387,15 @@ int Learner::bind(const Buffers& b) {
         // host-bound.  CDRL_GRAPH=1 enables it (parity suite passes in both modes).
         const char* genv = getenv("CDRL_GRAPH");
         graphs_enabled_ = genv && atoi(genv) != 0;
-        // the main stream carries the dependent chain (critical path): highest priority; the side stream
-        // (filter / bias gradients, small-modality nets) fills idle CUs at the lowest priority so that its wide
-        // reductions do not delay the short main-stream kernels.  CDRL_STREAM_PRIO=0 -> equal priorities.
+        // All three streams at the default priority.  Giving the main stream (the dependent chain) the highest and the side /
+        // aux streams the lowest priority (CDRL_STREAM_PRIO=1) changes nothing for the update-step (15.98 vs 16.01 ms) but costs
+        // rollout inference 4.4 ms per call: whenever the high-priority queue sits on a barrier that waits for a kernel of a
+        // low-priority queue (the small-modality nets on the aux stream: at 1..128 environments the main stream reaches the join
+        // first), the command processor comes back to the low-priority queue only after milliseconds -- predict() 5.5 ms instead
+        // of 1.1 ms at E = 1 (tools/bench_rollout_rows.py).
         int prio_lo = 0, prio_hi = 0;
         const char* penv = getenv("CDRL_STREAM_PRIO");
-        if (!(penv && atoi(penv) == 0)) CDRL_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        if (penv && atoi(penv) == 1) CDRL_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         CDRL_HIP(hipStreamCreateWithPriority(&main_, hipStreamNonBlocking, prio_hi));
         CDRL_HIP(hipEventCreateWithFlags(&ev_in_, hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_out_, hipEventDisableTiming));

@@ -48,7 +48,9 @@ def test_sp_norm_and_gae_properties():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,spike', [(1, False), (33, False), (256, True), (512, False), (3000, True)])
+# (2047 / 2048 / 2049 / 10000: the kernel stages the recurrences through LDS in chunks of 2048 steps)
+@pytest.mark.parametrize('n,spike', [(1, False), (33, False), (256, True), (512, False), (2047, True), (2048, False), (2049, True),
+                                     (3000, True), (10000, False)])
 def test_gae_kernel_matches_oracle(n, spike):
     import torch
     from carla_driving_rl_agent_amd.engine import gae_returns
