@@ -144,6 +144,27 @@ def main():
     out['f4_tf_checkpoint'] = dict(what='TensorFlow checkpoint-V2 (index SSTable + data shard, masked CRC-32C) of dynamics / policy / value '
                                         'written from and read back into the device arenas', bytes=size, save_ms=round(t_save * 1e3, 1),
                                    load_ms=round(t_load * 1e3, 1))
+    # ---- the whole collect / update cycle through the reference's entry point (configs[0]: FakeCARLAEnvironment defaults)
+    import contextlib
+    import io
+    env1 = FakeCARLAEnvironment(time_horizon=4, seed=3)
+    ag = CARLAgent(env1, batch_size=32, log_mode=None, seed=3, skip_data=1, aug_intensity=0.0, optimization_steps=(1, 1))
+    times = []
+    for rep in range(3):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            t0 = time.perf_counter()
+            ag.learn(episodes=1, timesteps=256, close=False)
+            torch.cuda.synchronize()
+            t_cycle = time.perf_counter() - t0
+        upd = [float(l.split()[2][:-1]) for l in buf.getvalue().splitlines() if l.startswith('Update took')]
+        times.append((t_cycle, upd[0] if upd else None))
+    t_cycle, t_upd = min(times)
+    out['c1_agent_cycle'] = dict(what='CARLAgent.learn(episodes=1, timesteps=256) on FakeCARLAEnvironment defaults (90x360x3, A=3, minibatch 32): '
+                                      '256 x (observation H2D, predict, action D2H, env.step, memory append) + GAE + update() = 8 policy + 8 value '
+                                      'minibatch passes (explicit index lists, device gathers); best of 3',
+                                 cycle_s=round(t_cycle, 3), update_s=t_upd, rollout_ms_per_env_step=round((t_cycle - (t_upd or 0.0)) / 256 * 1e3, 3),
+                                 update_ms_per_minibatch_pass=round((t_upd or 0.0) / 16 * 1e3, 3))
     print(json.dumps(out))
 
 
