@@ -4,6 +4,7 @@ PyTorch is used for device memory (parameter arenas, Adam state, workspace), str
 `torch.distributed` only; every arithmetic step of the learner runs in libcdrl_hip.so.
 """
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -184,10 +185,15 @@ class LearnerEngine:
         minibatches that live in fresh tensors every time (tf.data-style gathers) go through fixed
         staging buffers (one D2D copy, ~0.05 ms for a 256x4x90x120x3 minibatch)."""
         store = self._keep_stage.setdefault(slot, {})
+        # hipGraph replay is opt-in (CDRL_GRAPH=1; eager launches are faster on this stack, DESIGN.md section 3): without it the
+        # entry points take any contiguous device tensor, and the staging copy (a 133 MB D2D copy per B = 256 pass) is skipped
+        direct = os.environ.get('CDRL_GRAPH', '0') in ('', '0')
 
         def put(key, t):
             if t is None:
                 return None
+            if direct and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+                return t
             buf = store.get(key)
             if buf is None or buf.shape != t.shape:
                 buf = torch.empty_like(t, memory_format=torch.contiguous_format)
