@@ -191,6 +191,32 @@ int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* g
     return 0;
 }
 
+// Inference-mode statistics blocks of MANY BatchNorm layers in one launch (rollout inference, reference core/networks.py:181-193:
+// every layer normalises with its moving statistics): the per-layer inference branch of bn_finalize above was a third of the
+// launches of a predict() call, each doing a few hundred flops.  Same arithmetic as that branch.
+__global__ void __launch_bounds__(64) bn_inference_stats_many_kernel(const BnInfEntry* __restrict__ tab) {
+    const BnInfEntry e = tab[blockIdx.y];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= e.C) return;
+    const int GC = e.G * e.C;
+    const float gm = e.gamma[c], bt = e.beta[c];
+    const float mean = e.mov_mean[c];
+    const float invstd = (float)(1.0 / sqrt((double)e.mov_var[c] + (double)BN_EPS));
+    for (int g = 0; g < e.G; ++g) {
+        e.stats[0 * GC + g * e.C + c] = mean;
+        e.stats[1 * GC + g * e.C + c] = invstd;
+        e.stats[2 * GC + g * e.C + c] = gm * invstd;
+        e.stats[3 * GC + g * e.C + c] = bt - mean * gm * invstd;
+    }
+}
+
+int bn_inference_stats_many(const BnInfEntry* tab_dev, int n, int max_c, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(bn_inference_stats_many_kernel, dim3(cdiv(max_c, 64), n), dim3(64), 0, st, tab_dev);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Single-group BatchNorm over a few hundred rows (the control branches' and the trunk's dense BNs: B x 320..512) as ONE
 // kernel per direction: statistics + finalize + apply (forward), sums + coefficients + apply (backward).  As three

@@ -14,6 +14,13 @@ int colstats(View y, int G, int Mg, int C, double* part, hipStream_t st);
 int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* gamma, const float* beta,
                 float* mov_mean, float* mov_var, int bessel, int training, float* stats /*[4][G][C]*/,
                 hipStream_t st);
+// One launch for the inference-mode statistics blocks of many BatchNorm layers (the training == 0 branch of bn_finalize, batched)
+struct BnInfEntry {
+    const float *gamma, *beta, *mov_mean, *mov_var;
+    float* stats;           // [4][G][C]
+    int G, C;
+};
+int bn_inference_stats_many(const BnInfEntry* tab_dev, int n, int max_c, hipStream_t st);
 // dst = act(scale*y + shift); optional de-interleave shuffle on the destination channel index.
 // stats == nullptr -> plain copy.
 // pass_src / pass_dst: optional second tensor with the same C channels copied through the same shuffle store (the

@@ -360,6 +360,12 @@ private:
     // at the start of every trunk forward: the per-workgroup weight prologue of the persistent GEMM becomes KSM/4 16-byte loads
     std::string build_err_;                 // first configuration error met while the op lists were built (reported by create)
     void build_fail(const char* fmt, ...);
+    // inference-mode BatchNorm statistics of the trunk (tower + trunk tail, main and aux streams): one batched launch at the
+    // start of an inference forward instead of one per layer (bn_inference_stats_many)
+    std::vector<BnInfEntry> h_bninf_;
+    BnInfEntry* d_bninf_ = nullptr;
+    int bninf_max_c_ = 0;
+    void note_bn_inference(const float* gamma, const float* beta, const float* mm, const float* mv, float* stats, int G, int C);
     std::vector<PwPack> h_pack_;
     PwPack* d_pack_ = nullptr;
     float* pw_packed(const float* w, int K, int N, int sbk, int sbn, bool bf16 = false);

@@ -368,7 +368,13 @@ const void* Learner::gemm_x3_packed(const float* w, int K, int N, int sbk, int s
     return wp;
 }
 
+void Learner::note_bn_inference(const float* gamma, const float* beta, const float* mm, const float* mv, float* stats, int G, int C) {
+    h_bninf_.push_back(BnInfEntry{gamma, beta, mm, mv, stats, G, C});
+    if (C > bninf_max_c_) bninf_max_c_ = C;
+}
+
 int Learner::run_trunk_fwd(hipStream_t st, int training) {
+    if (!training) CDRL_TRY(bn_inference_stats_many(d_bninf_, (int)h_bninf_.size(), bninf_max_c_, st));
     CDRL_TRY(gemm_x3_pack_many(d_gpack_, (int)h_gpack_.size(), st));
     CDRL_TRY(pw_pack_many(d_pack_, (int)h_pack_.size(), st));       // this pass's weights in fragment order (fwd + bwd-data)
     CDRL_TRY(pw_x3_pack_many(d_pack3_, (int)h_pack3_.size(), st));
@@ -412,6 +418,9 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     std::shared_ptr<bool> fused = rec.reduce_fused;
     const int bes = bessel ? 1 : 0;
     Scratch* sc = build_scr_;
+    // trunk layers: the inference-mode statistics block comes from the batched launch at the start of the forward
+    const bool inf_batched = model == M_TRUNK;
+    if (inf_batched) note_bn_inference(gamma.p, beta.p, mm.p, mv.p, stats, G, C);
     // single-group BatchNorm over a few hundred rows (dense BNs of the trunk tail and the control branches): one launch per
     // direction instead of three
     static const bool small_env = !(getenv("CDRL_BN_SMALL") && atoi(getenv("CDRL_BN_SMALL")) == 0);
@@ -421,7 +430,7 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     if (small) {
         op.fwd = [=](hipStream_t st, int training) -> int {
             if (training) return bn_small_fwd(x, Mg, C, gamma.p, beta.p, mm.p, mv.p, stats, out, st);
-            CDRL_TRY(bn_finalize(sc->part, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
+            if (!inf_batched) CDRL_TRY(bn_finalize(sc->part, nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
             return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st);
         };
         op.bwd = [=](hipStream_t st) -> int { return bn_small_bwd(dout, x, Mg, C, stats, gamma.g, beta.g, coef, dx, st); };
@@ -430,7 +439,8 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     }
     op.fwd = [=](hipStream_t st, int training) -> int {
         if (training && !stats_nb) CDRL_TRY(colstats(x, G, Mg, C, sc->part, st));
-        CDRL_TRY(bn_finalize(sc->part, stats_nb ? stats_nb : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
+        if (training || !inf_batched)
+            CDRL_TRY(bn_finalize(sc->part, stats_nb ? stats_nb : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
         if (pass.fsrc.p) return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st, &pass.fsrc, &pass.fdst);
         return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st);
     };
@@ -575,6 +585,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
         mm1 = param(M_TRUNK, n1 + ".moving_mean", {C}, false);
         mv1 = param(M_TRUNK, n1 + ".moving_var", {C}, false);
         stats1 = stats1_ext ? stats1_ext : alloc((size_t)4 * G * C);
+        note_bn_inference(g1.p, b1.p, mm1.p, mv1.p, stats1, G, C);
         coef1 = coef1_ext ? coef1_ext : alloc((size_t)3 * G * C);
         note_named(n1 + ".stats", stats1, (size_t)4 * G * C * sizeof(float));
         note_named(n1 + ".x", x, (size_t)N * H * W * C * sizeof(float));
@@ -587,6 +598,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
     PRef mm2 = param(M_TRUNK, n2 + ".moving_mean", {C}, false);
     PRef mv2 = param(M_TRUNK, n2 + ".moving_var", {C}, false);
     float* stats2 = alloc((size_t)4 * G * C);
+    note_bn_inference(g2.p, b2.p, mm2.p, mv2.p, stats2, G, C);
     float* coef2 = alloc((size_t)3 * G * C);
     const int nb_in = vcol_geom(Mi, C).nb, nb_out = vcol_geom(Mo, C).nb;
     const int nbf = dwf_geom(B, G, H, W, C, stride).nb;
@@ -598,7 +610,8 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
     if (pre) {      // BN1: statistics only in the forward; backward = finalize of the sums the depthwise op produced
         Op op;
         op.fwd = [=](hipStream_t st, int training) -> int {
-            if (training && !pre_stats_nb) CDRL_TRY(colstats(xv, G, Mi, C, sc->part, st));
+            if (!training) return 0;                            // inference: statistics block from the batched launch
+            if (!pre_stats_nb) CDRL_TRY(colstats(xv, G, Mi, C, sc->part, st));
             return bn_finalize(sc->part, pre_stats_nb ? pre_stats_nb : nb_in, G, Mi, C, g1.p, b1.p, mm1.p, mv1.p, 1, training,
                                stats1, st);
         };
@@ -631,7 +644,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
     {               // BN2: finalize + apply in the forward; backward = sums + coefficients only (applied by the dw op)
         Op op;
         op.fwd = [=](hipStream_t st, int training) -> int {
-            CDRL_TRY(bn_finalize(sc->part, nbf, G, Mo, C, g2.p, b2.p, mm2.p, mv2.p, 1, training, stats2, st));
+            if (training) CDRL_TRY(bn_finalize(sc->part, nbf, G, Mo, C, g2.p, b2.p, mm2.p, mv2.p, 1, training, stats2, st));
             if (!post_apply) return 0;
             return bn_apply(y2v, G, Mo, C, stats2, ACT_NONE, out, 0, st);
         };
@@ -914,6 +927,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             PRef mm = param(M_TRUNK, "img.stem.bn.moving_mean", {C}, false);
             PRef mv = param(M_TRUNK, "img.stem.bn.moving_var", {C}, false);
             float* stats = stem_stats;
+            note_bn_inference(gamma.p, beta.p, mm.p, mv.p, stats, G, C);
             float* coef = stem_coef;
             const int nb = vcol_geom(Mg, C).nb;
             const int nb_pool = vcol_geom(B * Hp * Wp, C).nb;
@@ -922,8 +936,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             Op bn;
             bn.fwd = [=](hipStream_t st, int training) -> int {
                 if (training && !stem_fstats) CDRL_TRY(colstats(yv, G, Mg, C, scr_main_.part, st));
-                CDRL_TRY(bn_finalize(scr_main_.part, stem_fstats ? nb_stem : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, 1, training, stats,
-                                     st));
+                if (training)       // (inference: statistics block from the batched launch)
+                    CDRL_TRY(bn_finalize(scr_main_.part, stem_fstats ? nb_stem : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, 1, training, stats,
+                                         st));
                 return maxpool_bn_fwd(y.p, stats, G, B, pool.p, argmax, N, Hs, Ws, C, st);
             };
             bn.bwd = [=](hipStream_t st) -> int {
@@ -1262,7 +1277,10 @@ void Learner::build(bool dry) {
     h_pack_.clear();
     h_pack3_.clear();
     h_gpack_.clear();
+    h_bninf_.clear();
+    bninf_max_c_ = 0;
     build_trunk(trunk_ops_);
+    d_bninf_ = reinterpret_cast<BnInfEntry*>(alloc((h_bninf_.size() + 1) * sizeof(BnInfEntry) / sizeof(float) + 4));
     d_pack_ = reinterpret_cast<PwPack*>(alloc((h_pack_.size() + 1) * sizeof(PwPack) / sizeof(float) + 4));
     d_pack3_ = reinterpret_cast<PwX3Pack*>(alloc((h_pack3_.size() + 1) * sizeof(PwX3Pack) / sizeof(float) + 4));
     d_gpack_ = reinterpret_cast<GemmX3Pack*>(alloc((h_gpack_.size() + 1) * sizeof(GemmX3Pack) / sizeof(float) + 4));
@@ -1343,6 +1361,8 @@ int Learner::upload_seg_tables() {
         CDRL_HIP(hipMemcpy(d_pwt_, h_pwt_.data(), h_pwt_.size() * sizeof(PwTranspose), hipMemcpyHostToDevice));
     if (!h_pack_.empty())
         CDRL_HIP(hipMemcpy(d_pack_, h_pack_.data(), h_pack_.size() * sizeof(PwPack), hipMemcpyHostToDevice));
+    if (!h_bninf_.empty())
+        CDRL_HIP(hipMemcpy(d_bninf_, h_bninf_.data(), h_bninf_.size() * sizeof(BnInfEntry), hipMemcpyHostToDevice));
     if (!h_pack3_.empty())
         CDRL_HIP(hipMemcpy(d_pack3_, h_pack3_.data(), h_pack3_.size() * sizeof(PwX3Pack), hipMemcpyHostToDevice));
     if (!h_gpack_.empty())
