@@ -503,9 +503,14 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
     }
 }
 
+// (one runtime call per kernel instantiation and size, not one per launch: `allowed` is per template instantiation)
 template <class K>
 static int allow_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024) CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    static size_t allowed = 64 * 1024;
+    if (bytes > allowed) {
+        CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        allowed = bytes;
+    }
     return 0;
 }
 

@@ -518,7 +518,11 @@ static int launch_pw_bf(const PwArgs& a, hipStream_t st) {
     if (lds < red) lds = red;
     if (lds < (size_t)512 * sizeof(double)) lds = (size_t)512 * sizeof(double);      // PRO_BNBWD column-sum scratch
     auto kern = pw_nn_kernel<KSM, NT, PRO, EPI, BF, ACC>;
-    if (lds > 64 * 1024) CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t allowed = 64 * 1024;          // per instantiation: one runtime call per kernel and size, not one per launch
+    if (lds > allowed) {
+        CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed = lds;
+    }
     hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg, cdiv(a.N, 128)), dim3(256), lds, st, a);
     CDRL_LAUNCH_CHECK();
     return 0;
