@@ -72,6 +72,10 @@ class LearnerEngine:
         if device is None:
             return
         dev = torch.device(device)
+        if dev.type == 'cuda' and dev.index is not None and dev.index != torch.cuda.current_device():
+            # one process per GPU: the engine creates its HIP streams on the CURRENT device and every entry point runs there
+            raise ValueError(f'LearnerEngine(device={device!r}): call torch.cuda.set_device({dev.index}) first '
+                             f'(current device is {torch.cuda.current_device()})')
         if share_with is not None:
             self.params, self.grads = share_with.params, share_with.grads
             self.adam_m, self.adam_v = share_with.adam_m, share_with.adam_v
