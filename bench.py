@@ -250,6 +250,38 @@ def run_cpu_baseline_child(B_sample, T, H, W, threads, timeout=420):
         return dict(value=None, unit='update-steps/s', cores=threads, kind='port', sample=f'timed out after {timeout}s')
 
 
+class cpu_rollout_rows:
+    """CPU stand-ins of the rollout-side rows for tools/bench_rollout_rows.py: the oracle -- the
+    reference's algorithm restated in PyTorch / numpy -- on the host.  Part of the benchmark's baseline leg (like cpu_baseline
+    above), never of the product path."""
+
+    def __init__(self, H=90, W=120, A=2, threads=16):
+        import torch as _t
+        from oracle import model as OM
+        from oracle.spec import NetConfig, trunk_spec, policy_spec, value_spec
+        from carla_driving_rl_agent_amd import synthetic
+        _t.set_num_threads(threads)
+        cfg = NetConfig(H=H, W=W, A=A)
+        self._oracle = OM.OracleLearner(cfg, OM.init_params(trunk_spec(cfg), 1), OM.init_params(policy_spec(cfg), 2),
+                                        OM.init_params(value_spec(cfg), 3), dict(synthetic.DEFAULT_HP))
+        self._synthetic = synthetic
+
+    def predict(self, states):
+        return self._oracle.predict(states)
+
+    def beta(self, alpha, beta):
+        import numpy as _np
+        return self._synthetic.beta_sample_with_jacobian(alpha, beta, _np.random.default_rng(0))
+
+    def augment(self, stack, plan):
+        from oracle import augment as OA
+        return OA.augment(stack, plan)
+
+    def gae(self, rewards, values_be, gamma, lambda_):
+        from oracle import gae as OG
+        return OG.compute_returns(rewards, gamma), OG.compute_advantages(rewards, values_be, gamma, lambda_, 2.0)
+
+
 def spawn_ranks(n, argv):
     """`bench.py --gpus N` started as a plain process: start the N ranks as CHILDREN through torch.distributed.run (one
     process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, relay their output and
@@ -278,6 +310,9 @@ def main():
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help="bf16: configuration 3's compute mode (bf16 MFMA operands in the tower's 1x1 convolutions, float32 storage "
                          "and accumulation); quote it with --batch 1024")
+    ap.add_argument('--rollout-rows', action='store_true',
+                    help='measure the rollout-side rows (predict for E environments, Beta sampling, augmentation, GAE, checkpoint I/O, '
+                         'the agent-level collect / update cycle) with their CPU stand-ins and print that JSON instead of the benchmark line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=256)
     ap.add_argument('--cpu-threads', type=int, default=min(16, os.cpu_count() or 1),
@@ -289,6 +324,11 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.cpu_sample_batch, 4, args.height, args.width, args.cpu_threads)))
+        return
+    if args.rollout_rows:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import bench_rollout_rows
+        bench_rollout_rows.main(cpu=cpu_rollout_rows())
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))

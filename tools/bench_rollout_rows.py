@@ -9,7 +9,9 @@ its CPU stand-in timed on the host beside it (the oracle = the reference's algor
   (f)4  TensorFlow checkpoint-V2 writer + reader round trip of the three models (host code)
 
 Prints one JSON object; tools/final_round.sh stores it as profiles/<round>_rollout_rows.json.
-Usage (GPU box): python3 tools/bench_rollout_rows.py"""
+The CPU stand-ins are the oracle and therefore live in bench.py's baseline leg (`cpu_rollout_rows`, the only place besides tests/
+and smoke() that may execute oracle/): `python3 bench.py --rollout-rows` runs this file with them, `python3
+tools/bench_rollout_rows.py` alone reports the device side only."""
 import ctypes as C
 import json
 import os
@@ -58,27 +60,23 @@ def cpu_time(fn, iters, warm=1):
     return (time.perf_counter() - t0) / iters
 
 
-def main():
-    torch.set_num_threads(16)
+def main(cpu=None):
+    """cpu: optional object with predict(states) / beta(alpha, beta) / augment(stack, plan) / gae(rewards, values_be, gamma, lambda_)
+    callables that run the CPU stand-in once (bench.py::cpu_rollout_rows)."""
     out = {}
     H, W, T = 90, 120, 4
     env = FakeCARLAEnvironment(image_shape=(H, W, 3), time_horizon=T, num_waypoints=5, vehicle_features=4, num_actions=2, seed=1)
     agent = CARLAgent(env, batch_size=32, log_mode=None, seed=1, aug_intensity=0.0)
     net = agent.network
     # ---- (f)1 rollout inference
-    from oracle import model as OM
-    from oracle.spec import NetConfig, trunk_spec, policy_spec, value_spec
-    ocfg = NetConfig(H=H, W=W, A=2)
-    oracle = OM.OracleLearner(ocfg, OM.init_params(trunk_spec(ocfg), 1), OM.init_params(policy_spec(ocfg), 2),
-                              OM.init_params(value_spec(ocfg), 3), dict(synthetic.DEFAULT_HP))
     rows = []
     for E in (1, 8, 32, 128):
         r = synthetic.make_rollout(E, T=T, H=H, W=W, seed=E)
         st = {k: torch.as_tensor(v).to(DEV) for k, v in r['states'].items()}
         t_dev, t_wall = dev_time(lambda: net.predict(st), 30 if E <= 32 else 10)
         entry = dict(envs=E, device_ms=round(t_dev * 1e3, 3), wall_ms=round(t_wall * 1e3, 3), env_steps_per_s=round(E / t_wall, 1))
-        if E <= 32:
-            t_cpu = cpu_time(lambda: oracle.predict(r['states']), 3 if E <= 8 else 1)
+        if E <= 32 and cpu is not None:
+            t_cpu = cpu_time(lambda: cpu.predict(r['states']), 3 if E <= 8 else 1)
             entry.update(cpu_oracle_ms=round(t_cpu * 1e3, 1), cpu_env_steps_per_s=round(E / t_cpu, 2))
         rows.append(entry)
     out['f1_rollout_inference'] = dict(what='CARLANetwork.predict: inference forward (moving statistics, old_policy + value heads) + '
@@ -95,17 +93,15 @@ def main():
         u, da, db = (torch.empty(n, 2, device=DEV) for _ in range(3))
         t_dev, _ = dev_time(lambda: _lib.check(lib.cdrl_beta_sample(P(a), P(b), n, 2, 2, 7, 11, P(u), P(da), P(db), S())), 20)
         entry = dict(samples=2 * n, device_us=round(t_dev * 1e6, 1), samples_per_s=round(2 * n / t_dev))
-        if n <= 65536:
-            rng = np.random.default_rng(0)
+        if n <= 65536 and cpu is not None:
             an, bn = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
-            t_cpu = cpu_time(lambda: synthetic.beta_sample_with_jacobian(an, bn, rng), 1, warm=0)
+            t_cpu = cpu_time(lambda: cpu.beta(an, bn), 1, warm=0)
             entry.update(cpu_numpy_scipy_ms=round(t_cpu * 1e3, 1), cpu_samples_per_s=round(2 * n / t_cpu))
         rows.append(entry)
     out['f2_beta_sampling'] = dict(what='cdrl_beta_sample: Beta(alpha, beta) sample with implicit-reparameterisation gradients, Philox counter stream',
                                    rows=rows, cpu='synthetic.beta_sample_with_jacobian (numpy + scipy.special), 1 thread')
     # ---- (f)3 augmentation
     from carla_driving_rl_agent_amd.rl.augmentations import Augmenter, empty_plan
-    from oracle import augment as OA
     w3 = list(np.random.default_rng(9).normal(1.0, 0.25, 27).astype(np.float32)) + [0.0] * 48
     plan = empty_plan(seed=0x1234, offset=5)
     plan.update(jitter=1, brightness=0.05, contrast=1.2, saturation=1.3, hue=0.07, blur_size=3, blur_kernel=w3, salt_pepper=1, gauss_noise=1,
@@ -115,25 +111,26 @@ def main():
         x = torch.rand(T, h, w, 3, device=DEV)
         aug = Augmenter(DEV)
         t_dev, t_wall = dev_time(lambda: aug(x, plan), 30)
-        xn = x.cpu().numpy()
-        t_cpu = cpu_time(lambda: OA.augment(xn, plan), 2, warm=0)
-        rows.append(dict(stack=[T, h, w, 3], device_us=round(t_dev * 1e6, 1), wall_us=round(t_wall * 1e6, 1),
-                         stacks_per_s=round(1.0 / t_wall, 1), cpu_numpy_ms=round(t_cpu * 1e3, 1)))
+        entry = dict(stack=[T, h, w, 3], device_us=round(t_dev * 1e6, 1), wall_us=round(t_wall * 1e6, 1), stacks_per_s=round(1.0 / t_wall, 1))
+        if cpu is not None:
+            xn = x.cpu().numpy()
+            entry['cpu_numpy_ms'] = round(cpu_time(lambda: cpu.augment(xn, plan), 2, warm=0) * 1e3, 1)
+        rows.append(entry)
     out['f3_augmentation'] = dict(what="cdrl_augment_images, every stage of the reference's pipeline switched on (colour jitter, blur, "
                                        'salt-and-pepper, Gaussian noise, normalisation, cutout, coarse dropout) on one observation stack',
                                   rows=rows, cpu='oracle/augment.py (numpy), 1 thread')
     # ---- A13 returns + GAE
     from carla_driving_rl_agent_amd.engine import gae_returns
-    from oracle import gae as OG
     rows = []
     for n in (256, 4096, 65536):
         r = torch.randn(n + 1, device=DEV)
         v = torch.rand(n + 1, 2, device=DEV)
         t_dev, t_wall = dev_time(lambda: gae_returns(r, v, 0.9999, 0.999, 2.0), 30)
-        rn, vn = r.cpu().numpy().astype(np.float64), v.cpu().numpy().astype(np.float64)
-        rn32, vn32 = rn.astype(np.float32), vn.astype(np.float32)
-        t_cpu = cpu_time(lambda: (OG.compute_returns(rn32, 0.9999), OG.compute_advantages(rn32, vn32, 0.9999, 0.999, 2.0)), 3)
-        rows.append(dict(timesteps=n, device_us=round(t_dev * 1e6, 1), wall_us=round(t_wall * 1e6, 1), cpu_us=round(t_cpu * 1e6, 1)))
+        entry = dict(timesteps=n, device_us=round(t_dev * 1e6, 1), wall_us=round(t_wall * 1e6, 1))
+        if cpu is not None:
+            rn32, vn32 = r.cpu().numpy().astype(np.float32), v.cpu().numpy().astype(np.float32)
+            entry['cpu_us'] = round(cpu_time(lambda: cpu.gae(rn32, vn32, 0.9999, 0.999), 3) * 1e6, 1)
+        rows.append(entry)
     out['a13_returns_gae'] = dict(what='returns + GAE(lambda) advantages + base/exponent decomposition of one rollout buffer (float64 scan, one launch)',
                                   rows=rows, cpu='oracle/gae.py (scipy.signal.lfilter form), 1 thread')
     # ---- (f)4 checkpoint round trip

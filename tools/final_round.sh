@@ -33,7 +33,7 @@ d=json.load(open('$out/bench.json'))
 for k in d['kernel_rooflines']: print(k['kernel'][:70], k['shape'], k['us'], 'us', k['achieved_GBs'], 'GB/s', k['frac'])
 print('cpu_baseline', d.get('cpu_baseline'))
 " >> $cfg 2>&1
-python3 tools/bench_rollout_rows.py 2>/dev/null | tail -1 > $out/rollout_rows.json
+python3 bench.py --rollout-rows 2>/dev/null | tail -1 > $out/rollout_rows.json
 echo "== smoke" >> $cfg
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v Warning | tail -3 >> $cfg
 cat $cfg
