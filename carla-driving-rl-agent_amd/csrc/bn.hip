@@ -502,6 +502,29 @@ int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst
     return 0;
 }
 
+// BatchNorm apply + activation + global average pool in one pass over the raw conv output (the head of the tower: the 12288 x 768
+// activated tensor is neither written nor read; same operation order as bn_apply followed by gap_fwd_kernel, so the same bits)
+__global__ void bn_act_gap_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ out, int N,
+                                      int P, int C, int GC, int frames_per_group, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * C) return;
+    const int c = (int)(i % C);
+    const int64_t n = i / C;
+    const int g = (int)(n / frames_per_group);
+    const float sc = stats[2 * GC + g * C + c], sh = stats[3 * GC + g * C + c];
+    float s = 0.0f;
+    for (int p = 0; p < P; ++p) s += apply_act(fmaf(sc, y[(n * P + p) * C + c], sh), act);
+    out[i] = s / (float)P;
+}
+
+int bn_act_gap_fwd(const float* y, const float* stats, float* out, int G, int frames_per_group, int P, int C, int act, hipStream_t st) {
+    const int N = G * frames_per_group;
+    hipLaunchKernelGGL(bn_act_gap_fwd_kernel, dim3((unsigned)cdiv64((int64_t)N * C, 256)), dim3(256), 0, st, y, stats, out, N, P, C,
+                       G * C, frames_per_group, act);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
@@ -517,8 +540,16 @@ struct BnBwdReduceF {
     PoolSrc pool;
     View pgsrc, pgdst;      // optional: gradient of the unit's identity half, gathered through the same shuffle map
     bool al_pg;
+    int bcast;              // > 0: da has one row per `bcast` rows of y and is divided by it (gradient of a global average pool)
     __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
-        VecF<VEC> d = use_pool ? pool_gather<VEC>(pool, row, c0, C) : vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
+        VecF<VEC> d;
+        if (bcast > 0) {
+            d = vload_view<VEC>(da, row / bcast, c0, 0, al_da);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) d.v[i] = d.v[i] / (float)bcast;
+        } else {
+            d = use_pool ? pool_gather<VEC>(pool, row, c0, C) : vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
+        }
         const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_y);
         const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
         if (pgsrc.p) {
@@ -651,7 +682,7 @@ static void launch_bbr_shuf(const VColGeom& g, int G, hipStream_t st, View da, i
 }
 
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
-                  double* part, hipStream_t st, const PoolSrc* pool, const View* pass_gsrc, const View* pass_gdst) {
+                  double* part, hipStream_t st, const PoolSrc* pool, const View* pass_gsrc, const View* pass_gdst, int bcast_rows) {
     {
         static const bool fast = !(getenv("CDRL_BBR_FAST") && atoi(getenv("CDRL_BBR_FAST")) == 0);
         const VColGeom g = vcol_geom(Mg, C, NB_STATS);
@@ -662,7 +693,7 @@ int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const
         }
         const bool ydense = y.ld == C && y.coff == 0 && view_aligned(y, g.vec);
         const bool pok = !pgs.p || (pgd.p && view_aligned(pgd, g.vec));
-        if (fast && !pool && shuffle_ctot && act == ACT_RELU6 && g.nloop == 1 && ydense && pok && g.vec >= 2) {
+        if (fast && !pool && !bcast_rows && shuffle_ctot && act == ACT_RELU6 && g.nloop == 1 && ydense && pok && g.vec >= 2) {
             if (g.vec == 4) launch_bbr_shuf<4>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
             else launch_bbr_shuf<2>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
             CDRL_LAUNCH_CHECK();
@@ -679,7 +710,7 @@ int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const
     }
     return launch_vcolreduce<2, BnBwdReduceF>(G, Mg, C, part, st, NB_STATS, da, shuffle_ctot, y, stats, G * C, C, act,
                                               pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps,
-                                              pgs, pgd, pgd.p && view_aligned(pgd, vec));
+                                              pgs, pgd, pgd.p && view_aligned(pgd, vec), bcast_rows);
 }
 
 // BN-backward sums of a BatchNorm+ReLU6 whose output feeds a 3x3/s2 max-pool, in SCATTER form: iterate over the POOLED
@@ -889,8 +920,16 @@ struct BnBwdApplyF {
     bool al_da, al_y;
     bool use_pool;
     PoolSrc pool;
+    int bcast;              // as in BnBwdReduceF
     __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
-        VecF<VEC> d = use_pool ? pool_gather<VEC>(pool, row, c0, C) : vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
+        VecF<VEC> d;
+        if (bcast > 0) {
+            d = vload_view<VEC>(da, row / bcast, c0, 0, al_da);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) d.v[i] = d.v[i] / (float)bcast;
+        } else {
+            d = use_pool ? pool_gather<VEC>(pool, row, c0, C) : vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
+        }
         const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_y);
         const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
         if (act == ACT_RELU6) {
@@ -920,7 +959,7 @@ template <int VEC>
 __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int ctot, const float* __restrict__ y,
                                                                 const float* __restrict__ stats, const float* __restrict__ coef,
                                                                 int GC, int C, int Mg, int rb, int act, float* __restrict__ dy,
-                                                                double* __restrict__ part) {
+                                                                double* __restrict__ part, int bcast) {
     extern __shared__ double sm[];   // [CY][VEC][CX]
     constexpr int RU = 4;
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -956,7 +995,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int cto
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 const int64_t row = gbase + min(rr + u * CY, r1 - 1);
-                const float* dr = da.p + row * da.ld;
+                const float* dr = da.p + (bcast > 0 ? row / bcast : row) * da.ld;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) dz[u][i] = dr[dcol[i]];
                 yv[u] = vload<VEC>(y + row * C + c0);
@@ -970,6 +1009,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int cto
                 for (int i = 0; i < VEC; ++i) {
                     const float v = yv[u].v[i];
                     float d = dz[u][i];
+                    if (bcast > 0) d = d / (float)bcast;        // gradient of the global average pool over `bcast` rows
                     if (relu) {
                         const float z = fmaf(sc[i], v, sh[i]);
                         d = (z > 0.0f && z < 6.0f) ? d : 0.0f;
@@ -1002,7 +1042,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int cto
 }
 
 int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, const float* coef,
-                 int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool) {
+                 int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool, int bcast_rows) {
     {
         static const bool fast = !(getenv("CDRL_BBA_FAST") && atoi(getenv("CDRL_BBA_FAST")) == 0);
         const VColGeom g = vcol_geom(Mg, C, NB_STATS);
@@ -1011,9 +1051,9 @@ int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const 
             dim3 grid(g.nb, G), block(g.cx, g.cy);
             const size_t sm = (size_t)g.cy * g.vec * g.cx * sizeof(double);
             if (g.vec == 4)
-                hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<4>, grid, block, sm, st, da, shuffle_ctot, y.p, stats, coef, G * C, C, Mg, g.rb, act, dy, part2);
+                hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<4>, grid, block, sm, st, da, shuffle_ctot, y.p, stats, coef, G * C, C, Mg, g.rb, act, dy, part2, bcast_rows);
             else
-                hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<2>, grid, block, sm, st, da, shuffle_ctot, y.p, stats, coef, G * C, C, Mg, g.rb, act, dy, part2);
+                hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<2>, grid, block, sm, st, da, shuffle_ctot, y.p, stats, coef, G * C, C, Mg, g.rb, act, dy, part2, bcast_rows);
             CDRL_LAUNCH_CHECK();
             return 0;
         }
@@ -1026,7 +1066,7 @@ int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const 
         return -1;
     }
     return launch_vcolreduce<1, BnBwdApplyF>(G, Mg, C, part2, st, NB_STATS, da, shuffle_ctot, y, stats, coef, G * C, C, act,
-                                             dy, pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps);
+                                             dy, pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps, bcast_rows);
 }
 
 // Block = (CX outputs, 1024/CX partial lanes).  CX = 16 gives 128-byte row segments; CX = 4 is used when there are few

@@ -43,7 +43,9 @@ struct PoolSrc {
 // Backward: reduce (sum dz, sum dz*xhat) -> part [G][nb][2][C]
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
                   double* part, hipStream_t st, const PoolSrc* pool = nullptr, const View* pass_gsrc = nullptr,
-                  const View* pass_gdst = nullptr);     // pass_*: gradient of the identity half gathered in the same pass
+                  const View* pass_gdst = nullptr, int bcast_rows = 0);
+// bcast_rows > 0 (here and in bn_bwd_apply): `da` holds ONE row per bcast_rows rows of y and is divided by bcast_rows on load --
+// the gradient of a global average pool over bcast_rows pixels, never materialised (head of the tower)     // pass_*: gradient of the identity half gathered in the same pass
 // Same sums for a BN+ReLU6 that feeds a 3x3/s2 max-pool, in scatter form over the POOLED gradient (ps.dp, ps.argmax);
 // y: the BN's raw input [G*frames_per_group][ps.H][ps.W][C]; part [G][nb][2][C], nb = vcol_geom(frames*Ho*Wo, C).nb
 int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_group, int C, const float* stats, double* part,
@@ -53,7 +55,8 @@ int bn_bwd_finalize(const double* part, int nb, int G, int Mg, int C, const floa
                     float* dbeta, float* coef, hipStream_t st);
 // dy = k1*(dz - k2 - xhat*k3) (dense [G*Mg][C]); also column sums of dy -> part2 [G][nb][C]
 int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats,
-                 const float* coef, int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool = nullptr);
+                 const float* coef, int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool = nullptr,
+                 int bcast_rows = 0);
 // out[i] (+)= sum_p part[p*stride + i], i < n
 int reduce_partials(const double* part, int nparts, int n, int64_t stride, float* out, int accumulate,
                     hipStream_t st);
@@ -201,6 +204,8 @@ int maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_gro
 PoolSrc make_pool_src(const uint8_t* argmax, const float* dp, int H, int W);
 // mean over the P pixels of each frame: a [N][P][C] -> out [N][C]
 int gap_fwd(const float* a, float* out, int N, int P, int C, hipStream_t st);
+// out[n][c] = mean_p act(scale[g][c] * y[n*P + p][c] + shift[g][c]): BatchNorm apply + activation + global average pool fused
+int bn_act_gap_fwd(const float* y, const float* stats, float* out, int G, int frames_per_group, int P, int C, int act, hipStream_t st);
 int gap_bwd(const float* dout, float* da, int N, int P, int C, hipStream_t st);
 
 // batched transposes W[cin][cout] -> WT[cout][cin] of many small matrices in one launch (gemm.hip)

@@ -70,6 +70,11 @@ struct Op {
 struct Passthrough {
     View fsrc{nullptr, 0, 0}, fdst{nullptr, 0, 0};     // forward: X[:, :C] -> out (shuffled, channel offset 0)
     View gsrc{nullptr, 0, 0}, gdst{nullptr, 0, 0};     // backward: out.g (shuffled) -> X.g[:, :C]
+    // global average pool fused behind the BatchNorm (head of the tower): the forward writes mean_p act(BN(x)) to gap_out
+    // [frames][C] instead of the activated tensor, the backward reads the pooled gradient gap_dout [frames][C] (broadcast / P)
+    float* gap_out = nullptr;
+    const float* gap_dout = nullptr;
+    int gap_rows = 0;                                   // P pixels per frame
 };
 
 // BatchNorm work folded into a pointwise conv (gemm_pw.hip); all optional

@@ -425,7 +425,11 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     // direction instead of three
     static const bool small_env = !(getenv("CDRL_BN_SMALL") && atoi(getenv("CDRL_BN_SMALL")) == 0);
     const bool small = small_env && G == 1 && Mg <= 2048 && !bessel && act == ACT_NONE && !out_shuffle && !dout_shuffle && dx &&
-                       !stats_nb && !defer_apply && !pass.fsrc.p && !pass.gsrc.p;
+                       !stats_nb && !defer_apply && !pass.fsrc.p && !pass.gsrc.p && !pass.gap_out;
+    const bool gap = pass.gap_out != nullptr;
+    if (gap && (pass.gap_rows <= 0 || Mg % pass.gap_rows != 0 || x.ld != C || x.coff != 0 || out_shuffle || dout_shuffle || pass.fsrc.p ||
+                pass.gsrc.p))
+        build_fail("%s: fused global average pool needs a dense input and whole frames per group", prefix.c_str());
     Op op;
     if (small) {
         op.fwd = [=](hipStream_t st, int training) -> int {
@@ -441,17 +445,21 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
         if (training && !stats_nb) CDRL_TRY(colstats(x, G, Mg, C, sc->part, st));
         if (training || !inf_batched)
             CDRL_TRY(bn_finalize(sc->part, stats_nb ? stats_nb : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
+        if (gap) return bn_act_gap_fwd(x.p, stats, pass.gap_out, G, Mg / pass.gap_rows, pass.gap_rows, C, act, st);
         if (pass.fsrc.p) return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st, &pass.fsrc, &pass.fdst);
         return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st);
     };
     op.bwd = [=](hipStream_t st) -> int {
+        // fused global average pool: the gradient source is the pooled gradient, one row per gap_rows rows of x
+        const View dsrc = gap ? make_view(const_cast<float*>(pass.gap_dout), C) : dout;
+        const int bc = gap ? pass.gap_rows : 0;
         if (pass.gsrc.p) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, &pass.gsrc, &pass.gdst));
-        else if (!*fused) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st));
+        else if (!*fused) CDRL_TRY(bn_bwd_reduce(dsrc, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, nullptr, nullptr, bc));
         CDRL_TRY(bn_bwd_finalize(sc->part, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
         if (defer_apply) return 0;      // applied by the consumer GEMMs on load (PwFuse::bb)
-        if (dx) return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, sc->part2, st);
+        if (dx) return bn_bwd_apply(dsrc, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, sc->part2, st, nullptr, bc);
         CDRL_TRY(next_slot(st));       // tower: dy + db partials go to a rotating scratch slot
-        return bn_bwd_apply(dout, dout_shuffle, x, G, Mg, C, stats, coef, act, dys_[slot_], part2s_[slot_], st);
+        return bn_bwd_apply(dsrc, dout_shuffle, x, G, Mg, C, stats, coef, act, dys_[slot_], part2s_[slot_], st, nullptr, bc);
     };
     ops.push_back(op);
     return rec;
@@ -1125,16 +1133,29 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         }
         // ---- head conv + GAP (core/architectures.py:170-172)
         const int P = curH * curW, rows = N * P;
-        Tens yh = tens(rows, c.last, false), ah = tens(rows, c.last);
+        Tens yh = tens(rows, c.last, false);
         add_pw(ops, "img.head.conv", X.v(), rows, curC, c.last, yh.p, X.gv(), 0, bnrec(T, B * P, c.last));
-        add_bn(ops, M_TRUNK, "img.head.bn", yh.v(), T, B * P, c.last, true, ACT_RELU6, ah.v(), 0, ah.gv(), 0, nullptr);
         feat_ = tens(N, c.last);
-        Tens feat = feat_;
-        const int Cl = c.last;
-        Op gp;
-        gp.fwd = [=](hipStream_t st, int) -> int { return gap_fwd(ah.p, feat.p, N, P, Cl, st); };
-        gp.bwd = [=](hipStream_t st) -> int { return gap_bwd(feat.g, ah.g, N, P, Cl, st); };
-        ops.push_back(gp);
+        static const bool gap_fused = !(getenv("CDRL_FUSED_GAP") && atoi(getenv("CDRL_FUSED_GAP")) == 0);
+        if (gap_fused) {
+            // BatchNorm + ReLU6 + GlobalAveragePooling2D as one op: the 12288 x 768 activated tensor and its gradient are never
+            // written -- the forward pools on the fly, the backward reads the pooled gradient broadcast over the frame's pixels
+            Passthrough hp;
+            hp.gap_out = feat_.p;
+            hp.gap_dout = feat_.g;
+            hp.gap_rows = P;
+            add_bn(ops, M_TRUNK, "img.head.bn", yh.v(), T, B * P, c.last, true, ACT_RELU6, View{nullptr, 0, 0}, 0, View{nullptr, 0, 0}, 0,
+                   nullptr, 0, false, hp);
+        } else {
+            Tens ah = tens(rows, c.last);
+            add_bn(ops, M_TRUNK, "img.head.bn", yh.v(), T, B * P, c.last, true, ACT_RELU6, ah.v(), 0, ah.gv(), 0, nullptr);
+            Tens feat = feat_;
+            const int Cl = c.last;
+            Op gp;
+            gp.fwd = [=](hipStream_t st, int) -> int { return gap_fwd(ah.p, feat.p, N, P, Cl, st); };
+            gp.bwd = [=](hipStream_t st) -> int { return gap_bwd(feat.g, ah.g, N, P, Cl, st); };
+            ops.push_back(gp);
+        }
     }
 
     // ---- feature nets (core/architectures.py:9-27)
