@@ -875,8 +875,10 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         const char* e3 = getenv("CDRL_FUSED_BB");
         // measured at v19: 1 -> 25.5, 0 -> 25.8, 3 -> 26.0, 2 -> 26.2 ms/update-step; re-measured at v29 (buffer-load filter
         // gradient: the shuffle gather costs nothing there any more): 3 -> 20.66, 1 -> 20.80, 0 -> 21.0, 2 -> 21.3, and with
-        // the wide fused pointwise path 3 -> 20.21
-        fused_bb_ = e3 ? atoi(e3) : 3;
+        // the wide fused pointwise path 3 -> 20.21.  Bit 2: also for the first unit's conv with 24 input channels -- slower before
+        // the accumulate variant prefetched its old output tile (248 us against 165 us for apply + plain GEMM), now 15.91 vs 15.96
+        // ms/update-step and one 164 MB tensor less
+        fused_bb_ = e3 ? atoi(e3) : 7;
     }
 
     // ---- stem (core/architectures.py:159-161)
@@ -1027,8 +1029,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                                  pw_nn_supported(y1.v(), main_in, mid);
                 if (fpw) {
                     // BN-backward apply as GEMM operand prologue (needs the filter-gradient GEMM's fixed column mapping)
-                    // (not for N <= 32 outputs of the backward-data GEMM, i.e. the first unit's 24 input channels: the 128-row
-                    //  variant of the prologue kernel runs at 248 us vs ~165 us for apply + plain GEMM)
+                    // (bit 2 of CDRL_FUSED_BB: also for N <= 32 outputs of the backward-data GEMM, i.e. the first unit's 24 input
+                    //  channels; see the default above)
                     // (also for the wide stage-2 units: without the prologues there 19.55 vs 18.82 ms/update-step;
                     //  CU-masking the side stream re-measured at v33: 224 / 192 / 128 CUs -> 21.2 / 21.2 / 23.5 vs 18.7 ms)
                     const bool bb1 = (fused_bb_ & 1) && gemm_tn_dpro_supported(mid) && (main_in > 32 || (fused_bb_ & 4));
