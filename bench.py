@@ -88,10 +88,15 @@ def dominant_kernel(B, T, H, W):
         return None
     out = dict(source=os.path.relpath(files[-1], ROOT), kernel=name, avg_us=avg_us)
     if name.startswith('tn_direct_tr_kernel<4'):
-        # pw1 filter gradients (A = the unit's input, D = dz of BN1 recomputed in the operand prologue) of the stage-1 units
-        # (K = N = 116: 7 stride-1 units at M = B*T*48 rows and the stride-2 unit, whose pw1 runs at the INPUT resolution: B*T*180 rows)
-        # and of the stage-2 units (K = N = 232, two 128-column blocks: 3 stride-1 units at B*T*12 rows + the stride-2 unit at B*T*48)
-        shapes = [(184320, 116, 116)] + [(49152, 116, 116)] * 7 + [(49152, 232, 232)] + [(12288, 232, 232)] * 3
+        if name.startswith('tn_direct_tr_kernel<4, false'):
+            # pw1 filter gradients (A = the unit's input, D = dz of BN1 recomputed in the operand prologue) of the stage-1 units
+            # (K = N = 116: 7 stride-1 units at M = B*T*48 rows and the stride-2 unit, whose pw1 runs at the INPUT resolution: B*T*180 rows)
+            # and of the stage-2 units (K = N = 232, two 128-column blocks: 3 stride-1 units at B*T*12 rows + the stride-2 unit at B*T*48)
+            shapes = [(184320, 116, 116)] + [(49152, 116, 116)] * 7 + [(49152, 232, 232)] + [(12288, 232, 232)] * 3
+        else:
+            # pw2 filter gradients (A = BN2-applied depthwise output through the A prologue, D = dz of BN3): every unit at its OUTPUT
+            # resolution -- 8 stage-1 units at B*T*48 rows (K = N = 116), 4 stage-2 units at B*T*12 rows (K = N = 232)
+            shapes = [(49152, 116, 116)] * 8 + [(12288, 232, 232)] * 4
         by = sum(4.0 * m_ * (k + n) for m_, k, n in shapes) / len(shapes)
         out.update(algorithmic_bytes_per_launch=by, achieved_GBs=round(by / (avg_us * 1e-6) / 1e9, 1),
                    frac=round(by / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
