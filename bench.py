@@ -29,16 +29,16 @@ def alg_bytes_per_update_step(B, T, H, W):
     return 2 * 3 * 4 * B * T * ALG_ELEMS_PER_FRAME[(H, W)]
 
 
-def pmc_traffic(B, T, H, W):
-    """HBM bytes per update-step from the committed PMC run (profiles/*_pmc_traffic.json; collected and
-    corrected as MI355X_MICROARCH.md prescribes, see the file's `method`), or None if no run matches."""
+def pmc_traffic(B, T, H, W, dtype='f32'):
+    """HBM bytes per update-step from the committed PMC run of THIS workload and storage type (profiles/*_pmc_traffic.json;
+    collected and corrected as MI355X_MICROARCH.md prescribes, see the file's `method`), or None if no run matches."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
         try:
             d = json.load(open(f))
             w = d['workload']
-            if (w['B'], w['T'], w['H'], w['W']) == (B, T, H, W):
+            if (w['B'], w['T'], w['H'], w['W'], w.get('dtype', 'f32')) == (B, T, H, W, dtype):
                 best = d['bytes_per_update_step']
         except Exception:
             pass
@@ -60,6 +60,8 @@ def pmc_mfma(ms_per_step):
     flops16 = d.get('mfma_bf16_flops_issued_per_update_step')      # split-precision kernels: 6 bf16 products per float32 product
     return dict(source=os.path.relpath(files[-1], ROOT), mfma_util_all_kernel_time=d.get('mfma_util_all_kernels'),
                 mfma_util_gemm_kernels=[min(utils), max(utils)] if utils else None, f32_flops_issued_per_update_step=flops,
+                flops_note='counter products (SQ_INSTS_VALU_MFMA_MOPS_* x 512 of the profiled run): what was ISSUED to the matrix pipes, '
+                           'padding included and split-precision kernels counted on the bf16 pipe -- not the model\'s algorithmic FLOPs',
                 f32_mfma_tflops=round(flops / (ms_per_step * 1e-3) / 1e12, 2) if flops else None, f32_mfma_peak_tflops=157.3,
                 bf16_flops_issued_per_update_step=flops16,
                 bf16_mfma_tflops=round(flops16 / (ms_per_step * 1e-3) / 1e12, 2) if flops16 else None, bf16_mfma_peak_tflops=2500.0)
@@ -87,6 +89,9 @@ def dominant_kernel(B, T, H, W):
     else:
         return None
     out = dict(source=os.path.relpath(files[-1], ROOT), kernel=name, avg_us=avg_us)
+    crit = critical_stream_top_kernel()
+    if crit:
+        out['critical_stream_top_kernel'] = crit
     if name.startswith('tn_direct_tr_kernel<4'):
         if name.startswith('tn_direct_tr_kernel<4, false'):
             # pw1 filter gradients (A = the unit's input, D = dz of BN1 recomputed in the operand prologue) of the stage-1 units
@@ -102,6 +107,39 @@ def dominant_kernel(B, T, H, W):
                    frac=round(by / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                    note='side-stream kernel: its duration in the step includes sharing the CUs with the critical stream')
     return out
+
+
+def critical_stream_top_kernel():
+    """The kernel with the largest total time ON THE CRITICAL STREAM of one update-step, from the committed per-stream timeline
+    (profiles/rNN_timeline_step.txt, tools/timeline_step.py): the dominant kernel by total time may sit on the side stream."""
+    import glob
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', '*_timeline_step.txt'))
+                   if re.fullmatch(r'r\d+_timeline_step\.txt', os.path.basename(f)))
+    if not files:
+        return None
+    # format: "queue Q: N kernels, busy X ms" followed by "  total ms   launches   avg us  kernel" lines; the critical stream is the
+    # queue with the largest busy time
+    queues, cur = [], None
+    for line in open(files[-1]):
+        m = re.match(r'queue (\d+): (\d+) kernels, busy ([\d.]+) ms', line)
+        if m:
+            cur = dict(queue=int(m.group(1)), kernels=int(m.group(2)), busy_ms=float(m.group(3)), rows=[])
+            queues.append(cur)
+            continue
+        m = re.match(r'\s*([\d.]+) ms\s+(\d+)\s+([\d.]+) us\s+(\S.*)$', line)
+        if m and cur is not None:
+            cur['rows'].append((float(m.group(1)), int(m.group(2)), float(m.group(3)), m.group(4).strip()))
+    best = None
+    if queues:
+        crit = max(queues, key=lambda q: q['busy_ms'])
+        if crit['rows']:
+            tot, n, avg, name = max(crit['rows'])
+            best = dict(kernel=name, total_ms_per_step=tot, launches_per_step=n, avg_us=avg, critical_stream_kernels_per_step=crit['kernels'],
+                        critical_stream_busy_ms=crit['busy_ms'])
+    if best:
+        best['source'] = os.path.relpath(files[-1], ROOT)
+    return best
 
 
 def kernel_rooflines(B, T, nsets=8):
@@ -228,7 +266,19 @@ def cpu_baseline(B_sample, T, H, W, threads, one_thread_batch=32):
     med, best = statistics.median(times), min(times)
     one = _oracle_timer(one_thread_batch, T, H, W, 1, warmup=0, steps=1, budget_s=1.0)[0]
     scale = B_sample / 256.0
+    logical = os.cpu_count() or 0
+    try:        # physical cores = distinct (package, core id) pairs
+        phys, pkg = set(), None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                pkg = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                phys.add((pkg, line.split(':')[1].strip()))
+        physical = len(phys) or None
+    except Exception:
+        physical = None
     return dict(value=scale / med, unit='update-steps/s (256-sample update-steps)', cores=threads, kind='port',
+                host_logical_cores=logical, host_physical_cores=physical,
                 median_s_per_step=round(med, 3), min_s_per_step=round(best, 3), timed_steps=len(times), warmup_steps=2,
                 one_thread=dict(value=(one_thread_batch / 256.0) / one, s_per_step=round(one, 3), minibatch=one_thread_batch,
                                 note=f'1 update-step at minibatch {one_thread_batch} on 1 thread, scaled by {one_thread_batch}/256'),
@@ -307,8 +357,9 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200,
+                    help='timed update-steps (default 200: a timed region of ~3 s, long enough for an external GPU-busy sampler)')
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--height', type=int, default=90)
     ap.add_argument('--width', type=int, default=120)
@@ -319,6 +370,9 @@ def main():
                     help='measure the rollout-side rows (predict for E environments, Beta sampling, augmentation, GAE, checkpoint I/O, '
                          'the agent-level collect / update cycle) with their CPU stand-ins and print that JSON instead of the benchmark line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-rooflines', action='store_true',
+                    help='skip the isolated-kernel roofline launches (profiling passes: PMC totals and trace call counts then contain '
+                         'only the update-steps)')
     ap.add_argument('--cpu-sample-batch', type=int, default=256)
     ap.add_argument('--cpu-threads', type=int, default=min(16, os.cpu_count() or 1),
                     help='oracle intra-op threads; measured on the 2x64-core EPYC GPU host: 16 threads is the '
@@ -402,16 +456,22 @@ def main():
     for _ in range(args.warmup):
         one_step()
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # EXACTLY args.steps timed update-steps between two barrier + synchronize brackets; HIP events on the launch stream split
+    # them into (up to) 5 blocks so that the line can carry min / median per-step times besides the mean
+    nblk = min(5, args.steps)
+    edges = [round(i * args.steps / nblk) for i in range(nblk + 1)]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nblk + 1)]
     t0 = time.time()
-    ev0.record()
-    for _ in range(args.steps):
-        one_step()
-    ev1.record()
+    evs[0].record()
+    for b in range(nblk):
+        for _ in range(edges[b + 1] - edges[b]):
+            one_step()
+        evs[b + 1].record()
     host_ms = (time.time() - t0) / args.steps * 1e3       # host time to ENQUEUE one update-step (no sync inside the loop)
     barrier()
     elapsed = time.time() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    dev_ms = evs[0].elapsed_time(evs[-1])
+    block_ms = [evs[b].elapsed_time(evs[b + 1]) / (edges[b + 1] - edges[b]) for b in range(nblk)]
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -428,7 +488,7 @@ def main():
         if alg is not None:
             achieved = alg / dev_s_per_step / 1e9
             roof = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(B, T, H, W),
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(B, T, H, W, args.dtype),
                         kernel='one PPO update-step (all launches of the step, HIP-event timed on the launch stream)',
                         algorithmic_bytes_per_launch=alg)
         out = dict(metric='PPO update-steps/sec (batch=256, 4x90x120x3 obs)', value=round(value, 3), unit='update-steps/s',
@@ -440,7 +500,9 @@ def main():
                                per_gpu_batch=B, global_batch=B * world, time_horizon=T, image=[H, W, 3],
                                parallelism=f'dp{world}', passes_per_step=2,
                                policy_loss='stored-actions' if args.stored_actions else 'resampled (reference-faithful)'),
-                   roofline=roof, mfma=pmc_mfma(ms_per_step), dominant_kernel=dominant_kernel(B, T, H, W), kernel_rooflines=kernel_rooflines(B, T) if world == 1 else None, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3), host_enqueue_ms_per_step=round(host_ms, 3),
+                   roofline=roof, mfma=pmc_mfma(ms_per_step), dominant_kernel=dominant_kernel(B, T, H, W), kernel_rooflines=kernel_rooflines(B, T) if (world == 1 and not args.no_kernel_rooflines) else None, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3),
+                   device_ms_per_step_blocks=dict(blocks=[round(x, 3) for x in block_ms], min=round(min(block_ms), 3), median=round(sorted(block_ms)[len(block_ms) // 2], 3)),
+                   host_enqueue_ms_per_step=round(host_ms, 3),
                    final_losses=dict(policy=loss_p, value=loss_v))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = run_cpu_baseline_child(args.cpu_sample_batch, T, H, W, args.cpu_threads)

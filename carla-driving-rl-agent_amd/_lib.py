@@ -72,6 +72,7 @@ PROTOTYPES = {
     'cdrl_learner_set_hparams': (_i, [_L, C.POINTER(HParams), _fp]),
     'cdrl_learner_share_hparams': (_i, [_L, _L]),
     'cdrl_learner_set_comm_stream': (_i, [_L, _fp]),
+    'cdrl_learner_tail_offset': (_i64, [_L]),
     'cdrl_learner_reset_optimizer_steps': (_i, [_L, _fp]),
     'cdrl_learner_policy_forward_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
     'cdrl_learner_policy_forward': (_i, [_L, _fp, _fp, _fp, _fp, _fp]),
@@ -95,6 +96,8 @@ PROTOTYPES = {
     'cdrl_beta_sample_logp': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp]),
     'cdrl_beta_sample': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp, _fp]),
     'cdrl_gamma_implicit_grad': (_i, [_fp, _fp, _i, _fp, _fp]),
+    'cdrl_beta_sample_gammas': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp]),
+    'cdrl_philox_words': (_i, [C.c_uint64, C.c_uint64, C.c_uint64, _i, _i, _fp, _fp]),
     'cdrl_learner_policy_apply': (_i, [_L, _fp]),
     'cdrl_learner_value_forward_backward': (_i, [_L, C.POINTER(ValueBatch), _f, _fp]),
     'cdrl_learner_value_apply': (_i, [_L, _fp]),

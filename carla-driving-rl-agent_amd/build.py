@@ -31,13 +31,30 @@ def _digest():
     return h.hexdigest()
 
 
-def _compile(name):
+def _headers_digest():
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(HERE, '..', 'include')):
+        for f in sorted(os.listdir(root)):
+            if f.endswith('.h'):
+                h.update(f.encode())
+                h.update(open(os.path.join(root, f), 'rb').read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(name, hdig=None, force=False):
+    """One translation unit; skipped when its source, every header and the flags are unchanged (per-object stamp)."""
     src = os.path.join(CSRC, name + '.hip')
     obj = os.path.join(OBJ, name + '.o')
+    stamp = obj + '.digest'
+    dig = hashlib.sha256((hdig or _headers_digest()).encode() + open(src, 'rb').read()).hexdigest()
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return obj
     cmd = [_hipcc()] + FLAGS + ['-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed on {name}.hip:\n{r.stdout}\n{r.stderr}')
+    open(stamp, 'w').write(dig)
     return obj
 
 
@@ -49,8 +66,9 @@ def build(force=False, verbose=True):
         if verbose:
             print('[cdrl] libcdrl_hip.so up to date')
         return LIB
+    hdig = _headers_digest()
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(_compile, SOURCES))
+        objs = list(ex.map(lambda n: _compile(n, hdig, force), SOURCES))
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

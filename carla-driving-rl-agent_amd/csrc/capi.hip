@@ -28,19 +28,25 @@ int cdrl_version(void) { return CDRL_VERSION; }
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8 on the host: checksums of the TF-checkpoint-V2
 // writer (tf_checkpoint.py): every SSTable block and every tensor entry carries one
-uint32_t cdrl_crc32c(uint32_t crc, const void* data, size_t n) {
-    static uint32_t T[8][256];
-    static bool ready = false;
-    if (!ready) {
+namespace {
+struct Crc32cTable {
+    uint32_t t[8][256];
+    Crc32cTable() {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-            T[0][i] = c;
+            t[0][i] = c;
         }
         for (uint32_t i = 0; i < 256; ++i)
-            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xff];
-        ready = true;
+            for (int k = 1; k < 8; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xff];
     }
+};
+}  // namespace
+
+uint32_t cdrl_crc32c(uint32_t crc, const void* data, size_t n) {
+    // function-local static: initialised exactly once, thread-safe (ctypes releases the GIL around the call)
+    static const Crc32cTable table;
+    const uint32_t (*T)[256] = table.t;
     const unsigned char* p = static_cast<const unsigned char*>(data);
     uint32_t c = ~crc;
     while (n >= 8) {
@@ -217,6 +223,13 @@ int cdrl_learner_set_comm_stream(cdrl_learner* l, void* stream) {
     return 0;
 }
 
+int64_t cdrl_learner_tail_offset(const cdrl_learner* l) {
+    if (!l) return -1;
+    // with hipGraph replay the communication stream is never released mid-pass: no early bucket (everything is "tower")
+    if (l->impl->graphs_enabled()) return l->impl->trainable_elems(cdrl::M_TRUNK);
+    return l->impl->tail_offset();
+}
+
 int cdrl_learner_reset_optimizer_steps(cdrl_learner* l, void* stream) {
     CHECK_L(l);
     return l->impl->reset_counters(S(stream));
@@ -285,6 +298,23 @@ int cdrl_beta_sample(const float* alpha, const float* beta, int rows, int A, int
 
 int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* out, void* stream) {
     return gamma_implicit_grad(a, g, n, out, S(stream));
+}
+
+int cdrl_beta_sample_gammas(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,
+                            double* gammas, void* stream) {
+    if (!alpha || !beta || !gammas) {
+        cdrl::set_error("cdrl_beta_sample_gammas: null argument");
+        return -1;
+    }
+    return beta_sample(alpha, beta, rows, A, ld, seed, offset, nullptr, nullptr, nullptr, S(stream), nullptr, gammas);
+}
+
+int cdrl_philox_words(uint64_t seed, uint64_t offset, uint64_t idx0, int n, int nblocks, uint32_t* out, void* stream) {
+    if (!out) {
+        cdrl::set_error("cdrl_philox_words: null output");
+        return -1;
+    }
+    return philox_words(seed, offset, idx0, n, nblocks, out, S(stream));
 }
 
 int cdrl_learner_policy_apply(cdrl_learner* l, void* stream) {

@@ -326,8 +326,9 @@ int value_act(const float* lin, float* out /*[B][4] base,exp,speed,sim*/, int B,
 // u ~ Beta(alpha, beta) (as a Gamma ratio) with pathwise derivatives du/dalpha, du/dbeta (implicit
 // reparameterisation of the two Gamma samples).  Element (row, col): alpha[row*ld + col].
 int beta_sample(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset, float* u,
-                float* du_da, float* du_db, hipStream_t st, float* logp = nullptr);
+                float* du_da, float* du_db, hipStream_t st, float* logp = nullptr, double* gammas = nullptr);
 int gamma_implicit_grad(const double* a, const double* g, int n, double* out, hipStream_t st);
+int philox_words(uint64_t seed, uint64_t offset, uint64_t idx0, int n, int nblocks, uint32_t* out, hipStream_t st);
 
 // ---------------------------------------------------------------- rollout-time augmentation (augment.hip)
 struct AugPlan {           // same layout as cdrl_aug_plan (include/cdrl.h)

@@ -503,12 +503,14 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
     }
 }
 
-// (one runtime call per kernel instantiation and size, not one per launch: `allowed` is per template instantiation)
-template <class K>
-static int allow_lds(K kernel, size_t bytes) {
+// (one runtime call per kernel and size, not one per launch.  The kernel is a NON-TYPE template parameter: every
+//  dwf_fwd_kernel<S, VEC, PRE> has the same function-pointer TYPE, so a type-keyed static would be shared by all of them and the
+//  second instantiation that needs > 64 KB would never get its attribute set)
+template <auto Kern>
+static int allow_lds(size_t bytes) {
     static size_t allowed = 64 * 1024;
     if (bytes > allowed) {
-        CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         allowed = bytes;
     }
     return 0;
@@ -518,7 +520,7 @@ template <int S, int VEC, bool PRE>
 static int launch_dwf_fwd(const DwfGeom& g, hipStream_t st, const float* x, const float* pre_stats, const float* w,
                           const float* bias, float* y, double* part, int G, int B, int H, int W, int C) {
     const int Ho = same_out(H, S), Wo = same_out(W, S);
-    CDRL_TRY(allow_lds(dwf_fwd_kernel<S, VEC, PRE>, g.lds_fwd));
+    CDRL_TRY((allow_lds<dwf_fwd_kernel<S, VEC, PRE>>(g.lds_fwd)));
     hipLaunchKernelGGL((dwf_fwd_kernel<S, VEC, PRE>), dim3(cdiv(G * g.nb, 8) * 8 * g.nch), dim3(g.cx, g.cy), g.lds_fwd, st, x, pre_stats, w, bias,
                        y, part, B, H, W, Ho, Wo, C, G * C, same_pad_before(H, S), same_pad_before(W, S), g.fpb, g.nb, g.cchunk, G * g.nb);
     CDRL_LAUNCH_CHECK();
@@ -560,7 +562,7 @@ static int launch_dwf_bwd(const DwfGeom& g, hipStream_t st, const float* x, cons
                           const float* y2, const float* post_stats, const float* post_coef, const float* w, View dx,
                           double* part_bn, double* part_w, int G, int B, int H, int W, int C) {
     const int Ho = same_out(H, S), Wo = same_out(W, S);
-    CDRL_TRY(allow_lds(dwf_bwd_kernel<S, VEC, PRE>, g.lds_bwd));
+    CDRL_TRY((allow_lds<dwf_bwd_kernel<S, VEC, PRE>>(g.lds_bwd)));
     hipLaunchKernelGGL((dwf_bwd_kernel<S, VEC, PRE>), dim3(cdiv(G * g.nb, 8) * 8 * g.nch), dim3(g.cx_bwd, g.cy_bwd), g.lds_bwd, st, x, pre_stats, dout, y2,
                        post_stats, post_coef, w, dx, part_bn, part_w, B, H, W, Ho, Wo, C, G * C, same_pad_before(H, S),
                        same_pad_before(W, S), g.fpb, g.nb, g.cchunk, view_aligned(dx, g.vec_bwd), G * g.nb);

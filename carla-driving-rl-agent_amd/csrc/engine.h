@@ -153,6 +153,10 @@ public:
     // the point where the gradients of the heads and of the trunk tail (GRUs, feature nets, concat BN + Dense) are final --
     // a collective enqueued on `s` after the pass has been enqueued then runs UNDER the tower's backward.
     void set_comm_stream(hipStream_t s) { comm_ = s; }
+    // First element (inside the trunk's trainable region) of the TAIL tensors: everything registered behind the image tower,
+    // i.e. exactly the gradients that are final at the point the communication stream is released.  Fixed by the op list.
+    int64_t tail_offset() const { return tail_off_; }
+    bool graphs_enabled() const { return graphs_enabled_; }
     // Named internal tensors (parity tests: the raw BatchNorm inputs, statistics blocks, max-pool argmax codes and dense
     // pre-activations from which the discrete ReLU6 / max-pool decisions of the last forward are reconstructed)
     bool named_buffer(const std::string& name, void** p, int64_t* bytes) const {
@@ -382,6 +386,7 @@ private:
     const void* gemm_x3_packed(const float* w, int K, int N, int sbk, int sbn);
     int run_trunk_fwd(hipStream_t st, int training);
     hipStream_t comm_ = nullptr;
+    int64_t tail_off_ = 0;
     hipEvent_t ev_tail_main_ = nullptr, ev_tail_side_ = nullptr;
     std::vector<std::pair<void*, size_t>> zero_once_;    // workspace regions that must read as zero and are never written
     float* pw_transposed(const std::string& name, const float* w, int cin, int cout);

@@ -1160,6 +1160,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         }
     }
 
+    // every trunk parameter registered from here on is a TAIL tensor (feature nets, GRUs, concat BN + Dense): their gradients
+    // are final at the `mark` op below, those of the tower above only at the end of the backward
+    if (!table_frozen_) tail_off_ = tr_size_[M_TRUNK];
     // ---- feature nets (core/architectures.py:9-27)
     const char* fnames[3] = {"road", "vehicle", "navigation"};
     const int fdims[3] = {c.road, c.vehicle, c.navigation};
@@ -1197,7 +1200,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         Op mark;
         mark.fwd = [](hipStream_t, int) -> int { return 0; };
         mark.bwd = [=](hipStream_t st) -> int {
-            if (!comm_) return 0;
+            // under hipGraph capture the external communication stream must not be pulled into the capture (it would never be
+            // joined, and a replay would never release it): the caller falls back to the single post-pass all-reduce
+            if (!comm_ || graphs_enabled_) return 0;
             CDRL_TRY(aux_wait());
             CDRL_HIP(hipEventRecord(ev_tail_main_, st));
             CDRL_HIP(hipStreamWaitEvent(comm_, ev_tail_main_, 0));

@@ -1,6 +1,8 @@
 // Philox-4x32-10 counter RNG (Random123), shared by the Beta sampler and the augmentation kernels.
-// Stream = (seed, offset), element index idx: counter = {idx.lo, idx.hi, offset.lo, offset.hi}, key = {seed.lo, seed.hi};
-// words are consumed in order, further blocks of the same element increment counter word 2.
+// Stream = (seed, offset), element index idx (< 2^48): counter = {idx.lo, idx.hi | block << 16, offset.lo, offset.hi},
+// key = {seed.lo, seed.hi}; words are consumed in order, and the further blocks of one element are counted in the TOP 16 BITS OF
+// COUNTER WORD 1 -- never in the offset words -- so the streams of different offsets (consecutive rollout steps, ranks) are
+// disjoint whatever number of blocks an element consumes (a Marsaglia-Tsang Beta draw uses >= 2).
 #pragma once
 #include <stdint.h>
 
@@ -15,7 +17,7 @@ struct Philox {
         k[0] = (uint32_t)seed;
         k[1] = (uint32_t)(seed >> 32);
         c[0] = (uint32_t)idx;
-        c[1] = (uint32_t)(idx >> 32);
+        c[1] = (uint32_t)(idx >> 32) & 0xFFFFu;
         c[2] = (uint32_t)offset;
         c[3] = (uint32_t)(offset >> 32);
         used = 4;
@@ -39,7 +41,7 @@ struct Philox {
         }
         out[0] = ctr[0]; out[1] = ctr[1]; out[2] = ctr[2]; out[3] = ctr[3];
         // next block of the stream for this element
-        if (++c[2] == 0) ++c[3];
+        c[1] += 0x10000u;
         used = 0;
     }
     __device__ double uniform() {       // (0, 1), 32 bits

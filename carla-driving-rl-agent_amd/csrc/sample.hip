@@ -64,7 +64,7 @@ __device__ double gamma_grad(double a, double g) {
 // element i = (row, col): alpha[row*ld + col], beta[row*ld + col]; outputs are dense [rows][A]
 __global__ void beta_sample_kernel(const float* __restrict__ alpha, const float* __restrict__ beta, int n, int A, int ld,
                                    uint64_t seed, uint64_t offset, float* __restrict__ u, float* __restrict__ du_da,
-                                   float* __restrict__ du_db, float* __restrict__ logp) {
+                                   float* __restrict__ du_db, float* __restrict__ logp, double* __restrict__ gammas) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int row = i / A, col = i - row * A;
@@ -72,7 +72,11 @@ __global__ void beta_sample_kernel(const float* __restrict__ alpha, const float*
     Philox rng(seed, offset, (uint64_t)i);
     const double g1 = gamma_sample(a, rng), g2 = gamma_sample(b, rng);
     const double s = g1 + g2;
-    u[i] = (float)(g1 / s);
+    if (u) u[i] = (float)(g1 / s);
+    if (gammas) {       // test hook: the two Gamma draws behind u
+        gammas[2 * (int64_t)i] = g1;
+        gammas[2 * (int64_t)i + 1] = g2;
+    }
     if (du_da) du_da[i] = (float)(gamma_grad(a, g1) * g2 / (s * s));
     if (du_db) du_db[i] = (float)(-gamma_grad(b, g2) * g1 / (s * s));
     if (logp) {     // log-density of the CLIPPED sample, as PolicyNetwork.call evaluates it (core/networks.py:100-103,139-144)
@@ -83,11 +87,29 @@ __global__ void beta_sample_kernel(const float* __restrict__ alpha, const float*
 }
 
 int beta_sample(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset, float* u,
-                float* du_da, float* du_db, hipStream_t st, float* logp) {
+                float* du_da, float* du_db, hipStream_t st, float* logp, double* gammas) {
     const int n = rows * A;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(beta_sample_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, alpha, beta, n, A, ld, seed, offset, u, du_da,
-                       du_db, logp);
+                       du_db, logp, gammas);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// test hook: the first `nblocks` raw 128-bit blocks of the streams (seed, offset, idx0 + i), i < n -> out[i][nblocks][4]
+__global__ void philox_words_kernel(uint64_t seed, uint64_t offset, uint64_t idx0, int n, int nblocks, uint32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Philox rng(seed, offset, idx0 + (uint64_t)i);
+    for (int b = 0; b < nblocks; ++b) {
+        rng.refill();
+        for (int w = 0; w < 4; ++w) out[((int64_t)i * nblocks + b) * 4 + w] = rng.out[w];
+    }
+}
+
+int philox_words(uint64_t seed, uint64_t offset, uint64_t idx0, int n, int nblocks, uint32_t* out, hipStream_t st) {
+    if (n <= 0 || nblocks <= 0) return 0;
+    hipLaunchKernelGGL(philox_words_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, seed, offset, idx0, n, nblocks, out);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

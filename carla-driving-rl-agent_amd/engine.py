@@ -158,6 +158,13 @@ class LearnerEngine:
         _lib.check(self.lib.cdrl_learner_set_comm_stream(self.h, C.c_void_p(stream.cuda_stream) if stream is not None else None),
                    'set_comm_stream')
 
+    def tail_offset(self) -> int:
+        """See cdrl_learner_tail_offset: first trunk-gradient element that is final when the communication stream is released."""
+        off = int(self.lib.cdrl_learner_tail_offset(self.h))
+        if off < 0:
+            raise _lib.CdrlError('cdrl_learner_tail_offset failed')
+        return off
+
     def reset_optimizer(self):
         self.adam_m.zero_()
         self.adam_v.zero_()

@@ -31,11 +31,18 @@ class DataParallelLearner:
         # BN + Dense) sit at the END of the trunk region and are final ~1 ms into the backward, like the head's; they go out
         # as early buckets on a communication stream that the engine releases at that point, and only the tower's slice
         # waits for the end of the backward.  9.6 MB in total, latency-bound on 7 x 153 GB/s xGMI either way.
-        tower_n = t_n
-        table = getattr(engine, 'tables', None) or getattr(getattr(engine, 'layout', None), 'tables', None)
-        if table is not None:
-            tail = [e['offset'] for e in table['trunk'].entries if e['trainable'] and not e['name'].startswith('img.')]
-            tower_n = min(tail) if tail else t_n
+        # The boundary comes from the ENGINE (cdrl_learner_tail_offset: the same op-list position that releases the
+        # communication stream), so the early bucket can never contain a tensor whose gradient is still being written; the
+        # parameter table is only used to cross-check it.
+        tower_n = engine.tail_offset() if hasattr(engine, 'tail_offset') else t_n
+        assert 0 <= tower_n <= t_n, (tower_n, t_n)
+        table = getattr(engine, 'tables', None)
+        if table is not None and tower_n < t_n:
+            ents = [e for e in table['trunk'].entries if e['trainable']]
+            tower_end = max((e['offset'] + e['numel'] for e in ents if e['name'].startswith('img.')), default=0)
+            tail_begin = min((e['offset'] for e in ents if not e['name'].startswith('img.')), default=t_n)
+            assert tower_end <= tower_n <= tail_begin, \
+                f'image-tower tensors must precede the tail tensors in the trunk arena ({tower_end} <= {tower_n} <= {tail_begin})'
         self._tower = (t_off, t_off + tower_n)
         self._policy_early = [(0, p_n), (t_off + tower_n, t_off + t_n)]
         self._value_early = [(t_off + tower_n, t_off + t_n + v_n)]

@@ -121,6 +121,10 @@ int cdrl_learner_share_hparams(cdrl_learner* l, const cdrl_learner* owner);
  * tail (every trunk tensor behind the image tower) are final.  A collective enqueued on that stream after the call has
  * returned runs concurrently with the tower's backward; the tower's gradients are final when the call's own stream is. */
 int cdrl_learner_set_comm_stream(cdrl_learner* l, void* stream);
+/* Element offset, inside the trunk's trainable region, of the first TAIL tensor: gradients [tail_offset, trunk size) plus the
+ * head's are final when the communication stream is released, gradients [0, tail_offset) (the image tower) only when the
+ * pass's own stream is.  Equals the trunk size when the stream is never released mid-pass (hipGraph replay, CDRL_GRAPH=1). */
+int64_t cdrl_learner_tail_offset(const cdrl_learner* l);
 int cdrl_learner_reset_optimizer_steps(cdrl_learner* l, void* stream);
 
 /* CARLAgent.get_policy_gradients (core/carla_agent.py:351-373): train-mode trunk forward,
@@ -194,6 +198,14 @@ int cdrl_beta_sample(const float* alpha, const float* beta, int rows, int A, int
 int cdrl_beta_sample_logp(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,
                           float* u, float* log_prob, void* stream);
 int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* out, void* stream);
+/* Test hook: the two Gamma draws (g1 ~ Gamma(alpha), g2 ~ Gamma(beta)) behind the sample u = g1 / (g1 + g2) of the same
+ * (seed, offset) stream -> gammas[rows * A][2] doubles.  Lets a test check du/dalpha, du/dbeta sample by sample. */
+int cdrl_beta_sample_gammas(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,
+                            double* gammas, void* stream);
+/* Test hook: the first `nblocks` raw Philox-4x32-10 blocks of the streams (seed, offset, idx0 + i), i < n -> out[n][nblocks][4].
+ * (seed, offset) selects a stream: streams of different offsets are DISJOINT for any number of blocks per element (the block
+ * counter lives in the top 16 bits of the element-index word, not in the offset). */
+int cdrl_philox_words(uint64_t seed, uint64_t offset, uint64_t idx0, int n, int nblocks, uint32_t* out, void* stream);
 
 /* Float32 1x1 convolution on the bf16 matrix pipe (exact three-way bf16 split of both operands, six bf16 MFMAs per K = 16
  * step; float32 in / out, float32-accurate, not bit-identical to an fmaf chain).  W_packed: cdrl_pwconv_x3_packed_bytes(K)

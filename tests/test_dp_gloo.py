@@ -95,27 +95,30 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_equals_averaged_gradients(tmp_path):
+@pytest.mark.parametrize('world', [2, 3])
+def test_two_rank_data_parallel_equals_averaged_gradients(tmp_path, world):
+    """world = 3: the 1/world gradient scale is not a power of two (SUM of three 1/3-scaled shard gradients)."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    t0, t1 = torch.load(tmp_path / 'trunk0.pt'), torch.load(tmp_path / 'trunk1.pt')
-    p0, p1 = torch.load(tmp_path / 'policy0.pt'), torch.load(tmp_path / 'policy1.pt')
-    for k in t0:       # replicas stay identical: same averaged gradients, same Adam update on every rank
-        assert torch.equal(t0[k], t1[k]), k
-    for k in p0:
-        assert torch.equal(p0[k], p1[k]), k
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    t0, p0 = torch.load(tmp_path / 'trunk0.pt'), torch.load(tmp_path / 'policy0.pt')
+    for r in range(1, world):       # replicas stay identical: same averaged gradients, same Adam update on every rank
+        t1, p1 = torch.load(tmp_path / f'trunk{r}.pt'), torch.load(tmp_path / f'policy{r}.pt')
+        for k in t0:
+            assert torch.equal(t0[k], t1[k]), k
+        for k in p0:
+            assert torch.equal(p0[k], p1[k]), k
     # reference semantics: one learner, gradients averaged over the two env shards.  Compared on the
     # all-reduced GRADIENT arena (linear in the shard gradients -> exact to rounding); comparing weights
     # after Adam would only measure sign flips of noise-level gradients.
     sys.path.insert(0, ROOT)
     g0 = torch.load(tmp_path / 'grads_after_policy0.pt')
-    g1 = torch.load(tmp_path / 'grads_after_policy1.pt')
-    assert torch.equal(g0, g1)
+    for r in range(1, world):
+        assert torch.equal(g0, torch.load(tmp_path / f'grads_after_policy{r}.pt'))
     lay = OracleBackedEngine(seed=7)
-    shards = [OracleBackedEngine(seed=7).oracle for _ in range(2)]
+    shards = [OracleBackedEngine(seed=7).oracle for _ in range(world)]
     grads = [sh.policy_grads(_batches(r)[0]) for r, sh in enumerate(shards)]
     for model, idx in (('policy', 1), ('trunk', 2)):
         off, _ = lay.region(model, True)
@@ -123,7 +126,7 @@ def test_two_rank_data_parallel_equals_averaged_gradients(tmp_path):
         for e in lay.layout.tables[model].entries:
             if not e['trainable']:
                 continue
-            avg = (grads[0][idx][e['name']] + grads[1][idx][e['name']]).detach() * 0.5
+            avg = sum(grads[r][idx][e['name']].detach().double() for r in range(world)).float() / world
             got = g0[off + e['offset']: off + e['offset'] + e['numel']].view(e['shape'])
             assert float((got - avg).abs().max()) <= 1e-5 * gmax, (model, e['name'])   # oracle run-to-run thread noise ~1e-6
     # the value-head region was not part of the policy all-reduce slice and must be untouched (zeros)

@@ -66,3 +66,65 @@ def test_two_rank_rccl_data_parallel(tmp_path):
     mean = 0.5 * (r0['local'][lo:hi] + r1['local'][lo:hi])
     scale = float(mean.abs().max())
     assert float((r0['reduced'][lo:hi] - mean).abs().max()) <= 2e-6 * scale
+
+
+def _worker_world1(rank, world, port, out, graph):
+    """ONE rank, a real NCCL (= RCCL) process group, collectives forced: the communication stream, the early buckets released in
+    the middle of the backward, the tower bucket, the moving-statistics reduce -- everything the N-GPU path enqueues."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if graph:
+        os.environ['CDRL_GRAPH'] = '1'
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    from carla_driving_rl_agent_amd.engine import LearnerEngine
+    from carla_driving_rl_agent_amd.init import init_engine_parameters
+    from carla_driving_rl_agent_amd.parallel import DataParallelLearner
+    from tests.util import make_batches, to_dev
+    res = {}
+    for tag, force in (('plain', False), ('forced', True)):
+        eng = LearnerEngine(B, device='cuda:0', H=H, W=W)
+        init_engine_parameters(eng, seed=5)
+        dp = DataParallelLearner(eng, force_collectives=force)
+        if force:
+            t_off, t_n = eng.region('trunk', True)
+            if graph:       # hipGraph replay never releases the communication stream mid-pass: no early bucket
+                assert eng.tail_offset() == t_n and dp._tower == (t_off, t_off + t_n)
+            else:
+                assert dp._comm is not None and 0 < eng.tail_offset() < t_n
+                names = [e['name'] for e in eng.tables['trunk'].entries if e['trainable'] and e['offset'] >= eng.tail_offset()]
+                assert names and not any(n.startswith('img.') for n in names)
+        dp.broadcast_parameters()
+        pol, val = make_batches(B, H, W, seed=61)
+        dpol, dval = to_dev(pol), to_dev(val)
+        steps = []
+        for k in range(3):
+            dp.update_step(dpol, dval, resample=(11, k))
+            torch.cuda.synchronize()
+            steps.append(eng.grads.clone().cpu())
+        res[tag] = dict(grads=steps, params=eng.params.clone().cpu(), m=eng.adam_m.clone().cpu(), v=eng.adam_v.clone().cpu())
+    torch.save(res, os.path.join(out, 'w1.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_world1_nccl_collective_path_is_bit_identical(tmp_path, graph):
+    """The data-parallel code path on ONE GPU (the driver's box has one): a world-1 NCCL group in a child process,
+    DataParallelLearner(force_collectives=True) -- communication stream, mid-backward release, 5 collectives per
+    update-step -- must reproduce the collective-free update-steps bit for bit (SUM over one rank, scale 1/1), over three
+    update-steps (the second and third start from weights the first one wrote: a bucket enqueued too early would show).
+    graph=True: the same with hipGraph replay of the passes (CDRL_GRAPH=1), where the engine must NOT pull the communication
+    stream into the capture."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_world1, args=(1, port, str(tmp_path), graph), nprocs=1, join=True)
+    r = torch.load(tmp_path / 'w1.pt')
+    for k in range(3):
+        assert torch.equal(r['plain']['grads'][k], r['forced']['grads'][k]), k
+    for key in ('params', 'm', 'v'):
+        assert torch.equal(r['plain'][key], r['forced'][key]), key
+    assert torch.isfinite(r['plain']['params']).all()

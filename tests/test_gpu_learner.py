@@ -37,6 +37,12 @@ def _pinned_group(name):
 # BatchNorm gradient (6e-8 per element, as in the reference) is amplified by the cancellation ratio; measured 1.0e-4..1.8e-4
 # at B = 32..64 for the engine and 0.7e-4..1.7e-4 for the float32 torch oracle on the same decisions.
 PINNED_TOL = dict(tower=TOL, tail=TOL, featnet=2 * TOL)
+# ... and at north_star's own minibatch of 256 every group, the feature nets included, is held to 1e-4
+# (test_pinned_decisions_gradients_and_weights[256-90-120-2-True]); _pinned_tol(B) is what the checks use.
+
+
+def _pinned_tol(B):
+    return dict(tower=TOL, tail=TOL, featnet=TOL if B >= 256 else 2 * TOL)
 
 
 def _compare(eng_views, ref32, ref64, tol, what, floor_frac=0.0, skip=lambda n: False, slack=3.0):
@@ -213,9 +219,10 @@ def _adam_update(g, m0, v0, t, lr, b1=0.9, b2=0.999, eps=1e-7):
     return lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t) * m / (np.sqrt(v) + eps)
 
 
-def _pinned_grad_check(eng_grads, g64, what, tol=TOL, floor_frac=1e-3, g32=None):
+def _pinned_grad_check(eng_grads, g64, what, tol=TOL, floor_frac=1e-3, g32=None, bounds=None):
     """Engine gradients vs the float64 oracle evaluated ON THE ENGINE'S OWN DISCRETE DECISIONS: a smooth function on both
     sides, so north_star's 1e-4 (relative to each tensor's scale) applies with no noise allowance."""
+    bounds = bounds or PINNED_TOL
     gmax = max(float(np.abs(_np(g)).max()) for g in g64.values())
     worst = {}
     zero_noise = 0.0
@@ -229,10 +236,16 @@ def _pinned_grad_check(eng_grads, g64, what, tol=TOL, floor_frac=1e-3, g32=None)
         r = _np(g).astype(np.float64)
         scale = max(np.abs(r).max(), floor_frac * gmax, 1e-30)
         e = float(np.abs(_np(eng_grads[name]).astype(np.float64) - r).max() / scale)
+        own = max(np.abs(r).max(), 1e-30)           # informational: error relative to the tensor's OWN scale, no floor
+        e_own = float(np.abs(_np(eng_grads[name]).astype(np.float64) - r).max() / own)
         e32 = float(np.abs(_np(eng_grads[name]).astype(np.float64) - _np(g32[name]).astype(np.float64)).max() / scale) if g32 else None
         grp = _pinned_group(name)
-        w = worst.setdefault(grp, dict(err=0.0, tensor='', errs=[], err_vs_oracle32=0.0))
+        w = worst.setdefault(grp, dict(err=0.0, tensor='', errs=[], err_vs_oracle32=0.0, floored=0, err_own=0.0, tensor_own=''))
         w['errs'].append(e)
+        if own < floor_frac * gmax:
+            w['floored'] += 1
+        if e_own >= w['err_own']:
+            w['err_own'], w['tensor_own'] = e_own, name
         if e >= w['err']:
             w['err'], w['tensor'] = e, name
         if e32 is not None:
@@ -242,17 +255,20 @@ def _pinned_grad_check(eng_grads, g64, what, tol=TOL, floor_frac=1e-3, g32=None)
         REPORT.append(dict(what=f'{what} (decision-pinned float64 oracle)', group=grp, tensors=len(w['errs']),
                            zero_gradient_bias_noise_rel_gmax=zero_noise,
                            engine_worst_err=w['err'], tensor=w['tensor'], engine_median_err=float(np.median(w['errs'])),
-                           engine_vs_pinned_oracle32_worst=w['err_vs_oracle32'], bound=PINNED_TOL[grp]))
+                           tensors_below_scale_floor=w['floored'], worst_err_rel_own_scale_no_floor=w['err_own'],
+                           tensor_worst_no_floor=w['tensor_own'],
+                           engine_vs_pinned_oracle32_worst=w['err_vs_oracle32'], bound=bounds[grp]))
     for grp, w in worst.items():
-        assert w['err'] <= PINNED_TOL[grp], f"{what} [{grp}] {w['tensor']}: {w['err']:.3e} > {PINNED_TOL[grp]:.1e} (decisions pinned)"
+        assert w['err'] <= bounds[grp], f"{what} [{grp}] {w['tensor']}: {w['err']:.3e} > {bounds[grp]:.1e} (decisions pinned)"
 
 
-def _pinned_weight_check(views, w64, g64, m0, v0, t, lr, what, tol=TOL, floor_frac=1e-3):
+def _pinned_weight_check(views, w64, g64, m0, v0, t, lr, what, tol=TOL, floor_frac=1e-3, bounds=None):
     """Updated weights after one Adam step.  Adam's decrement lr_t * m / (sqrt(v) + eps) is NOT Lipschitz in the gradient
     around g = 0 (at t = 1 it is lr * sign(g)), so "updated weights within 1e-4" is only well defined through the gradient
     tolerance: with every engine gradient element inside [g - d, g + d], d = tol * scale(tensor) (what _pinned_grad_check
     asserts), the engine's weight must lie inside the image of that interval under the oracle's own Adam update.  Elements
     with |g| >> d (the vast majority) are thereby held to ~1e-7 relative; elements with |g| <= d may move by up to 2 lr."""
+    bounds = bounds or PINNED_TOL
     gmax = max(float(np.abs(_np(g)).max()) for g in g64.values())
     nsure = ntot = 0
     worst_sure = 0.0
@@ -260,7 +276,7 @@ def _pinned_weight_check(views, w64, g64, m0, v0, t, lr, what, tol=TOL, floor_fr
         if is_degenerate_bias(name):
             continue
         g = _np(g).astype(np.float64)
-        d = PINNED_TOL[_pinned_group(name)] * max(np.abs(g).max(), floor_frac * gmax, 1e-30)
+        d = bounds[_pinned_group(name)] * max(np.abs(g).max(), floor_frac * gmax, 1e-30)
         mm = _np(m0[name]).astype(np.float64) if m0 is not None else np.zeros_like(g)
         vv = _np(v0[name]).astype(np.float64) if v0 is not None else np.zeros_like(g)
         ref = _adam_update(g, mm, vv, t, lr)
@@ -283,8 +299,9 @@ def _pinned_weight_check(views, w64, g64, m0, v0, t, lr, what, tol=TOL, floor_fr
     assert worst_sure <= tol
 
 
-@pytest.mark.parametrize('B,H,W,A,faithful', [(64, 48, 64, 2, True), (64, 41, 58, 3, False), (64, 90, 120, 2, True)])
-def test_pinned_decisions_gradients_and_weights(B, H, W, A, faithful):
+@pytest.mark.parametrize('B,H,W,A,faithful,heads', [(64, 48, 64, 2, True, 'init'), (64, 41, 58, 3, False, 'init'), (64, 90, 120, 2, True, 'init'),
+                                                    (64, 48, 64, 2, True, 'trained'), (256, 90, 120, 2, True, 'init')])
+def test_pinned_decisions_gradients_and_weights(B, H, W, A, faithful, heads):
     """A11 at north_star's bar: gradients and updated weights within 1e-4 of the oracle, measured on a WELL-DEFINED
     quantity.  ReLU6 regions and max-pool argmax are discrete decisions on float32 pre-activations; two implementations
     that differ by one rounding flip an element and move a tower gradient by percents (the float32 oracle itself sits
@@ -295,13 +312,18 @@ def test_pinned_decisions_gradients_and_weights(B, H, W, A, faithful):
     conditioning alone costs 1.2e-4..1.8e-4 on `vehicle.fc0.w` (measured; the float32 torch oracle shows 0.7e-4..1.7e-4 on its
     own worst tail tensor at those sizes) -- north_star quotes the bar at B = 256."""
     from oracle import model as OM
-    from tests.util import engine_decisions
-    oracle, eng = make_pair(B, H, W, seed=3, A=A, with64=True)
+    from tests.util import engine_decisions, trained_heads
+    # heads == 'trained': the policy / value branches are the reference's SHIPPED trained weights (stage-s5-curriculum; BatchNorm
+    # moving variances of mean 36, trained gammas) instead of a random initialisation -- tests/golden/ref_trained_heads.npz.
+    # B = 256, 90x120: north_star's own size -- every group INCLUDING the feature nets at 1e-4 (the float64 oracle on the host
+    # takes about a minute per pass there).
+    oracle, eng = make_pair(B, H, W, seed=3, A=A, with64=True, heads=trained_heads() if heads == 'trained' else None)
     o64 = oracle.o64
     pol, val = make_batches(B, H, W, seed=3, A=A, faithful=faithful)
     dpol, dval = to_dev(pol), to_dev(val)
     del REPORT[:]
     hp = oracle.hp
+    bounds = _pinned_tol(B)
 
     with32 = H * W < 90 * 120          # the float32 replay is informational (engine vs float32 oracle on the same decisions)
 
@@ -328,13 +350,13 @@ def test_pinned_decisions_gradients_and_weights(B, H, W, A, faithful):
         ax = eng.buffer(_lib.BUF_AUX_P, (B, 4, A)).cpu().numpy()
         for i, k in enumerate(('alpha', 'beta', 'log_prob')):
             assert rel_err(ax[:, i], _np(aux64[k])) < TOL, k
-        _pinned_grad_check(eng.grad_views('policy'), gp64, 'policy grad', g32=gp32)
-        _pinned_grad_check(eng.grad_views('trunk'), gt64, 'trunk grad (policy pass)', g32=gt32)
+        _pinned_grad_check(eng.grad_views('policy'), gp64, 'policy grad', g32=gp32, bounds=bounds)
+        _pinned_grad_check(eng.grad_views('trunk'), gt64, 'trunk grad (policy pass)', g32=gt32, bounds=bounds)
         o64.policy_step(None, grads=(loss64, gp64, gt64, aux64))
         eng.policy_apply()
-        _pinned_weight_check(eng.param_views('trunk'), o64.trunk, gt64, None, None, 1, hp['dynamics_lr'], 'updated trunk weights')
+        _pinned_weight_check(eng.param_views('trunk'), o64.trunk, gt64, None, None, 1, hp['dynamics_lr'], 'updated trunk weights', bounds=bounds)
         gpc = {n: OM.clip_by_norm(g, hp['clip_norm_policy']) for n, g in gp64.items()}
-        _pinned_weight_check(eng.param_views('policy'), o64.policy, gpc, None, None, 1, hp['policy_lr'], 'updated policy weights')
+        _pinned_weight_check(eng.param_views('policy'), o64.policy, gpc, None, None, 1, hp['policy_lr'], 'updated policy weights', bounds=bounds)
         # BatchNorm moving statistics of the training forward are smooth: plain 1e-4
         for name, t64 in o64.trunk.items():
             if 'moving' in name:
@@ -350,15 +372,15 @@ def test_pinned_decisions_gradients_and_weights(B, H, W, A, faithful):
         assert abs(mv['loss'] - float(loss64.detach())) < TOL * max(1.0, abs(float(loss64.detach())))
         vals = eng.buffer(_lib.BUF_AUX_V, (B, 2)).cpu().numpy()
         assert rel_err(vals, _np(aux64['values'])) < TOL
-        _pinned_grad_check(eng.grad_views('value'), gv64, 'value grad', g32=gv32)
-        _pinned_grad_check(eng.grad_views('trunk'), gt64, 'trunk grad (value pass)', g32=gt32)
+        _pinned_grad_check(eng.grad_views('value'), gv64, 'value grad', g32=gv32, bounds=bounds)
+        _pinned_grad_check(eng.grad_views('trunk'), gt64, 'trunk grad (value pass)', g32=gt32, bounds=bounds)
         o64.value_step(None, grads=(loss64, gv64, gt64, aux64))
         eng.value_apply()
-        _pinned_weight_check(eng.param_views('trunk'), o64.trunk, gt64, m0, v0, 2, hp['dynamics_lr'], 'updated trunk weights (t=2)')
+        _pinned_weight_check(eng.param_views('trunk'), o64.trunk, gt64, m0, v0, 2, hp['dynamics_lr'], 'updated trunk weights (t=2)', bounds=bounds)
         gvc = {n: OM.clip_by_norm(g, hp['clip_norm_value']) for n, g in gv64.items()}
-        _pinned_weight_check(eng.param_views('value'), o64.value, gvc, None, None, 1, hp['value_lr'], 'updated value weights')
+        _pinned_weight_check(eng.param_views('value'), o64.value, gvc, None, None, 1, hp['value_lr'], 'updated value weights', bounds=bounds)
     finally:
-        _dump_report(f'pinned_B{B}_{H}x{W}')
+        _dump_report(f'pinned_B{B}_{H}x{W}' + ('_trained_heads' if heads == 'trained' else ''))
 
 
 @pytest.mark.parametrize('A', [2, 3])
@@ -513,3 +535,18 @@ def test_bad_inputs_fail_loudly():
         eng.policy_forward_backward(bad)
     with pytest.raises(_lib.CdrlError):
         _lib.check(eng.lib.cdrl_learner_policy_forward_backward(eng.h, None, 1.0, None), 'null batch')
+
+
+def test_trained_heads_predict():
+    """CARLANetwork.predict (core/networks.py:181-193) through the reference's SHIPPED trained policy / value branches: the
+    inference-mode BatchNorms divide by sqrt(moving_var + eps) with moving variances of mean 36 (max 121), a regime the
+    randomly initialised heads of the other tests never reach."""
+    from tests.util import trained_heads
+    B, H, W = 16, 48, 64
+    oracle, eng = make_pair(B, H, W, seed=5, heads=trained_heads())
+    pol, _ = make_batches(B, H, W, seed=5)
+    alpha, beta, value, dyn = oracle.predict(pol['states'])
+    out = eng.predict(to_dev(pol['states']))
+    assert float(eng.param_views('policy')['pi.bn0.moving_var'].mean()) > 30.0
+    for k, ref in (('dynamics', dyn), ('alpha', alpha), ('beta', beta), ('value', value)):
+        assert rel_err(out[k].cpu().numpy(), ref.numpy()) < TOL, k

@@ -77,3 +77,59 @@ def test_resampled_policy_step_runs_and_uses_new_policy_sample():
     eng.policy_forward_backward_resample(d, seed=5, offset=2)          # another offset -> another sample / gradient
     assert not torch.equal(u1, eng.buffer(_lib.BUF_SAMPLE, (B, 2)))
     assert not torch.equal(g1, eng.grads)
+
+
+def test_philox_streams_of_consecutive_offsets_are_disjoint(lib):
+    """(seed, offset) selects a stream; a Beta draw consumes >= 2 blocks per element, so the further blocks of an element
+    must not be block 1 of the next offset (rollout step t+1 / rank r+1 would reuse the words that produced g2 at step t)."""
+    n, nb = 64, 6
+    words = []
+    for off in (10, 11, 12):
+        out = torch.zeros((n, nb, 4), dtype=torch.int32, device=DEV)
+        _lib.check(lib.cdrl_philox_words(99, off, 0, n, nb, P(out), S()))
+        words.append(out.cpu().numpy().view(np.uint32))
+    for i in range(3):
+        flat = words[i].reshape(-1, 4)
+        assert len({tuple(b) for b in flat}) == len(flat)                    # blocks of one stream are distinct
+        for j in range(i + 1, 3):
+            other = {tuple(b) for b in words[j].reshape(-1, 4)}
+            assert not ({tuple(b) for b in flat} & other), (i, j)
+    # first block = the documented counter layout (the augmentation oracle's numpy Philox reproduces it): unchanged
+    from oracle.augment import _block
+    assert np.array_equal(words[0][:, 0, :], _block(99, 10, np.arange(n, dtype=np.uint64)))
+
+
+def test_beta_sample_per_sample_jacobians_match_quantile_finite_differences(lib):
+    """Per-sample pathwise Jacobians of u = g1 / (g1 + g2) (core/networks.py:96-110 through TFP's implicitly
+    reparameterised Gamma draws): with the two draws held at their CDF levels p1 = P(alpha, g1), p2 = P(beta, g2),
+    du/dalpha and du/dbeta are the derivatives of u(alpha, beta) = q(p1; alpha) / (q(p1; alpha) + q(p2; beta)), q = Gamma
+    quantile.  Checked SAMPLE BY SAMPLE against central differences of scipy's quantile function; the draws themselves come
+    from the cdrl_beta_sample_gammas hook on the same stream."""
+    rows, A = 192, 2
+    rng = np.random.default_rng(4)
+    al = rng.uniform(1.01, 12.0, (rows, A)).astype(np.float32)
+    be = rng.uniform(1.01, 12.0, (rows, A)).astype(np.float32)
+    al[0], be[0] = (1.01, 1.01), (1.01, 30.0)                            # the softplus + 1.01 floor of the heads, a lopsided pair
+    ab = torch.tensor(np.concatenate([al, be], 1), device=DEV)
+    u = torch.zeros((rows, A), device=DEV)
+    ja, jb = torch.zeros_like(u), torch.zeros_like(u)
+    gm = torch.zeros((rows, A, 2), dtype=torch.float64, device=DEV)
+    bptr = C.c_void_p(ab.data_ptr() + 4 * A)
+    _lib.check(lib.cdrl_beta_sample(P(ab), bptr, rows, A, 2 * A, 77, 3, P(u), P(ja), P(jb), S()))
+    _lib.check(lib.cdrl_beta_sample_gammas(P(ab), bptr, rows, A, 2 * A, 77, 3, P(gm), S()))
+    g = gm.cpu().numpy()
+    g1, g2 = g[..., 0], g[..., 1]
+    a, b = al.astype(np.float64), be.astype(np.float64)
+    un = u.cpu().numpy().astype(np.float64)
+    assert np.allclose(un, g1 / (g1 + g2), rtol=2e-7)                    # the same stream, u rounded to float32
+    p1, p2 = stats.gamma.cdf(g1, a), stats.gamma.cdf(g2, b)
+    keep = (p1 > 1e-6) & (p1 < 1 - 1e-6) & (p2 > 1e-6) & (p2 < 1 - 1e-6)     # (the quantile FD is ill-conditioned in the far tails)
+    h = 1e-5
+    q = stats.gamma.ppf
+    fa = (q(p1, a + h) / (q(p1, a + h) + g2) - q(p1, a - h) / (q(p1, a - h) + g2)) / (2 * h)
+    fb = (g1 / (g1 + q(p2, b + h)) - g1 / (g1 + q(p2, b - h))) / (2 * h)
+    jan, jbn = ja.cpu().numpy().astype(np.float64), jb.cpu().numpy().astype(np.float64)
+    assert keep.sum() > 0.95 * keep.size
+    assert np.allclose(jan[keep], fa[keep], rtol=2e-5, atol=1e-8), float(np.abs(jan - fa)[keep].max())
+    assert np.allclose(jbn[keep], fb[keep], rtol=2e-5, atol=1e-8), float(np.abs(jbn - fb)[keep].max())
+    assert (jan[keep] > 0).all() and (jbn[keep] < 0).all()

@@ -64,3 +64,65 @@ def test_gae_kernel_matches_oracle(n, spike):
     a = adv.cpu().numpy()
     assert np.allclose(a, adv_ref, rtol=1e-6, atol=1e-6 * np.abs(adv_ref).max())   # powf(10,x) may differ by 1 ulp
     assert np.allclose(advn.cpu().numpy(), advn_ref, rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Golden vectors produced by the REFERENCE's own functions (tests/golden/make_gae_vectors.py executes the AST nodes of
+# discount_cumsum / gae / decompose_number / np_normalize / clip from /root/reference/rl/utils.py:53-151 in the build
+# container; the .npz holds inputs and outputs only).  This is the reference-run pin of row A13.
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_gae_vectors.npz')
+
+
+def _golden():
+    z = np.load(GOLDEN)
+    return z, [str(c) for c in z['cases']]
+
+
+def test_golden_file_lists_the_reference_lines():
+    z, cases = _golden()
+    assert len(cases) == 7
+    names = {s.split(':')[0] for s in map(str, z['reference_lines'])}
+    assert names == {'np_normalize', 'discount_cumsum', 'gae', 'clip', 'decompose_number'}
+
+
+@pytest.mark.parametrize('case', _golden()[1])
+def test_oracle_matches_reference_functions_bitwise(case):
+    z, _ = _golden()
+    r, vbe = z[f'{case}.rewards'], z[f'{case}.values_be']
+    gamma, lam = (float(x) for x in z[f'{case}.gamma_lambda'])
+    # returns: float64 recurrence of the reference's lfilter call, bit for bit; then its float32 cast and decomposition
+    assert np.array_equal(OG.discount_cumsum(r, gamma)[:-1], z[f'{case}.returns64'])
+    ret, dec = OG.compute_returns(r, gamma)
+    assert np.array_equal(ret, z[f'{case}.returns64'].astype(np.float32))
+    assert np.array_equal(dec, z[f'{case}.returns_dec'])
+    values, adv, _ = OG.compute_advantages(r, vbe, gamma, lam)
+    assert np.array_equal(values, z[f'{case}.values'])
+    ref_adv = z[f'{case}.adv']
+    assert str(z[f'{case}.adv_dtype']) == ('float32' if lam == 0.0 else 'float64')
+    assert np.array_equal(adv, ref_adv.astype(np.float32))            # the reference's to_float() of the lfilter output
+
+
+def test_oracle_decompose_matches_reference_on_probes():
+    z, _ = _golden()
+    got = np.array([OG.decompose_number(x) for x in z['decompose.in']], np.float32)
+    assert np.array_equal(got, z['decompose.f32'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', _golden()[1])
+def test_gae_kernel_matches_reference_functions(case):
+    """cdrl_gae_returns vs the outputs of the reference's own discount_cumsum / gae / decompose_number."""
+    import torch
+    from carla_driving_rl_agent_amd.engine import gae_returns
+    z, _ = _golden()
+    r, vbe = z[f'{case}.rewards'], z[f'{case}.values_be']
+    gamma, lam = (float(x) for x in z[f'{case}.gamma_lambda'])
+    ret, dec, adv, advn = gae_returns(torch.tensor(r).cuda(), torch.tensor(vbe).cuda(), gamma, lam, 2.0)
+    assert np.array_equal(ret.cpu().numpy(), z[f'{case}.returns64'].astype(np.float32))       # bit-exact
+    assert np.array_equal(dec.cpu().numpy(), z[f'{case}.returns_dec'])                        # bit-exact
+    ref_adv = z[f'{case}.adv'].astype(np.float32)
+    a = adv.cpu().numpy()
+    # values = base * 10**exp goes through the device powf (<= 1 ulp from numpy's): the recurrence itself is exact
+    assert np.allclose(a, ref_adv, rtol=1e-6, atol=1e-6 * max(np.abs(ref_adv).max(), 1e-30))

@@ -24,11 +24,25 @@ def is_zero_gradient(name: str) -> bool:
     return is_degenerate_bias(name) or name.endswith('.bn2.beta') or name.endswith('.sc_bn1.beta') or name == 'dyn.bn.beta'
 
 
-def make_pair(B, H, W, seed=0, device='cuda:0', A=2, hp=None, with64=False, compute='f32', **cfg):
+def trained_heads():
+    """The reference's SHIPPED trained policy / value branches (tests/golden/ref_trained_heads.npz, written by
+    tests/golden/make_trained_heads.py from weights/stage-s5-curriculum): ({name: array}, {name: array}), A = 2."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_trained_heads.npz'))
+    pp = {k.split('/', 1)[1]: z[k] for k in z.files if k.startswith('policy/')}
+    vp = {k.split('/', 1)[1]: z[k] for k in z.files if k.startswith('value/')}
+    return pp, vp
+
+
+def make_pair(B, H, W, seed=0, device='cuda:0', A=2, hp=None, with64=False, compute='f32', heads=None, **cfg):
     ocfg = NetConfig(H=H, W=W, A=A, **cfg)
     tp = OM.init_params(trunk_spec(ocfg), seed + 1)
     pp = OM.init_params(policy_spec(ocfg), seed + 2)
     vp = OM.init_params(value_spec(ocfg), seed + 3)
+    if heads is not None:           # (policy, value) parameter dicts replacing the random initialisation
+        assert set(heads[0]) == set(pp) and set(heads[1]) == set(vp)
+        pp = {k: np.asarray(heads[0][k], np.float32).reshape(pp[k].shape) for k in pp}
+        vp = {k: np.asarray(heads[1][k], np.float32).reshape(vp[k].shape) for k in vp}
     hp = dict(synthetic.DEFAULT_HP if hp is None else hp)
     oracle = OM.OracleLearner(ocfg, tp, pp, vp, hp)
     if with64:

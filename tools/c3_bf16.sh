@@ -17,7 +17,7 @@ cp gpurun_out/pmc_mfma_c3$r/mfma.json $out/pmc_mfma.json
 mkdir -p $out/pmc && cp gpurun_out/pmc_mfma_c3$r/*.txt $out/pmc/
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $out -o step_$ctr -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --dtype bf16 --batch 1024 > $out/step_$ctr.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $out -o step_$ctr -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-rooflines --dtype bf16 --batch 1024 > $out/step_$ctr.log 2>&1
   python3 tools/rocpd_pmc.py $out/step_${ctr}_results.db cdrl > $out/pmc/step_$ctr.txt 2>&1
   rm -f $out/*_results.db
 done

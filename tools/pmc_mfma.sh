@@ -7,7 +7,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for ctr in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32" "SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   name=$(echo $ctr | tr ' ' '+')
-  timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $out -o step_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/step_$name.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $out -o step_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-rooflines "$@" > $out/step_$name.log 2>&1
   python3 tools/rocpd_pmc.py $out/step_${name}_results.db cdrl > $out/step_$name.txt 2>&1
   rm -f $out/*_results.db
 done

@@ -6,7 +6,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 timeout 300 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | tail -1 > $out/bench.log
-timeout 400 rocprofv3 --kernel-trace --stats -d $out -o trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $out/run.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $out -o trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-rooflines "$@" > $out/run.log 2>&1
 python3 tools/rocpd_summary.py $out/trace_results.db 45 > $out/summary.md
 rm -f $out/trace_results.db
 python3 -c "
