@@ -24,9 +24,10 @@ ALG_ELEMS_PER_FRAME = {(90, 120): 979500, (90, 360): 2902212, (135, 180): 227524
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def alg_bytes_per_update_step(B, T, H, W):
-    """ALG_BYTES_pass = 3 * 4 B * B * T * sum(in+out); an update-step is 2 passes."""
-    return 2 * 3 * 4 * B * T * ALG_ELEMS_PER_FRAME[(H, W)]
+def alg_bytes_per_update_step(B, T, H, W, elem_bytes=4):
+    """ALG_BYTES_pass = 3 * sizeof(dtype) * B * T * sum(in+out); an update-step is 2 passes (24.07 GB at
+    B=256 float32, 48.14 GB at B=1024 bf16)."""
+    return 2 * 3 * elem_bytes * B * T * ALG_ELEMS_PER_FRAME[(H, W)]
 
 
 def pmc_traffic(B, T, H, W, dtype='f32'):
@@ -363,9 +364,10 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--height', type=int, default=90)
     ap.add_argument('--width', type=int, default=120)
-    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
-                    help="bf16: configuration 3's compute mode (bf16 MFMA operands in the tower's 1x1 convolutions, float32 storage "
-                         "and accumulation); quote it with --batch 1024")
+    ap.add_argument('--dtype', choices=['f32', 'bf16', 'bf16s'], default='f32',
+                    help="bf16s: configuration 3 (bf16 activation STORAGE in the image tower + bf16 MFMA operands in its 1x1 convolutions, "
+                         "float32 accumulation / statistics / weights); bf16: the operand mode alone (float32 tensors); quote either with "
+                         "--batch 1024")
     ap.add_argument('--rollout-rows', action='store_true',
                     help='measure the rollout-side rows (predict for E environments, Beta sampling, augmentation, GAE, checkpoint I/O, '
                          'the agent-level collect / update cycle) with their CPU stand-ins and print that JSON instead of the benchmark line')
@@ -489,7 +491,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
-        alg = alg_bytes_per_update_step(B, T, H, W) if (H, W) in ALG_ELEMS_PER_FRAME else None
+        alg = alg_bytes_per_update_step(B, T, H, W, 2 if args.dtype == 'bf16s' else 4) if (H, W) in ALG_ELEMS_PER_FRAME else None
         dev_s_per_step = dev_ms * 1e-3 / args.steps
         roof = None
         if alg is not None:
@@ -501,9 +503,13 @@ def main():
         out = dict(metric='PPO update-steps/sec (batch=256, 4x90x120x3 obs)', value=round(value, 3), unit='update-steps/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
                    higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype='f32' if args.dtype == 'f32' else 'bf16 MFMA operands in the 1x1 convolutions (fwd, bwd-data), f32 storage/accumulate', data='synthetic',
+                   dtype={'f32': 'f32', 'bf16': 'bf16 MFMA operands in the 1x1 convolutions (fwd, bwd-data, filter gradient), f32 storage/accumulate',
+                          'bf16s': 'bf16 (activation storage + MFMA operands of the image tower; f32 accumulate / statistics / weights)'}[args.dtype],
+                   data='synthetic',
                    config=dict(workload=f'configs[1]: synthetic rollout buffer {B}x{T}-frame {H}x{W}x3 obs per GPU, full '
-                                        f'CARLANetwork fwd/bwd + PPO (re-sampled Beta, pathwise) / value loss + clip + Adam, ' + ('fp32' if args.dtype == 'f32' else 'bf16-operand compute mode (configs[2])'),
+                                        f'CARLANetwork fwd/bwd + PPO (re-sampled Beta, pathwise) / value loss + clip + Adam, ' +
+                                        {'f32': 'fp32', 'bf16': 'bf16-operand compute mode (configs[2] arithmetic, float32 tensors)',
+                                         'bf16s': 'bf16 storage + bf16 MFMA (configs[2])'}[args.dtype],
                                per_gpu_batch=B, global_batch=B * world, time_horizon=T, image=[H, W, 3],
                                parallelism=f'dp{world}', passes_per_step=2,
                                policy_loss='stored-actions' if args.stored_actions else 'resampled (reference-faithful)'),

@@ -21,7 +21,7 @@ class Config(C.Structure):
                 ('head', C.c_int32), ('exp_scale', C.c_float), ('compute', C.c_int32)]
 
 
-COMPUTE_F32, COMPUTE_BF16_OPERANDS = 0, 1
+COMPUTE_F32, COMPUTE_BF16_OPERANDS, COMPUTE_BF16_STORAGE = 0, 1, 2
 
 
 class ParamInfo(C.Structure):
@@ -96,6 +96,7 @@ PROTOTYPES = {
     'cdrl_beta_sample_logp': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp]),
     'cdrl_beta_sample': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp, _fp]),
     'cdrl_gamma_implicit_grad': (_i, [_fp, _fp, _i, _fp, _fp]),
+    'cdrl_set_op_activation_type': (_i, [_i]),
     'cdrl_beta_sample_gammas': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp]),
     'cdrl_philox_words': (_i, [C.c_uint64, C.c_uint64, C.c_uint64, _i, _i, _fp, _fp]),
     'cdrl_learner_policy_apply': (_i, [_L, _fp]),

@@ -15,12 +15,12 @@ namespace cdrl {
 
 #define BN_EPS 1e-3f
 
-template <int VEC>
+template <int VEC, class T = float>
 struct StatsF {
     View y;
     bool al;
     __device__ void operator()(int, int64_t row, int c0, double (*acc)[VEC]) const {
-        const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al);
+        const VecF<VEC> v = vload_view<VEC, T>(y, row, c0, 0, al);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const double d = (double)v.v[i];
@@ -30,9 +30,10 @@ struct StatsF {
     }
 };
 
-int colstats(View y, int G, int Mg, int C, double* part, hipStream_t st) {
+int colstats(View y, int G, int Mg, int C, double* part, hipStream_t st, int at) {
     const bool al = view_aligned(y, vcol_geom(Mg, C).vec);
-    return launch_vcolreduce<2, StatsF>(G, Mg, C, part, st, NB_STATS, y, al);
+    if (at) return launch_vcolreduce_t<2, StatsF, bf16_t>(G, Mg, C, part, st, NB_STATS, y, al);
+    return launch_vcolreduce_t<2, StatsF, float>(G, Mg, C, part, st, NB_STATS, y, al);
 }
 
 template <int VEC>
@@ -378,7 +379,7 @@ __device__ __forceinline__ float apply_act(float z, int act) {
     return z;
 }
 
-template <int VEC>
+template <int VEC, class T>
 __global__ void __launch_bounds__(256) bn_apply_kernel(View y, int Mg, int C, int rb, int nloop, int GC,
                                                        const float* __restrict__ stats, int act, View dst,
                                                        int shuffle_ctot, bool al_in, bool al_out, View psrc, View pdst,
@@ -403,13 +404,13 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(View y, int Mg, int C, in
         }
         for (int r = r0 + ty; r < r1; r += CY) {
             const int64_t row = (int64_t)g * Mg + r;
-            VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_in);
+            VecF<VEC> v = vload_view<VEC, T>(y, row, c0, 0, al_in);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v.v[i] = apply_act(fmaf(sc.v[i], v.v[i], sh.v[i]), act);
-            vstore_view<VEC>(dst, row, c0, shuffle_ctot, al_out, v);
+            vstore_view<VEC, T>(dst, row, c0, shuffle_ctot, al_out, v);
             if (psrc.p) {       // the unit's identity half goes through the same concat + shuffle store (same C channels)
-                const VecF<VEC> pv = vload_view<VEC>(psrc, row, c0, 0, al_ps);
-                vstore_view<VEC>(pdst, row, c0, shuffle_ctot, false, pv);
+                const VecF<VEC> pv = vload_view<VEC, T>(psrc, row, c0, 0, al_ps);
+                vstore_view<VEC, T>(pdst, row, c0, shuffle_ctot, false, pv);
             }
         }
     }
@@ -418,9 +419,13 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(View y, int Mg, int C, in
 // Fast path of bn_apply for the unit output (concat + channel shuffle as a destination permutation, optionally with the
 // identity half): RU rows of loads are issued before the first store -- gfx9 counts loads and stores in one in-order
 // counter, so "load, store, load, use" (the generic loop) waits for a store round trip per row.
-template <int VEC, bool PASS>
+template <int VEC, bool PASS, class T>
 __global__ void __launch_bounds__(256) bn_apply_shuf_kernel(View y, int Mg, int C, int rb, int GC, const float* __restrict__ stats,
                                                             int act, View dst, int ctot, View psrc, View pdst) {
+    const T* yp = vptr<T>(y);
+    const T* psp = vptr<T>(psrc);
+    T* dstp = vptr<T>(dst);
+    T* pdp = vptr<T>(pdst);
     constexpr int RU = 4;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int CY = blockDim.y;
@@ -441,27 +446,28 @@ __global__ void __launch_bounds__(256) bn_apply_shuf_kernel(View y, int Mg, int 
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const int64_t row = gbase + min(rr + u * CY, r1 - 1);
-            v[u] = vload<VEC>(y.p + row * y.ld + y.coff + c0);
-            if (PASS) pv[u] = vload<VEC>(psrc.p + row * psrc.ld + psrc.coff + c0);
+            v[u] = vload<VEC>(yp + row * y.ld + y.coff + c0);
+            if (PASS) pv[u] = vload<VEC>(psp + row * psrc.ld + psrc.coff + c0);
         }
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             if (rr + u * CY >= r1) break;
             const int64_t row = gbase + rr + u * CY;
-            float* dr = dst.p + row * dst.ld;
+            T* dr = dstp + row * dst.ld;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) dr[dcol[i]] = apply_act(fmaf(sc.v[i], v[u].v[i], sh.v[i]), act);
+            for (int i = 0; i < VEC; ++i) stf(dr + dcol[i], apply_act(fmaf(sc.v[i], v[u].v[i], sh.v[i]), act));
             if (PASS) {
-                float* pr = pdst.p + row * pdst.ld;
+                T* pr = pdp + row * pdst.ld;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) pr[pcol[i]] = pv[u].v[i];
+                for (int i = 0; i < VEC; ++i) stf(pr + pcol[i], pv[u].v[i]);
             }
         }
     }
 }
 
-int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
-             hipStream_t st, const View* pass_src, const View* pass_dst) {
+template <class T>
+static int bn_apply_t(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
+                      hipStream_t st, const View* pass_src, const View* pass_dst) {
     {
         static const bool fast = !(getenv("CDRL_APPLY_FAST") && atoi(getenv("CDRL_APPLY_FAST")) == 0);
         const VColGeom g = vcol_geom(Mg, C, 2048);
@@ -473,11 +479,11 @@ int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst
         if (fast && stats && shuffle_ctot && g.nloop == 1 && g.vec >= 2 && view_aligned(y, g.vec) && (!ps.p || view_aligned(ps, g.vec))) {
             dim3 grid(g.nb, G), block(g.cx, g.cy);
             if (g.vec == 4) {
-                if (ps.p) hipLaunchKernelGGL((bn_apply_shuf_kernel<4, true>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
-                else hipLaunchKernelGGL((bn_apply_shuf_kernel<4, false>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
+                if (ps.p) hipLaunchKernelGGL((bn_apply_shuf_kernel<4, true, T>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
+                else hipLaunchKernelGGL((bn_apply_shuf_kernel<4, false, T>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
             } else {
-                if (ps.p) hipLaunchKernelGGL((bn_apply_shuf_kernel<2, true>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
-                else hipLaunchKernelGGL((bn_apply_shuf_kernel<2, false>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
+                if (ps.p) hipLaunchKernelGGL((bn_apply_shuf_kernel<2, true, T>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
+                else hipLaunchKernelGGL((bn_apply_shuf_kernel<2, false, T>), grid, block, 0, st, y, Mg, C, g.rb, G * C, stats, act, dst, shuffle_ctot, ps, pd);
             }
             CDRL_LAUNCH_CHECK();
             return 0;
@@ -493,18 +499,25 @@ int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst
     const bool aps = ps.p && view_aligned(ps, g.vec);
     dim3 grid(g.nb, G), block(g.cx, g.cy);
     if (g.vec == 4)
-        hipLaunchKernelGGL(bn_apply_kernel<4>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao, ps, pd, aps);
+        hipLaunchKernelGGL((bn_apply_kernel<4, T>), grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao, ps, pd, aps);
     else if (g.vec == 2)
-        hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao, ps, pd, aps);
+        hipLaunchKernelGGL((bn_apply_kernel<2, T>), grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao, ps, pd, aps);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao, ps, pd, aps);
+        hipLaunchKernelGGL((bn_apply_kernel<1, T>), grid, block, 0, st, y, Mg, C, g.rb, g.nloop, G * C, stats, act, dst, shuffle_ctot, ai, ao, ps, pd, aps);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
 
+int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
+             hipStream_t st, const View* pass_src, const View* pass_dst, int at) {
+    if (at) return bn_apply_t<bf16_t>(y, G, Mg, C, stats, act, dst, shuffle_ctot, st, pass_src, pass_dst);
+    return bn_apply_t<float>(y, G, Mg, C, stats, act, dst, shuffle_ctot, st, pass_src, pass_dst);
+}
+
 // BatchNorm apply + activation + global average pool in one pass over the raw conv output (the head of the tower: the 12288 x 768
 // activated tensor is neither written nor read; same operation order as bn_apply followed by gap_fwd_kernel, so the same bits)
-__global__ void bn_act_gap_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ out, int N,
+template <class T>
+__global__ void bn_act_gap_fwd_kernel(const T* __restrict__ y, const float* __restrict__ stats, float* __restrict__ out, int N,
                                       int P, int C, int GC, int frames_per_group, int act) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * C) return;
@@ -513,14 +526,19 @@ __global__ void bn_act_gap_fwd_kernel(const float* __restrict__ y, const float* 
     const int g = (int)(n / frames_per_group);
     const float sc = stats[2 * GC + g * C + c], sh = stats[3 * GC + g * C + c];
     float s = 0.0f;
-    for (int p = 0; p < P; ++p) s += apply_act(fmaf(sc, y[(n * P + p) * C + c], sh), act);
+    for (int p = 0; p < P; ++p) s += apply_act(fmaf(sc, ldf(y + (n * P + p) * C + c), sh), act);
     out[i] = s / (float)P;
 }
 
-int bn_act_gap_fwd(const float* y, const float* stats, float* out, int G, int frames_per_group, int P, int C, int act, hipStream_t st) {
+int bn_act_gap_fwd(const float* y, const float* stats, float* out, int G, int frames_per_group, int P, int C, int act, hipStream_t st,
+                   int at) {
     const int N = G * frames_per_group;
-    hipLaunchKernelGGL(bn_act_gap_fwd_kernel, dim3((unsigned)cdiv64((int64_t)N * C, 256)), dim3(256), 0, st, y, stats, out, N, P, C,
-                       G * C, frames_per_group, act);
+    if (at)
+        hipLaunchKernelGGL(bn_act_gap_fwd_kernel<bf16_t>, dim3((unsigned)cdiv64((int64_t)N * C, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const bf16_t*>(y), stats, out, N, P, C, G * C, frames_per_group, act);
+    else
+        hipLaunchKernelGGL(bn_act_gap_fwd_kernel<float>, dim3((unsigned)cdiv64((int64_t)N * C, 256)), dim3(256), 0, st, y, stats, out, N, P, C,
+                           G * C, frames_per_group, act);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -528,7 +546,7 @@ int bn_act_gap_fwd(const float* y, const float* stats, float* out, int G, int fr
 // ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, class T = float>
 struct BnBwdReduceF {
     View da;
     int shuffle_ctot;
@@ -543,18 +561,18 @@ struct BnBwdReduceF {
     int bcast;              // > 0: da has one row per `bcast` rows of y and is divided by it (gradient of a global average pool)
     __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
         VecF<VEC> d;
-        if (bcast > 0) {
-            d = vload_view<VEC>(da, row / bcast, c0, 0, al_da);
+        if (bcast > 0) {        // the pooled gradient (one row per frame) is a float32 tensor in either storage mode
+            d = vload_view<VEC, float>(da, row / bcast, c0, 0, al_da);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) d.v[i] = d.v[i] / (float)bcast;
         } else {
-            d = use_pool ? pool_gather<VEC>(pool, row, c0, C) : vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
+            d = use_pool ? pool_gather<VEC, T>(pool, row, c0, C) : vload_view<VEC, T>(da, row, c0, shuffle_ctot, al_da);
         }
-        const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_y);
+        const VecF<VEC> v = vload_view<VEC, T>(y, row, c0, 0, al_y);
         const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
         if (pgsrc.p) {
-            const VecF<VEC> pv = vload_view<VEC>(pgsrc, row, c0, shuffle_ctot, false);
-            vstore_view<VEC>(pgdst, row, c0, 0, al_pg, pv);
+            const VecF<VEC> pv = vload_view<VEC, T>(pgsrc, row, c0, shuffle_ctot, false);
+            vstore_view<VEC, T>(pgdst, row, c0, 0, al_pg, pv);
         }
         if (act == ACT_RELU6) {
             const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
@@ -578,8 +596,8 @@ struct BnBwdReduceF {
 // skeleton, but the per-channel columns / coefficients are computed once per thread and RU rows are loaded before any of
 // them is consumed (the generic functor re-derives everything per row and, with its pass-through store between the loads,
 // runs one row's round trip at a time; at 6-21 rows per thread the kernel was latency, not bandwidth).
-template <int VEC, bool PASS>
-__global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ctot, const float* __restrict__ y,
+template <int VEC, bool PASS, class T>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ctot, const T* __restrict__ y,
                                                                  const float* __restrict__ stats, int GC, int C, int Mg, int rb,
                                                                  View pgs, View pgd, double* __restrict__ part) {
     extern __shared__ double sm[];   // [CY][VEC][CX]
@@ -612,14 +630,14 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ct
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 const int64_t row = gbase + min(rr + u * CY, r1 - 1);          // clamped: unconditional loads
-                const float* dr = da.p + row * da.ld;
+                const T* dr = vptr<T>(da) + row * da.ld;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) dz[u][i] = dr[dcol[i]];
+                for (int i = 0; i < VEC; ++i) dz[u][i] = ldf(dr + dcol[i]);
                 yv[u] = vload<VEC>(y + row * C + c0);
                 if (PASS) {
-                    const float* pr = pgs.p + row * pgs.ld;
+                    const T* pr = vptr<T>(pgs) + row * pgs.ld;
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) pv[u][i] = pr[pcol[i]];
+                    for (int i = 0; i < VEC; ++i) pv[u][i] = ldf(pr + pcol[i]);
                 }
             }
 #pragma unroll
@@ -639,7 +657,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ct
                     VecF<VEC> o;
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) o.v[i] = pv[u][i];
-                    vstore<VEC>(pgd.p + row * pgd.ld + pgd.coff + c0, o);
+                    vstore<VEC>(vptr<T>(pgd) + row * pgd.ld + pgd.coff + c0, o);
                 }
             }
         }
@@ -670,19 +688,20 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ct
     }
 }
 
-template <int VEC>
+template <int VEC, class T>
 static void launch_bbr_shuf(const VColGeom& g, int G, hipStream_t st, View da, int ctot, const float* y, const float* stats, int C,
                             int Mg, View pgs, View pgd, double* part) {
     dim3 grid(g.nb, G), block(g.cx, g.cy);
     const size_t sm = (size_t)g.cy * VEC * g.cx * sizeof(double);
+    const T* yt = reinterpret_cast<const T*>(y);
     if (pgs.p)
-        hipLaunchKernelGGL((bn_bwd_reduce_shuf_kernel<VEC, true>), grid, block, sm, st, da, ctot, y, stats, G * C, C, Mg, g.rb, pgs, pgd, part);
+        hipLaunchKernelGGL((bn_bwd_reduce_shuf_kernel<VEC, true, T>), grid, block, sm, st, da, ctot, yt, stats, G * C, C, Mg, g.rb, pgs, pgd, part);
     else
-        hipLaunchKernelGGL((bn_bwd_reduce_shuf_kernel<VEC, false>), grid, block, sm, st, da, ctot, y, stats, G * C, C, Mg, g.rb, pgs, pgd, part);
+        hipLaunchKernelGGL((bn_bwd_reduce_shuf_kernel<VEC, false, T>), grid, block, sm, st, da, ctot, yt, stats, G * C, C, Mg, g.rb, pgs, pgd, part);
 }
 
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
-                  double* part, hipStream_t st, const PoolSrc* pool, const View* pass_gsrc, const View* pass_gdst, int bcast_rows) {
+                  double* part, hipStream_t st, const PoolSrc* pool, const View* pass_gsrc, const View* pass_gdst, int bcast_rows, int at) {
     {
         static const bool fast = !(getenv("CDRL_BBR_FAST") && atoi(getenv("CDRL_BBR_FAST")) == 0);
         const VColGeom g = vcol_geom(Mg, C, NB_STATS);
@@ -694,8 +713,13 @@ int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const
         const bool ydense = y.ld == C && y.coff == 0 && view_aligned(y, g.vec);
         const bool pok = !pgs.p || (pgd.p && view_aligned(pgd, g.vec));
         if (fast && !pool && !bcast_rows && shuffle_ctot && act == ACT_RELU6 && g.nloop == 1 && ydense && pok && g.vec >= 2) {
-            if (g.vec == 4) launch_bbr_shuf<4>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
-            else launch_bbr_shuf<2>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
+            if (at) {
+                if (g.vec == 4) launch_bbr_shuf<4, bf16_t>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
+                else launch_bbr_shuf<2, bf16_t>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
+            } else {
+                if (g.vec == 4) launch_bbr_shuf<4, float>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
+                else launch_bbr_shuf<2, float>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
+            }
             CDRL_LAUNCH_CHECK();
             return 0;
         }
@@ -708,9 +732,13 @@ int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const
         pgs = *pass_gsrc;
         pgd = *pass_gdst;
     }
-    return launch_vcolreduce<2, BnBwdReduceF>(G, Mg, C, part, st, NB_STATS, da, shuffle_ctot, y, stats, G * C, C, act,
-                                              pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps,
-                                              pgs, pgd, pgd.p && view_aligned(pgd, vec), bcast_rows);
+    if (at)
+        return launch_vcolreduce_t<2, BnBwdReduceF, bf16_t>(G, Mg, C, part, st, NB_STATS, da, shuffle_ctot, y, stats, G * C, C, act,
+                                                            pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps,
+                                                            pgs, pgd, pgd.p && view_aligned(pgd, vec), bcast_rows);
+    return launch_vcolreduce_t<2, BnBwdReduceF, float>(G, Mg, C, part, st, NB_STATS, da, shuffle_ctot, y, stats, G * C, C, act,
+                                                       pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps,
+                                                       pgs, pgd, pgd.p && view_aligned(pgd, vec), bcast_rows);
 }
 
 // BN-backward sums of a BatchNorm+ReLU6 whose output feeds a 3x3/s2 max-pool, in SCATTER form: iterate over the POOLED
@@ -718,10 +746,10 @@ int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const
 // location (its saved argmax), so  sum_a dz[a] = sum_o dp[o]*mask(a(o))  and  sum_a dz[a]*xhat[a] = sum_o dp[o]*mask*xhat(y[a(o)]).
 // Traffic: dp + argmax + one gathered y per pooled element, instead of y + up to 4 window probes per pre-pool element
 // (the gather form took 506 us on the 255 MB stem tensor for ~70 us of HBM time).
-template <int VEC>
+template <int VEC, class T = float>
 struct PoolBnReduceF {
     PoolSrc ps;
-    const float* y;         // pre-pool BN input [N][H][W][C]
+    const float* y;         // pre-pool BN input [N][H][W][C] (T elements)
     const float* stats;
     int GC, C;
     __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
@@ -729,7 +757,7 @@ struct PoolBnReduceF {
         const int64_t q = row / ps.Wo;
         const int oy = (int)(q % ps.Ho);
         const int64_t n = q / ps.Ho;
-        const VecF<VEC> d = vload<VEC>(ps.dp + row * C + c0);
+        const VecF<VEC> d = vload<VEC>(reinterpret_cast<const T*>(ps.dp) + row * C + c0);
         const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
         const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
         uint32_t am = 0;
@@ -739,7 +767,7 @@ struct PoolBnReduceF {
             const int k = VEC == 4 ? (int)((am >> (8 * i)) & 0xffu) : (int)ps.argmax[row * C + c0 + i];
             const int ky = k / 3, kx = k - 3 * ky;
             const int iy = 2 * oy - ps.pt + ky, ix = 2 * ox - ps.pl + kx;
-            const float v = y[((n * ps.H + iy) * ps.W + ix) * C + c0 + i];
+            const float v = ldf(reinterpret_cast<const T*>(y) + ((n * ps.H + iy) * ps.W + ix) * C + c0 + i);
             const float z = fmaf(sc.v[i], v, sh.v[i]);
             if (z > 0.0f && z < 6.0f) {
                 const float xh = (v - mean.v[i]) * invstd.v[i];
@@ -753,7 +781,8 @@ struct PoolBnReduceF {
 // Fast path of pool_bn_bwd_reduce (4 channels per thread): the scatter-form sums need two DEPENDENT round trips per pooled
 // element (argmax, then the gathered pre-pool value); the generic row loop paid them row by row (16 rows per thread).  Here
 // RU rows go through the two phases together: all pooled-gradient / argmax loads, then all 4*RU gathers, then the sums.
-__global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, const float* __restrict__ y,
+template <class T>
+__global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, const T* __restrict__ y,
                                                                     const float* __restrict__ stats, int GC, int C, int Mg,
                                                                     int rb, double* __restrict__ part) {
     extern __shared__ double sm[];   // [CY][4][CX]
@@ -778,7 +807,7 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 const int64_t row = gbase + min(rr + u * CY, r1 - 1);          // clamped: unconditional loads
-                d[u] = vload<VEC>(ps.dp + row * C + c0);
+                d[u] = vload<VEC>(reinterpret_cast<const T*>(ps.dp) + row * C + c0);
                 am[u] = *reinterpret_cast<const uint32_t*>(ps.argmax + row * C + c0);
                 const int ox = (int)(row % ps.Wo);
                 const int64_t q = row / ps.Wo;
@@ -794,7 +823,7 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
                 for (int i = 0; i < VEC; ++i) {
                     const int k = (int)((am[u] >> (8 * i)) & 0xffu);
                     const int ky = k / 3, kx = k - 3 * ky;
-                    v[u][i] = y[ybase[u] + ((int64_t)ky * ps.W + kx) * C + i];
+                    v[u][i] = ldf(y + ybase[u] + ((int64_t)ky * ps.W + kx) * C + i);
                 }
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
@@ -837,7 +866,7 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
 }
 
 int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_group, int C, const float* stats, double* part,
-                       hipStream_t st) {
+                       hipStream_t st, int at) {
     {
         static const bool fast = !(getenv("CDRL_POOLRED_FAST") && atoi(getenv("CDRL_POOLRED_FAST")) == 0);
         const int Mg = frames_per_group * ps.Ho * ps.Wo;
@@ -845,12 +874,14 @@ int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_
         if (fast && g.vec == 4 && g.nloop == 1) {
             dim3 grid(g.nb, G), block(g.cx, g.cy);
             const size_t smb = (size_t)g.cy * 4 * g.cx * sizeof(double);
-            hipLaunchKernelGGL(pool_bn_bwd_reduce_v4_kernel, grid, block, smb, st, ps, y, stats, G * C, C, Mg, g.rb, part);
+            if (at) hipLaunchKernelGGL(pool_bn_bwd_reduce_v4_kernel<bf16_t>, grid, block, smb, st, ps, reinterpret_cast<const bf16_t*>(y), stats, G * C, C, Mg, g.rb, part);
+            else hipLaunchKernelGGL(pool_bn_bwd_reduce_v4_kernel<float>, grid, block, smb, st, ps, y, stats, G * C, C, Mg, g.rb, part);
             CDRL_LAUNCH_CHECK();
             return 0;
         }
     }
-    return launch_vcolreduce<2, PoolBnReduceF>(G, frames_per_group * ps.Ho * ps.Wo, C, part, st, NB_STATS, ps, y, stats, G * C, C);
+    if (at) return launch_vcolreduce_t<2, PoolBnReduceF, bf16_t>(G, frames_per_group * ps.Ho * ps.Wo, C, part, st, NB_STATS, ps, y, stats, G * C, C);
+    return launch_vcolreduce_t<2, PoolBnReduceF, float>(G, frames_per_group * ps.Ho * ps.Wo, C, part, st, NB_STATS, ps, y, stats, G * C, C);
 }
 
 template <int FIN_PY>
@@ -908,7 +939,7 @@ int bn_bwd_finalize(const double* part, int nb, int G, int Mg, int C, const floa
     return 0;
 }
 
-template <int VEC>
+template <int VEC, class T = float>
 struct BnBwdApplyF {
     View da;
     int shuffle_ctot;
@@ -923,14 +954,14 @@ struct BnBwdApplyF {
     int bcast;              // as in BnBwdReduceF
     __device__ void operator()(int g, int64_t row, int c0, double (*acc)[VEC]) const {
         VecF<VEC> d;
-        if (bcast > 0) {
-            d = vload_view<VEC>(da, row / bcast, c0, 0, al_da);
+        if (bcast > 0) {        // float32 pooled gradient (see BnBwdReduceF)
+            d = vload_view<VEC, float>(da, row / bcast, c0, 0, al_da);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) d.v[i] = d.v[i] / (float)bcast;
         } else {
-            d = use_pool ? pool_gather<VEC>(pool, row, c0, C) : vload_view<VEC>(da, row, c0, shuffle_ctot, al_da);
+            d = use_pool ? pool_gather<VEC, T>(pool, row, c0, C) : vload_view<VEC, T>(da, row, c0, shuffle_ctot, al_da);
         }
-        const VecF<VEC> v = vload_view<VEC>(y, row, c0, 0, al_y);
+        const VecF<VEC> v = vload_view<VEC, T>(y, row, c0, 0, al_y);
         const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
         if (act == ACT_RELU6) {
             const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
@@ -949,16 +980,16 @@ struct BnBwdApplyF {
             o.v[i] = k1.v[i] * (d.v[i] - k2.v[i] - xh * k3.v[i]);
             acc[0][i] += (double)o.v[i];
         }
-        vstore<VEC>(dy + row * C + c0, o);
+        vstore<VEC>(reinterpret_cast<T*>(dy) + row * C + c0, o);
     }
 };
 
 // Fast path of bn_bwd_apply (no pool source): RU rows of loads ahead of the stores, columns / coefficients once per thread;
 // same partial layout ([G][nb][C] column sums of dy) as the generic skeleton.
-template <int VEC>
-__global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int ctot, const float* __restrict__ y,
+template <int VEC, class T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int ctot, const T* __restrict__ y,
                                                                 const float* __restrict__ stats, const float* __restrict__ coef,
-                                                                int GC, int C, int Mg, int rb, int act, float* __restrict__ dy,
+                                                                int GC, int C, int Mg, int rb, int act, T* __restrict__ dy,
                                                                 double* __restrict__ part, int bcast) {
     extern __shared__ double sm[];   // [CY][VEC][CX]
     constexpr int RU = 4;
@@ -995,9 +1026,15 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int cto
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 const int64_t row = gbase + min(rr + u * CY, r1 - 1);
-                const float* dr = da.p + (bcast > 0 ? row / bcast : row) * da.ld;
+                if (bcast > 0) {        // float32 pooled gradient
+                    const float* dr = da.p + (row / bcast) * da.ld;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) dz[u][i] = dr[dcol[i]];
+                    for (int i = 0; i < VEC; ++i) dz[u][i] = dr[dcol[i]];
+                } else {
+                    const T* dr = vptr<T>(da) + row * da.ld;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) dz[u][i] = ldf(dr + dcol[i]);
+                }
                 yv[u] = vload<VEC>(y + row * C + c0);
             }
 #pragma unroll
@@ -1042,7 +1079,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int cto
 }
 
 int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, const float* coef,
-                 int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool, int bcast_rows) {
+                 int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool, int bcast_rows, int at) {
     {
         static const bool fast = !(getenv("CDRL_BBA_FAST") && atoi(getenv("CDRL_BBA_FAST")) == 0);
         const VColGeom g = vcol_geom(Mg, C, NB_STATS);
@@ -1050,10 +1087,16 @@ int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const 
         if (fast && !pool && g.nloop == 1 && g.vec >= 2 && ydense && (reinterpret_cast<uintptr_t>(dy) % (4 * g.vec)) == 0) {
             dim3 grid(g.nb, G), block(g.cx, g.cy);
             const size_t sm = (size_t)g.cy * g.vec * g.cx * sizeof(double);
-            if (g.vec == 4)
-                hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<4>, grid, block, sm, st, da, shuffle_ctot, y.p, stats, coef, G * C, C, Mg, g.rb, act, dy, part2, bcast_rows);
+            const bf16_t* yb = reinterpret_cast<const bf16_t*>(y.p);
+            bf16_t* dyb = reinterpret_cast<bf16_t*>(dy);
+            if (at && g.vec == 4)
+                hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<4, bf16_t>), grid, block, sm, st, da, shuffle_ctot, yb, stats, coef, G * C, C, Mg, g.rb, act, dyb, part2, bcast_rows);
+            else if (at)
+                hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<2, bf16_t>), grid, block, sm, st, da, shuffle_ctot, yb, stats, coef, G * C, C, Mg, g.rb, act, dyb, part2, bcast_rows);
+            else if (g.vec == 4)
+                hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<4, float>), grid, block, sm, st, da, shuffle_ctot, y.p, stats, coef, G * C, C, Mg, g.rb, act, dy, part2, bcast_rows);
             else
-                hipLaunchKernelGGL(bn_bwd_apply_fast_kernel<2>, grid, block, sm, st, da, shuffle_ctot, y.p, stats, coef, G * C, C, Mg, g.rb, act, dy, part2, bcast_rows);
+                hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<2, float>), grid, block, sm, st, da, shuffle_ctot, y.p, stats, coef, G * C, C, Mg, g.rb, act, dy, part2, bcast_rows);
             CDRL_LAUNCH_CHECK();
             return 0;
         }
@@ -1065,8 +1108,11 @@ int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const 
         set_error("bn_bwd_apply: dy must be %d-byte aligned", 4 * vec);
         return -1;
     }
-    return launch_vcolreduce<1, BnBwdApplyF>(G, Mg, C, part2, st, NB_STATS, da, shuffle_ctot, y, stats, coef, G * C, C, act,
-                                             dy, pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps, bcast_rows);
+    if (at)
+        return launch_vcolreduce_t<1, BnBwdApplyF, bf16_t>(G, Mg, C, part2, st, NB_STATS, da, shuffle_ctot, y, stats, coef, G * C, C, act,
+                                                           dy, pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps, bcast_rows);
+    return launch_vcolreduce_t<1, BnBwdApplyF, float>(G, Mg, C, part2, st, NB_STATS, da, shuffle_ctot, y, stats, coef, G * C, C, act,
+                                                      dy, pool ? false : view_aligned(da, vec), view_aligned(y, vec), pool != nullptr, ps, bcast_rows);
 }
 
 // Block = (CX outputs, 1024/CX partial lanes).  CX = 16 gives 128-byte row segments; CX = 4 is used when there are few

@@ -21,7 +21,19 @@ static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); 
         return -1;                         \
     }
 
+// element type of the activation tensors handed to the OP-LEVEL entry points below (cdrl_set_op_activation_type): 0 float32, 1 bf16
+static thread_local int g_op_at = 0;
+
 extern "C" {
+
+int cdrl_set_op_activation_type(int at) {
+    if (at != 0 && at != 1) {
+        cdrl::set_error("cdrl_set_op_activation_type: 0 (float32) or 1 (bf16)");
+        return -1;
+    }
+    g_op_at = at;
+    return 0;
+}
 
 const char* cdrl_last_error(void) { return cdrl::last_error(); }
 int cdrl_version(void) { return CDRL_VERSION; }
@@ -96,7 +108,7 @@ int cdrl_learner_create(const cdrl_config* c, cdrl_learner** out) {
     for (int i = 0; i < 3; ++i) { d.stage_c[i] = c->stage_c[i]; d.stage_n[i] = c->stage_n[i]; }
     d.last = c->last; d.feat = c->feat; d.rnn_image = c->rnn_image; d.rnn_small = c->rnn_small;
     d.dyn = c->dyn; d.head = c->head; d.exp_scale = c->exp_scale;
-    if (c->compute != CDRL_COMPUTE_F32 && c->compute != CDRL_COMPUTE_BF16_OPERANDS) {
+    if (c->compute != CDRL_COMPUTE_F32 && c->compute != CDRL_COMPUTE_BF16_OPERANDS && c->compute != CDRL_COMPUTE_BF16_STORAGE) {
         cdrl::set_error("cdrl_learner_create: unknown compute mode %d", c->compute);
         return -1;
     }
@@ -439,7 +451,7 @@ int cdrl_gemm_x3(const float* A, int lda, int a_coff, const void* B_packed, cons
         return -1;
     }
     return gemm_x3(make_view(const_cast<float*>(A), lda, a_coff), B_packed, bias, make_view(C, ldc, c_coff), M, N, K, accumulate,
-                   S(stream));
+                   S(stream), g_op_at != 0, g_op_at);
 }
 
 int cdrl_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
@@ -507,7 +519,7 @@ int64_t cdrl_gemm_tn_workspace_elems(int M, int N, int K) { return gemm_tn_part_
 int cdrl_gemm_tn(const float* A, int lda, int a_coff, const float* D, int ldd, int d_coff, float* out, int M, int N,
                  int K, float* workspace, int accumulate, void* stream) {
     return gemm_tn(make_view(const_cast<float*>(A), lda, a_coff), make_view(const_cast<float*>(D), ldd, d_coff), out, M, N,
-                   K, workspace, accumulate, S(stream));
+                   K, workspace, accumulate, S(stream), 1, nullptr, nullptr, g_op_at != 0, g_op_at);
 }
 
 int cdrl_stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
@@ -577,9 +589,9 @@ int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, cons
     const int nb = vcol_geom(B * Hp * Wp, Cout).nb;
     double* part = workspace;
     double* fpart = workspace + (int64_t)T * nb * 2 * Cout;
-    CDRL_TRY(pool_bn_bwd_reduce(ps, y, T, B, Cout, stats, part, st));
+    CDRL_TRY(pool_bn_bwd_reduce(ps, y, T, B, Cout, stats, part, st, g_op_at));
     CDRL_TRY(bn_bwd_finalize(part, nb, T, B * Ho * Wo, Cout, stats, dgamma, dbeta, coef, st));
-    return stem_bwd_filter_fused(x, ps, y, stats, coef, dw, db, B, T, H, W, Cout, fpart, st);
+    return stem_bwd_filter_fused(x, ps, y, stats, coef, dw, db, B, T, H, W, Cout, fpart, st, g_op_at);
 }
 
 int cdrl_pwconv_fused_partial_rows(int G, int Mg, int N, int K) { return pw_nn_plan(G, Mg, N, K).nbpg; }
@@ -614,7 +626,7 @@ int cdrl_pwconv_fused_packed(const float* a, int lda, int a_coff, const float* p
         return -1;
     }
     return pw_nn(make_view(const_cast<float*>(a), lda, a_coff), pro_stats, w, sbk, sbn, bias, make_view(c, ldc, c_coff),
-                 accumulate, G, Mg, N, K, epilogue, epi_y, epi_stats, part, S(stream), nullptr, w_packed, packed_bf16 != 0);
+                 accumulate, G, Mg, N, K, epilogue, epi_y, epi_stats, part, S(stream), nullptr, w_packed, packed_bf16 != 0, g_op_at);
 }
 
 static int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
@@ -640,15 +652,15 @@ static int pwconv_bn_bwd_impl(const float* dout, int dout_ld, int dout_coff, int
     float* tn = reinterpret_cast<float*>(ws);
     View vd = make_view(const_cast<float*>(dout), dout_ld, dout_coff), vy = make_view(const_cast<float*>(y), N);
     View vx = make_view(const_cast<float*>(x), x_ld, x_coff);
-    CDRL_TRY(bn_bwd_reduce(vd, shuffle_ctot, vy, G, Mg, N, stats, act, part, st, nullptr));
+    CDRL_TRY(bn_bwd_reduce(vd, shuffle_ctot, vy, G, Mg, N, stats, act, part, st, nullptr, nullptr, nullptr, 0, g_op_at));
     CDRL_TRY(bn_bwd_finalize(part, nbr, G, Mg, N, stats, dgamma, dbeta, coef, st));
     PwBnBwd bb{y, stats, coef, shuffle_ctot, act, part2};
     // dx[m,k] = sum_n dy[m,n] W[k,n]: GEMM with "K" = N (reduction over the conv outputs) and "N" = K
     CDRL_TRY(pw_nn(vd, nullptr, w, 1, N, nullptr, make_view(dx, dx_ld, dx_coff), accumulate, G, Mg, K, N, 0, nullptr, nullptr, nullptr,
-                   st, &bb, wt_packed, packed_bf16 != 0));
+                   st, &bb, wt_packed, packed_bf16 != 0, g_op_at));
     CDRL_TRY(reduce_partials(part2, G * nbp, N, N, db, 0, st));
     TnBnBwd tb{y, stats, coef, shuffle_ctot, act};
-    return gemm_tn(vx, vd, dw, G * Mg, N, K, tn, 0, st, G, x_pro_stats, &tb, wt_packed && packed_bf16 != 0);
+    return gemm_tn(vx, vd, dw, G * Mg, N, K, tn, 0, st, G, x_pro_stats, &tb, wt_packed && packed_bf16 != 0, g_op_at);
 }
 
 int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
@@ -683,7 +695,7 @@ int cdrl_dwconv_bn_fwd(const float* x, const float* pre_stats, const float* w, c
                        int H, int W, int C, int stride, const float* gamma, const float* beta, float* moving_mean,
                        float* moving_var, int bessel, float* post_stats, double* workspace, void* stream) {
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
-    CDRL_TRY(dwf_fwd(x, pre_stats, w, bias, y, workspace, G, B, H, W, C, stride, S(stream)));
+    CDRL_TRY(dwf_fwd(x, pre_stats, w, bias, y, workspace, G, B, H, W, C, stride, S(stream), g_op_at));
     return bn_finalize(workspace, dwf_geom(B, G, H, W, C, stride).nb, G, B * Ho * Wo, C, gamma, beta, moving_mean, moving_var,
                        bessel, 1, post_stats, S(stream));
 }
@@ -700,15 +712,15 @@ int cdrl_dwconv_bn_bwd(const float* x, const float* pre_stats, const float* dout
     double* part_r = part_w + dwf_filter_part_elems(B, G, H, W, C, stride);
     hipStream_t st = S(stream);
     View vd = make_view(const_cast<float*>(dout), C), vy = make_view(const_cast<float*>(y), C);
-    CDRL_TRY(bn_bwd_reduce(vd, 0, vy, G, Mo, C, post_stats, ACT_NONE, part_r, st, nullptr));
+    CDRL_TRY(bn_bwd_reduce(vd, 0, vy, G, Mo, C, post_stats, ACT_NONE, part_r, st, nullptr, nullptr, nullptr, 0, g_op_at));
     CDRL_TRY(bn_bwd_finalize(part_r, vcol_geom(Mo, C).nb, G, Mo, C, post_stats, dgamma_post, dbeta_post, coef_post, st));
-    CDRL_TRY(dwf_bwd(x, pre_stats, dout, y, post_stats, coef_post, w, make_view(dx, C), part_bn, part_w, G, B, H, W, C, stride, st));
+    CDRL_TRY(dwf_bwd(x, pre_stats, dout, y, post_stats, coef_post, w, make_view(dx, C), part_bn, part_w, G, B, H, W, C, stride, st, g_op_at));
     CDRL_TRY(reduce_partials(part_w, G * g.nb, 9 * C, (int64_t)10 * C, dw, 0, st));
     CDRL_TRY(reduce_partials(part_w + 9 * C, G * g.nb, C, (int64_t)10 * C, db, 0, st));
     if (pre_stats) {
         CDRL_TRY(bn_bwd_finalize(part_bn, g.nb, G, Mi, C, pre_stats, dgamma_pre, dbeta_pre, coef_pre, st));
         View vx = make_view(const_cast<float*>(x), C);
-        CDRL_TRY(bn_bwd_apply(make_view(dx, C), 0, vx, G, Mi, C, pre_stats, coef_pre, ACT_NONE, dx, part_r, st, nullptr));
+        CDRL_TRY(bn_bwd_apply(make_view(dx, C), 0, vx, G, Mi, C, pre_stats, coef_pre, ACT_NONE, dx, part_r, st, nullptr, 0, g_op_at));
     }
     return 0;
 }
@@ -726,10 +738,10 @@ int cdrl_bn_train_fwd(const float* y, int G, int Mg, int C, const float* gamma, 
                       float* stats, double* workspace, void* stream) {
     View yv = make_view(const_cast<float*>(y), C);
     const int nb = vcol_geom(Mg, C).nb;
-    CDRL_TRY(colstats(yv, G, Mg, C, workspace, S(stream)));
+    CDRL_TRY(colstats(yv, G, Mg, C, workspace, S(stream), g_op_at));
     CDRL_TRY(bn_finalize(workspace, nb, G, Mg, C, gamma, beta, moving_mean, moving_var, bessel, 1, stats, S(stream)));
     return bn_apply(yv, G, Mg, C, stats, relu6 ? ACT_RELU6 : ACT_NONE, make_view(out, out_ld, out_coff), shuffle_ctot,
-                    S(stream));
+                    S(stream), nullptr, nullptr, g_op_at);
 }
 
 int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, const float* y, int G, int Mg,
@@ -739,9 +751,9 @@ int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle
     View dv = make_view(const_cast<float*>(dout), dout_ld, dout_coff);
     const int nb = vcol_geom(Mg, C).nb;
     const int act = relu6 ? ACT_RELU6 : ACT_NONE;
-    CDRL_TRY(bn_bwd_reduce(dv, shuffle_ctot, yv, G, Mg, C, stats, act, workspace, S(stream)));
+    CDRL_TRY(bn_bwd_reduce(dv, shuffle_ctot, yv, G, Mg, C, stats, act, workspace, S(stream), nullptr, nullptr, nullptr, 0, g_op_at));
     CDRL_TRY(bn_bwd_finalize(workspace, nb, G, Mg, C, stats, dgamma, dbeta, coef, S(stream)));
-    return bn_bwd_apply(dv, shuffle_ctot, yv, G, Mg, C, stats, coef, act, dy, workspace, S(stream));
+    return bn_bwd_apply(dv, shuffle_ctot, yv, G, Mg, C, stats, coef, act, dy, workspace, S(stream), nullptr, 0, g_op_at);
 }
 
 int cdrl_bn_small_fwd(const float* y, int M, int C, const float* gamma, const float* beta, float* moving_mean,
@@ -795,7 +807,7 @@ int cdrl_linear_heads_bwd(const float* a, int nheads, const int* n, const float*
 
 int cdrl_maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax,
                         int N, int H, int W, int C, void* stream) {
-    return maxpool_bn_fwd(y, stats, G, frames_per_group, p, argmax, N, H, W, C, S(stream));
+    return maxpool_bn_fwd(y, stats, G, frames_per_group, p, argmax, N, H, W, C, S(stream), g_op_at);
 }
 
 int cdrl_bn_train_bwd_pooled(const uint8_t* argmax, const float* dp, int H, int W, const float* y, int G, int Mg, int C,

@@ -8,7 +8,9 @@ namespace cdrl {
 // ---------------------------------------------------------------- BatchNorm family (bn.hip)
 // Per-group column statistics of y (rows grouped contiguously: group g = rows [g*Mg,(g+1)*Mg)).
 // part layout: [G][nb][2][C] (sum, sum of squares); nb from col_geom(Mg, C).
-int colstats(View y, int G, int Mg, int C, double* part, hipStream_t st);
+// at (here and below): element type of the ACTIVATION tensors the pointers / views refer to -- 0: float32, 1: bf16 (storage only:
+// everything computed, reduced or kept as statistics stays float32 / double; configuration 3)
+int colstats(View y, int G, int Mg, int C, double* part, hipStream_t st, int at = 0);
 // Turns partials (training) or moving statistics (inference) into per-(group,channel) mean /
 // invstd / scale / shift and applies the T sequential EMA updates.
 int bn_finalize(const double* part, int nb, int G, int Mg, int C, const float* gamma, const float* beta,
@@ -26,7 +28,7 @@ int bn_inference_stats_many(const BnInfEntry* tab_dev, int n, int max_c, hipStre
 // pass_src / pass_dst: optional second tensor with the same C channels copied through the same shuffle store (the
 // identity half of a ShuffleNet unit: concat + shuffle of both halves in one launch)
 int bn_apply(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
-             hipStream_t st, const View* pass_src = nullptr, const View* pass_dst = nullptr);
+             hipStream_t st, const View* pass_src = nullptr, const View* pass_dst = nullptr, int at = 0);
 // single-group BatchNorm over few rows, one launch per direction (G = 1, no activation, no shuffle; training mode)
 int bn_small_fwd(View x, int M, int C, const float* gamma, const float* beta, float* mov_mean, float* mov_var, float* stats,
                  View out, hipStream_t st);
@@ -43,20 +45,20 @@ struct PoolSrc {
 // Backward: reduce (sum dz, sum dz*xhat) -> part [G][nb][2][C]
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
                   double* part, hipStream_t st, const PoolSrc* pool = nullptr, const View* pass_gsrc = nullptr,
-                  const View* pass_gdst = nullptr, int bcast_rows = 0);
+                  const View* pass_gdst = nullptr, int bcast_rows = 0, int at = 0);
 // bcast_rows > 0 (here and in bn_bwd_apply): `da` holds ONE row per bcast_rows rows of y and is divided by bcast_rows on load --
 // the gradient of a global average pool over bcast_rows pixels, never materialised (head of the tower)     // pass_*: gradient of the identity half gathered in the same pass
 // Same sums for a BN+ReLU6 that feeds a 3x3/s2 max-pool, in scatter form over the POOLED gradient (ps.dp, ps.argmax);
 // y: the BN's raw input [G*frames_per_group][ps.H][ps.W][C]; part [G][nb][2][C], nb = vcol_geom(frames*Ho*Wo, C).nb
 int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_group, int C, const float* stats, double* part,
-                       hipStream_t st);
+                       hipStream_t st, int at = 0);
 // dgamma/dbeta (+= over groups; `accumulate` keeps previous content) and coefficients coef[3][G][C]
 int bn_bwd_finalize(const double* part, int nb, int G, int Mg, int C, const float* stats, float* dgamma,
                     float* dbeta, float* coef, hipStream_t st);
 // dy = k1*(dz - k2 - xhat*k3) (dense [G*Mg][C]); also column sums of dy -> part2 [G][nb][C]
 int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats,
                  const float* coef, int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool = nullptr,
-                 int bcast_rows = 0);
+                 int bcast_rows = 0, int at = 0);
 // out[i] (+)= sum_p part[p*stride + i], i < n
 int reduce_partials(const double* part, int nparts, int n, int64_t stride, float* out, int accumulate,
                     hipStream_t st);
@@ -99,7 +101,7 @@ bool gemm_tn_dpro_supported(int N);
 int64_t gemm_tn_part_elems(int M, int N, int K, int G = 1);
 // bf16_operands: both operands rounded to bf16 AFTER their prologues, v_mfma_f32_32x32x16_bf16 over 16-row steps (configuration 3)
 int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G = 1,
-            const float* pro_stats = nullptr, const TnBnBwd* dpro = nullptr, bool bf16_operands = false);
+            const float* pro_stats = nullptr, const TnBnBwd* dpro = nullptr, bool bf16_operands = false, int at = 0);
 
 // ---------------------------------------------------------------- fused pointwise conv (gemm_pw.hip)
 // Persistent skinny GEMM for K, N <= 128: C[m,n] (+)= sum_k pro(A[m,k]) W(k,n) + bias[n] over G groups of Mg rows.
@@ -126,7 +128,7 @@ PwPlan pw_nn_plan(int G, int Mg, int N, int K);
 // tensors / accumulation / statistics: the compute mode of configuration 3)
 int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, const float* bias, View C, int accumulate, int G,
           int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st,
-          const PwBnBwd* bnbwd = nullptr, const float* Wp = nullptr, bool wp_bf16 = false);
+          const PwBnBwd* bnbwd = nullptr, const float* Wp = nullptr, bool wp_bf16 = false, int at = 0);
 struct PwPack {             // one operand to pack: B(k, n) = w[k * sbk + n * sbn], K x N
     const float* w;
     float* wp;
@@ -148,7 +150,7 @@ int stem_fwd(const float* x, const float* w, const float* bias, float* y, int B,
 bool stem_fwd_stats_supported(int Cout);
 int stem_fwd_stats_nb(int B, int H, int W);
 int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* part, int B, int T, int H, int W, int Cout,
-                   hipStream_t st);
+                   hipStream_t st, int at = 0);
 int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout);
 // stem filter gradient with the stem BatchNorm's backward apply + max-pool gather fused into the operand load (dy is
 // never materialised); y: raw stem conv output, stats/coef: the stem BN's [4|3][T][Cout] blocks
@@ -160,7 +162,7 @@ int stem_bwd_direct(const float* x, const PoolSrc& ps, const float* y, const flo
                     float* dw, float* db, int B, int T, int H, int W, int Cout, float* ws, hipStream_t st);
 bool stem_bwd_fused_supported(int Cout);
 int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, const float* stats, const float* coef, float* dw,
-                          float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st);
+                          float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st, int at = 0);
 int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,
                     double* part, hipStream_t st);
 // depthwise 3x3, TF 'SAME' (asymmetric) padding, stride 1|2.  N = frames.
@@ -187,7 +189,7 @@ int64_t dwf_filter_part_elems(int B, int G, int H, int W, int C, int stride);   
 // y = dw3x3(pre_stats ? relu6(scale*x+shift) : x) + bias and the per-block (sum y, sum y^2) partials of the
 // BatchNorm that follows (layout of bn_finalize with nb = dwf_geom().nb).
 int dwf_fwd(const float* x, const float* pre_stats, const float* w, const float* bias, float* y, double* part, int G,
-            int B, int H, int W, int C, int stride, hipStream_t st);
+            int B, int H, int W, int C, int stride, hipStream_t st, int at = 0);
 // dout: gradient w.r.t. the output of the BatchNorm (no activation) that follows the depthwise conv; y2: the raw
 // depthwise output; post_stats / post_coef: that BN's statistics and backward coefficients (k1,k2,k3).
 // Writes the filter / bias partials (part_w: reduce with reduce_partials over G*nb parts, row stride 10*C) and
@@ -195,17 +197,18 @@ int dwf_fwd(const float* x, const float* pre_stats, const float* w, const float*
 //   pre_stats == null: dx = gradient w.r.t. x.
 int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const float* y2, const float* post_stats,
             const float* post_coef, const float* w, View dx, double* part_bn, double* part_w, int G, int B, int H, int W,
-            int C, int stride, hipStream_t st);
+            int C, int stride, hipStream_t st, int at = 0);
 int maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, hipStream_t st);
 int maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H, int W, int C, hipStream_t st);
 // fused BN-apply + ReLU6 + max-pool on the raw conv output y (frames of group g = [g*frames_per_group, ...))
 int maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax, int N,
-                   int H, int W, int C, hipStream_t st);
+                   int H, int W, int C, hipStream_t st, int at = 0);
 PoolSrc make_pool_src(const uint8_t* argmax, const float* dp, int H, int W);
 // mean over the P pixels of each frame: a [N][P][C] -> out [N][C]
 int gap_fwd(const float* a, float* out, int N, int P, int C, hipStream_t st);
 // out[n][c] = mean_p act(scale[g][c] * y[n*P + p][c] + shift[g][c]): BatchNorm apply + activation + global average pool fused
-int bn_act_gap_fwd(const float* y, const float* stats, float* out, int G, int frames_per_group, int P, int C, int act, hipStream_t st);
+int bn_act_gap_fwd(const float* y, const float* stats, float* out, int G, int frames_per_group, int P, int C, int act, hipStream_t st,
+                   int at = 0);
 int gap_bwd(const float* dout, float* da, int N, int P, int C, hipStream_t st);
 
 // batched transposes W[cin][cout] -> WT[cout][cin] of many small matrices in one launch (gemm.hip)
@@ -245,7 +248,7 @@ GemmX3Pack gemm_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, i
 int gemm_x3_pack_many(const GemmX3Pack* tab_dev, int n, hipStream_t st);
 // bf16_operands: one product per step on the first plane only (operands rounded to bf16: configuration 3's compute mode)
 int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st,
-            bool bf16_operands = false);
+            bool bf16_operands = false, int at = 0);
 
 // ---------------------------------------------------------------- bf16 pointwise conv (gemm_pw_bf16.hip)
 // bf16 activations (A, C), float32 master weights / bias / BatchNorm blocks, bf16 MFMA with float32 accumulate; optional

@@ -86,37 +86,86 @@ __device__ __forceinline__ void vstore(float* p, const VecF<VEC>& r) {
     else *p = r.v[0];
 }
 
-// loads VEC channels of a view; `shuffle_ctot` != 0 -> element-wise through the de-interleave map
+// ---- bf16 ACTIVATION STORAGE (configuration 3): the same kernels read / write activation tensors as bf16 (round to nearest
+// even on store, exact widening on load); everything a kernel computes with -- registers, LDS tiles, statistics, partials,
+// coefficients, weights -- stays float32 / double.  A tensor's element type is a template parameter T of the kernel (float
+// instantiations are the float32 path, unchanged); on the host side the pointers keep their `float*` / View spelling and an
+// `at` flag (0: float32, 1: bf16) says what they point to.
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t bf_pack(float a, float b) {
+    bf16x2_t h;
+    h[0] = (bf16_t)a;
+    h[1] = (bf16_t)b;
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)v; }
+
 template <int VEC>
-__device__ __forceinline__ VecF<VEC> vload_view(const View& v, int64_t row, int c0, int shuffle_ctot, bool aligned) {
+__device__ __forceinline__ VecF<VEC> vload(const bf16_t* p) {
     VecF<VEC> r;
-    if (!shuffle_ctot && aligned) return vload<VEC>(v.p + row * v.ld + v.coff + c0);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        int cc = v.coff + c0 + i;
-        if (shuffle_ctot) cc = shuffle_dst(cc, shuffle_ctot);
-        r.v[i] = v.p[row * v.ld + cc];
+    if (VEC == 4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        r.v[0] = bf_lo(t.x); r.v[1 % VEC] = bf_hi(t.x); r.v[2 % VEC] = bf_lo(t.y); r.v[3 % VEC] = bf_hi(t.y);
+    } else if (VEC == 2) {
+        const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+        r.v[0] = bf_lo(t); r.v[1 % VEC] = bf_hi(t);
+    } else {
+        r.v[0] = (float)*p;
     }
     return r;
 }
 
 template <int VEC>
+__device__ __forceinline__ void vstore(bf16_t* p, const VecF<VEC>& r) {
+    if (VEC == 4) *reinterpret_cast<uint2*>(p) = make_uint2(bf_pack(r.v[0], r.v[1 % VEC]), bf_pack(r.v[2 % VEC], r.v[3 % VEC]));
+    else if (VEC == 2) *reinterpret_cast<uint32_t*>(p) = bf_pack(r.v[0], r.v[1 % VEC]);
+    else *p = (bf16_t)r.v[0];
+}
+
+// typed base pointer of a view (the View struct itself is type-erased: p points to T elements, ld / coff count elements)
+template <class T>
+__device__ __forceinline__ T* vptr(const View& v) { return reinterpret_cast<T*>(v.p); }
+
+// loads VEC channels of a view; `shuffle_ctot` != 0 -> element-wise through the de-interleave map
+template <int VEC, class T = float>
+__device__ __forceinline__ VecF<VEC> vload_view(const View& v, int64_t row, int c0, int shuffle_ctot, bool aligned) {
+    VecF<VEC> r;
+    const T* vp = vptr<T>(v);
+    if (!shuffle_ctot && aligned) return vload<VEC>(vp + row * v.ld + v.coff + c0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        int cc = v.coff + c0 + i;
+        if (shuffle_ctot) cc = shuffle_dst(cc, shuffle_ctot);
+        r.v[i] = ldf(vp + row * v.ld + cc);
+    }
+    return r;
+}
+
+template <int VEC, class T = float>
 __device__ __forceinline__ void vstore_view(const View& v, int64_t row, int c0, int shuffle_ctot, bool aligned,
                                             const VecF<VEC>& r) {
+    T* vp = vptr<T>(v);
     if (!shuffle_ctot && aligned) {
-        vstore<VEC>(v.p + row * v.ld + v.coff + c0, r);
+        vstore<VEC>(vp + row * v.ld + v.coff + c0, r);
         return;
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         int cc = v.coff + c0 + i;
         if (shuffle_ctot) cc = shuffle_dst(cc, shuffle_ctot);
-        v.p[row * v.ld + cc] = r.v[i];
+        stf(vp + row * v.ld + cc, r.v[i]);
     }
 }
 
 // gradient w.r.t. the pre-pool activation, gathered from the pooled gradient through the saved argmax
-template <int VEC>
+template <int VEC, class T = float>
 __device__ __forceinline__ VecF<VEC> pool_gather(const PoolSrc& ps, int64_t row, int c0, int C) {
     const int ix = (int)(row % ps.W);
     const int64_t q = row / ps.W;
@@ -138,7 +187,7 @@ __device__ __forceinline__ VecF<VEC> pool_gather(const PoolSrc& ps, int64_t row,
             const int ox = nx >> 1;
             if (ox >= ps.Wo) continue;
             const int64_t o = ((n * ps.Ho + oy) * ps.Wo + ox) * C + c0;
-            const VecF<VEC> d = vload<VEC>(ps.dp + o);
+            const VecF<VEC> d = vload<VEC>(reinterpret_cast<const T*>(ps.dp) + o);
             if (VEC == 4) {       // the 4 argmax bytes of this lane in one 32-bit load
                 const uint32_t am = *reinterpret_cast<const uint32_t*>(ps.argmax + o);
 #pragma unroll
@@ -221,6 +270,26 @@ static int launch_vcolreduce(int G, int Mg, int C, double* part, hipStream_t st,
     } else {
         F<1> f{args...};
         hipLaunchKernelGGL((vcolreduce_kernel<NQ, 1, F<1>>), grid, block, sm, st, f, Mg, C, g.rb, g.nloop, part);
+    }
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same for functors F<VEC, T> over activation tensors of element type T (at: 0 float32, 1 bf16)
+template <int NQ, template <int, class> class F, class T, class... Args>
+static int launch_vcolreduce_t(int G, int Mg, int C, double* part, hipStream_t st, int max_blocks, Args... args) {
+    VColGeom g = vcol_geom(Mg, C, max_blocks);
+    dim3 grid(g.nb, G), block(g.cx, g.cy);
+    const size_t sm = (size_t)g.cy * g.vec * g.cx * sizeof(double);
+    if (g.vec == 4) {
+        F<4, T> f{args...};
+        hipLaunchKernelGGL((vcolreduce_kernel<NQ, 4, F<4, T>>), grid, block, sm, st, f, Mg, C, g.rb, g.nloop, part);
+    } else if (g.vec == 2) {
+        F<2, T> f{args...};
+        hipLaunchKernelGGL((vcolreduce_kernel<NQ, 2, F<2, T>>), grid, block, sm, st, f, Mg, C, g.rb, g.nloop, part);
+    } else {
+        F<1, T> f{args...};
+        hipLaunchKernelGGL((vcolreduce_kernel<NQ, 1, F<1, T>>), grid, block, sm, st, f, Mg, C, g.rb, g.nloop, part);
     }
     CDRL_LAUNCH_CHECK();
     return 0;

@@ -78,9 +78,9 @@ __global__ void __launch_bounds__(256) stem_fwd_scalar_kernel(const float* __res
 // Stem conv with the following BatchNorm's statistics in the epilogue: one workgroup = a contiguous pixel range of ONE
 // time slice, block = (Cout/4 channel lanes, pixel lanes); per-thread (sum, sum of squares) in double, LDS fold over the
 // pixel lanes, one partial row per workgroup in bn_finalize's [T][nb][2][Cout] layout (no second pass over the 255 MB y).
-template <int NP>
+template <int NP, class AT>
 __global__ void __launch_bounds__(256) stem_fwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             const float* __restrict__ bias, AT* __restrict__ y,
                                                              double* __restrict__ part, int B, int T, int H, int W, int Ho,
                                                              int Wo, int Cout, int rb) {
     extern __shared__ __attribute__((aligned(16))) float ws[];      // [27][Cout] + [Cout], then the reduction scratch
@@ -147,12 +147,15 @@ __global__ void __launch_bounds__(256) stem_fwd_stats_kernel(const float* __rest
         for (int u = 0; u < NP; ++u) {
             const int r = rr + u * CY;
             if (r >= r1) continue;
-            *reinterpret_cast<float4*>(&y[((int64_t)g * Mg + r) * Cout + co]) = acc[u];
-            const float a4[4] = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
+            VecF<4> o4;
+            o4.v[0] = acc[u].x; o4.v[1] = acc[u].y; o4.v[2] = acc[u].z; o4.v[3] = acc[u].w;
+            vstore<4>(y + ((int64_t)g * Mg + r) * Cout + co, o4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                s[i] += (double)a4[i];
-                q[i] += (double)a4[i] * (double)a4[i];
+                // bf16 storage: statistics of the values the consumers will read (the rounded ones)
+                const double a = sizeof(AT) == 2 ? (double)(float)(bf16_t)o4.v[i] : (double)o4.v[i];
+                s[i] += a;
+                q[i] += a * a;
             }
         }
     }
@@ -182,7 +185,7 @@ int stem_fwd_stats_nb(int B, int H, int W) {
 }
 
 int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* part, int B, int T, int H, int W, int Cout,
-                   hipStream_t st) {
+                   hipStream_t st, int at) {
     if (!stem_fwd_stats_supported(Cout) || (reinterpret_cast<uintptr_t>(y) & 15) != 0) {
         set_error("stem_fwd_stats: Cout=%d / alignment not supported", Cout);
         return -1;
@@ -196,9 +199,10 @@ int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, 
     const size_t red = (size_t)8 * cy * cx * sizeof(double);
     if (lds < red) lds = red;
     static const int np = getenv("CDRL_STEM_NP") ? atoi(getenv("CDRL_STEM_NP")) : 4;
-    if (np >= 4) hipLaunchKernelGGL(stem_fwd_stats_kernel<4>, dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
-    else if (np >= 2) hipLaunchKernelGGL(stem_fwd_stats_kernel<2>, dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
-    else hipLaunchKernelGGL(stem_fwd_stats_kernel<1>, dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
+    if (at) hipLaunchKernelGGL((stem_fwd_stats_kernel<4, bf16_t>), dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, reinterpret_cast<bf16_t*>(y), part, B, T, H, W, Ho, Wo, Cout, rb);
+    else if (np >= 4) hipLaunchKernelGGL((stem_fwd_stats_kernel<4, float>), dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
+    else if (np >= 2) hipLaunchKernelGGL((stem_fwd_stats_kernel<2, float>), dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
+    else hipLaunchKernelGGL((stem_fwd_stats_kernel<1, float>), dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
@@ -269,7 +273,8 @@ __device__ __forceinline__ void stem_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool FUSED, int NCH>
+// AT: element type of the pooled gradient and of the raw conv output y in the FUSED form (bf16 activation storage)
+template <bool FUSED, int NCH, class AT = float>
 __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ part, int B, int T, int H, int W, int Ho,
                                                             int Wo, int Cout, int rows, int rows_per, StemBnBwd bb) {
@@ -304,9 +309,9 @@ __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restr
     __amdgpu_buffer_rsrc_t rsDP, rsAM, rsY;
     if (FUSED) {
         const int64_t pel = (int64_t)B * T * bb.ps.Ho * bb.ps.Wo * Cout;
-        rsDP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.ps.dp), 0, (int)(pel * 4), 0x00020000);
+        rsDP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.ps.dp), 0, (int)(pel * sizeof(AT)), 0x00020000);
         rsAM = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bb.ps.argmax), 0, (int)pel, 0x00020000);
-        rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.y), 0, (int)((int64_t)rows * Cout * 4), 0x00020000);
+        rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.y), 0, (int)((int64_t)rows * Cout * sizeof(AT)), 0x00020000);
     }
     for (int base = r0; base < r1; base += 128) {
         const int wrow0 = base + wave * 32;
@@ -374,8 +379,19 @@ __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restr
             wk[3] = (kyA + 2) * 3 + kxA + 2;
             const uint32_t yo = ok ? (uint32_t)row * (uint32_t)Cout : OOR;
             typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
             u32x4_t gd[NCH][4], gy[NCH];
             uint32_t ga[NCH][4];
+            // 4 channels of the pooled gradient / of y as float bit patterns (bf16 storage: 8-byte loads, widened here)
+            auto load4 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t eo) -> u32x4_t {
+                if (sizeof(AT) == 2) {
+                    const u32x2_t h = __builtin_amdgcn_raw_buffer_load_b64(rs, eo == OOR ? OOR : eo * 2u, 0, 0);
+                    u32x4_t o;
+                    o[0] = h[0] << 16; o[1] = h[0] & 0xffff0000u; o[2] = h[1] << 16; o[3] = h[1] & 0xffff0000u;
+                    return o;
+                }
+                return __builtin_amdgcn_raw_buffer_load_b128(rs, eo == OOR ? OOR : eo * 4u, 0, 0);
+            };
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const int c0 = (half * nch + j) * 4;
@@ -383,10 +399,10 @@ __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restr
 #pragma unroll
                 for (int w4 = 0; w4 < 4; ++w4) {
                     const uint32_t eo = (on && wo[w4] != OOR) ? wo[w4] + c0 : OOR;
-                    gd[j][w4] = __builtin_amdgcn_raw_buffer_load_b128(rsDP, eo == OOR ? OOR : eo * 4u, 0, 0);
+                    gd[j][w4] = load4(rsDP, eo);
                     ga[j][w4] = __builtin_amdgcn_raw_buffer_load_b32(rsAM, eo, 0, 0);
                 }
-                gy[j] = __builtin_amdgcn_raw_buffer_load_b128(rsY, (on && yo != OOR) ? (yo + c0) * 4u : OOR, 0, 0);
+                gy[j] = load4(rsY, (on && yo != OOR) ? yo + c0 : OOR);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -470,7 +486,7 @@ int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B
 bool stem_bwd_fused_supported(int Cout) { return Cout <= 32 && (Cout % 4) == 0; }
 
 int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, const float* stats, const float* coef, float* dw,
-                          float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st) {
+                          float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st, int at) {
     if (!stem_bwd_fused_supported(Cout)) {
         set_error("stem_bwd_filter_fused: Cout=%d not supported", Cout);
         return -1;
@@ -485,7 +501,14 @@ int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, con
     int rows_per = cdiv(cdiv(rows, STEM_NBLK), 128) * 128;
     const int nblk = cdiv(rows, rows_per);
     StemBnBwd bb{ps, y, stats, coef};
-    if (((Cout >> 2) + 1) / 2 <= 3)
+    const bool n3 = ((Cout >> 2) + 1) / 2 <= 3;
+    if (at && n3)
+        hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, 3, bf16_t>), dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                           rows_per, bb);
+    else if (at)
+        hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, 4, bf16_t>), dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                           rows_per, bb);
+    else if (n3)
         hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, 3>), dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
                            rows_per, bb);
     else
@@ -846,9 +869,9 @@ int maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H,
 
 // fused BN-apply + ReLU6 + max-pool: reads the RAW stem conv output, so the 255 MB activated tensor
 // is never materialised (the backward needs only y, the statistics and the argmax).
-template <int VEC>
-__global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
-                                                             int GC, int fpg, float* __restrict__ p,
+template <int VEC, class T>
+__global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const T* __restrict__ y, const float* __restrict__ stats,
+                                                             int GC, int fpg, T* __restrict__ p,
                                                              uint8_t* __restrict__ argmax, int rows, int H, int W, int Ho,
                                                              int Wo, int C, int pt, int pl, int rb, int nloop) {
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -915,15 +938,21 @@ __global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const float* __rest
 }
 
 int maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax, int N,
-                   int H, int W, int C, hipStream_t st) {
+                   int H, int W, int C, hipStream_t st, int at) {
     const int Ho = same_out(H, 2), Wo = same_out(W, 2);
     const int rows = N * Ho * Wo;
     VColGeom g = vcol_geom(rows, C, 4096);
     dim3 grid(g.nb), block(g.cx, g.cy);
     const int pt = same_pad_before(H, 2), pl = same_pad_before(W, 2);
-    if (g.vec == 4) hipLaunchKernelGGL(maxpool_bn_fwd_kernel<4>, grid, block, 0, st, y, stats, G * C, frames_per_group, p, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
-    else if (g.vec == 2) hipLaunchKernelGGL(maxpool_bn_fwd_kernel<2>, grid, block, 0, st, y, stats, G * C, frames_per_group, p, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
-    else hipLaunchKernelGGL(maxpool_bn_fwd_kernel<1>, grid, block, 0, st, y, stats, G * C, frames_per_group, p, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
+    if (at) {
+        const bf16_t* yb = reinterpret_cast<const bf16_t*>(y);
+        bf16_t* pb = reinterpret_cast<bf16_t*>(p);
+        if (g.vec == 4) hipLaunchKernelGGL((maxpool_bn_fwd_kernel<4, bf16_t>), grid, block, 0, st, yb, stats, G * C, frames_per_group, pb, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
+        else if (g.vec == 2) hipLaunchKernelGGL((maxpool_bn_fwd_kernel<2, bf16_t>), grid, block, 0, st, yb, stats, G * C, frames_per_group, pb, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
+        else hipLaunchKernelGGL((maxpool_bn_fwd_kernel<1, bf16_t>), grid, block, 0, st, yb, stats, G * C, frames_per_group, pb, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
+    } else if (g.vec == 4) hipLaunchKernelGGL((maxpool_bn_fwd_kernel<4, float>), grid, block, 0, st, y, stats, G * C, frames_per_group, p, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
+    else if (g.vec == 2) hipLaunchKernelGGL((maxpool_bn_fwd_kernel<2, float>), grid, block, 0, st, y, stats, G * C, frames_per_group, p, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
+    else hipLaunchKernelGGL((maxpool_bn_fwd_kernel<1, float>), grid, block, 0, st, y, stats, G * C, frames_per_group, p, argmax, rows, H, W, Ho, Wo, C, pt, pl, g.rb, g.nloop);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

@@ -161,10 +161,10 @@ __device__ __forceinline__ void zero_border(float* t, int Hp, int Wp, int cchunk
     }
 }
 
-template <int S, int VEC, bool PRE>
-__global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pre_stats,
+template <int S, int VEC, bool PRE, class T>
+__global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const T* __restrict__ x, const float* __restrict__ pre_stats,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
-                                                      float* __restrict__ y, double* __restrict__ part, int Bf, int H, int W,
+                                                      T* __restrict__ y, double* __restrict__ part, int Bf, int H, int W,
                                                       int Ho, int Wo, int C, int GC, int pt, int pl, int fpb, int nb,
                                                       int cchunk, int nfb) {
     extern __shared__ __attribute__((aligned(16))) float tile[];     // [H*W][cc]
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restr
         const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f;
         __syncthreads();
         if (on) {
-            const float* xp = x + n * P * C + c;
+            const T* xp = x + n * P * C + c;
             for (int p0 = ty; p0 < P; p0 += CY * DWF_UF) {       // DWF_UF independent loads in flight per thread
                 VecF<VEC> v[DWF_UF];
 #pragma unroll
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restr
         }
         __syncthreads();
         if (on) {
-            float* yp = y + n * Po * C + c;
+            T* yp = y + n * Po * C + c;
             for (int p = ty; p < Po; p += CY) {
                 const int oy = (int)(((float)p + 0.5f) * invWo), ox = p - oy * Wo;
                 const int o0 = ((oy * S + 1 - pt) * Wp + ox * S + 1 - pl) * cchunk + tx * VEC;    // (index, not pointer:
@@ -247,7 +247,8 @@ __global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restr
                 vstore<VEC>(yp + (int64_t)p * C, acc);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
-                    const double d = (double)acc.v[i];
+                    // (bf16 storage: the statistics are those of the values the consumers will read, i.e. the rounded ones)
+                    const double d = sizeof(T) == 2 ? (double)(float)(bf16_t)acc.v[i] : (double)acc.v[i];
                     s1[i] += d;
                     s2[i] += d * d;
                 }
@@ -265,9 +266,9 @@ __global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const float* __restr
     block_colsum_all<2, VEC>(sm, sq, tx, ty, CX, CY, on, part + ((int64_t)g * nb + b) * 2 * C + c, C);
 }
 
-template <int S, int VEC, bool PRE>
-__global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restrict__ x, const float* __restrict__ pre_stats,
-                                                      const float* __restrict__ dout, const float* __restrict__ y2,
+template <int S, int VEC, bool PRE, class T>
+__global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict__ x, const float* __restrict__ pre_stats,
+                                                      const T* __restrict__ dout, const T* __restrict__ y2,
                                                       const float* __restrict__ post_stats,
                                                       const float* __restrict__ post_coef, const float* __restrict__ w,
                                                       View dx, double* __restrict__ part_bn, double* __restrict__ part_w,
@@ -327,13 +328,13 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
     for (int f = 0; f < fpb; ++f) {
         const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f;
         __syncthreads();
-        const float* xp = x + n * P * C + c;
+        const T* xp = x + n * P * C + c;
         if (on) {
             // one merged load loop for the three tensors (x, dout, y2): 3*DWF_U independent loads in flight per thread.
             // Tile A holds the ACTIVATED input relu6(scale1*y1+shift1) (x itself without a pre-BN); tile D the
             // BatchNorm-backward-applied gradient of the depthwise output.
-            const float* dp = dout + n * Po * C + c;
-            const float* yp = y2 + n * Po * C + c;
+            const T* dp = dout + n * Po * C + c;
+            const T* yp = y2 + n * Po * C + c;
             for (int p0 = ty; p0 < P; p0 += CY * DWF_U) {
                 VecF<VEC> xa[DWF_U], d[DWF_U], v[DWF_U];
 #pragma unroll
@@ -479,7 +480,7 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const float* __restr
 #pragma unroll
                 for (int u = 0; u < DXU; ++u) {
                     const int p = p0 + u * CY;
-                    if (p < P) vstore_view<VEC>(dx, n * P + p, c, 0, dx_al, acc[u]);
+                    if (p < P) vstore_view<VEC, T>(dx, n * P + p, c, 0, dx_al, acc[u]);
                 }
             }
         }
@@ -516,26 +517,31 @@ static int allow_lds(size_t bytes) {
     return 0;
 }
 
-template <int S, int VEC, bool PRE>
+template <int S, int VEC, bool PRE, class T>
 static int launch_dwf_fwd(const DwfGeom& g, hipStream_t st, const float* x, const float* pre_stats, const float* w,
                           const float* bias, float* y, double* part, int G, int B, int H, int W, int C) {
     const int Ho = same_out(H, S), Wo = same_out(W, S);
-    CDRL_TRY((allow_lds<dwf_fwd_kernel<S, VEC, PRE>>(g.lds_fwd)));
-    hipLaunchKernelGGL((dwf_fwd_kernel<S, VEC, PRE>), dim3(cdiv(G * g.nb, 8) * 8 * g.nch), dim3(g.cx, g.cy), g.lds_fwd, st, x, pre_stats, w, bias,
-                       y, part, B, H, W, Ho, Wo, C, G * C, same_pad_before(H, S), same_pad_before(W, S), g.fpb, g.nb, g.cchunk, G * g.nb);
+    CDRL_TRY((allow_lds<dwf_fwd_kernel<S, VEC, PRE, T>>(g.lds_fwd)));
+    hipLaunchKernelGGL((dwf_fwd_kernel<S, VEC, PRE, T>), dim3(cdiv(G * g.nb, 8) * 8 * g.nch), dim3(g.cx, g.cy), g.lds_fwd, st,
+                       reinterpret_cast<const T*>(x), pre_stats, w, bias, reinterpret_cast<T*>(y), part, B, H, W, Ho, Wo, C, G * C,
+                       same_pad_before(H, S), same_pad_before(W, S), g.fpb, g.nb, g.cchunk, G * g.nb);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
 
 template <int S, int VEC>
 static int launch_dwf_fwd_pre(const DwfGeom& g, hipStream_t st, const float* x, const float* pre_stats, const float* w,
-                              const float* bias, float* y, double* part, int G, int B, int H, int W, int C) {
-    if (pre_stats) return launch_dwf_fwd<S, VEC, true>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C);
-    return launch_dwf_fwd<S, VEC, false>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C);
+                              const float* bias, float* y, double* part, int G, int B, int H, int W, int C, int at) {
+    if (at) {
+        if (pre_stats) return launch_dwf_fwd<S, VEC, true, bf16_t>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C);
+        return launch_dwf_fwd<S, VEC, false, bf16_t>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C);
+    }
+    if (pre_stats) return launch_dwf_fwd<S, VEC, true, float>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C);
+    return launch_dwf_fwd<S, VEC, false, float>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C);
 }
 
 int dwf_fwd(const float* x, const float* pre_stats, const float* w, const float* bias, float* y, double* part, int G,
-            int B, int H, int W, int C, int stride, hipStream_t st) {
+            int B, int H, int W, int C, int stride, hipStream_t st, int at) {
     if (stride != 1 && stride != 2) {
         set_error("dwf_fwd: stride must be 1 or 2");
         return -1;
@@ -545,7 +551,7 @@ int dwf_fwd(const float* x, const float* pre_stats, const float* w, const float*
         set_error("dwf_fwd: frame %dx%d does not fit LDS even at %d channels", H, W, g.cchunk);
         return -1;
     }
-#define CDRL_DWF_FWD(S, V) return launch_dwf_fwd_pre<S, V>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C)
+#define CDRL_DWF_FWD(S, V) return launch_dwf_fwd_pre<S, V>(g, st, x, pre_stats, w, bias, y, part, G, B, H, W, C, at)
     if (stride == 1) {
         if (g.vec == 4) CDRL_DWF_FWD(1, 4);
         if (g.vec == 2) CDRL_DWF_FWD(1, 2);
@@ -557,13 +563,14 @@ int dwf_fwd(const float* x, const float* pre_stats, const float* w, const float*
 #undef CDRL_DWF_FWD
 }
 
-template <int S, int VEC, bool PRE>
+template <int S, int VEC, bool PRE, class T>
 static int launch_dwf_bwd(const DwfGeom& g, hipStream_t st, const float* x, const float* pre_stats, const float* dout,
                           const float* y2, const float* post_stats, const float* post_coef, const float* w, View dx,
                           double* part_bn, double* part_w, int G, int B, int H, int W, int C) {
     const int Ho = same_out(H, S), Wo = same_out(W, S);
-    CDRL_TRY((allow_lds<dwf_bwd_kernel<S, VEC, PRE>>(g.lds_bwd)));
-    hipLaunchKernelGGL((dwf_bwd_kernel<S, VEC, PRE>), dim3(cdiv(G * g.nb, 8) * 8 * g.nch), dim3(g.cx_bwd, g.cy_bwd), g.lds_bwd, st, x, pre_stats, dout, y2,
+    CDRL_TRY((allow_lds<dwf_bwd_kernel<S, VEC, PRE, T>>(g.lds_bwd)));
+    hipLaunchKernelGGL((dwf_bwd_kernel<S, VEC, PRE, T>), dim3(cdiv(G * g.nb, 8) * 8 * g.nch), dim3(g.cx_bwd, g.cy_bwd), g.lds_bwd, st,
+                       reinterpret_cast<const T*>(x), pre_stats, reinterpret_cast<const T*>(dout), reinterpret_cast<const T*>(y2),
                        post_stats, post_coef, w, dx, part_bn, part_w, B, H, W, Ho, Wo, C, G * C, same_pad_before(H, S),
                        same_pad_before(W, S), g.fpb, g.nb, g.cchunk, view_aligned(dx, g.vec_bwd), G * g.nb);
     CDRL_LAUNCH_CHECK();
@@ -573,15 +580,20 @@ static int launch_dwf_bwd(const DwfGeom& g, hipStream_t st, const float* x, cons
 template <int S, int VEC>
 static int launch_dwf_bwd_pre(const DwfGeom& g, hipStream_t st, const float* x, const float* pre_stats, const float* dout,
                               const float* y2, const float* post_stats, const float* post_coef, const float* w, View dx,
-                              double* part_bn, double* part_w, int G, int B, int H, int W, int C) {
+                              double* part_bn, double* part_w, int G, int B, int H, int W, int C, int at) {
+    if (at) {
+        if (pre_stats)
+            return launch_dwf_bwd<S, VEC, true, bf16_t>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C);
+        return launch_dwf_bwd<S, VEC, false, bf16_t>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C);
+    }
     if (pre_stats)
-        return launch_dwf_bwd<S, VEC, true>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C);
-    return launch_dwf_bwd<S, VEC, false>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C);
+        return launch_dwf_bwd<S, VEC, true, float>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C);
+    return launch_dwf_bwd<S, VEC, false, float>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C);
 }
 
 int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const float* y2, const float* post_stats,
             const float* post_coef, const float* w, View dx, double* part_bn, double* part_w, int G, int B, int H, int W,
-            int C, int stride, hipStream_t st) {
+            int C, int stride, hipStream_t st, int at) {
     if (stride != 1 && stride != 2) {
         set_error("dwf_bwd: stride must be 1 or 2");
         return -1;
@@ -596,7 +608,7 @@ int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const flo
         return -1;
     }
 #define CDRL_DWF_BWD(S, V) \
-    return launch_dwf_bwd_pre<S, V>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C)
+    return launch_dwf_bwd_pre<S, V>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C, at)
     if (stride == 1) {
         if (g.vec_bwd == 2) CDRL_DWF_BWD(1, 2);
         CDRL_DWF_BWD(1, 1);

@@ -27,7 +27,9 @@ struct Config {
     int dyn = 512;
     int head = 320;
     float exp_scale = 6.0f;
-    int compute = 0;        // 0: float32 products; 1: bf16 MFMA operands in the tower's 1x1 convolutions (configuration 3)
+    int compute = 0;        // 0: float32 products; 1: bf16 MFMA operands in the tower's 1x1 convolutions (configuration 3);
+                            // 2: 1 + bf16 ACTIVATION STORAGE: every activation / activation-gradient tensor of the image tower
+                            //    is bf16 in HBM (statistics, partials, coefficients, weights, accumulators stay float32 / double)
 };
 
 enum Model : int { M_TRUNK = 0, M_POLICY = 1, M_VALUE = 2, M_OLD_POLICY = 3 };
@@ -195,6 +197,11 @@ private:
     float* alloc(size_t n);
     double* alloc_d(size_t n);
     Tens tens(int rows, int C, bool grad = true);
+    // tower tensor in the activation type of the build (float32, or bf16 with Config::compute == 2); same Tens / View spelling,
+    // p and g then point to bf16 elements (ld and channel offsets count elements)
+    Tens tens_a(int rows, int C, bool grad = true);
+    int at_ = 0;            // activation type of the tower: 0 float32, 1 bf16 (compute == 2)
+    size_t esz() const { return at_ ? 2 : 4; }
     PRef param(int model, const std::string& name, std::initializer_list<int> shape, bool trainable);
     void build_trunk(std::vector<Op>& ops);
     void build_head(std::vector<Op>& ops, int model, const std::string& prefix, Tens& lin, int nheads,

@@ -37,6 +37,7 @@ Learner::Learner(const Config& cfg) : cfg_(cfg) {
     hp_host_.beta1 = 0.9f;
     hp_host_.beta2 = 0.999f;
     hp_host_.eps = 1e-7f;
+    at_ = cfg_.compute == 2 ? 1 : 0;
     build(true);
     table_frozen_ = true;
     build_seg_tables();
@@ -289,6 +290,16 @@ Learner::Tens Learner::tens(int rows, int C, bool grad) {
     return t;
 }
 
+Learner::Tens Learner::tens_a(int rows, int C, bool grad) {
+    Tens t;
+    t.rows = rows;
+    t.C = C;
+    const size_t n = ((size_t)rows * C * esz() + 3) / 4;        // float-sized slots
+    t.p = alloc(n);
+    if (grad) t.g = alloc(n);
+    return t;
+}
+
 Learner::PRef Learner::param(int model, const std::string& name, std::initializer_list<int> shape, bool trainable) {
     const int tm = model == M_OLD_POLICY ? (int)M_POLICY : model;
     int idx;
@@ -402,7 +413,7 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     float* stats = alloc((size_t)4 * G * C);
     float* coef = alloc((size_t)3 * G * C);
     note_named(prefix + ".stats", stats, (size_t)4 * G * C * sizeof(float));
-    if (x.ld == C && x.coff == 0) note_named(prefix + ".x", x.p, (size_t)G * Mg * C * sizeof(float));
+    if (x.ld == C && x.coff == 0) note_named(prefix + ".x", x.p, (size_t)G * Mg * C * (model == M_TRUNK && prefix.compare(0, 4, "img.") == 0 ? esz() : 4));
     const int nb = vcol_geom(Mg, C).nb;
     note_scratch((size_t)G * std::max(nb, stats_nb) * 2 * C, (size_t)G * nb * C, 0, 0);
     BnRec rec;
@@ -427,6 +438,8 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     const bool small = small_env && G == 1 && Mg <= 2048 && !bessel && act == ACT_NONE && !out_shuffle && !dout_shuffle && dx &&
                        !stats_nb && !defer_apply && !pass.fsrc.p && !pass.gsrc.p && !pass.gap_out;
     const bool gap = pass.gap_out != nullptr;
+    const int at = model == M_TRUNK && prefix.compare(0, 4, "img.") == 0 ? at_ : 0;     // tower tensors only
+    if (at && small) build_fail("%s: single-launch BatchNorm has no bf16-storage form", prefix.c_str());
     if (gap && (pass.gap_rows <= 0 || Mg % pass.gap_rows != 0 || x.ld != C || x.coff != 0 || out_shuffle || dout_shuffle || pass.fsrc.p ||
                 pass.gsrc.p))
         build_fail("%s: fused global average pool needs a dense input and whole frames per group", prefix.c_str());
@@ -442,24 +455,24 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
         return rec;
     }
     op.fwd = [=](hipStream_t st, int training) -> int {
-        if (training && !stats_nb) CDRL_TRY(colstats(x, G, Mg, C, sc->part, st));
+        if (training && !stats_nb) CDRL_TRY(colstats(x, G, Mg, C, sc->part, st, at));
         if (training || !inf_batched)
             CDRL_TRY(bn_finalize(sc->part, stats_nb ? stats_nb : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, bes, training, stats, st));
-        if (gap) return bn_act_gap_fwd(x.p, stats, pass.gap_out, G, Mg / pass.gap_rows, pass.gap_rows, C, act, st);
-        if (pass.fsrc.p) return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st, &pass.fsrc, &pass.fdst);
-        return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st);
+        if (gap) return bn_act_gap_fwd(x.p, stats, pass.gap_out, G, Mg / pass.gap_rows, pass.gap_rows, C, act, st, at);
+        if (pass.fsrc.p) return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st, &pass.fsrc, &pass.fdst, at);
+        return bn_apply(x, G, Mg, C, stats, act, out, out_shuffle, st, nullptr, nullptr, at);
     };
     op.bwd = [=](hipStream_t st) -> int {
         // fused global average pool: the gradient source is the pooled gradient, one row per gap_rows rows of x
         const View dsrc = gap ? make_view(const_cast<float*>(pass.gap_dout), C) : dout;
         const int bc = gap ? pass.gap_rows : 0;
-        if (pass.gsrc.p) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, &pass.gsrc, &pass.gdst));
-        else if (!*fused) CDRL_TRY(bn_bwd_reduce(dsrc, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, nullptr, nullptr, bc));
+        if (pass.gsrc.p) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, &pass.gsrc, &pass.gdst, 0, at));
+        else if (!*fused) CDRL_TRY(bn_bwd_reduce(dsrc, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, nullptr, nullptr, bc, at));
         CDRL_TRY(bn_bwd_finalize(sc->part, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
         if (defer_apply) return 0;      // applied by the consumer GEMMs on load (PwFuse::bb)
-        if (dx) return bn_bwd_apply(dsrc, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, sc->part2, st, nullptr, bc);
+        if (dx) return bn_bwd_apply(dsrc, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, sc->part2, st, nullptr, bc, at);
         CDRL_TRY(next_slot(st));       // tower: dy + db partials go to a rotating scratch slot
-        return bn_bwd_apply(dsrc, dout_shuffle, x, G, Mg, C, stats, coef, act, dys_[slot_], part2s_[slot_], st, nullptr, bc);
+        return bn_bwd_apply(dsrc, dout_shuffle, x, G, Mg, C, stats, coef, act, dys_[slot_], part2s_[slot_], st, nullptr, bc, at);
     };
     ops.push_back(op);
     return rec;
@@ -478,7 +491,8 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     // compute mode 1 (configuration 3): every 1x1 convolution of the tower multiplies bf16-rounded operands -- forward,
     // backward-data and filter gradient: the fused kernels in their BF variant, the plain wide ones through gemm_x3's
     // single-plane form, the filter gradients through tn_direct's BF variant
-    const bool bfc = cfg_.compute == 1;
+    const bool bfc = cfg_.compute >= 1;
+    const int at = at_;
     // forward on the bf16 matrix pipe (exact three-way operand split, gemm_pw_x3.hip) where the shape allows it
     static const bool x3_env = !(getenv("CDRL_PW_X3") && atoi(getenv("CDRL_PW_X3")) == 0);
     const void* w3f = (!bfc && x3_env && fuse.fwd_pw && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
@@ -507,8 +521,8 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
                          nb_fwd);
         if (fuse.fwd_pw)
             return pw_nn(in, fuse.pro_stats, w.p, Cout, 1, b.p, make_view(y, Cout), 0, G, Mg, Cout, Cin, fuse.epi_stats ? 1 : 0,
-                         nullptr, nullptr, scr_main_.part, st, nullptr, wpf, bfc);
-        if (g3f) return gemm_x3(in, g3f, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st, bfc);
+                         nullptr, nullptr, scr_main_.part, st, nullptr, wpf, bfc, at);
+        if (g3f) return gemm_x3(in, g3f, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st, bfc, at);
         return gemm_nn(in, w.p, Cout, 1, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
     };
     const int nbp_bwd = fuse.bb ? pw_nn_plan(G, Mg, Cin, Cout).nbpg : 0;
@@ -520,11 +534,11 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             const View dz = fuse.bb_dz.p ? fuse.bb_dz : make_view(dys_[slot_], Cout);
             hipStream_t side = fork_side(st);
             TnBnBwd tb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act};
-            CDRL_TRY(gemm_tn(in, dz, w.g, rows, Cout, Cin, tns_[slot_], 0, side, G, fuse.pro_stats, &tb, bfc));
+            CDRL_TRY(gemm_tn(in, dz, w.g, rows, Cout, Cin, tns_[slot_], 0, side, G, fuse.pro_stats, &tb, bfc, at));
             CDRL_TRY(done_side(side));
             PwBnBwd pb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act, part2s_[slot_]};
             CDRL_TRY(pw_nn(dz, nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
-                           fuse.bwd_epi_stats, scr_main_.part, st, &pb, wpb, bfc));
+                           fuse.bwd_epi_stats, scr_main_.part, st, &pb, wpb, bfc, at));
             // bias gradient = column sums of the (virtual) dy, reduced from the GEMM's partials: rides on the next fork
             double* p2 = part2s_[slot_];
             return defer_side(st, [=](hipStream_t sd) -> int { return reduce_partials(p2, G * nbp_bwd, Cout, Cout, b.g, 0, sd); });
@@ -533,14 +547,14 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         // side stream: bias gradient (column sums of dy, reduced per block by bn_bwd_apply) + filter gradient
         hipStream_t side = fork_side(st);
         CDRL_TRY(reduce_partials(part2s_[slot_], bn_after.G * bn_after.nb, Cout, Cout, b.g, 0, side));
-        CDRL_TRY(gemm_tn(in, make_view(dy, Cout), w.g, rows, Cout, Cin, tns_[slot_], 0, side, tn_groups, fuse.pro_stats, nullptr, bfc));
+        CDRL_TRY(gemm_tn(in, make_view(dy, Cout), w.g, rows, Cout, Cin, tns_[slot_], 0, side, tn_groups, fuse.pro_stats, nullptr, bfc, at));
         CDRL_TRY(done_side(side));
         // main stream: the critical path to the previous layer
         if (din.p) {
             if (fuse.bwd_pw)
                 return pw_nn(make_view(dy, Cout), nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout,
-                             fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, scr_main_.part, st, nullptr, wpb, bfc);
-            if (g3b) return gemm_x3(make_view(dy, Cout), g3b, nullptr, din, rows, Cin, Cout, din_acc, st, bfc);
+                             fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, scr_main_.part, st, nullptr, wpb, bfc, at);
+            if (g3b) return gemm_x3(make_view(dy, Cout), g3b, nullptr, din, rows, Cin, Cout, din_acc, st, bfc, at);
             CDRL_TRY(gemm_nn(make_view(dy, Cout), w.p, 1, Cout, nullptr, din, rows, Cin, Cout, din_acc, st));
         }
         return 0;
@@ -561,6 +575,7 @@ void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, i
         pre = *pre_bn;
         *pre.reduce_fused = true;
     }
+    if (at_) build_fail("%s: the unfused depthwise path has no bf16-storage form (CDRL_FUSED_DW=0 is set)", prefix.c_str());
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int { return dw_fwd(in, w.p, b.p, y, N, H, W, C, stride, st); };
     op.bwd = [=](hipStream_t st) -> int {
@@ -596,7 +611,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
         note_bn_inference(g1.p, b1.p, mm1.p, mv1.p, stats1, G, C);
         coef1 = coef1_ext ? coef1_ext : alloc((size_t)3 * G * C);
         note_named(n1 + ".stats", stats1, (size_t)4 * G * C * sizeof(float));
-        note_named(n1 + ".x", x, (size_t)N * H * W * C * sizeof(float));
+        note_named(n1 + ".x", x, (size_t)N * H * W * C * esz());
     }
     PRef w = param(M_TRUNK, unit + "." + dw + ".w", {3, 3, C, 1}, true);
     PRef b = param(M_TRUNK, unit + "." + dw + ".b", {C}, true);
@@ -614,12 +629,13 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
     note_scratch((size_t)G * nbmax * 2 * C, (size_t)G * nbmax * C, (size_t)N * H * W * C, 0,
                  (size_t)dwf_filter_part_elems(B, G, H, W, C, stride));
     const View xv = make_view(x, C), y2v = make_view(y2, C);
+    const int at = at_;
 
     if (pre) {      // BN1: statistics only in the forward; backward = finalize of the sums the depthwise op produced
         Op op;
         op.fwd = [=](hipStream_t st, int training) -> int {
             if (!training) return 0;                            // inference: statistics block from the batched launch
-            if (!pre_stats_nb) CDRL_TRY(colstats(xv, G, Mi, C, sc->part, st));
+            if (!pre_stats_nb) CDRL_TRY(colstats(xv, G, Mi, C, sc->part, st, at));
             return bn_finalize(sc->part, pre_stats_nb ? pre_stats_nb : nb_in, G, Mi, C, g1.p, b1.p, mm1.p, mv1.p, 1, training,
                                stats1, st);
         };
@@ -629,20 +645,20 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
             const float* dz = dys_[slot_];                 // masked gradient left there by the depthwise op
             CDRL_TRY(next_slot(st));
             return bn_bwd_apply(make_view(const_cast<float*>(dz), C), 0, xv, G, Mi, C, stats1, coef1, ACT_NONE, dys_[slot_],
-                                part2s_[slot_], st);
+                                part2s_[slot_], st, nullptr, 0, at);
         };
         ops.push_back(op);
     }
     {
         Op op;
         op.fwd = [=](hipStream_t st, int) -> int {
-            return dwf_fwd(x, stats1, w.p, b.p, y2, sc->part, G, B, H, W, C, stride, st);
+            return dwf_fwd(x, stats1, w.p, b.p, y2, sc->part, G, B, H, W, C, stride, st, at);
         };
         op.bwd = [=](hipStream_t st) -> int {
             CDRL_TRY(next_slot(st));
             double* pw = fparts_[slot_];
             const View dx = pre ? make_view(dys_[slot_], C) : din;
-            CDRL_TRY(dwf_bwd(x, stats1, dout.p, y2, stats2, coef2, w.p, dx, sc->part, pw, G, B, H, W, C, stride, st));
+            CDRL_TRY(dwf_bwd(x, stats1, dout.p, y2, stats2, coef2, w.p, dx, sc->part, pw, G, B, H, W, C, stride, st, at));
             return defer_side(st, [=](hipStream_t sd) -> int {
                 return reduce_partials2(pw, G * nbf, 9 * C, C, (int64_t)10 * C, w.g, b.g, 0, sd);
             });
@@ -654,10 +670,10 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
         op.fwd = [=](hipStream_t st, int training) -> int {
             if (training) CDRL_TRY(bn_finalize(sc->part, nbf, G, Mo, C, g2.p, b2.p, mm2.p, mv2.p, 1, training, stats2, st));
             if (!post_apply) return 0;
-            return bn_apply(y2v, G, Mo, C, stats2, ACT_NONE, out, 0, st);
+            return bn_apply(y2v, G, Mo, C, stats2, ACT_NONE, out, 0, st, nullptr, nullptr, at);
         };
         op.bwd = [=](hipStream_t st) -> int {
-            if (!post_bwd_nb) CDRL_TRY(bn_bwd_reduce(dout, 0, y2v, G, Mo, C, stats2, ACT_NONE, sc->part, st));
+            if (!post_bwd_nb) CDRL_TRY(bn_bwd_reduce(dout, 0, y2v, G, Mo, C, stats2, ACT_NONE, sc->part, st, nullptr, nullptr, nullptr, 0, at));
             return bn_bwd_finalize(sc->part, post_bwd_nb ? post_bwd_nb : nb_out, G, Mo, C, stats2, g2.g, b2.g, coef2, st);
         };
         ops.push_back(op);
@@ -883,7 +899,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
 
     // ---- stem (core/architectures.py:159-161)
     {
-        Tens y = tens(N * Hs * Ws, c.stem, false);
+        const int at = at_;
+        Tens y = tens_a(N * Hs * Ws, c.stem, false);
         PRef w = param(M_TRUNK, "img.stem.conv.w", {3, 3, 3, c.stem}, true);
         PRef b = param(M_TRUNK, "img.stem.conv.b", {c.stem}, true);
         note_scratch(0, 0, (size_t)N * Hs * Ws * c.stem, 0, (size_t)stem_bwd_part_elems(B, T, c.H, c.W, c.stem));
@@ -892,8 +909,10 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         // forward: BN statistics in the conv's epilogue (training only; inference uses the moving statistics)
         const bool stem_fstats = stem_fwd_stats_supported(Cs) && !(getenv("CDRL_FUSED_STEM") && atoi(getenv("CDRL_FUSED_STEM")) == 0);
         const int nb_stem = stem_fstats ? stem_fwd_stats_nb(B, H, W) : 0;
+        if (at && !stem_fstats) build_fail("bf16 activation storage needs the fused stem forward (stem channels %d, CDRL_FUSED_STEM)", Cs);
         op.fwd = [=](hipStream_t st, int training) -> int {
-            if (stem_fstats && training) return stem_fwd_stats(in_image_, w.p, b.p, y.p, scr_main_.part, B, T, H, W, Cs, st);
+            // (bf16 storage: the statistics form is the one with a bf16 store; its partials are simply unused in inference)
+            if (stem_fstats && (training || at)) return stem_fwd_stats(in_image_, w.p, b.p, y.p, scr_main_.part, B, T, H, W, Cs, st, at);
             return stem_fwd(in_image_, w.p, b.p, y.p, B, T, H, W, Cs, st);
         };
         const bool stem_fused = stem_bwd_fused_supported(Cs) && !(getenv("CDRL_FUSED_STEM") && atoi(getenv("CDRL_FUSED_STEM")) == 0);
@@ -901,15 +920,16 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         float* stem_stats = alloc((size_t)4 * T * Cs);
         float* stem_coef = alloc((size_t)3 * T * Cs);
         const int Hp0 = same_out_h(Hs, 2), Wp0 = same_out_h(Ws, 2);
-        Tens pool = tens(N * Hp0 * Wp0, c.stem);
+        Tens pool = tens_a(N * Hp0 * Wp0, c.stem);
+        if (at && !stem_fused) build_fail("bf16 activation storage needs the fused stem backward (stem channels %d, CDRL_FUSED_STEM)", Cs);
         uint8_t* argmax = reinterpret_cast<uint8_t*>(alloc(((size_t)N * Hp0 * Wp0 * c.stem + 3) / 4));
         note_named("img.stem.bn.stats", stem_stats, (size_t)4 * T * Cs * sizeof(float));
-        note_named("img.stem.bn.x", y.p, (size_t)N * Hs * Ws * Cs * sizeof(float));
+        note_named("img.stem.bn.x", y.p, (size_t)N * Hs * Ws * Cs * esz());
         note_named("img.stem.pool.argmax", argmax, (size_t)N * Hp0 * Wp0 * Cs);
         // one-pass form (stem_bwd.hip): BN sums and filter sums together, everything in the BN op's backward.  Opt-in
         // (CDRL_STEM_DIRECT=1): measured 747 us (three accumulator tiles, 64 KB LDS -> two workgroups per CU) against
         // 206 + 453 us for the two-pass form whose second pass overlaps on the side stream: 22.3 vs 22.0 ms/update-step.
-        const bool stem_direct = stem_fused && stem_bwd_direct_supported(Cs) &&
+        const bool stem_direct = !at && stem_fused && stem_bwd_direct_supported(Cs) &&
                                  (getenv("CDRL_STEM_DIRECT") && atoi(getenv("CDRL_STEM_DIRECT")) == 1);
         float* stem_ws = stem_direct ? alloc((size_t)stem_bwd_direct_ws_floats(B, T, H, W)) : nullptr;
         op.bwd = [=](hipStream_t st) -> int {
@@ -918,7 +938,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 CDRL_TRY(next_slot(st));
                 hipStream_t side = fork_side(st);
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
-                CDRL_TRY(stem_bwd_filter_fused(in_image_, ps, y.p, stem_stats, stem_coef, w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side));
+                CDRL_TRY(stem_bwd_filter_fused(in_image_, ps, y.p, stem_stats, stem_coef, w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side, at));
                 return done_side(side);
             }
             hipStream_t side = fork_side(st);
@@ -949,7 +969,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 if (training)       // (inference: statistics block from the batched launch)
                     CDRL_TRY(bn_finalize(scr_main_.part, stem_fstats ? nb_stem : nb, G, Mg, C, gamma.p, beta.p, mm.p, mv.p, 1, training, stats,
                                          st));
-                return maxpool_bn_fwd(y.p, stats, G, B, pool.p, argmax, N, Hs, Ws, C, st);
+                return maxpool_bn_fwd(y.p, stats, G, B, pool.p, argmax, N, Hs, Ws, C, st, at);
             };
             bn.bwd = [=](hipStream_t st) -> int {
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
@@ -957,7 +977,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 if (stem_direct)
                     return stem_bwd_direct(in_image_, ps, y.p, stats, gamma.g, beta.g, coef, w.g, b.g, B, T, H, W, C, stem_ws, st);
                 if (stem_fused) {       // sums in scatter form over the pooled gradient; the apply happens inside the stem filter-gradient GEMM
-                    CDRL_TRY(pool_bn_bwd_reduce(ps, y.p, G, B, C, stats, scr_main_.part, st));
+                    CDRL_TRY(pool_bn_bwd_reduce(ps, y.p, G, B, C, stats, scr_main_.part, st, at));
                     return bn_bwd_finalize(scr_main_.part, nb_pool, G, Mg, C, stats, gamma.g, beta.g, coef, st);
                 }
                 CDRL_TRY(bn_bwd_reduce(none, 0, yv, G, Mg, C, stats, ACT_RELU6, scr_main_.part, st, &ps));
@@ -983,7 +1003,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 const int rows_in = N * curH * curW, rows_out = N * Ho * Wo;
                 const int Mg_in = B * curH * curW, Mg_out = B * Ho * Wo;
                 const std::string pre = "img.s" + std::to_string(s) + ".u" + std::to_string(u);
-                Tens out = tens(rows_out, C);
+                Tens out = tens_a(rows_out, C);
                 // stride-2 units: the shortcut branch (dw3x3/s2 -> BN -> 1x1 -> BN+ReLU6) only depends on the unit input; in the
                 // FORWARD pass (where the side stream is idle) it runs on the side stream next to the main branch
                 static const bool sc_overlap_env = !(getenv("CDRL_SC_OVERLAP") && atoi(getenv("CDRL_SC_OVERLAP")) == 0);
@@ -1009,6 +1029,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     pass.gsrc = out.gv(0);
                     pass.gdst = X.gv(0);
                 } else if (stride == 1) {
+                    if (at) build_fail("%s: the stand-alone identity-half copy has no bf16-storage form (CDRL_FUSED_PASS=0 is set)", pre.c_str());
                     Op cp;                      // shortcut half: identity through concat + shuffle
                     View src = X.v(0), dst = out.v(0), gsrc = out.gv(0), gdst = X.gv(0);
                     cp.fwd = [=](hipStream_t st, int) -> int {
@@ -1017,9 +1038,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     cp.bwd = [=](hipStream_t st) -> int { return gather_view(gsrc, C, rows_in, sc_c, gdst, 0, st); };
                     ops.push_back(cp);
                 }
-                Tens y1 = tens(rows_in, mid, false);
-                Tens y2 = tens(rows_out, mid, false), a2 = tens(rows_out, mid);
-                Tens y3 = tens(rows_out, main_out, false);
+                Tens y1 = tens_a(rows_in, mid, false);
+                Tens y2 = tens_a(rows_out, mid, false), a2 = tens_a(rows_out, mid);
+                Tens y3 = tens_a(rows_out, main_out, false);
                 // BatchNorm work folded into the 1x1-conv GEMMs (K, N <= 128: stages 0 and 1)
                 // (the K, N = 232 variants of stage 2 run at one workgroup per CU -- 116 W-fragment VGPRs per wave; slower than the
                 //  tiled GEMM + separate BN passes at v19 (+0.15 ms), faster at v29 (-0.24 ms/update-step): CDRL_FUSED_PW=1 -> off)
@@ -1084,7 +1105,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                         add_dw_block(ops, pre, "bn1", "dw", "bn2", y1.p, curH, curW, mid, stride, y2.p, a2.v(), a2.gv(),
                                      View{nullptr, 0, 0});
                     } else {
-                        Tens a1 = tens(rows_in, mid);
+                        Tens a1 = tens_a(rows_in, mid);
                         BnRec r1 = add_bn(ops, M_TRUNK, pre + ".bn1", y1.v(), T, Mg_in, mid, true, ACT_RELU6, a1.v(), 0, a1.gv(), 0,
                                           nullptr);
                         add_dw(ops, pre + ".dw", a1.v(), N, curH, curW, mid, stride, y2.p, a1.gv(), 0, &r1);
@@ -1097,7 +1118,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 if (stride == 2) {
                     const size_t sc_begin = ops.size();
                     if (sc_overlap) build_scr_ = &scr_sc_;
-                    Tens ys1 = tens(rows_out, sc_c, false), b1 = tens(rows_out, sc_c);
+                    Tens ys1 = tens_a(rows_out, sc_c, false), b1 = tens_a(rows_out, sc_c);
                     if (fused_dw_) {
                         add_dw_block(ops, pre, nullptr, "sc_dw", "sc_bn1", X.p, curH, curW, sc_c, 2, ys1.p, b1.v(), b1.gv(),
                                      X.gv(0));
@@ -1106,7 +1127,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                         add_bn(ops, M_TRUNK, pre + ".sc_bn1", ys1.v(), T, Mg_out, sc_c, true, ACT_NONE, b1.v(), 0, b1.gv(), 0,
                                nullptr);
                     }
-                    Tens ys2 = tens(rows_out, sc_c, false);
+                    Tens ys2 = tens_a(rows_out, sc_c, false);
                     add_pw(ops, pre + ".sc_pw", b1.v(), rows_out, sc_c, sc_c, ys2.p, b1.gv(), 0, bnrec(T, Mg_out, sc_c));
                     add_bn(ops, M_TRUNK, pre + ".sc_bn2", ys2.v(), T, Mg_out, sc_c, true, ACT_RELU6, out.v(0), C, out.gv(0),
                            C, nullptr);
@@ -1135,7 +1156,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         }
         // ---- head conv + GAP (core/architectures.py:170-172)
         const int P = curH * curW, rows = N * P;
-        Tens yh = tens(rows, c.last, false);
+        Tens yh = tens_a(rows, c.last, false);
         add_pw(ops, "img.head.conv", X.v(), rows, curC, c.last, yh.p, X.gv(), 0, bnrec(T, B * P, c.last));
         feat_ = tens(N, c.last);
         static const bool gap_fused = !(getenv("CDRL_FUSED_GAP") && atoi(getenv("CDRL_FUSED_GAP")) == 0);
@@ -1149,6 +1170,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             add_bn(ops, M_TRUNK, "img.head.bn", yh.v(), T, B * P, c.last, true, ACT_RELU6, View{nullptr, 0, 0}, 0, View{nullptr, 0, 0}, 0,
                    nullptr, 0, false, hp);
         } else {
+            if (at) build_fail("bf16 activation storage needs the fused head pool (CDRL_FUSED_GAP=0 is set)");
             Tens ah = tens(rows, c.last);
             add_bn(ops, M_TRUNK, "img.head.bn", yh.v(), T, B * P, c.last, true, ACT_RELU6, ah.v(), 0, ah.gv(), 0, nullptr);
             Tens feat = feat_;
@@ -1292,7 +1314,7 @@ void Learner::build(bool dry) {
         scr_sc_.part2 = alloc_d(max_part2_);
         scr_sc_.tn = scr_aux_.tn;           // (unused by the shortcut ops)
         for (int i = 0; i < NSLOT; ++i) {
-            dys_[i] = alloc(max_dy_);
+            dys_[i] = alloc((max_dy_ * esz() + 3) / 4);      // tower gradients: activation-typed
             part2s_[i] = alloc_d(max_part2_);
             tns_[i] = alloc(max_tn_);
             fparts_[i] = alloc_d(max_fpart_);
@@ -1354,7 +1376,7 @@ void Learner::build(bool dry) {
         ws_off_ += 2 * (align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
                         align_up(max_tn_ * sizeof(float), 256)) +
                    align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
-                   NSLOT * (align_up(max_dy_ * sizeof(float), 256) + align_up(max_part2_ * sizeof(double), 256) +
+                   NSLOT * (align_up((max_dy_ * esz() + 3) / 4 * sizeof(float), 256) + align_up(max_part2_ * sizeof(double), 256) +
                             align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256));
         ws_bytes_ = ws_off_ + 4096;
     }

@@ -21,7 +21,7 @@
 //               EPI_BNRED:   (sum c, sum c * xhat) with xhat from the raw input `ey` of the BatchNorm that C is the
 //                            output-gradient of (backward-data GEMM feeding a BN backward: no separate reduce pass).
 // Partials are double, one row per workgroup, combined in fixed order by bn_finalize / bn_bwd_finalize.
-#include "cdrl_kernels.h"
+#include "colreduce.h"
 
 namespace cdrl {
 
@@ -49,6 +49,7 @@ struct PwArgs {
     double* part;               // [G][nbpg][2][N]
     int N, K, G, Mg, nbpg, tpb;
     int bf;                     // host dispatch only: Wp holds bf16 fragments -> BF variant
+    int at;                     // host dispatch only: 1 = the activation tensors (A, a_y, C, ey) are bf16 in HBM (needs bf)
 };
 
 // register budget: W fragments (NTW*KSM) + accumulators + one prefetched A tile; the K > 64 and 3-column-tile variants
@@ -63,8 +64,14 @@ constexpr int pw_wc(int nt) { return nt == 3 ? 1 : nt; }
 // prologue), W when it is packed -- and the product runs as v_mfma_f32_32x32x16_bf16: 1/8 of the float32 matrix-pipe time and
 // half the W registers / LDS tile.
 // ACC (instantiated for EPI == 0 only): C += product with the old values of the tile prefetched before the MFMA chain.
-template <int KSM, int NT, int PRO, int EPI, bool BF, bool ACC>
+// MODE 0: float32; 1: BF (bf16 MFMA operands, float32 tensors); 2: BF + bf16 ACTIVATION STORAGE -- A / a_y / ey are read and C is
+// written as bf16 (2- and 4-byte buffer loads, round-to-nearest-even stores), the EPI_STATS sums are those of the rounded outputs;
+// prologues, accumulation, partials and coefficients as in mode 1.
+template <int KSM, int NT, int PRO, int EPI, int MODE, bool ACC>
 __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a) {
+    constexpr bool BF = MODE >= 1, BH = MODE == 2;
+    typedef typename std::conditional<BH, bf16_t, float>::type T;
+    constexpr uint32_t ESZ = BH ? 2u : 4u;
     constexpr int WC = pw_wc(NT);                   // wave columns
     constexpr int WR = 4 / WC;                      // wave rows
     constexpr int NTW = NT / WC;                    // column tiles per wave
@@ -193,31 +200,44 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
     // two tiles ahead, was measured slower: it costs a wave of occupancy, 25.6 -> 29.4 us at K = N = 58)
     const bool dz_vec = PRO == 2 && !a.a_shuffle && (a.A.ld % 2 == 0) && (a.A.coff % 2 == 0) &&
                         ((reinterpret_cast<uintptr_t>(a.A.p) & 7) == 0);
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     float2 ra0[NA2], ry0[PRO == 2 ? NA2 : 1];
     // Tile loads through buffer descriptors: a thread's rows of a tile are r = tid / KSM + (256 / KSM) * i, so the row
     // offset of load i is wave-uniform (SGPR soffset) and the thread's byte offset inside it is a constant voffset --
     // no 64-bit address arithmetic and no address registers (the <64, 4, 2, 2> variant spilled 41 VGPRs with flat loads).
     // Masked lanes (k beyond K, rows beyond the group in the last tile) point out of range and read 0.
-    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     constexpr int RSTEP = 256 / KSM;                 // rows between consecutive loads of a thread
     const uint32_t OOR = 0x80000000u;               // host checks that the operands are < 2 GB
     const int r_t = tid / KSM;
     const int64_t Mtot = (int64_t)a.G * a.Mg;
     const __amdgpu_buffer_rsrc_t rsA =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A.p), 0, (int)(Mtot * a.A.ld * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A.p), 0, (int)(Mtot * a.A.ld * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(PRO == 2 ? a.a_y : a.A.p), 0, (int)(Mtot * (PRO == 2 ? K : a.A.ld) * 4), 0x00020000);
+        const_cast<float*>(PRO == 2 ? a.a_y : a.A.p), 0, (int)(Mtot * (PRO == 2 ? K : a.A.ld) * ESZ), 0x00020000);
     uint32_t voA0 = OOR, voA1 = OOR, voY = OOR;
     if (kon) {
         if (PRO == 2) {
-            voA0 = (uint32_t)(r_t * a.A.ld + dcol0) * 4u;
-            voA1 = (uint32_t)(r_t * a.A.ld + dcol1) * 4u;
-            voY = (uint32_t)(r_t * K + 2 * kk_t) * 4u;
+            voA0 = (uint32_t)(r_t * a.A.ld + dcol0) * ESZ;
+            voA1 = (uint32_t)(r_t * a.A.ld + dcol1) * ESZ;
+            voY = (uint32_t)(r_t * K + 2 * kk_t) * ESZ;
         } else {
-            voA0 = (uint32_t)(r_t * a.A.ld + a.A.coff + 2 * kk_t) * 4u;
+            voA0 = (uint32_t)(r_t * a.A.ld + a.A.coff + 2 * kk_t) * ESZ;
         }
     }
-    const uint32_t rowA = (uint32_t)a.A.ld * 4u, rowY = (uint32_t)K * 4u;
+    const uint32_t rowA = (uint32_t)a.A.ld * ESZ, rowY = (uint32_t)K * ESZ;
+    // two consecutive activation elements at a buffer offset (8-byte load; bf16 storage: 4-byte load, widened)
+    auto ld2 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t vo, uint32_t so) -> float2 {
+        if (BH) {
+            const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
+            return make_float2(bf_lo(w), bf_hi(w));
+        }
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+        return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+    };
+    auto ld1 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t vo, uint32_t so) -> float {
+        if (BH) return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0) << 16);
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+    };
     auto load_tile = [&](int t, float2* ra, float2* ry) {
         const int64_t m0 = mbeg + (int64_t)t * BM;
         const uint32_t mu = (uint32_t)m0;
@@ -229,17 +249,14 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
             if (!full) msk = (m0 + i * RSTEP + r_t) < mend ? 0u : OOR;      // last tile of the group only
             if (PRO == 2) {
                 if (dz_vec) {       // dense gradient (no shuffle map): one 8-byte load
-                    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsA, voA0 | msk, r * rowA, 0);
-                    ra[i] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+                    ra[i] = ld2(rsA, voA0 | msk, r * rowA);
                 } else {
-                    ra[i].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsA, voA0 | msk, r * rowA, 0));
-                    ra[i].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsA, voA1 | msk, r * rowA, 0));
+                    ra[i].x = ld1(rsA, voA0 | msk, r * rowA);
+                    ra[i].y = ld1(rsA, voA1 | msk, r * rowA);
                 }
-                const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rsY, voY | msk, r * rowY, 0);
-                ry[i] = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
+                ry[i] = ld2(rsY, voY | msk, r * rowY);
             } else {
-                const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsA, voA0 | msk, r * rowA, 0);
-                ra[i] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+                ra[i] = ld2(rsA, voA0 | msk, r * rowA);
             }
         }
     };
@@ -319,7 +336,7 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t m = me0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    eyv[j][r] = (n < N && m < mend) ? a.ey[m * N + n] : 0.0f;
+                    eyv[j][r] = (n < N && m < mend) ? ldf(reinterpret_cast<const T*>(a.ey) + m * N + n) : 0.0f;
                 }
             }
         }
@@ -336,7 +353,7 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t m = mc0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    cold[ACC_PF ? j : 0][ACC_PF ? r : 0] = (n < N && m < mend) ? a.C.p[m * a.C.ld + a.C.coff + n] : 0.0f;
+                    cold[ACC_PF ? j : 0][ACC_PF ? r : 0] = (n < N && m < mend) ? ldf(vptr<T>(a.C) + m * a.C.ld + a.C.coff + n) : 0.0f;
                 }
             }
         }
@@ -369,9 +386,10 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (m < mend) {
-                    float* c = &a.C.p[m * a.C.ld + a.C.coff + n];
+                    T* c = vptr<T>(a.C) + m * a.C.ld + a.C.coff + n;
                     float v = acc[j][r] + bv[j];
                     if (EPI == 1) {
+                        if (BH) v = (float)(bf16_t)v;       // statistics of the stored (rounded) values
                         s1[j] += (double)v;
                         s2[j] += (double)v * (double)v;
                     } else if (EPI == 2) {
@@ -380,8 +398,8 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
                         s2[j] += (double)v * (double)xh;
                     }
                     if (ACC_PF) v += cold[ACC_PF ? j : 0][ACC_PF ? r : 0];
-                    else if (a.accumulate) v += *c;
-                    *c = v;
+                    else if (a.accumulate) v += ldf(c);
+                    stf(c, v);
                 }
             }
         }
@@ -509,7 +527,7 @@ PwPlan pw_nn_plan(int G, int Mg, int N, int K) {
     return p;
 }
 
-template <int KSM, int NT, int PRO, int EPI, bool BF, bool ACC>
+template <int KSM, int NT, int PRO, int EPI, int MODE, bool ACC>
 static int launch_pw_bf(const PwArgs& a, hipStream_t st) {
     constexpr int WR = 4 / pw_wc(NT);
     constexpr int BM = 32 * WR;
@@ -517,7 +535,7 @@ static int launch_pw_bf(const PwArgs& a, hipStream_t st) {
     const size_t red = (size_t)WR * 2 * 32 * NT * sizeof(double);
     if (lds < red) lds = red;
     if (lds < (size_t)512 * sizeof(double)) lds = (size_t)512 * sizeof(double);      // PRO_BNBWD column-sum scratch
-    auto kern = pw_nn_kernel<KSM, NT, PRO, EPI, BF, ACC>;
+    auto kern = pw_nn_kernel<KSM, NT, PRO, EPI, MODE, ACC>;
     static size_t allowed = 64 * 1024;          // per instantiation: one runtime call per kernel and size, not one per launch
     if (lds > allowed) {
         CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -531,9 +549,13 @@ static int launch_pw_bf(const PwArgs& a, hipStream_t st) {
 template <int KSM, int NT, int PRO, int EPI>
 static int launch_pw(const PwArgs& a, hipStream_t st) {
     if constexpr (EPI == 0) {
-        if (a.accumulate) return a.bf ? launch_pw_bf<KSM, NT, PRO, EPI, true, true>(a, st) : launch_pw_bf<KSM, NT, PRO, EPI, false, true>(a, st);
+        if (a.accumulate) {
+            if (a.at) return launch_pw_bf<KSM, NT, PRO, EPI, 2, true>(a, st);
+            return a.bf ? launch_pw_bf<KSM, NT, PRO, EPI, 1, true>(a, st) : launch_pw_bf<KSM, NT, PRO, EPI, 0, true>(a, st);
+        }
     }
-    return a.bf ? launch_pw_bf<KSM, NT, PRO, EPI, true, false>(a, st) : launch_pw_bf<KSM, NT, PRO, EPI, false, false>(a, st);
+    if (a.at) return launch_pw_bf<KSM, NT, PRO, EPI, 2, false>(a, st);
+    return a.bf ? launch_pw_bf<KSM, NT, PRO, EPI, 1, false>(a, st) : launch_pw_bf<KSM, NT, PRO, EPI, 0, false>(a, st);
 }
 
 template <int KSM, int NT>
@@ -565,7 +587,7 @@ static int launch_pw_nt(int nt, int pro, int epi, const PwArgs& a, hipStream_t s
 
 int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, const float* bias, View C, int accumulate, int G,
           int Mg, int N, int K, int epilogue, const float* ey, const float* epi_stats, double* part, hipStream_t st,
-          const PwBnBwd* bb, const float* Wp, bool wp_bf16) {
+          const PwBnBwd* bb, const float* Wp, bool wp_bf16, int at) {
     if (!pw_nn_supported(bb ? make_view(const_cast<float*>(bb->y), K) : A, N, K)) {
         set_error("pw_nn: shape K=%d N=%d / alignment not supported", K, N);
         return -1;
@@ -593,6 +615,11 @@ int pw_nn(View A, const float* pro_stats, const float* W, int sbk, int sbn, cons
     a.sbn = sbn;
     a.Wp = Wp;
     a.bf = (wp_bf16 && Wp) ? 1 : 0;
+    a.at = at ? 1 : 0;
+    if (a.at && !a.bf) {
+        set_error("pw_nn: bf16 activation storage needs the bf16-operand variant (packed bf16 weights)");
+        return -1;
+    }
     a.bias = bias;
     a.C = C;
     a.accumulate = accumulate;

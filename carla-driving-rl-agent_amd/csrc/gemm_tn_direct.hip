@@ -23,7 +23,7 @@
 // operand prologues in float32, then one round-to-nearest-even pack of 8 values per operand and 1/16 of the matrix-pipe time.
 #include <stdlib.h>
 
-#include "cdrl_kernels.h"
+#include "colreduce.h"
 
 namespace cdrl {
 
@@ -44,8 +44,18 @@ struct TnDirectArgs {
 };
 
 
-template <int NJW, bool APRO, bool DPRO, int U, bool BF>
+// MODE 0: float32; 1: BF (bf16 MFMA operands, float32 tensors); 2: BF + bf16 activation storage (A, D and the BN input y of the
+// D prologue are bf16 in HBM: 2-byte buffer loads per lane, widened; prologues and partials unchanged)
+template <int MODE>
+__device__ __forceinline__ float tnd_ld(const __amdgpu_buffer_rsrc_t& rs, uint32_t vo, uint32_t so) {
+    if (MODE == 2) return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0) << 16);
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+}
+
+template <int NJW, bool APRO, bool DPRO, int U, int MODE>
 __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
+    constexpr bool BF = MODE >= 1;
+    constexpr uint32_t ESZ = MODE == 2 ? 2u : 4u;
     static_assert(!BF || U == 8, "BF: one batch = one K = 16 MFMA step (8 rows per half-wave)");
     constexpr int LHR = BF ? 8 : 1;             // rows between the two half-waves of a load
     extern __shared__ float tnd_red[];          // RS2 == 2: [4 waves][NJW][16][64]
@@ -118,19 +128,19 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
     // arithmetic and no per-load select in the steady state, which is what lets U = 8 / 16 fit in registers.
     const uint32_t OOR = 0x80000000u;           // host checks that every tensor is < 2 GB
     const __amdgpu_buffer_rsrc_t rA =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A.p), 0, (int)((int64_t)a.M * a.A.ld * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A.p), 0, (int)((int64_t)a.M * a.A.ld * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t rD =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D.p), 0, (int)((int64_t)a.M * a.D.ld * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D.p), 0, (int)((int64_t)a.M * a.D.ld * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(DPRO ? a.db.y : a.D.p), 0, (int)((int64_t)a.M * (DPRO ? N : a.D.ld) * 4), 0x00020000);
-    const uint32_t voA = kon ? (uint32_t)(LHR * lh * a.A.ld + a.A.coff + k) * 4u : OOR;
+        const_cast<float*>(DPRO ? a.db.y : a.D.p), 0, (int)((int64_t)a.M * (DPRO ? N : a.D.ld) * ESZ), 0x00020000);
+    const uint32_t voA = kon ? (uint32_t)(LHR * lh * a.A.ld + a.A.coff + k) * ESZ : OOR;
     uint32_t voD[NJW], voY[NJW];
 #pragma unroll
     for (int j = 0; j < NJW; ++j) {
-        voD[j] = non[j] ? (uint32_t)(LHR * lh * a.D.ld + dcol[j]) * 4u : OOR;
-        voY[j] = non[j] ? (uint32_t)(LHR * lh * N + ncol[j]) * 4u : OOR;
+        voD[j] = non[j] ? (uint32_t)(LHR * lh * a.D.ld + dcol[j]) * ESZ : OOR;
+        voY[j] = non[j] ? (uint32_t)(LHR * lh * N + ncol[j]) * ESZ : OOR;
     }
-    const uint32_t sA = (uint32_t)a.A.ld * 4u, sD = (uint32_t)a.D.ld * 4u, sY = (uint32_t)N * 4u;      // row strides in bytes
+    const uint32_t sA = (uint32_t)a.A.ld * ESZ, sD = (uint32_t)a.D.ld * ESZ, sY = (uint32_t)N * ESZ;      // row strides in bytes
     float av0[U], dv0[U][NJW], yv0[DPRO ? U : 1][DPRO ? NJW : 1];
     // row range of this wave as wave-uniform 32-bit scalars (the loop counter and the row offsets live in SGPRs)
     const int mb = __builtin_amdgcn_readfirstlane((int)mbeg), me = __builtin_amdgcn_readfirstlane((int)mend);
@@ -142,11 +152,11 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
             const uint32_t r = (uint32_t)(BF ? m0 + u : m0 + 2 * u);
             uint32_t msk = 0u;
             if (tail) msk = (BF ? m0 + u + 8 * lh : m0 + 2 * u + lh) < me ? 0u : OOR;
-            av[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, voA | msk, r * sA, 0));
+            av[u] = tnd_ld<MODE>(rA, voA | msk, r * sA);
 #pragma unroll
             for (int j = 0; j < NJW; ++j) {
-                dv[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rD, voD[j] | msk, r * sD, 0));
-                if (DPRO) yv[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rY, voY[j] | msk, r * sY, 0));
+                dv[u][j] = tnd_ld<MODE>(rD, voD[j] | msk, r * sD);
+                if (DPRO) yv[u][j] = tnd_ld<MODE>(rY, voY[j] | msk, r * sY);
             }
         }
         // keep the whole batch of loads ahead of the MFMAs (left alone, the scheduler interleaves load / s_waitcnt 0 /
@@ -242,8 +252,10 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
 // BatchNorm-backward transform of a D element (2 loads + ~10 VALU) is computed once per workgroup instead of once per
 // k-tile wave (4x), and a row pair costs NJW + 2 loads instead of 2*NJW + 1.  The cheap side (A, at most one fma) is the
 // one that is re-read by the 4 waves.  Same partial layout and reduction as tn_direct_kernel.
-template <int NJW, bool APRO, bool DPRO, int U, bool BF>
+template <int NJW, bool APRO, bool DPRO, int U, int MODE>
 __global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
+    constexpr bool BF = MODE >= 1;
+    constexpr uint32_t ESZ = MODE == 2 ? 2u : 4u;
     static_assert(!BF || U == 8, "BF: one batch = one K = 16 MFMA step (8 rows per half-wave)");
     constexpr int LHR = BF ? 8 : 1;
     extern __shared__ float tnd_red[];          // RS2 == 2: [4 waves][NJW][16][64]
@@ -311,17 +323,17 @@ __global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
 
     const uint32_t OOR = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rA =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A.p), 0, (int)((int64_t)a.M * a.A.ld * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A.p), 0, (int)((int64_t)a.M * a.A.ld * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t rD =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D.p), 0, (int)((int64_t)a.M * a.D.ld * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D.p), 0, (int)((int64_t)a.M * a.D.ld * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(DPRO ? a.db.y : a.D.p), 0, (int)((int64_t)a.M * (DPRO ? N : a.D.ld) * 4), 0x00020000);
-    const uint32_t voD = non ? (uint32_t)(LHR * lh * a.D.ld + dcol) * 4u : OOR;
-    const uint32_t voY = non ? (uint32_t)(LHR * lh * N + n) * 4u : OOR;
+        const_cast<float*>(DPRO ? a.db.y : a.D.p), 0, (int)((int64_t)a.M * (DPRO ? N : a.D.ld) * ESZ), 0x00020000);
+    const uint32_t voD = non ? (uint32_t)(LHR * lh * a.D.ld + dcol) * ESZ : OOR;
+    const uint32_t voY = non ? (uint32_t)(LHR * lh * N + n) * ESZ : OOR;
     uint32_t voA[NJW];
 #pragma unroll
-    for (int j = 0; j < NJW; ++j) voA[j] = kon[j] ? (uint32_t)(LHR * lh * a.A.ld + a.A.coff + kcol[j]) * 4u : OOR;
-    const uint32_t sA = (uint32_t)a.A.ld * 4u, sD = (uint32_t)a.D.ld * 4u, sY = (uint32_t)N * 4u;
+    for (int j = 0; j < NJW; ++j) voA[j] = kon[j] ? (uint32_t)(LHR * lh * a.A.ld + a.A.coff + kcol[j]) * ESZ : OOR;
+    const uint32_t sA = (uint32_t)a.A.ld * ESZ, sD = (uint32_t)a.D.ld * ESZ, sY = (uint32_t)N * ESZ;
     const int mb = __builtin_amdgcn_readfirstlane((int)mbeg), me = __builtin_amdgcn_readfirstlane((int)mend);
     float av0[U][NJW], dv0[U], yv0[U], av1[U][NJW], dv1[U], yv1[U];
     auto load_batch = [&](int m0, bool tail, float (*av)[NJW], float* dv, float* yv) {
@@ -330,10 +342,10 @@ __global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
             const uint32_t r = (uint32_t)(BF ? m0 + u : m0 + 2 * u);
             uint32_t msk = 0u;
             if (tail) msk = (BF ? m0 + u + 8 * lh : m0 + 2 * u + lh) < me ? 0u : OOR;
-            dv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rD, voD | msk, r * sD, 0));
-            if (DPRO) yv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rY, voY | msk, r * sY, 0));
+            dv[u] = tnd_ld<MODE>(rD, voD | msk, r * sD);
+            if (DPRO) yv[u] = tnd_ld<MODE>(rY, voY | msk, r * sY);
 #pragma unroll
-            for (int j = 0; j < NJW; ++j) av[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rA, voA[j] | msk, r * sA, 0));
+            for (int j = 0; j < NJW; ++j) av[u][j] = tnd_ld<MODE>(rA, voA[j] | msk, r * sA);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -466,7 +478,7 @@ int64_t gemm_tn_part_elems(int M, int N, int K, int G) {
 
 bool gemm_tn_dpro_supported(int) { return true; }
 
-template <int NJW, int U, bool BF>
+template <int NJW, int U, int BF>
 static void launch_tnd_u(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a) {
     const dim3 blk(256 * a.RS2);
     const size_t lds = a.RS2 == 2 ? (size_t)4 * NJW * 16 * 64 * sizeof(float) : 0;     // <= 64 KB
@@ -482,26 +494,34 @@ static void launch_tnd_u(bool apro, bool dpro, dim3 grid, hipStream_t st, const 
 }
 
 template <int NJW>
-static void launch_tnd(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a, bool bf) {
+static void launch_tnd(bool apro, bool dpro, dim3 grid, hipStream_t st, const TnDirectArgs& a, bool bf, int at) {
+    if (at) {           // bf16 operands AND bf16 activation storage
+        launch_tnd_u<NJW, 8, 2>(apro, dpro, grid, st, a);
+        return;
+    }
     if (bf) {           // bf16 operands: a batch is one 16-row MFMA step
-        launch_tnd_u<NJW, 8, true>(apro, dpro, grid, st, a);
+        launch_tnd_u<NJW, 8, 1>(apro, dpro, grid, st, a);
         return;
     }
     static const int u = getenv("CDRL_TN_U") ? atoi(getenv("CDRL_TN_U")) : 4;
     static const int ud = getenv("CDRL_TN_UD") ? atoi(getenv("CDRL_TN_UD")) : 8;      // D prologue (transposed mapping: 200 VGPRs at U = 8; 19.6 -> 19.2 ms/update-step over U = 4)
     const int uu = dpro ? ud : u;
-    if (uu >= 16 && !dpro) launch_tnd_u<NJW, 16, false>(apro, dpro, grid, st, a);
-    else if (uu >= 8) launch_tnd_u<NJW, 8, false>(apro, dpro, grid, st, a);
-    else launch_tnd_u<NJW, 4, false>(apro, dpro, grid, st, a);
+    if (uu >= 16 && !dpro) launch_tnd_u<NJW, 16, 0>(apro, dpro, grid, st, a);
+    else if (uu >= 8) launch_tnd_u<NJW, 8, 0>(apro, dpro, grid, st, a);
+    else launch_tnd_u<NJW, 4, 0>(apro, dpro, grid, st, a);
 }
 
 int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G,
-            const float* pro_stats, const TnBnBwd* dpro, bool bf16_operands) {
+            const float* pro_stats, const TnBnBwd* dpro, bool bf16_operands, int at) {
     if (G < 1 || M % G != 0) {
         set_error("gemm_tn: M=%d is not a multiple of G=%d", M, G);
         return -1;
     }
     if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (at && !bf16_operands) {
+        set_error("gemm_tn: bf16 activation storage needs the bf16-operand variant");
+        return -1;
+    }
     if ((int64_t)M * A.ld * 4 >= (1ll << 31) || (int64_t)M * D.ld * 4 >= (1ll << 31) || (int64_t)M * N * 4 >= (1ll << 31)) {
         set_error("gemm_tn: operands of 2 GB or more are not supported (M=%d)", M);
         return -1;
@@ -531,9 +551,9 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     if (dpro) a.db = *dpro;
     dim3 grid(p.nsplit, p.gy, p.gz);
     switch (p.NJW) {
-        case 1: launch_tnd<1>(pro_stats != nullptr, dpro != nullptr, grid, st, a, bf16_operands); break;
-        case 2: launch_tnd<2>(pro_stats != nullptr, dpro != nullptr, grid, st, a, bf16_operands); break;
-        default: launch_tnd<4>(pro_stats != nullptr, dpro != nullptr, grid, st, a, bf16_operands); break;
+        case 1: launch_tnd<1>(pro_stats != nullptr, dpro != nullptr, grid, st, a, bf16_operands, at); break;
+        case 2: launch_tnd<2>(pro_stats != nullptr, dpro != nullptr, grid, st, a, bf16_operands, at); break;
+        default: launch_tnd<4>(pro_stats != nullptr, dpro != nullptr, grid, st, a, bf16_operands, at); break;
     }
     CDRL_LAUNCH_CHECK();
     const int64_t n = (int64_t)K * N;

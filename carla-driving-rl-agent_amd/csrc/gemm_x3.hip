@@ -10,7 +10,7 @@
 //   * A is loaded as float32 (16-byte lanes), split on its way into LDS (three bf16 planes, 128 rows x 32 k per stage), double
 //     buffered: the loads of stage i+1 are issued before the MFMAs of stage i;
 //   * 128 x 128 output tile per workgroup, 2 x 2 waves of 64 x 64 (four 32x32 accumulators each).
-#include "cdrl_kernels.h"
+#include "colreduce.h"
 
 namespace cdrl {
 
@@ -36,8 +36,13 @@ __device__ __forceinline__ void gx3_split(float x, __bf16& h1, __bf16& h2, __bf1
 
 // NS = 3: exact three-way split (float32-accurate product).  NS = 1: the bf16-operand compute mode of configuration 3 -- both
 // operands rounded once to bf16 (plane 0 of the split = round-to-nearest-even), one MFMA per K = 16 step.
-template <int NS>
+// BH (with NS = 1 only): bf16 ACTIVATION STORAGE -- A and C are bf16 in HBM: the A chunks (4 elements, 8 bytes) go to LDS as they
+// are, C is rounded on store (and read as bf16 when accumulating).
+template <int NS, bool BH = false>
 __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
+    static_assert(!BH || NS == 1, "bf16 storage implies bf16 operands");
+    typedef typename std::conditional<BH, bf16_t, float>::type T;
+    constexpr uint32_t ESZ = BH ? 2u : 4u;
     constexpr int BM = 128, BK = 32, LDA = BK + 8;          // bf16 elements per LDS row (+16 bytes)
     __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][BM * LDA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,7 +55,8 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
     // A stage loads: 128 rows x 8 chunks of 4 floats = 1024 chunks, 4 per thread
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     const uint32_t OOR = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a.A.p, 0, (int)((int64_t)a.M * a.A.ld * 4), 0x00020000);
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a.A.p, 0, (int)((int64_t)a.M * a.A.ld * ESZ), 0x00020000);
     const int cr = tid >> 3, ck = 4 * (tid & 7);            // chunk row (0..31, +32 i), chunk k
     auto load_stage = [&](int s, u32x4_t (&ra)[4]) {
         const int k = s * BK + ck;
@@ -58,12 +64,26 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
         for (int i = 0; i < 4; ++i) {
             const int64_t m = m0 + cr + 32 * i;
             const bool ok = m < a.M && k < K;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (uint32_t)((m * a.A.ld + a.A.coff + k) * 4) : OOR, 0, 0);
+            const uint32_t off = ok ? (uint32_t)((m * a.A.ld + a.A.coff + k) * ESZ) : OOR;
+            if (BH) {
+                const u32x2_t h = __builtin_amdgcn_raw_buffer_load_b64(rsA, off, 0, 0);
+                ra[i][0] = h[0];
+                ra[i][1] = h[1];
+            } else {
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+            }
         }
     };
     auto store_stage = [&](int buf, const u32x4_t (&ra)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (BH) {       // already bf16: 4 elements = 2 dwords
+                u32x2_t h2;
+                h2[0] = ra[i][0];
+                h2[1] = ra[i][1];
+                *reinterpret_cast<u32x2_t*>(&As[buf][0][(cr + 32 * i) * LDA + ck]) = h2;
+                continue;
+            }
             bf16x4 h[3];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -156,10 +176,10 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (m < a.M) {
-                    float* c = &a.C.p[m * a.C.ld + a.C.coff + n];
+                    T* c = vptr<T>(a.C) + m * a.C.ld + a.C.coff + n;
                     float v = acc[i][j][r] + bv;
-                    if (a.accumulate) v += *c;
-                    *c = v;
+                    if (a.accumulate) v += ldf(c);
+                    stf(c, v);
                 }
             }
     }
@@ -214,7 +234,8 @@ bool gemm_x3_supported(View A, int K) {
     return K >= 4 && K % 4 == 0 && A.ld % 4 == 0 && A.coff % 4 == 0 && (reinterpret_cast<uintptr_t>(A.p) & 15) == 0;
 }
 
-int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st, bool bf16_operands) {
+int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st, bool bf16_operands,
+            int at) {
     if (M <= 0 || N <= 0) return 0;
     if (!gemm_x3_supported(A, K) || !Bp) {
         set_error("gemm_x3: unsupported alignment K=%d ld=%d coff=%d", K, A.ld, A.coff);
@@ -225,7 +246,12 @@ int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int
         return -1;
     }
     GemmX3Args a{A, reinterpret_cast<const __bf16*>(Bp), bias, C, accumulate, M, N, K, cdiv(K, 16), cdiv(N, 128) * 128};
-    if (bf16_operands) hipLaunchKernelGGL(gemm_x3_kernel<1>, dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
+    if (at && !bf16_operands) {
+        set_error("gemm_x3: bf16 activation storage needs the bf16-operand variant");
+        return -1;
+    }
+    if (at) hipLaunchKernelGGL((gemm_x3_kernel<1, true>), dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
+    else if (bf16_operands) hipLaunchKernelGGL(gemm_x3_kernel<1>, dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm_x3_kernel<3>, dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
     CDRL_LAUNCH_CHECK();
     return 0;

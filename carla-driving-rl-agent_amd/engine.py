@@ -23,8 +23,10 @@ def make_config(B, T=4, H=90, W=120, road=9, vehicle=4, navigation=5, A=2, **kw)
     cfg.B, cfg.T, cfg.H, cfg.W = B, T, H, W
     cfg.road, cfg.vehicle, cfg.navigation, cfg.A = road, vehicle, navigation, A
     for k, v in kw.items():
-        if k == 'compute' and isinstance(v, str):       # 'f32' | 'bf16' (bf16 MFMA operands in the tower's 1x1 convs: configuration 3)
-            v = {'f32': _lib.COMPUTE_F32, 'bf16': _lib.COMPUTE_BF16_OPERANDS}[v]
+        if k == 'compute' and isinstance(v, str):
+            # 'f32' | 'bf16' (bf16 MFMA operands in the tower's 1x1 convs, float32 tensors) | 'bf16s' (+ bf16 activation STORAGE in
+            # the tower: configuration 3 in full)
+            v = {'f32': _lib.COMPUTE_F32, 'bf16': _lib.COMPUTE_BF16_OPERANDS, 'bf16s': _lib.COMPUTE_BF16_STORAGE}[v]
         if k in ('stage_c', 'stage_n'):
             for i in range(3):
                 getattr(cfg, k)[i] = v[i]

@@ -42,8 +42,13 @@ typedef struct cdrl_config {
 
 /* CDRL_COMPUTE_BF16_OPERANDS (BASELINE.json configs[2]): the 1x1 convolutions of the image tower (core/architectures.py:130,140,
  * 170) multiply bf16-rounded operands on v_mfma_f32_32x32x16_bf16 -- forward, backward-data and filter gradient; float32
- * accumulation, float32 tensors in HBM, float32 BatchNorm statistics, bias gradients, optimizer and master weights. */
-enum { CDRL_COMPUTE_F32 = 0, CDRL_COMPUTE_BF16_OPERANDS = 1 };
+ * accumulation, float32 tensors in HBM, float32 BatchNorm statistics, bias gradients, optimizer and master weights.
+ * CDRL_COMPUTE_BF16_STORAGE (configs[2] in full): the same arithmetic AND bf16 activation storage -- every activation and
+ * activation-gradient tensor of the image tower (raw conv outputs, unit outputs, their gradients, the scratch gradients) lives
+ * in HBM as bf16 (round-to-nearest-even on store); BatchNorm statistics are those of the stored values; LDS tiles, accumulators,
+ * statistics / partial sums (double), coefficients, weights, gradients of weights and everything behind the global average
+ * pool stay float32.  Half the activation traffic of the float32 path. */
+enum { CDRL_COMPUTE_F32 = 0, CDRL_COMPUTE_BF16_OPERANDS = 1, CDRL_COMPUTE_BF16_STORAGE = 2 };
 
 enum { CDRL_TRUNK = 0, CDRL_POLICY = 1, CDRL_VALUE = 2, CDRL_OLD_POLICY = 3 };
 
@@ -197,6 +202,13 @@ int cdrl_beta_sample(const float* alpha, const float* beta, int rows, int A, int
  * log-density of the sample clipped to [eps, 1 - eps], no Jacobians. */
 int cdrl_beta_sample_logp(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,
                           float* u, float* log_prob, void* stream);
+/* bf16 ACTIVATION STORAGE at op level (configuration 3): after cdrl_set_op_activation_type(1) the activation tensors of the op-level
+ * entry points that have a bf16-storage form -- cdrl_bn_train_fwd / _bwd (y, out, dout, dy), cdrl_dwconv_bn_fwd / _bwd (x, y, dout,
+ * dx), cdrl_pwconv_fused_packed and cdrl_pwconv_bn_bwd_packed with packed_bf16 = 1 (a, c, epi_y; dout, y, x, dx), cdrl_gemm_tn (A, D),
+ * cdrl_gemm_x3 (A, C), cdrl_maxpool_bn_fwd (y, p), cdrl_stem_block_bwd (y, dp) -- are bf16 (same pointer spelling, element strides
+ * and offsets; round-to-nearest-even on store); statistics, coefficient blocks, partial sums, weights and weight gradients stay
+ * float32 / double.  The switch is per calling thread and does not touch cdrl_learner_* (Config::compute selects its storage). */
+int cdrl_set_op_activation_type(int at);
 int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* out, void* stream);
 /* Test hook: the two Gamma draws (g1 ~ Gamma(alpha), g2 ~ Gamma(beta)) behind the sample u = g1 / (g1 + g2) of the same
  * (seed, offset) stream -> gammas[rows * A][2] doubles.  Lets a test check du/dalpha, du/dbeta sample by sample. */
