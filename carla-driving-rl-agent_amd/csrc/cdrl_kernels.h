@@ -103,6 +103,13 @@ int64_t gemm_tn_part_elems(int M, int N, int K, int G = 1);
 int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G = 1,
             const float* pro_stats = nullptr, const TnBnBwd* dpro = nullptr, bool bf16_operands = false, int at = 0);
 
+// LDS-staged form for the bf16 modes (gemm_tn_lds.hip): same contract as gemm_tn with bf16_operands = true; at: 0 float32 / 1 bf16
+// tensors.  gemm_tn dispatches to it (CDRL_TN_LDS=0 keeps the direct form).
+bool gemm_tn_lds_supported(View A, View D, int N, int K, const TnBnBwd* dpro);
+int64_t gemm_tn_lds_part_elems(int M, int N, int K, int G = 1);
+int gemm_tn_lds(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G,
+                const float* pro_stats, const TnBnBwd* dpro, int at);
+
 // ---------------------------------------------------------------- fused pointwise conv (gemm_pw.hip)
 // Persistent skinny GEMM for K, N <= 128: C[m,n] (+)= sum_k pro(A[m,k]) W(k,n) + bias[n] over G groups of Mg rows.
 //   pro_stats != null : A <- scale[g][k]*A + shift[g][k]  (BatchNorm apply of the previous layer)

@@ -59,6 +59,33 @@ constexpr int pw_occ(int ksm, int nt) { return ((ksm == 32 && nt == 3) || (ksm =
 // the W fragments then cost only KSM VGPRs per wave and 2+ workgroups fit a CU even at K = 128
 constexpr int pw_wc(int nt) { return nt == 3 ? 1 : nt; }
 
+// value of the adjacent lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float lane_swap1(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+
+// bf16 storage, epilogue access pattern: a lane owns ONE column of the 32x32 MFMA output tile (16 rows in 16 registers), which as
+// 2-byte elements means 16 sub-dword accesses per lane and tile.  Lanes (2i, 2i+1) own adjacent columns: the even lane takes the
+// EVEN registers (rows) of both columns, the odd lane the odd ones -- 8 four-byte accesses per lane instead of 16 two-byte ones.
+//   load:  lane reads the pair (col even, col odd) of ITS rows, hands the half that belongs to the partner over by DPP
+//   store: lane receives the partner's value of ITS rows by DPP and writes the pair
+// (N is even and the pair's first column is even, so a pair is valid or invalid as a whole; 4-byte loads at 2-byte-aligned
+//  addresses are fine on gfx950: tools/ubench_unaligned.hip)
+template <class F>
+__device__ __forceinline__ void pair_load16(const __amdgpu_buffer_rsrc_t& rs, bool odd, F off_of /* (r) -> byte offset of (row(r), even col) or OOR */,
+                                            float* out /*[16]*/) {
+    uint32_t w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = __builtin_amdgcn_raw_buffer_load_b32(rs, off_of(2 * q + (odd ? 1 : 0)), 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float lo = bf_lo(w[q]), hi = bf_hi(w[q]);
+        const float recv = lane_swap1(odd ? lo : hi);
+        out[2 * q] = odd ? recv : lo;
+        out[2 * q + 1] = odd ? hi : recv;
+    }
+}
+
 // BF (bf16-operand compute mode, configuration 3): same skeleton, same float32 tensors in HBM, float32 accumulation, statistics
 // and epilogues, but both MFMA operands are rounded to bf16 (round-to-nearest-even) -- A on its way into LDS (after the
 // prologue), W when it is packed -- and the product runs as v_mfma_f32_32x32x16_bf16: 1/8 of the float32 matrix-pipe time and
@@ -214,6 +241,10 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A.p), 0, (int)(Mtot * a.A.ld * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(PRO == 2 ? a.a_y : a.A.p), 0, (int)(Mtot * (PRO == 2 ? K : a.A.ld) * ESZ), 0x00020000);
+    // bf16 storage: descriptors for the epilogue's raw-BN-input tile (EPI_BNRED) and the old output tile (ACC)
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((BH && EPI == 2) ? a.ey : a.A.p), 0,
+                                                                         (int)(Mtot * N * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.C.p, 0, (int)(Mtot * a.C.ld * 2), 0x00020000);
     uint32_t voA0 = OOR, voA1 = OOR, voY = OOR;
     if (kon) {
         if (PRO == 2) {
@@ -333,10 +364,17 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int n = nb0 + (wc + j * WC) * 32 + lrow;
+                if constexpr (BH && EPI == 2) {         // paired 4-byte buffer loads, unconditional (out-of-range offsets read 0)
+                    pair_load16(rsE, (lane & 1) != 0, [&](int r) -> uint32_t {
+                        const int64_t m = me0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        return (n < N && m < mend) ? (uint32_t)((m * N + (n & ~1)) * 2) : OOR;
+                    }, &eyv[EPI == 2 ? j : 0][0]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = me0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    eyv[j][r] = (n < N && m < mend) ? ldf(reinterpret_cast<const T*>(a.ey) + m * N + n) : 0.0f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t m = me0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        eyv[j][r] = (n < N && m < mend) ? a.ey[m * N + n] : 0.0f;
+                    }
                 }
             }
         }
@@ -350,10 +388,17 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int n = nb0 + (wc + j * WC) * 32 + lrow;
+                if constexpr (BH && ACC_PF) {
+                    pair_load16(rsC, (lane & 1) != 0, [&](int r) -> uint32_t {
+                        const int64_t m = mc0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        return (n < N && m < mend) ? (uint32_t)((m * a.C.ld + a.C.coff + (n & ~1)) * 2) : OOR;
+                    }, &cold[ACC_PF ? j : 0][0]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = mc0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    cold[ACC_PF ? j : 0][ACC_PF ? r : 0] = (n < N && m < mend) ? ldf(vptr<T>(a.C) + m * a.C.ld + a.C.coff + n) : 0.0f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t m = mc0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        cold[ACC_PF ? j : 0][ACC_PF ? r : 0] = (n < N && m < mend) ? a.C.p[m * a.C.ld + a.C.coff + n] : 0.0f;
+                    }
                 }
             }
         }
@@ -382,6 +427,39 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
         for (int j = 0; j < NTW; ++j) {
             const int n = nb0 + (wc + j * WC) * 32 + lrow;
             if (n >= N) continue;
+            if constexpr (BH) {
+                if (ACC_PF || !a.accumulate) {          // paired 4-byte stores (see pair_load16)
+                    const bool odd = (lane & 1) != 0;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        v[r] = acc[j][r] + bv[j];
+                        if (EPI == 1) v[r] = (float)(bf16_t)v[r];       // statistics of the stored (rounded) values
+                        if (m < mend) {
+                            if (EPI == 1) {
+                                s1[j] += (double)v[r];
+                                s2[j] += (double)v[r] * (double)v[r];
+                            } else if (EPI == 2) {
+                                const float xh = (eyv[EPI == 2 ? j : 0][EPI == 2 ? r : 0] - emean[j]) * einv[j];
+                                s1[j] += (double)v[r];
+                                s2[j] += (double)v[r] * (double)xh;
+                            }
+                        }
+                        if (ACC_PF) v[r] += cold[ACC_PF ? j : 0][ACC_PF ? r : 0];
+                    }
+                    bf16_t* cp = vptr<bf16_t>(a.C) + a.C.coff + (n & ~1);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float recv = lane_swap1(odd ? v[2 * q] : v[2 * q + 1]);
+                        const float lo = odd ? recv : v[2 * q], hi = odd ? v[2 * q + 1] : recv;
+                        const int r = 2 * q + (odd ? 1 : 0);
+                        const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        if (m < mend) *reinterpret_cast<uint32_t*>(cp + m * a.C.ld) = bf_pack(lo, hi);
+                    }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;

@@ -23,6 +23,8 @@
 // operand prologues in float32, then one round-to-nearest-even pack of 8 values per operand and 1/16 of the matrix-pipe time.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "colreduce.h"
 
 namespace cdrl {
@@ -473,7 +475,8 @@ static TndPlan tnd_plan(int M, int N, int K, int G, bool dpro = false) {
 int64_t gemm_tn_part_elems(int M, int N, int K, int G) {
     const TndPlan p = tnd_plan(M, N, K, G, false), q = tnd_plan(M, N, K, G, true);
     const int64_t a = (int64_t)p.nsplit * p.RS * K * N, b = (int64_t)q.nsplit * q.RS * K * N;
-    return a > b ? a : b;
+    const int64_t c = gemm_tn_lds_part_elems(M, N, K, G);          // the LDS-staged form of the bf16 modes (gemm_tn_lds.hip)
+    return std::max(std::max(a, b), c);
 }
 
 bool gemm_tn_dpro_supported(int) { return true; }
@@ -528,6 +531,11 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     }
     static const bool diag_skip = getenv("CDRL_DIAG_SKIP_TN") && atoi(getenv("CDRL_DIAG_SKIP_TN")) == 1;   // timing diagnostics only
     if (diag_skip) return 0;
+    // bf16 modes: operands staged once per workgroup through LDS (gemm_tn_lds.hip) -- the direct form is a stream of 2-byte loads
+    // there; CDRL_TN_LDS=0 keeps the direct form
+    static const bool lds_on = !(getenv("CDRL_TN_LDS") && atoi(getenv("CDRL_TN_LDS")) == 0);
+    if (bf16_operands && lds_on && gemm_tn_lds_supported(A, D, N, K, dpro))
+        return gemm_tn_lds(A, D, Cout, M, N, K, part, accumulate, st, G, pro_stats, dpro, at);
     const TndPlan p = tnd_plan(M, N, K, G, dpro != nullptr);
     TnDirectArgs a;
     a.A = A;

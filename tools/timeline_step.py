@@ -9,7 +9,7 @@ from collections import defaultdict
 def main():
     rows = list(csv.DictReader(open(sys.argv[1]), delimiter='\t'))
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 14
-    idx = [i for i, r in enumerate(rows) if r['kernel'].startswith('stem_fwd')]
+    idx = [i for i, r in enumerate(rows) if 'stem_fwd' in r['kernel'] and 'stem_bwd' not in r['kernel']]     # (names of __bf16 instantiations come out mangled)
     a, b = idx[-3], idx[-1]
     sub = rows[a:b]
     s = [float(r['start_us']) for r in sub]
