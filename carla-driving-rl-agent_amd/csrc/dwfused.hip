@@ -30,7 +30,11 @@
 
 namespace cdrl {
 
-static constexpr size_t DWF_LDS_BUDGET = 76 * 1024;      // 2 workgroups per CU (160 KB LDS)
+// 4 workgroups per CU (160 KB LDS): frames wider than ~60 channels at 6x8 pixels run as two channel chunks (adjacent on one XCD, see
+// the block map in the kernels).  Re-measured in round 3 (ms / update-step at 38 | 52 | 76 KB): float32 B = 256 15.91 | 15.94 | 16.07,
+// float32 B = 1024 49.0 | - | 49.7, bf16 storage B = 1024 41.1 | 41.7 | 43.6 -- the phases of these kernels are separated by
+// barriers, and two resident workgroups (8 waves per CU) do not cover them.
+static constexpr size_t DWF_LDS_BUDGET = 38 * 1024;
 #define DWF_T_FWD 512                                    // threads per workgroup, forward / backward
 #define DWF_T_BWD 512
 #define DWF_T_FWD_DEFAULT 256                            // (tunable: CDRL_DWF_TF / CDRL_DWF_TB, <= the maxima above; 256 vs 512 forward: -0.1 ms/update-step at v39)

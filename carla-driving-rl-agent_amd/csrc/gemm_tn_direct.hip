@@ -534,7 +534,9 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     // bf16 modes: operands staged once per workgroup through LDS (gemm_tn_lds.hip) -- the direct form is a stream of 2-byte loads
     // there; CDRL_TN_LDS=0 keeps the direct form
     static const bool lds_on = !(getenv("CDRL_TN_LDS") && atoi(getenv("CDRL_TN_LDS")) == 0);
-    if (bf16_operands && lds_on && gemm_tn_lds_supported(A, D, N, K, dpro))
+    // (its 128 x 128 column block with one k tile per wave only pays for wide products -- measured isolated at B = 1024:
+    //  K = N = 116: 47.6 vs 64.2 us, 232: 40.9 vs 58.3 us, but K = N = 58: 82.9 vs 68.2 us and 24 x 58: 264 vs 126 us)
+    if (bf16_operands && lds_on && K >= 96 && N >= 96 && gemm_tn_lds_supported(A, D, N, K, dpro))
         return gemm_tn_lds(A, D, Cout, M, N, K, part, accumulate, st, G, pro_stats, dpro, at);
     const TndPlan p = tnd_plan(M, N, K, G, dpro != nullptr);
     TnDirectArgs a;
