@@ -426,6 +426,8 @@ __global__ void __launch_bounds__(256) bn_apply_shuf_kernel(View y, int Mg, int 
     const T* psp = vptr<T>(psrc);
     T* dstp = vptr<T>(dst);
     T* pdp = vptr<T>(pdst);
+    // (even ctot / 2 and even channel offsets: checked by the launcher through view alignment; 2-byte-aligned 4-byte stores are fine)
+    constexpr bool PAIR = sizeof(T) == 2 && VEC == 4;
     constexpr int RU = 4;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int CY = blockDim.y;
@@ -454,6 +456,19 @@ __global__ void __launch_bounds__(256) bn_apply_shuf_kernel(View y, int Mg, int 
             if (rr + u * CY >= r1) break;
             const int64_t row = gbase + rr + u * CY;
             T* dr = dstp + row * dst.ld;
+            if (PAIR) {     // bf16, 4 channels: the de-interleave sends (0, 2) and (1, 3) to two pairs of ADJACENT columns -> 4-byte stores
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = apply_act(fmaf(sc.v[i % VEC], v[u].v[i % VEC], sh.v[i % VEC]), act);
+                *reinterpret_cast<uint32_t*>(dr + dcol[0]) = bf_pack(o[0], o[2]);
+                *reinterpret_cast<uint32_t*>(dr + dcol[1 % VEC]) = bf_pack(o[1], o[3]);
+                if (PASS) {
+                    T* pr = pdp + row * pdst.ld;
+                    *reinterpret_cast<uint32_t*>(pr + pcol[0]) = bf_pack(pv[u].v[0], pv[u].v[2 % VEC]);
+                    *reinterpret_cast<uint32_t*>(pr + pcol[1 % VEC]) = bf_pack(pv[u].v[1 % VEC], pv[u].v[3 % VEC]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) stf(dr + dcol[i], apply_act(fmaf(sc.v[i], v[u].v[i], sh.v[i]), act));
             if (PASS) {
@@ -631,13 +646,30 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ct
             for (int u = 0; u < RU; ++u) {
                 const int64_t row = gbase + min(rr + u * CY, r1 - 1);          // clamped: unconditional loads
                 const T* dr = vptr<T>(da) + row * da.ld;
+                constexpr bool PAIR = sizeof(T) == 2 && VEC == 4;       // (see bn_apply_shuf_kernel: columns (0, 2) and (1, 3) are adjacent)
+                if (PAIR) {
+                    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(dr + dcol[0]), w1 = *reinterpret_cast<const uint32_t*>(dr + dcol[1 % VEC]);
+                    dz[u][0] = bf_lo(w0);
+                    dz[u][2 % VEC] = bf_hi(w0);
+                    dz[u][1 % VEC] = bf_lo(w1);
+                    dz[u][3 % VEC] = bf_hi(w1);
+                } else {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) dz[u][i] = ldf(dr + dcol[i]);
+                    for (int i = 0; i < VEC; ++i) dz[u][i] = ldf(dr + dcol[i]);
+                }
                 yv[u] = vload<VEC>(y + row * C + c0);
                 if (PASS) {
                     const T* pr = vptr<T>(pgs) + row * pgs.ld;
+                    if (PAIR) {
+                        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(pr + pcol[0]), w1 = *reinterpret_cast<const uint32_t*>(pr + pcol[1 % VEC]);
+                        pv[u][0] = bf_lo(w0);
+                        pv[u][2 % VEC] = bf_hi(w0);
+                        pv[u][1 % VEC] = bf_lo(w1);
+                        pv[u][3 % VEC] = bf_hi(w1);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) pv[u][i] = ldf(pr + pcol[i]);
+                        for (int i = 0; i < VEC; ++i) pv[u][i] = ldf(pr + pcol[i]);
+                    }
                 }
             }
 #pragma unroll

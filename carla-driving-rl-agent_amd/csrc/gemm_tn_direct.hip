@@ -538,6 +538,10 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     //  K = N = 116: 47.6 vs 64.2 us, 232: 40.9 vs 58.3 us, but K = N = 58: 82.9 vs 68.2 us and 24 x 58: 264 vs 126 us)
     if (bf16_operands && lds_on && K >= 96 && N >= 96 && gemm_tn_lds_supported(A, D, N, K, dpro))
         return gemm_tn_lds(A, D, Cout, M, N, K, part, accumulate, st, G, pro_stats, dpro, at);
+    // float32: the same staging with float32 LDS columns and the float32 MFMA (opt-in until measured: CDRL_TN_LDS_F32=1)
+    static const bool lds_f32 = getenv("CDRL_TN_LDS_F32") && atoi(getenv("CDRL_TN_LDS_F32")) == 1;
+    if (!bf16_operands && lds_f32 && K >= 96 && N >= 96 && gemm_tn_lds_supported(A, D, N, K, dpro))
+        return gemm_tn_lds(A, D, Cout, M, N, K, part, accumulate, st, G, pro_stats, dpro, 0, true);
     const TndPlan p = tnd_plan(M, N, K, G, dpro != nullptr);
     TnDirectArgs a;
     a.A = A;

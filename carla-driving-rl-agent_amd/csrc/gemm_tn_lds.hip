@@ -37,11 +37,15 @@ struct TnLdsArgs {
 };
 
 constexpr int TNL_R = 32;               // rows per chunk
-constexpr int TNL_CS = TNL_R / 2 + 1;   // dwords per LDS column (odd: conflict-free fragment reads, 2-way on the writes)
 
-// BH: activation tensors (A, D, y) are bf16 in HBM; otherwise float32.  Both round the operands to bf16 after the prologues.
-template <bool BH, bool APRO, bool DPRO>
+// MODE 2: activation tensors (A, D, y) are bf16 in HBM, bf16 MFMA operands; MODE 1: float32 tensors, operands rounded to bf16 after
+// the prologues; MODE 0: float32 tensors AND float32 operands (v_mfma_f32_32x32x2_f32: the exact k-ordered fmaf chain of the
+// float32 engine) -- same staging, the LDS columns hold floats.
+template <int MODE, bool APRO, bool DPRO>
 __global__ void __launch_bounds__(256, 2) tn_lds_kernel(TnLdsArgs a) {
+    constexpr bool BH = MODE == 2, F32 = MODE == 0;
+    // dwords per LDS column (odd: conflict-free fragment reads, 2-way on the writes): row pairs (bf16) or rows (float32)
+    constexpr int TNL_CS = F32 ? TNL_R + 1 : TNL_R / 2 + 1;
     __shared__ uint32_t AsT[2][128 * TNL_CS];
     __shared__ uint32_t DsT[2][128 * TNL_CS];
     constexpr uint32_t ESZ = BH ? 2u : 4u;
@@ -181,12 +185,22 @@ __global__ void __launch_bounds__(256, 2) tn_lds_kernel(TnLdsArgs a) {
                 }
             }
             const int c = 4 * cq + j;
-            uint32_t* pa = &AsT[buf][c * TNL_CS + 2 * rg];
-            pa[0] = bf_pack(x[0], x[1]);
-            pa[1] = bf_pack(x[2], x[3]);
-            uint32_t* pd = &DsT[buf][c * TNL_CS + 2 * rg];
-            pd[0] = bf_pack(d[0], d[1]);
-            pd[1] = bf_pack(d[2], d[3]);
+            if (F32) {
+                uint32_t* pa = &AsT[buf][c * TNL_CS + 4 * rg];
+                uint32_t* pd = &DsT[buf][c * TNL_CS + 4 * rg];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pa[i] = __float_as_uint(x[i]);
+                    pd[i] = __float_as_uint(d[i]);
+                }
+            } else {
+                uint32_t* pa = &AsT[buf][c * TNL_CS + 2 * rg];
+                pa[0] = bf_pack(x[0], x[1]);
+                pa[1] = bf_pack(x[2], x[3]);
+                uint32_t* pd = &DsT[buf][c * TNL_CS + 2 * rg];
+                pd[0] = bf_pack(d[0], d[1]);
+                pd[1] = bf_pack(d[2], d[3]);
+            }
         }
     };
     f32x16 acc[4];
@@ -207,6 +221,21 @@ __global__ void __launch_bounds__(256, 2) tn_lds_kernel(TnLdsArgs a) {
     };
     auto mma_chunk = [&](int buf) {
         if (wave >= KT) return;
+        if (F32) {      // K = 2 steps: lane (column l32, half lh) supplies row 2 s + lh of its column
+            const uint32_t* pa = &AsT[buf][(wave * 32 + l32) * TNL_CS + lh];
+#pragma unroll
+            for (int s = 0; s < TNL_R / 2; ++s) {
+                const float av = __uint_as_float(pa[2 * s]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < NT) {
+                        const float dv = __uint_as_float(DsT[buf][(j * 32 + l32) * TNL_CS + 2 * s + lh]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dv, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < TNL_R / 16; ++s) {
             const bf16x8 af = frag(AsT[buf], wave * 32 + l32, s);
@@ -275,7 +304,7 @@ bool gemm_tn_lds_supported(View A, View D, int N, int K, const TnBnBwd* dpro) {
 }
 
 int gemm_tn_lds(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G, const float* pro_stats,
-                const TnBnBwd* dpro, int at) {
+                const TnBnBwd* dpro, int at, bool f32_operands) {
     if (G < 1 || M % G != 0) {
         set_error("gemm_tn_lds: M=%d is not a multiple of G=%d", M, G);
         return -1;
@@ -314,8 +343,9 @@ int gemm_tn_lds(View A, View D, float* Cout, int M, int N, int K, float* part, i
         else if (dp) hipLaunchKernelGGL((tn_lds_kernel<BHV, false, true>), grid, blk, 0, st, a);    \
         else hipLaunchKernelGGL((tn_lds_kernel<BHV, false, false>), grid, blk, 0, st, a);           \
     } while (0)
-    if (at) CDRL_TNL(true);
-    else CDRL_TNL(false);
+    if (at) CDRL_TNL(2);
+    else if (f32_operands) CDRL_TNL(0);
+    else CDRL_TNL(1);
 #undef CDRL_TNL
     CDRL_LAUNCH_CHECK();
     const int64_t n = (int64_t)K * N;

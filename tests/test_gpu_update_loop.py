@@ -55,7 +55,7 @@ def _oracle_for(agent, H, W):
     eng = agent.network.engine
     hp = dict(eng.hp)
     tp, pp, vp = eng.export_params('trunk'), eng.export_params('policy'), eng.export_params('value')
-    return OM.OracleLearner(ocfg, tp, pp, vp, dict(hp, dynamics_lr=hp['dynamics_lr'])), ocfg
+    return OM.OracleLearner(ocfg, tp, pp, vp, dict(hp, dynamics_lr=hp['dynamics_lr']), dtype=torch.float64), ocfg
 
 
 def _sync_oracle_from_engine(oracle, eng, steps):
@@ -73,19 +73,39 @@ def _sync_oracle_from_engine(oracle, eng, steps):
                 opt.m[name].copy_(m_e[name].cpu())
                 opt.v[name].copy_(v_e[name].cpu())
             opt.t = steps[model]
-        oracle.old_policy = {k: v.cpu().clone() for k, v in eng.param_views('old_policy').items()}
+        oracle.old_policy = {k: v.cpu().clone().to(next(iter(oracle.policy.values())).dtype) for k, v in eng.param_views('old_policy').items()}
 
 
-def _head_grads_close(views, ref, seen, tol=2e-3):
-    """Head gradients of one minibatch step vs the float32 oracle stepping from the same state, decisions NOT pinned: this
-    test checks SEQUENCING (index lists, minibatch rows, optimizer state carried from step to step, step order) -- a slip there
-    shows as an O(1) difference.  The numerical gate at 1e-4 is tests/test_gpu_learner.py::test_pinned_decisions_*; here
-    32-row BatchNorms amplify float32 rounding and single-element bias gradients are cancelling sums, hence 2e-3 of the
-    branch's largest gradient tensor scale."""
+def _head_grads_close(views, ref, seen, tol=2e-4):
+    """Head gradients of one minibatch step vs the FLOAT64 oracle stepping from the same state ON THE ENGINE'S OWN DISCRETE
+    DECISIONS (ReLU6 regions / max-pool argmax of this very forward, tests/util.py::engine_decisions) -- both sides are then the
+    same smooth function, as in tests/test_gpu_learner.py::test_pinned_decisions_*.  Bound 2e-4 relative to each tensor's scale
+    (floored at 1e-3 of the branch's largest gradient): the minibatch here is 32 rows, where the heads' BatchNorms over 32
+    rows cost float32 a factor ~2 over the 64- and 256-row cases that are held to 1e-4 there (measured worst 1.1e-4)."""
     gmax = max(float(g.abs().max()) for g in ref.values())
     for name, g in ref.items():
-        e = float((views[name].cpu() - g).abs().max()) / max(float(g.abs().max()), 1e-2 * gmax)
+        e = float((views[name].cpu().double() - g).abs().max()) / max(float(g.abs().max()), 1e-3 * gmax)
         assert e < tol, (seen, name, e)
+
+
+# Minibatch steps of each kind (of 7) that are compared numerically with the float64 oracle from the engine's state; EVERY step's
+# rows / advantages / returns are checked bit for bit against the recomputed index lists, and the state the late steps start from is
+# the product of all the earlier ones (a sequencing slip in between shows at the next compared step).
+PINNED_STEPS = (0, 3, 6)
+
+
+def _pinned(eng, ocfg, fn, batch):
+    """fn(batch) of the float64 oracle, evaluated on the decisions the engine took in its last training forward."""
+    from oracle import model as OM
+    from tests.util import engine_decisions
+    OM.DEC.items = engine_decisions(eng, ocfg)
+    try:
+        OM.DEC.start('replay')
+        out = fn(batch)
+        assert OM.DEC.cursor == len(OM.DEC.items)
+    finally:
+        OM.DEC.start('off')
+    return out
 
 
 def test_update_loop_matches_oracle_step_by_step():
@@ -136,12 +156,15 @@ def test_update_loop_matches_oracle_step_by_step():
                   similarity=similarity.cpu().numpy().reshape(-1, 1), u=eng.named_buffer('sample.u').view(B, -1).cpu().numpy(),
                   du_da=eng.named_buffer('sample.du_dalpha').view(B, -1).cpu().numpy(),
                   du_db=eng.named_buffer('sample.du_dbeta').view(B, -1).cpu().numpy())
-        loss, gp, gt, aux = oracle.policy_grads(ob)
+        if seen['policy'] not in PINNED_STEPS:        # (the float64 oracle costs ~12 s per step on the host: first, middle and last step)
+            seen['policy'] += 1
+            return out
+        loss, gp, gt, aux = _pinned(eng, state['ocfg'], oracle.policy_grads, ob)
         m = eng.metrics('policy')
-        assert abs(m['loss'] - float(loss)) < TOL * max(1.0, abs(float(loss))), (seen, m['loss'], float(loss))
+        assert abs(m['loss'] - float(loss.detach())) < TOL * max(1.0, abs(float(loss.detach()))), (seen, m['loss'], float(loss.detach()))
         ax = eng.buffer(_lib.BUF_AUX_P, (B, 4, eng.cfg.A)).cpu().numpy()
         for i, k in enumerate(('alpha', 'beta', 'log_prob')):
-            assert rel_err(ax[:, i], aux[k].detach().numpy()) < 2 * TOL, (seen, k)
+            assert rel_err(ax[:, i], aux[k].detach().numpy()) < TOL, (seen, k)
         _head_grads_close(eng.grad_views('policy'), gp, seen)
         seen['policy'] += 1
         return out
@@ -156,11 +179,14 @@ def test_update_loop_matches_oracle_step_by_step():
         out = orig_vg(batch)
         ob = dict(states={k: states[k].cpu().numpy() for k in STATE_KEYS}, returns=returns.cpu().numpy(),
                   speed=speed.cpu().numpy().reshape(-1, 1), similarity=similarity.cpu().numpy().reshape(-1, 1))
-        loss, gv, gt, aux = oracle.value_grads(ob)
+        if seen['value'] not in PINNED_STEPS:
+            seen['value'] += 1
+            return out
+        loss, gv, gt, aux = _pinned(eng, state['ocfg'], oracle.value_grads, ob)
         m = eng.metrics('value')
-        assert abs(m['loss'] - float(loss)) < TOL * max(1.0, abs(float(loss))), (seen, m['loss'], float(loss))
+        assert abs(m['loss'] - float(loss.detach())) < TOL * max(1.0, abs(float(loss.detach()))), (seen, m['loss'], float(loss.detach()))
         vals = eng.buffer(_lib.BUF_AUX_V, (B, 2)).cpu().numpy()
-        assert rel_err(vals, aux['values'].detach().numpy()) < 2 * TOL
+        assert rel_err(vals, aux['values'].detach().numpy()) < TOL
         _head_grads_close(eng.grad_views('value'), gv, seen)
         seen['value'] += 1
         return out
