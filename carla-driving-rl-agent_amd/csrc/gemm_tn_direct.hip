@@ -532,11 +532,16 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     static const bool diag_skip = getenv("CDRL_DIAG_SKIP_TN") && atoi(getenv("CDRL_DIAG_SKIP_TN")) == 1;   // timing diagnostics only
     if (diag_skip) return 0;
     // bf16 modes: operands staged once per workgroup through LDS (gemm_tn_lds.hip) -- the direct form is a stream of 2-byte loads
-    // there; CDRL_TN_LDS=0 keeps the direct form
-    static const bool lds_on = !(getenv("CDRL_TN_LDS") && atoi(getenv("CDRL_TN_LDS")) == 0);
-    // (its 128 x 128 column block with one k tile per wave only pays for wide products -- measured isolated at B = 1024:
-    //  K = N = 116: 47.6 vs 64.2 us, 232: 40.9 vs 58.3 us, but K = N = 58: 82.9 vs 68.2 us and 24 x 58: 264 vs 126 us)
-    if (bf16_operands && lds_on && K >= 96 && N >= 96 && gemm_tn_lds_supported(A, D, N, K, dpro))
+    // there; CDRL_TN_LDS=0 keeps the direct form, CDRL_TN_LDS=2 lifts the width limit below.
+    // Shapes: its 128 x 128 column block with one k tile per wave only pays for wide products -- measured isolated at B = 1024:
+    // K = N = 116: 47.6 vs 64.2 us, 232: 40.9 vs 58.3 us, but K = N = 58: 82.9 vs 68.2 us and 24 x 58: 264 vs 126 us -- and it is
+    // used for ONE column block only (96 <= K, N <= 128, the stage-1 units): with several column blocks (K, N = 232, the 464 x 768
+    // head conv) the bf16-storage engine lost its bit-wise run-to-run reproducibility (tools/det_engine.py: two outcomes of the
+    // backward pass from the first such launch on, ~1 pass in 3; every kernel is deterministic in isolation, tools/det_tn.py /
+    // det_pw.py, and the single-block shapes are clean over 40 passes).  Unexplained, so those shapes stay on the direct form.
+    static const int lds_mode = getenv("CDRL_TN_LDS") ? atoi(getenv("CDRL_TN_LDS")) : 1;
+    const bool lds_shape = K >= 96 && N >= 96 && (lds_mode == 2 || (K <= 128 && N <= 128));
+    if (bf16_operands && lds_mode != 0 && lds_shape && gemm_tn_lds_supported(A, D, N, K, dpro))
         return gemm_tn_lds(A, D, Cout, M, N, K, part, accumulate, st, G, pro_stats, dpro, at);
     // float32: the same staging with float32 LDS columns and the float32 MFMA (opt-in until measured: CDRL_TN_LDS_F32=1)
     static const bool lds_f32 = getenv("CDRL_TN_LDS_F32") && atoi(getenv("CDRL_TN_LDS_F32")) == 1;

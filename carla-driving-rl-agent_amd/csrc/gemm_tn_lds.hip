@@ -293,7 +293,10 @@ static TnlPlan tnl_plan(int M, int N, int K, int G) {
     return p;
 }
 
-int64_t gemm_tn_lds_part_elems(int M, int N, int K, int G) { return (int64_t)tnl_plan(M, N, K, G).nsplit * K * N; }
+int64_t gemm_tn_lds_part_elems(int M, int N, int K, int G) {
+    static const int diag_x = getenv("CDRL_DIAG_TNL_PARTX") ? atoi(getenv("CDRL_DIAG_TNL_PARTX")) : 1;      // (diagnostic: oversize the partial buffer)
+    return (int64_t)tnl_plan(M, N, K, G).nsplit * K * N * diag_x;
+}
 
 bool gemm_tn_lds_supported(View A, View D, int N, int K, const TnBnBwd* dpro) {
     // adjacent-column pairs: even leading dimensions / offsets / widths (every tower tensor); the shuffle gather needs the two

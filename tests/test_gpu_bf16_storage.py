@@ -424,7 +424,7 @@ def test_config3_full_size_properties(compute):
     eng.value_forward_backward(val)
     torch.cuda.synchronize()
     v1 = region(('trunk', 'value'))
-    for _ in range(2):                                                      # (1)
+    for _ in range(5):                                                      # (1) (repeated: cross-stream races are timing dependent)
         p2, l2 = grads(pol)
         assert torch.equal(p1, p2) and l1 == l2
         eng.value_forward_backward(val)
