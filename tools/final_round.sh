@@ -33,6 +33,17 @@ d=json.load(open('$out/bench.json'))
 for k in d['kernel_rooflines']: print(k['kernel'][:70], k['shape'], k['us'], 'us', k['achieved_GBs'], 'GB/s', k['frac'])
 print('cpu_baseline', d.get('cpu_baseline'))
 " >> $cfg 2>&1
+# configuration 3 (bf16 storage, B = 1024): bench lines, kernel trace, per-stream timeline, HBM traffic
+c3=$out/c3
+mkdir -p $c3
+for a in "--dtype bf16s --batch 1024 --steps 30" "--dtype bf16 --batch 1024 --steps 30" "--dtype f32 --batch 1024 --steps 30" "--dtype bf16s --batch 256 --steps 100"; do
+  echo "== $a" >> $c3/bench_lines.txt
+  timeout 600 python bench.py --no-cpu-baseline --no-kernel-rooflines $a 2>/dev/null | tail -1 >> $c3/bench_lines.txt
+done
+bash tools/prof_bench.sh c3$r --dtype bf16s --batch 1024 > $c3/prof.log 2>&1
+cp gpurun_out/prof_c3$r/summary.md $c3/kernel_trace_summary.md
+bash tools/c3_traffic.sh $r --dtype bf16s --batch 1024 > $c3/traffic.log 2>&1
+cp gpurun_out/c3t_$r/step_FETCH_SIZE.txt gpurun_out/c3t_$r/step_WRITE_SIZE.txt gpurun_out/c3t_$r/timeline_step.txt $c3/
 python3 bench.py --rollout-rows 2>/dev/null | tail -1 > $out/rollout_rows.json
 echo "== smoke" >> $cfg
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v Warning | tail -3 >> $cfg
