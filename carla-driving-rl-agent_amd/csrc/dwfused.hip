@@ -50,7 +50,12 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     const size_t a_px = (size_t)(H + 2) * (W + 2);
     const size_t d_px = (size_t)(Ho + 2) * (Wo + 2);
     const size_t per_c = (a_px + d_px) * sizeof(float);
-    static const size_t lds_budget = getenv("CDRL_DWF_LDS_KB") ? (size_t)atoi(getenv("CDRL_DWF_LDS_KB")) * 1024 : DWF_LDS_BUDGET;
+    // (a separate budget for the stride-2 blocks, CDRL_DWF_LDS_KB_S2: 38 | 52 | 76 | 110 KB -> 15.76 | 15.74 | 15.82 | 16.07 ms / update-step
+    //  at float32 B = 256 and 40.6 | - | 41.9 ms at bf16-storage B = 1024: their backward kernel alone is faster with the larger tile
+    //  (105 vs 119 us), the step is not)
+    static const size_t lds_budget_s1 = getenv("CDRL_DWF_LDS_KB") ? (size_t)atoi(getenv("CDRL_DWF_LDS_KB")) * 1024 : DWF_LDS_BUDGET;
+    static const size_t lds_budget_s2 = getenv("CDRL_DWF_LDS_KB_S2") ? (size_t)atoi(getenv("CDRL_DWF_LDS_KB_S2")) * 1024 : lds_budget_s1;
+    const size_t lds_budget = stride == 2 ? lds_budget_s2 : lds_budget_s1;
     int maxc = (int)(lds_budget / per_c) / g.vec * g.vec;
     if (maxc < g.vec) maxc = g.vec;
     if (maxc > 256) maxc = 256;
