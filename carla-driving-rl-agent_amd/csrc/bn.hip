@@ -594,7 +594,7 @@ struct BnBwdReduceF {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const float z = fmaf(sc.v[i], v.v[i], sh.v[i]);
-                if (!(z > 0.0f && z < 6.0f)) d.v[i] = 0.0f;
+                if (!relu6_open(z)) d.v[i] = 0.0f;
             }
         }
 #pragma unroll
@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ct
                 for (int i = 0; i < VEC; ++i) {
                     const float v = yv[u].v[i];
                     const float z = fmaf(sc[i], v, sh[i]);
-                    const float d = (z > 0.0f && z < 6.0f) ? dz[u][i] : 0.0f;
+                    const float d = relu6_open(z) ? dz[u][i] : 0.0f;
                     const float xh = (v - mean[i]) * inv[i];
                     acc[0][i] += (double)d;
                     acc[1][i] += (double)d * (double)xh;
@@ -801,7 +801,7 @@ struct PoolBnReduceF {
             const int iy = 2 * oy - ps.pt + ky, ix = 2 * ox - ps.pl + kx;
             const float v = ldf(reinterpret_cast<const T*>(y) + ((n * ps.H + iy) * ps.W + ix) * C + c0 + i);
             const float z = fmaf(sc.v[i], v, sh.v[i]);
-            if (z > 0.0f && z < 6.0f) {
+            if (relu6_open(z)) {
                 const float xh = (v - mean.v[i]) * invstd.v[i];
                 acc[0][i] += (double)d.v[i];
                 acc[1][i] += (double)d.v[i] * (double)xh;
@@ -863,7 +863,7 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const float z = fmaf(sc.v[i], v[u][i], sh.v[i]);
-                    if (z > 0.0f && z < 6.0f) {
+                    if (relu6_open(z)) {
                         const float xh = (v[u][i] - mean.v[i]) * invstd.v[i];
                         acc[0][i] += (double)d[u].v[i];
                         acc[1][i] += (double)d[u].v[i] * (double)xh;
@@ -1000,7 +1000,7 @@ struct BnBwdApplyF {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const float z = fmaf(sc.v[i], v.v[i], sh.v[i]);
-                if (!(z > 0.0f && z < 6.0f)) d.v[i] = 0.0f;
+                if (!relu6_open(z)) d.v[i] = 0.0f;
             }
         }
         const VecF<VEC> k1 = vload<VEC>(coef + 0 * GC + g * C + c0), k2 = vload<VEC>(coef + 1 * GC + g * C + c0),
@@ -1081,7 +1081,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int cto
                     if (bcast > 0) d = d / (float)bcast;        // gradient of the global average pool over `bcast` rows
                     if (relu) {
                         const float z = fmaf(sc[i], v, sh[i]);
-                        d = (z > 0.0f && z < 6.0f) ? d : 0.0f;
+                        d = relu6_open(z) ? d : 0.0f;
                     }
                     const float xh = (v - mean[i]) * inv[i];
                     o.v[i] = k1[i] * (d - k2[i] - xh * k3[i]);
@@ -1252,7 +1252,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ z, const float* __restr
         const float x = z[i];
         float d = da[i];
         if (act == ACT_RELU6) {
-            if (!(x > 0.0f && x < 6.0f)) d = 0.0f;
+            if (!relu6_open(x)) d = 0.0f;
         } else if (act == ACT_SWISH6) {
             const float s = sigmoidf_(x);
             d = (x * s < 6.0f) ? d * (s * (1.0f + x * (1.0f - s))) : 0.0f;

@@ -27,6 +27,12 @@ enum Act : int { ACT_NONE = 0, ACT_RELU6 = 1, ACT_SWISH6 = 2, ACT_TANH = 3, ACT_
 
 // De-interleaving channel shuffle of the reference (core/architectures.py:109-118, F7):
 // concat index i -> output channel (i & 1) * (C/2) + (i >> 1).
+// ReLU6 pass-through test 0 < z < 6 as ONE vector compare.  min(z, 6 - z) > 0 is exactly that predicate (6 - z is exact near 6 and
+// never rounds to 0 unless z == 6; NaN -> false like the two-sided form).  The two-sided form compiles to two v_cmp into scalar
+// register pairs combined by s_and_b64 right in front of the v_cndmask that consumes it; see DESIGN.md ("What round 3 found"):
+// with another kernel's waves on the same SIMD the top lanes of that mask were occasionally stale.
+__device__ __forceinline__ bool relu6_open(float z) { return fminf(z, 6.0f - z) > 0.0f; }
+
 __host__ __device__ inline int shuffle_dst(int i, int ctot) { return (i & 1) * (ctot >> 1) + (i >> 1); }
 
 void set_error(const char* fmt, ...);

@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restr
                     const float mean = CF[gs][0][c0 + i], inv = CF[gs][1][c0 + i], sc = CF[gs][2][c0 + i], sh = CF[gs][3][c0 + i];
                     const float k1 = CF[gs][4][c0 + i], k2 = CF[gs][5][c0 + i], k3 = CF[gs][6][c0 + i];
                     const float z = fmaf(sc, v, sh);
-                    if (!(z > 0.0f && z < 6.0f)) d = 0.0f;
+                    if (!relu6_open(z)) d = 0.0f;
                     const float xh = (v - mean) * inv;
                     o[i] = ok ? k1 * (d - k2 - xh * k3) : 0.0f;
                 }
@@ -700,7 +700,7 @@ struct DwBwdDataBnF {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const float z = fmaf(sc.v[i], v.v[i], sh.v[i]);
-                if (!(z > 0.0f && z < 6.0f)) d.v[i] = 0.0f;
+                if (!relu6_open(z)) d.v[i] = 0.0f;
             }
         }
 #pragma unroll

@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
                     const VecF<VEC> av = vload<VEC>(&tile[((iy + 1) * Wp + ix + 1) * cchunk + tx * VEC]);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i)
-                        if (!(av.v[i] > 0.0f && av.v[i] < 6.0f)) acc.v[i] = 0.0f;
+                        if (!relu6_open(av.v[i])) acc.v[i] = 0.0f;
                 }
                 return acc;
             };

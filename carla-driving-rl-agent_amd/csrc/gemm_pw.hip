@@ -308,8 +308,8 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
                     if (QREG) {
                         if (a.a_act == ACT_RELU6) {
                             const float z0 = fmaf(qr[2][0], yv.x, qr[3][0]), z1 = fmaf(qr[2][1], yv.y, qr[3][1]);
-                            if (!(z0 > 0.0f && z0 < 6.0f)) v.x = 0.0f;
-                            if (!(z1 > 0.0f && z1 < 6.0f)) v.y = 0.0f;
+                            if (!relu6_open(z0)) v.x = 0.0f;
+                            if (!relu6_open(z1)) v.y = 0.0f;
                         }
                         const float xh0 = (yv.x - qr[0][0]) * qr[1][0], xh1 = (yv.y - qr[0][1]) * qr[1][1];
                         v.x = qr[4][0] * (v.x - qr[5][0] - xh0 * qr[6][0]);
@@ -330,8 +330,8 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
                     if (a.a_act == ACT_RELU6) {
                         const float z0 = fmaf(q0[2 * 2 * KSM], yv.x, q0[3 * 2 * KSM]);
                         const float z1 = fmaf(q0[2 * 2 * KSM + 1], yv.y, q0[3 * 2 * KSM + 1]);
-                        if (!(z0 > 0.0f && z0 < 6.0f)) v.x = 0.0f;
-                        if (!(z1 > 0.0f && z1 < 6.0f)) v.y = 0.0f;
+                        if (!relu6_open(z0)) v.x = 0.0f;
+                        if (!relu6_open(z1)) v.y = 0.0f;
                     }
                     const float xh0 = (yv.x - q0[0]) * q0[2 * KSM], xh1 = (yv.y - q0[1]) * q0[2 * KSM + 1];
                     v.x = q0[4 * 2 * KSM] * (v.x - q0[5 * 2 * KSM] - xh0 * q0[6 * 2 * KSM]);

@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(512) tn_direct_kernel(TnDirectArgs a) {
                     const float y = yv[u][j];
                     if (a.db.act == ACT_RELU6) {
                         const float z = fmaf(qsc[j], y, qsh[j]);
-                        d = (z > 0.0f && z < 6.0f) ? d : 0.0f;
+                        d = relu6_open(z) ? d : 0.0f;
                     }
                     const float xh = (y - qm[j]) * qi[j];
                     d = keep * (qk1[j] * (d - qk2[j] - xh * qk3[j]));
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(512) tn_direct_tr_kernel(TnDirectArgs a) {
                 const float y = yv[u];
                 if (a.db.act == ACT_RELU6) {
                     const float z = fmaf(qsc, y, qsh);
-                    d = (z > 0.0f && z < 6.0f) ? d : 0.0f;
+                    d = relu6_open(z) ? d : 0.0f;
                 }
                 const float xh = (y - qm) * qi;
                 d = keep * (qk1 * (d - qk2 - xh * qk3));
@@ -532,14 +532,13 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     static const bool diag_skip = getenv("CDRL_DIAG_SKIP_TN") && atoi(getenv("CDRL_DIAG_SKIP_TN")) == 1;   // timing diagnostics only
     if (diag_skip) return 0;
     // bf16 modes: operands staged once per workgroup through LDS (gemm_tn_lds.hip) -- the direct form is a stream of 2-byte loads
-    // there; CDRL_TN_LDS=0 keeps the direct form, CDRL_TN_LDS=2 lifts the width limit below.
+    // there; CDRL_TN_LDS=0 keeps the direct form, CDRL_TN_LDS=1 restricts the LDS form to one column block (96 <= K, N <= 128).
     // Shapes: its 128 x 128 column block with one k tile per wave only pays for wide products -- measured isolated at B = 1024:
-    // K = N = 116: 47.6 vs 64.2 us, 232: 40.9 vs 58.3 us, but K = N = 58: 82.9 vs 68.2 us and 24 x 58: 264 vs 126 us -- and it is
-    // used for ONE column block only (96 <= K, N <= 128, the stage-1 units): with several column blocks (K, N = 232, the 464 x 768
-    // head conv) the bf16-storage engine lost its bit-wise run-to-run reproducibility (tools/det_engine.py: two outcomes of the
-    // backward pass from the first such launch on, ~1 pass in 3; every kernel is deterministic in isolation, tools/det_tn.py /
-    // det_pw.py, and the single-block shapes are clean over 40 passes).  Unexplained, so those shapes stay on the direct form.
-    static const int lds_mode = getenv("CDRL_TN_LDS") ? atoi(getenv("CDRL_TN_LDS")) : 1;
+    // K = N = 116: 47.6 vs 64.2 us, 232: 40.9 vs 58.3 us, but K = N = 58: 82.9 vs 68.2 us and 24 x 58: 264 vs 126 us.
+    // (Until the ReLU6 masks became single compares -- relu6_open(), cdrl_common.h -- the shapes with several column blocks were kept
+    //  off this path: next to them the fused backward-data GEMM on the main stream lost its run-to-run reproducibility.  The cause
+    //  was in that kernel's mask code, not here: DESIGN.md "What round 3 found", tools/det_co.py.)
+    static const int lds_mode = getenv("CDRL_TN_LDS") ? atoi(getenv("CDRL_TN_LDS")) : 2;
     const bool lds_shape = K >= 96 && N >= 96 && (lds_mode == 2 || (K <= 128 && N <= 128));
     if (bf16_operands && lds_mode != 0 && lds_shape && gemm_tn_lds_supported(A, D, N, K, dpro))
         return gemm_tn_lds(A, D, Cout, M, N, K, part, accumulate, st, G, pro_stats, dpro, at);

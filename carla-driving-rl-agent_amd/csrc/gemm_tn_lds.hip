@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256, 2) tn_lds_kernel(TnLdsArgs a) {
                     const float y = r.y[DPRO ? i : 0][DPRO ? j : 0];
                     if (relu) {
                         const float z = fmaf(qsc[j], y, qsh[j]);
-                        d[i] = (z > 0.0f && z < 6.0f) ? d[i] : 0.0f;
+                        d[i] = relu6_open(z) ? d[i] : 0.0f;
                     }
                     const float xh = (y - qm[j]) * qi[j];
                     d[i] = keep[i] * (qk1[j] * (d[i] - qk2[j] - xh * qk3[j]));
@@ -293,10 +293,7 @@ static TnlPlan tnl_plan(int M, int N, int K, int G) {
     return p;
 }
 
-int64_t gemm_tn_lds_part_elems(int M, int N, int K, int G) {
-    static const int diag_x = getenv("CDRL_DIAG_TNL_PARTX") ? atoi(getenv("CDRL_DIAG_TNL_PARTX")) : 1;      // (diagnostic: oversize the partial buffer)
-    return (int64_t)tnl_plan(M, N, K, G).nsplit * K * N * diag_x;
-}
+int64_t gemm_tn_lds_part_elems(int M, int N, int K, int G) { return (int64_t)tnl_plan(M, N, K, G).nsplit * K * N; }
 
 bool gemm_tn_lds_supported(View A, View D, int N, int K, const TnBnBwd* dpro) {
     // adjacent-column pairs: even leading dimensions / offsets / widths (every tower tensor); the shuffle gather needs the two

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) stem_bwd_onepass_kernel(const float* __re
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float z = fmaf(sp[2 * GC + i], v.v[i], sp[3 * GC + i]);
-                    dz[i] = (z > 0.0f && z < 6.0f) ? d.v[i] : 0.0f;
+                    dz[i] = relu6_open(z) ? d.v[i] : 0.0f;
                     xh[i] = (v.v[i] - sp[i]) * sp[GC + i];
                 }
             }
