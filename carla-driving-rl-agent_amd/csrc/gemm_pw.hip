@@ -256,38 +256,53 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
         }
     }
     const uint32_t rowA = (uint32_t)a.A.ld * ESZ, rowY = (uint32_t)K * ESZ;
-    // two consecutive activation elements at a buffer offset (8-byte load; bf16 storage: 4-byte load, widened)
+    // Tile loads return RAW words: with bf16 storage the widening (shift / mask) happens in store_tile, not here -- a conversion
+    // right behind its load is a use of the loaded register, i.e. an s_waitcnt in the middle of the prefetch (the first bf16-storage
+    // version converted on load and waited for every load of the next tile before the MFMA chain of the current one).
+    //   float32 tensors: ld2 = the two floats, ld1 = the float.
+    //   bf16 storage:    ld2 = ONE dword (two bf16) in .x, ld1 = the zero-extended 16 bits (as float bit patterns)
     auto ld2 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t vo, uint32_t so) -> float2 {
-        if (BH) {
-            const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
-            return make_float2(bf_lo(w), bf_hi(w));
-        }
+        if (BH) return make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0)), 0.0f);
         const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
         return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
     };
     auto ld1 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t vo, uint32_t so) -> float {
-        if (BH) return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0) << 16);
+        if (BH) return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0));
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+    };
+    // decode of a raw tile word pair (no-ops for float32 tensors)
+    auto dec2 = [&](float2 r) -> float2 {          // from ld2
+        if (!BH) return r;
+        const uint32_t w = __float_as_uint(r.x);
+        return make_float2(bf_lo(w), bf_hi(w));
+    };
+    auto dec11 = [&](float2 r) -> float2 {         // from two ld1
+        if (!BH) return r;
+        return make_float2(__uint_as_float(__float_as_uint(r.x) << 16), __uint_as_float(__float_as_uint(r.y) << 16));
     };
     auto load_tile = [&](int t, float2* ra, float2* ry) {
         const int64_t m0 = mbeg + (int64_t)t * BM;
         const uint32_t mu = (uint32_t)m0;
         const bool full = m0 + BM <= mend;
+        // (the dz_vec test is hoisted out of the load loop: inside it every load was its own basic block)
+        if (PRO == 2 && !dz_vec) {
 #pragma unroll
-        for (int i = 0; i < NA2; ++i) {
-            const uint32_t r = mu + (uint32_t)(i * RSTEP);
-            uint32_t msk = 0u;
-            if (!full) msk = (m0 + i * RSTEP + r_t) < mend ? 0u : OOR;      // last tile of the group only
-            if (PRO == 2) {
-                if (dz_vec) {       // dense gradient (no shuffle map): one 8-byte load
-                    ra[i] = ld2(rsA, voA0 | msk, r * rowA);
-                } else {
-                    ra[i].x = ld1(rsA, voA0 | msk, r * rowA);
-                    ra[i].y = ld1(rsA, voA1 | msk, r * rowA);
-                }
-                ry[i] = ld2(rsY, voY | msk, r * rowY);
-            } else {
-                ra[i] = ld2(rsA, voA0 | msk, r * rowA);
+            for (int i = 0; i < NA2; ++i) {
+                const uint32_t r = mu + (uint32_t)(i * RSTEP);
+                uint32_t msk = 0u;
+                if (!full) msk = (m0 + i * RSTEP + r_t) < mend ? 0u : OOR;      // last tile of the group only
+                ra[i].x = ld1(rsA, voA0 | msk, r * rowA);
+                ra[i].y = ld1(rsA, voA1 | msk, r * rowA);
+                ry[PRO == 2 ? i : 0] = ld2(rsY, voY | msk, r * rowY);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA2; ++i) {
+                const uint32_t r = mu + (uint32_t)(i * RSTEP);
+                uint32_t msk = 0u;
+                if (!full) msk = (m0 + i * RSTEP + r_t) < mend ? 0u : OOR;
+                ra[i] = ld2(rsA, voA0 | msk, r * rowA);       // dense gradient / plain operand: one 8-byte (bf16: 4-byte) load
+                if (PRO == 2) ry[PRO == 2 ? i : 0] = ld2(rsY, voY | msk, r * rowY);
             }
         }
     };
@@ -296,7 +311,7 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
 #pragma unroll
         for (int i = 0; i < NA2; ++i) {
             const int r = (tid + 256 * i) / KSM;
-            float2 v = ra[i];
+            float2 v = (PRO == 2 && !dz_vec) ? dec11(ra[i]) : dec2(ra[i]);
             if (PRO == 1) {
                 if (m0 + r < mend && kon) {
                     v.x = fmaf(psc0, v.x, psh0);
@@ -304,7 +319,7 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
                 }
             } else if (PRO == 2) {
                 if (m0 + r < mend && kon) {
-                    const float2 yv = ry[i];
+                    const float2 yv = dec2(ry[i]);
                     if (QREG) {
                         if (a.a_act == ACT_RELU6) {
                             const float z0 = fmaf(qr[2][0], yv.x, qr[3][0]), z1 = fmaf(qr[2][1], yv.y, qr[3][1]);
