@@ -122,6 +122,43 @@ __device__ __forceinline__ VecF<VEC> vload(const bf16_t* p) {
     return r;
 }
 
+// RAW loads: the words as they are in memory, widened later by vdecode().  A bf16 vload() widens right behind the load, and when
+// the load sits in a conditional block (`if (p < P) v[u] = vload(...)`) the widening sits there too: every load of an unrolled
+// batch then waits for its own data before the next one is issued (s_waitcnt vmcnt(0) per load; the float32 instantiation has
+// nothing to do on the loaded registers and issues the whole batch).  Kernels that keep several loads in flight use
+//     raw[u] = vload_raw<VEC>(p);  ...all loads of the batch...;  vdecode<VEC>(raw[u], (const T*)nullptr);
+// float32: vload_raw == vload, vdecode is a no-op.  bf16: VEC = 4 -> words in v[0], v[1]; 2 -> v[0]; 1 -> the 16 bits in v[0].
+template <int VEC>
+__device__ __forceinline__ VecF<VEC> vload_raw(const float* p) { return vload<VEC>(p); }
+template <int VEC>
+__device__ __forceinline__ VecF<VEC> vload_raw(const bf16_t* p) {
+    VecF<VEC> r;
+    if (VEC == 4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        r.v[0] = __uint_as_float(t.x);
+        r.v[1 % VEC] = __uint_as_float(t.y);
+    } else if (VEC == 2) {
+        r.v[0] = __uint_as_float(*reinterpret_cast<const uint32_t*>(p));
+    } else {
+        r.v[0] = __uint_as_float((uint32_t)*reinterpret_cast<const uint16_t*>(p));
+    }
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void vdecode(VecF<VEC>&, const float*) {}
+template <int VEC>
+__device__ __forceinline__ void vdecode(VecF<VEC>& r, const bf16_t*) {
+    if (VEC == 4) {
+        const uint32_t a = __float_as_uint(r.v[0]), b = __float_as_uint(r.v[1 % VEC]);
+        r.v[0] = bf_lo(a); r.v[1 % VEC] = bf_hi(a); r.v[2 % VEC] = bf_lo(b); r.v[3 % VEC] = bf_hi(b);
+    } else if (VEC == 2) {
+        const uint32_t a = __float_as_uint(r.v[0]);
+        r.v[0] = bf_lo(a); r.v[1 % VEC] = bf_hi(a);
+    } else {
+        r.v[0] = __uint_as_float(__float_as_uint(r.v[0]) << 16);
+    }
+}
+
 template <int VEC>
 __device__ __forceinline__ void vstore(bf16_t* p, const VecF<VEC>& r) {
     if (VEC == 4) *reinterpret_cast<uint2*>(p) = make_uint2(bf_pack(r.v[0], r.v[1 % VEC]), bf_pack(r.v[2 % VEC], r.v[3 % VEC]));

@@ -222,12 +222,13 @@ __global__ void __launch_bounds__(DWF_T_FWD) dwf_fwd_kernel(const T* __restrict_
 #pragma unroll
                 for (int u = 0; u < DWF_UF; ++u) {
                     const int p = p0 + u * CY;
-                    if (p < P) v[u] = vload<VEC>(xp + (int64_t)p * C);
+                    if (p < P) v[u] = vload_raw<VEC>(xp + (int64_t)p * C);
                 }
 #pragma unroll
                 for (int u = 0; u < DWF_UF; ++u) {
                     const int p = p0 + u * CY;
                     if (p < P) {
+                        vdecode<VEC>(v[u], xp);
                         if (PRE) {
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) v[u].v[i] = fminf(fmaxf(fmaf(sc.v[i], v[u].v[i], sh.v[i]), 0.0f), 6.0f);
@@ -349,16 +350,17 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
 #pragma unroll
                 for (int u = 0; u < DWF_U; ++u) {
                     const int p = p0 + u * CY;
-                    if (p < P) xa[u] = vload<VEC>(xp + (int64_t)p * C);
+                    if (p < P) xa[u] = vload_raw<VEC>(xp + (int64_t)p * C);
                     if (p < Po) {
-                        d[u] = vload<VEC>(dp + (int64_t)p * C);
-                        v[u] = vload<VEC>(yp + (int64_t)p * C);
+                        d[u] = vload_raw<VEC>(dp + (int64_t)p * C);
+                        v[u] = vload_raw<VEC>(yp + (int64_t)p * C);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < DWF_U; ++u) {
                     const int p = p0 + u * CY;
                     if (p < P) {
+                        vdecode<VEC>(xa[u], xp);
                         if (PRE) {
 #pragma unroll
                             for (int i = 0; i < VEC; ++i) xa[u].v[i] = fminf(fmaxf(fmaf(sc.v[i], xa[u].v[i], sh.v[i]), 0.0f), 6.0f);
@@ -367,6 +369,8 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
                         vstore<VEC>(&tile[((iy + 1) * Wp + ix + 1) * cchunk + tx * VEC], xa[u]);
                     }
                     if (p < Po) {
+                        vdecode<VEC>(d[u], xp);
+                        vdecode<VEC>(v[u], xp);
                         VecF<VEC> o;
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) {
@@ -460,7 +464,7 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
             VecF<VEC> yb[DXU];
             if (PRE) {
 #pragma unroll
-                for (int u = 0; u < DXU; ++u) yb[u] = vload<VEC>(xp + (int64_t)min(ty + u * CY, P - 1) * C);
+                for (int u = 0; u < DXU; ++u) yb[u] = vload_raw<VEC>(xp + (int64_t)min(ty + u * CY, P - 1) * C);
             }
             for (int p0 = ty; p0 < P; p0 += CY * DXU) {
                 VecF<VEC> acc[DXU];
@@ -474,6 +478,7 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
                     for (int u = 0; u < DXU; ++u) {
                         const int p = p0 + u * CY;
                         if (p >= P) continue;
+                        vdecode<VEC>(yb[u], xp);
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) {
                             const float xh = (yb[u].v[i] - mean1.v[i]) * inv1.v[i];
@@ -483,7 +488,7 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
                     }
                     // next batch's y1 (clamped addresses: unconditional loads), ahead of this batch's stores
 #pragma unroll
-                    for (int u = 0; u < DXU; ++u) yb[u] = vload<VEC>(xp + (int64_t)min(p0 + (DXU + u) * CY, P - 1) * C);
+                    for (int u = 0; u < DXU; ++u) yb[u] = vload_raw<VEC>(xp + (int64_t)min(p0 + (DXU + u) * CY, P - 1) * C);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
