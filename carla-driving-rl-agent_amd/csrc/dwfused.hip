@@ -81,6 +81,11 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     int fpb = 1;
     const int work = Ho * Wo * g.cx;
     while (fpb < 8 && work * fpb * 2 <= 4096 && B % (fpb * 2) == 0 && (int64_t)G * (B / (fpb * 2)) * g.nch >= 512) fpb *= 2;
+    // large batches (configuration 3): once every CU has two rounds of 4 workgroups anyway, more frames per workgroup only shrink
+    // the partial rows (10 + 2 doubles per channel and workgroup: 38 MB per launch at B = 1024 with one frame each) and the
+    // finalize kernels that read them
+    static const int min_blocks = getenv("CDRL_DWF_MINBLOCKS") ? atoi(getenv("CDRL_DWF_MINBLOCKS")) : 2048;
+    while (fpb < 8 && B % (fpb * 2) == 0 && (int64_t)G * (B / (fpb * 2)) * g.nch >= min_blocks) fpb *= 2;
     g.fpb = fpb;
     g.nb = B / fpb;
     // backward: 12 double accumulators per channel lane -> at 4 channels per thread the kernel needs > 256 VGPRs (one
