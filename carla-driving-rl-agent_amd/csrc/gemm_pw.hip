@@ -313,10 +313,11 @@ __global__ void __launch_bounds__(256, (pw_occ(KSM, NT))) pw_nn_kernel(PwArgs a)
             const int r = (tid + 256 * i) / KSM;
             float2 v = (PRO == 2 && !dz_vec) ? dec11(ra[i]) : dec2(ra[i]);
             if (PRO == 1) {
-                if (m0 + r < mend && kon) {
-                    v.x = fmaf(psc0, v.x, psh0);
-                    v.y = fmaf(psc1, v.y, psh1);
-                }
+                // unconditional: columns beyond K carry scale 1 / shift 0 (and loaded 0), rows beyond the group end only feed
+                // output rows that are neither stored nor counted -- and a compound lane condition in front of a select is the
+                // mask pattern of "What round 3 found" 
+                v.x = fmaf(psc0, v.x, psh0);
+                v.y = fmaf(psc1, v.y, psh1);
             } else if (PRO == 2) {
                 if (m0 + r < mend && kon) {
                     const float2 yv = dec2(ry[i]);
