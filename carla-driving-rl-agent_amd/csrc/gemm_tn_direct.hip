@@ -529,12 +529,18 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
         set_error("gemm_tn: operands of 2 GB or more are not supported (M=%d)", M);
         return -1;
     }
+    static const bool trace = getenv("CDRL_TN_TRACE") && atoi(getenv("CDRL_TN_TRACE")) == 1;      // shapes of the filter-gradient GEMMs
+    if (trace) fprintf(stderr, "gemm_tn M=%d K=%d N=%d G=%d apro=%d dpro=%d shuffle=%d bf16=%d at=%d\n", M, K, N, G, pro_stats != nullptr, dpro != nullptr, dpro ? dpro->shuffle_ctot : 0, (int)bf16_operands, at);
     static const bool diag_skip = getenv("CDRL_DIAG_SKIP_TN") && atoi(getenv("CDRL_DIAG_SKIP_TN")) == 1;   // timing diagnostics only
     if (diag_skip) return 0;
     // bf16 modes: operands staged once per workgroup through LDS (gemm_tn_lds.hip) -- the direct form is a stream of 2-byte loads
     // there; CDRL_TN_LDS=0 keeps the direct form, CDRL_TN_LDS=1 restricts the LDS form to one column block (96 <= K, N <= 128).
     // Shapes: its 128 x 128 column block with one k tile per wave only pays for wide products -- measured isolated at B = 1024:
     // K = N = 116: 47.6 vs 64.2 us, 232: 40.9 vs 58.3 us, but K = N = 58: 82.9 vs 68.2 us and 24 x 58: 264 vs 126 us.
+    // (A NARROW geometry of the LDS kernel for the K, N <= 64 convs of stage 0 -- one 64-column block, 64-row chunks, the <= 4 tile
+    //  products spread over the waves -- was built and measured in round 3: isolated 52 vs 68 us at 58 x 58, 150 vs 126 us at
+    //  24 x 58 (B = 1024), and NO change of the update-step (32.76 vs 32.80 ms): next to the main stream these kernels take 3-4x
+    //  their isolated time either way.  Not kept.)
     // (Until the ReLU6 masks became single compares -- relu6_open(), cdrl_common.h -- the shapes with several column blocks were kept
     //  off this path: next to them the fused backward-data GEMM on the main stream lost its run-to-run reproducibility.  The cause
     //  was in that kernel's mask code, not here: DESIGN.md "What round 3 found", tools/det_co.py.)
