@@ -806,7 +806,9 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
 // gradient of the concat exists and run under the tower's backward.
 void Learner::add_aux_fork(std::vector<Op>& ops) {
     Op op;
+    static const int diag_skip_aux = getenv("CDRL_DIAG_SKIP_AUX") ? atoi(getenv("CDRL_DIAG_SKIP_AUX")) : 0;     // timing diagnostics only (wrong results)
     op.fwd = [=](hipStream_t st, int training) -> int {
+        if (diag_skip_aux & 1) return 0;
         if (!side_enabled_) return run_fwd(aux_ops_, st, training);
         CDRL_HIP(hipEventRecord(ev_aux_fork_, st));           // parameters / inputs produced on the main stream
         if (aux_worker_ && !graphs_enabled_) {
@@ -838,7 +840,9 @@ void Learner::add_aux_join(std::vector<Op>& ops) {
         }
         return 0;
     };
+    static const int diag_skip_aux = getenv("CDRL_DIAG_SKIP_AUX") ? atoi(getenv("CDRL_DIAG_SKIP_AUX")) : 0;     // timing diagnostics only (wrong results)
     op.bwd = [=](hipStream_t st) -> int {
+        if (diag_skip_aux & 2) return 0;
         if (!side_enabled_) return run_bwd(aux_ops_, st);
         // Own stream: ~90 tiny dependent kernels (0.8 ms).  On the filter-gradient side stream they blocked, in stream
         // order, the slot events the main stream waits on (measured: a 0.84 ms hole in the critical stream per pass).
