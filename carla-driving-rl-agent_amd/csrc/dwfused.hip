@@ -55,7 +55,19 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     //  (105 vs 119 us), the step is not)
     static const size_t lds_budget_s1 = getenv("CDRL_DWF_LDS_KB") ? (size_t)atoi(getenv("CDRL_DWF_LDS_KB")) * 1024 : DWF_LDS_BUDGET;
     static const size_t lds_budget_s2 = getenv("CDRL_DWF_LDS_KB_S2") ? (size_t)atoi(getenv("CDRL_DWF_LDS_KB_S2")) * 1024 : lds_budget_s1;
-    const size_t lds_budget = stride == 2 ? lds_budget_s2 : lds_budget_s1;
+    size_t lds_budget = stride == 2 ? lds_budget_s2 : lds_budget_s1;
+    // wide frames (three-camera 90x360, 135x180): at 38 KB their channel chunks drop below ~24 channels -- a dozen channel lanes
+    // per workgroup and 5-6 chunks per frame (40.9 vs 38.3 ms / update-step at 90x360 with 76 KB) -- so the budget grows in steps
+    // until a chunk holds at least CDRL_DWF_MINCHUNK channels (or the whole frame)
+    // (22: the 11x15x58 units of the 90x120 configuration sit exactly there and were measured best at 38 KB; the stride-2 blocks of that
+    //  configuration, 8 channels per chunk, likewise: see above)
+    static const int min_chunk = getenv("CDRL_DWF_MINCHUNK") ? atoi(getenv("CDRL_DWF_MINCHUNK")) : 22;
+    static const int min_chunk_s2 = getenv("CDRL_DWF_MINCHUNK_S2") ? atoi(getenv("CDRL_DWF_MINCHUNK_S2")) : 8;   // (22x30x24 at 38 KB: 8)
+    for (const size_t kb : {52, 76}) {
+        const int mc = (int)(lds_budget / per_c) / g.vec * g.vec;
+        if (mc >= C || mc >= (stride == 2 ? min_chunk_s2 : min_chunk)) break;
+        if (lds_budget < kb * 1024) lds_budget = kb * 1024;
+    }
     int maxc = (int)(lds_budget / per_c) / g.vec * g.vec;
     if (maxc < g.vec) maxc = g.vec;
     if (maxc > 256) maxc = 256;

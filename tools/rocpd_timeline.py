@@ -7,7 +7,20 @@ import sqlite3
 import sys
 
 
+def demangle_bf16(name):
+    """rocprofv3 leaves names with the __bf16 builtin (Itanium `DF16b`) mangled; spell it as a vendor type and ask c++filt."""
+    if not name.startswith('_Z') or 'DF16b' not in name:
+        return name
+    import subprocess
+    try:
+        out = subprocess.run(['c++filt', name.replace('DF16b', 'u6__bf16')], capture_output=True, text=True, timeout=5).stdout.strip()
+        return out or name
+    except Exception:
+        return name
+
+
 def short(name):
+    name = demangle_bf16(name)
     name = re.sub(r'\(.*$', '', name)
     return name.replace('void ', '').replace('cdrl::', '')[:70]
 
