@@ -107,9 +107,10 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
 // tensors.  gemm_tn dispatches to it (CDRL_TN_LDS=0 keeps the direct form).
 bool gemm_tn_lds_supported(View A, View D, int N, int K, const TnBnBwd* dpro);
 int64_t gemm_tn_lds_part_elems(int M, int N, int K, int G = 1);
-// f32_operands (with at = 0): float32 operands on v_mfma_f32_32x32x2_f32 (the float32 engine's arithmetic)
+// f32_mode (with at = 0): 1 = float32 operands on v_mfma_f32_32x32x2_f32 (the float32 engine's arithmetic); 2 = float32-accurate
+// product from three bf16 planes per operand on v_mfma_f32_32x32x16_bf16 (six plane products)
 int gemm_tn_lds(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G,
-                const float* pro_stats, const TnBnBwd* dpro, int at, bool f32_operands = false);
+                const float* pro_stats, const TnBnBwd* dpro, int at, int f32_mode = 0);
 
 // ---------------------------------------------------------------- fused pointwise conv (gemm_pw.hip)
 // Persistent skinny GEMM for K, N <= 128: C[m,n] (+)= sum_k pro(A[m,k]) W(k,n) + bias[n] over G groups of Mg rows.

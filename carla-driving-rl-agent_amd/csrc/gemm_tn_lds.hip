@@ -40,14 +40,19 @@ constexpr int TNL_R = 32;               // rows per chunk
 
 // MODE 2: activation tensors (A, D, y) are bf16 in HBM, bf16 MFMA operands; MODE 1: float32 tensors, operands rounded to bf16 after
 // the prologues; MODE 0: float32 tensors AND float32 operands (v_mfma_f32_32x32x2_f32: the exact k-ordered fmaf chain of the
-// float32 engine) -- same staging, the LDS columns hold floats.
+// float32 engine) -- same staging, the LDS columns hold floats.  MODE 3: float32 tensors, float32-ACCURATE product on the bf16 pipe:
+// after the prologues every operand value is split into three bf16 planes (x = x1 + x2 + x3 to 24 mantissa bits, as gemm_x3.hip /
+// gemm_pw_x3.hip do for the forward GEMMs) and the product is the six plane products x1 d1 + x1 d2 + x2 d1 + x1 d3 + x3 d1 + x2 d2:
+// 6 x 32 matrix-pipe cycles per 16 rows and tile pair instead of 8 x 64 for v_mfma_f32_32x32x2_f32.  Three planes per operand do
+// not leave room for a second LDS buffer at two workgroups per CU: one buffer, two barriers per chunk.
 template <int MODE, bool APRO, bool DPRO>
 __global__ void __launch_bounds__(256, 2) tn_lds_kernel(TnLdsArgs a) {
-    constexpr bool BH = MODE == 2, F32 = MODE == 0;
+    constexpr bool BH = MODE == 2, F32 = MODE == 0, X3 = MODE == 3;
+    constexpr int NBUF = X3 ? 1 : 2, PL = X3 ? 3 : 1;         // LDS buffers, bf16 planes per operand
     // dwords per LDS column (odd: conflict-free fragment reads, 2-way on the writes): row pairs (bf16) or rows (float32)
     constexpr int TNL_CS = F32 ? TNL_R + 1 : TNL_R / 2 + 1;
-    __shared__ uint32_t AsT[2][128 * TNL_CS];
-    __shared__ uint32_t DsT[2][128 * TNL_CS];
+    __shared__ uint32_t AsT[NBUF * PL][128 * TNL_CS];
+    __shared__ uint32_t DsT[NBUF * PL][128 * TNL_CS];
     constexpr uint32_t ESZ = BH ? 2u : 4u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, lh = lane >> 5;
@@ -193,6 +198,25 @@ __global__ void __launch_bounds__(256, 2) tn_lds_kernel(TnLdsArgs a) {
                     pa[i] = __float_as_uint(x[i]);
                     pd[i] = __float_as_uint(d[i]);
                 }
+            } else if (X3) {
+                // three bf16 planes: h1 = bf16(v), h2 = bf16(v - h1), h3 = bf16(v - h1 - h2) (the subtractions are exact)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    float hx[4], hd[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        hx[i] = (float)(bf16_t)x[i];
+                        hd[i] = (float)(bf16_t)d[i];
+                        x[i] -= hx[i];
+                        d[i] -= hd[i];
+                    }
+                    uint32_t* pa = &AsT[pl][c * TNL_CS + 2 * rg];
+                    pa[0] = bf_pack(hx[0], hx[1]);
+                    pa[1] = bf_pack(hx[2], hx[3]);
+                    uint32_t* pd = &DsT[pl][c * TNL_CS + 2 * rg];
+                    pd[0] = bf_pack(hd[0], hd[1]);
+                    pd[1] = bf_pack(hd[2], hd[3]);
+                }
             } else {
                 uint32_t* pa = &AsT[buf][c * TNL_CS + 2 * rg];
                 pa[0] = bf_pack(x[0], x[1]);
@@ -236,6 +260,28 @@ __global__ void __launch_bounds__(256, 2) tn_lds_kernel(TnLdsArgs a) {
             }
             return;
         }
+        if (X3) {
+#pragma unroll
+            for (int s = 0; s < TNL_R / 16; ++s) {
+                const bf16x8 a1 = frag(AsT[0], wave * 32 + l32, s), a2 = frag(AsT[X3 ? 1 : 0], wave * 32 + l32, s),
+                             a3 = frag(AsT[X3 ? 2 : 0], wave * 32 + l32, s);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < NT) {
+                        const bf16x8 d1 = frag(DsT[0], j * 32 + l32, s), d2 = frag(DsT[X3 ? 1 : 0], j * 32 + l32, s),
+                                     d3 = frag(DsT[X3 ? 2 : 0], j * 32 + l32, s);
+                        // smallest terms first
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, d2, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, d1, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, d3, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, d1, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, d2, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, d1, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < TNL_R / 16; ++s) {
             const bf16x8 af = frag(AsT[buf], wave * 32 + l32, s);
@@ -252,10 +298,11 @@ __global__ void __launch_bounds__(256, 2) tn_lds_kernel(TnLdsArgs a) {
     int c = 0;
     if (mb < me) load_chunk(mb, r0);
     for (int m0 = mb; m0 < me; m0 += TNL_R, ++c) {
-        store_chunk(m0, c & 1, r0);
+        store_chunk(m0, X3 ? 0 : (c & 1), r0);
         __syncthreads();
         if (m0 + TNL_R < me) load_chunk(m0 + TNL_R, r0);
-        mma_chunk(c & 1);
+        mma_chunk(X3 ? 0 : (c & 1));
+        if (X3) __syncthreads();           // one buffer: every wave is done with the fragments before the next chunk is stored
     }
     if (wave >= KT) return;
     // C/D layout: column (n) = lane & 31, row (k) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -307,7 +354,7 @@ bool gemm_tn_lds_supported(View A, View D, int N, int K, const TnBnBwd* dpro) {
 }
 
 int gemm_tn_lds(View A, View D, float* Cout, int M, int N, int K, float* part, int accumulate, hipStream_t st, int G, const float* pro_stats,
-                const TnBnBwd* dpro, int at, bool f32_operands) {
+                const TnBnBwd* dpro, int at, int f32_mode) {
     if (G < 1 || M % G != 0) {
         set_error("gemm_tn_lds: M=%d is not a multiple of G=%d", M, G);
         return -1;
@@ -347,7 +394,8 @@ int gemm_tn_lds(View A, View D, float* Cout, int M, int N, int K, float* part, i
         else hipLaunchKernelGGL((tn_lds_kernel<BHV, false, false>), grid, blk, 0, st, a);           \
     } while (0)
     if (at) CDRL_TNL(2);
-    else if (f32_operands) CDRL_TNL(0);
+    else if (f32_mode == 2) CDRL_TNL(3);
+    else if (f32_mode == 1) CDRL_TNL(0);
     else CDRL_TNL(1);
 #undef CDRL_TNL
     CDRL_LAUNCH_CHECK();

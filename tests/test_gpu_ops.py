@@ -2,6 +2,7 @@
 CPU reference of the same Keras op (tolerance: 1e-4 relative to the tensor scale, the bar
 BASELINE.json's north_star states for fp32; most ops land at ~1e-6)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -65,6 +66,20 @@ def test_gemm_tn(lib, M, K, N):
     _lib.check(lib.cdrl_gemm_tn(P(A), K + 5, 2, P(D), N, 0, P(out), M, N, K, P(ws), 0, S()))
     ref = a[:, 2:2 + K].astype(np.float64).T @ d.astype(np.float64)
     assert rel_err(out.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize('mode', ['1', '2'])
+def test_gemm_tn_lds_float32_forms(mode):
+    """The opt-in LDS-staged filter gradients for float32 tensors (CDRL_TN_LDS_F32 = 1: float32 MFMA from LDS; 2: three bf16 planes
+    per operand, six plane products on the bf16 pipe) keep float32 accuracy -- plain product and the fused BN-backward op.  The
+    switch is read once per process: child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CDRL_TN_LDS_F32=mode)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k',
+                        'test_gemm_tn and (116 or 232 or 464) or test_pwconv_bn_bwd'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout, r.stdout[-500:]
 
 
 @pytest.mark.parametrize('G,Mg,K,N,pro,epi,bt', [(4, 700, 58, 58, 0, 1, 0), (4, 333, 116, 116, 1, 1, 0), (2, 1000, 24, 58, 0, 1, 0),
