@@ -6,6 +6,18 @@ import sqlite3
 import sys
 
 
+def demangle_bf16(name):
+    """rocprofv3 leaves names with the __bf16 builtin (Itanium `DF16b`) mangled; spell it as a vendor type and ask c++filt."""
+    if not name.startswith('_Z') or 'DF16b' not in name:
+        return name
+    import subprocess
+    try:
+        out = subprocess.run(['c++filt', name.replace('DF16b', 'u6__bf16')], capture_output=True, text=True, timeout=5).stdout.strip()
+        return out or name
+    except Exception:
+        return name
+
+
 def main():
     db = sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 else ''
@@ -19,7 +31,7 @@ def main():
     for cn, kn, n, s in rows:
         if flt and flt not in kn:
             continue
-        short = re.sub(r'\(.*$', '', kn).replace('void ', '').replace('cdrl::', '')[:70]
+        short = re.sub(r'\(.*$', '', demangle_bf16(kn)).replace('void ', '').replace('cdrl::', '')[:70]
         print(f'{cn}\t{short}\t{n}\t{s:.0f}')
         tot[cn] = tot.get(cn, 0.0) + s
     for k, v in tot.items():
