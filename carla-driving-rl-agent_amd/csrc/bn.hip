@@ -416,6 +416,11 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(View y, int Mg, int C, in
     }
 }
 
+// two adjacent floats at 4-byte alignment (one 8-byte access: global memory takes it unaligned)
+struct __attribute__((packed, aligned(4))) F2U {
+    float x, y;
+};
+
 // Fast path of bn_apply for the unit output (concat + channel shuffle as a destination permutation, optionally with the
 // identity half): RU rows of loads are issued before the first store -- gfx9 counts loads and stores in one in-order
 // counter, so "load, store, load, use" (the generic loop) waits for a store round trip per row.
@@ -466,6 +471,19 @@ __global__ void __launch_bounds__(256) bn_apply_shuf_kernel(View y, int Mg, int 
                     T* pr = pdp + row * pdst.ld;
                     *reinterpret_cast<uint32_t*>(pr + pcol[0]) = bf_pack(pv[u].v[0], pv[u].v[2 % VEC]);
                     *reinterpret_cast<uint32_t*>(pr + pcol[1 % VEC]) = bf_pack(pv[u].v[1 % VEC], pv[u].v[3 % VEC]);
+                }
+                continue;
+            }
+            if (sizeof(T) == 4 && VEC == 4) {      // float32, 4 channels: the same two pairs as 8-byte stores at 4-byte alignment
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = apply_act(fmaf(sc.v[i % VEC], v[u].v[i % VEC], sh.v[i % VEC]), act);
+                *reinterpret_cast<F2U*>(dr + dcol[0]) = F2U{o[0], o[2]};
+                *reinterpret_cast<F2U*>(dr + dcol[1 % VEC]) = F2U{o[1], o[3]};
+                if (PASS) {
+                    T* pr = pdp + row * pdst.ld;
+                    *reinterpret_cast<F2U*>(pr + pcol[0]) = F2U{pv[u].v[0], pv[u].v[2 % VEC]};
+                    *reinterpret_cast<F2U*>(pr + pcol[1 % VEC]) = F2U{pv[u].v[1 % VEC], pv[u].v[3 % VEC]};
                 }
                 continue;
             }
@@ -647,12 +665,21 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ct
                 const int64_t row = gbase + min(rr + u * CY, r1 - 1);          // clamped: unconditional loads
                 const T* dr = vptr<T>(da) + row * da.ld;
                 constexpr bool PAIR = sizeof(T) == 2 && VEC == 4;       // (see bn_apply_shuf_kernel: columns (0, 2) and (1, 3) are adjacent)
+                // float32: the same pairs as 8-byte loads at 4-byte alignment (columns coff/2 + 2 tx: a wave's 4-byte loads covered
+                // every second dword of its segment, twice)
+                constexpr bool PAIRF = sizeof(T) == 4 && VEC == 4;
                 if (PAIR) {
                     const uint32_t w0 = *reinterpret_cast<const uint32_t*>(dr + dcol[0]), w1 = *reinterpret_cast<const uint32_t*>(dr + dcol[1 % VEC]);
                     dz[u][0] = bf_lo(w0);
                     dz[u][2 % VEC] = bf_hi(w0);
                     dz[u][1 % VEC] = bf_lo(w1);
                     dz[u][3 % VEC] = bf_hi(w1);
+                } else if (PAIRF) {
+                    const F2U w0 = *reinterpret_cast<const F2U*>(dr + dcol[0]), w1 = *reinterpret_cast<const F2U*>(dr + dcol[1 % VEC]);
+                    dz[u][0] = w0.x;
+                    dz[u][2 % VEC] = w0.y;
+                    dz[u][1 % VEC] = w1.x;
+                    dz[u][3 % VEC] = w1.y;
                 } else {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) dz[u][i] = ldf(dr + dcol[i]);
@@ -666,6 +693,12 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ct
                         pv[u][2 % VEC] = bf_hi(w0);
                         pv[u][1 % VEC] = bf_lo(w1);
                         pv[u][3 % VEC] = bf_hi(w1);
+                    } else if (PAIRF) {
+                        const F2U w0 = *reinterpret_cast<const F2U*>(pr + pcol[0]), w1 = *reinterpret_cast<const F2U*>(pr + pcol[1 % VEC]);
+                        pv[u][0] = w0.x;
+                        pv[u][2 % VEC] = w0.y;
+                        pv[u][1 % VEC] = w1.x;
+                        pv[u][3 % VEC] = w1.y;
                     } else {
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) pv[u][i] = ldf(pr + pcol[i]);
