@@ -846,7 +846,13 @@ struct PoolBnReduceF {
 // Fast path of pool_bn_bwd_reduce (4 channels per thread): the scatter-form sums need two DEPENDENT round trips per pooled
 // element (argmax, then the gathered pre-pool value); the generic row loop paid them row by row (16 rows per thread).  Here
 // RU rows go through the two phases together: all pooled-gradient / argmax loads, then all 4*RU gathers, then the sums.
-template <class T>
+// POOLED (float32 tensors, ps.pa given): the gathered pre-pool value is only needed for (a) the ReLU6 mask and (b) xhat -- and both
+// follow from the pooled activated output a = relu6(scale y + shift) the forward stored: 0 < a < 6 is the same decision as
+// 0 < scale y + shift < 6 (a IS that value, clamped), and where it holds y = (a - shift) / scale.  One dense 16-byte load per 4
+// channels instead of 4 scattered 4-byte gathers out of a tensor 4x the size (the kernel sits in the exposed tail of every pass:
+// 150 -> 60 us at B = 256).  Channels whose |scale| is below 0.05 (gamma ~ 0: the division would amplify the rounding of a) take
+// the gather path, thread by thread.
+template <class T, bool POOLED>
 __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, const T* __restrict__ y,
                                                                     const float* __restrict__ stats, int GC, int C, int Mg,
                                                                     int rb, double* __restrict__ part) {
@@ -865,6 +871,38 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
         const VecF<VEC> mean = vload<VEC>(stats + 0 * GC + g * C + c0), invstd = vload<VEC>(stats + 1 * GC + g * C + c0);
         const VecF<VEC> sc = vload<VEC>(stats + 2 * GC + g * C + c0), sh = vload<VEC>(stats + 3 * GC + g * C + c0);
         const int64_t gbase = (int64_t)g * Mg;
+        bool pooled = POOLED;
+        if (POOLED) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) pooled = pooled && fabsf(sc.v[i]) >= 0.05f;
+        }
+        if (POOLED && pooled) {
+            float isc[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) isc[i] = 1.0f / sc.v[i];
+            for (int rr = r0 + ty; rr < r1; rr += CY * RU) {
+                VecF<VEC> d[RU], a[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int64_t row = gbase + min(rr + u * CY, r1 - 1);          // clamped: unconditional loads
+                    d[u] = vload<VEC>(ps.dp + row * C + c0);
+                    a[u] = vload<VEC>(ps.pa + row * C + c0);
+                }
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    if (rr + u * CY >= r1) break;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        if (relu6_open(a[u].v[i])) {
+                            const float v = (a[u].v[i] - sh.v[i]) * isc[i];
+                            const float xh = (v - mean.v[i]) * invstd.v[i];
+                            acc[0][i] += (double)d[u].v[i];
+                            acc[1][i] += (double)d[u].v[i] * (double)xh;
+                        }
+                    }
+                }
+            }
+        } else
         for (int rr = r0 + ty; rr < r1; rr += CY * RU) {
             VecF<VEC> d[RU];
             uint32_t am[RU];
@@ -939,8 +977,10 @@ int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_
         if (fast && g.vec == 4 && g.nloop == 1) {
             dim3 grid(g.nb, G), block(g.cx, g.cy);
             const size_t smb = (size_t)g.cy * 4 * g.cx * sizeof(double);
-            if (at) hipLaunchKernelGGL(pool_bn_bwd_reduce_v4_kernel<bf16_t>, grid, block, smb, st, ps, reinterpret_cast<const bf16_t*>(y), stats, G * C, C, Mg, g.rb, part);
-            else hipLaunchKernelGGL(pool_bn_bwd_reduce_v4_kernel<float>, grid, block, smb, st, ps, y, stats, G * C, C, Mg, g.rb, part);
+            static const bool pooled_env = !(getenv("CDRL_POOLRED_POOLED") && atoi(getenv("CDRL_POOLRED_POOLED")) == 0);
+            if (at) hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<bf16_t, false>), grid, block, smb, st, ps, reinterpret_cast<const bf16_t*>(y), stats, G * C, C, Mg, g.rb, part);
+            else if (ps.pa && pooled_env) hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<float, true>), grid, block, smb, st, ps, y, stats, G * C, C, Mg, g.rb, part);
+            else hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<float, false>), grid, block, smb, st, ps, y, stats, G * C, C, Mg, g.rb, part);
             CDRL_LAUNCH_CHECK();
             return 0;
         }

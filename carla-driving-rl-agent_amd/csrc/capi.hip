@@ -579,10 +579,21 @@ int64_t cdrl_stem_block_bwd_workspace_doubles(int B, int T, int H, int W, int Co
 int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, int B, int T,
                         int H, int W, int Cout, float* dgamma, float* dbeta, float* coef, float* dw, float* db,
                         double* workspace, void* stream) {
+    return cdrl_stem_block_bwd_pooled(x, y, stats, argmax, dp, nullptr, B, T, H, W, Cout, dgamma, dbeta, coef, dw, db, workspace, stream);
+}
+
+int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp,
+                               const float* pooled, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta, float* coef,
+                               float* dw, float* db, double* workspace, void* stream) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
     hipStream_t st = S(stream);
-    const PoolSrc ps = make_pool_src(argmax, dp, Ho, Wo);
+    PoolSrc ps = make_pool_src(argmax, dp, Ho, Wo);
+    if (pooled && g_op_at) {
+        set_error("cdrl_stem_block_bwd_pooled: the pooled-output form is float32 only");
+        return -1;
+    }
+    ps.pa = pooled;
     static const bool one_pass = getenv("CDRL_STEM_DIRECT") && atoi(getenv("CDRL_STEM_DIRECT")) == 1;
     if (one_pass && stem_bwd_direct_supported(Cout))        // one pass: BN sums + filter sums together (stem_bwd.hip), opt-in
         return stem_bwd_direct(x, ps, y, stats, dgamma, dbeta, coef, dw, db, B, T, H, W, Cout, reinterpret_cast<float*>(workspace), st);

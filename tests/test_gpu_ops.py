@@ -467,6 +467,15 @@ def test_stem_block_bwd(lib, B, T, H, W):
     assert rel_err(dbt.cpu().numpy(), p['b.beta'].grad.numpy()) < 2e-5
     assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < 3e-5
     assert np.abs(db.cpu().numpy()).max() < 1e-4 * np.abs(dw.cpu().numpy()).max()
+    # the pooled-output form (mask and xhat from the pooled activated output instead of the argmax gather: what the float32 engine runs)
+    dg2, dbt2, coef2 = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(3 * T * Cc, device=DEV)
+    dw2, db2 = torch.zeros((3, 3, 3, Cc), device=DEV), torch.zeros(Cc, device=DEV)
+    _lib.check(lib.cdrl_stem_block_bwd_pooled(P(X), P(y), P(stats), P(am), P(DP), P(pool), B, T, H, W, Cc, P(dg2), P(dbt2), P(coef2), P(dw2),
+                                              P(db2), P(ws), S()))
+    assert rel_err(dg2.cpu().numpy(), p['b.gamma'].grad.numpy()) < 2e-5
+    assert rel_err(dbt2.cpu().numpy(), p['b.beta'].grad.numpy()) < 2e-5
+    assert rel_err(dw2.cpu().numpy(), wt.grad.numpy()) < 3e-5
+    assert torch.equal(dbt, dbt2)                                       # sum dz: same decisions, same addends
 
 
 @pytest.mark.parametrize('M,Cc', [(256, 512), (256, 320), (37, 352), (1024, 16), (5, 3)])
