@@ -846,7 +846,7 @@ struct PoolBnReduceF {
 // Fast path of pool_bn_bwd_reduce (4 channels per thread): the scatter-form sums need two DEPENDENT round trips per pooled
 // element (argmax, then the gathered pre-pool value); the generic row loop paid them row by row (16 rows per thread).  Here
 // RU rows go through the two phases together: all pooled-gradient / argmax loads, then all 4*RU gathers, then the sums.
-// POOLED (float32 tensors, ps.pa given): the gathered pre-pool value is only needed for (a) the ReLU6 mask and (b) xhat -- and both
+// POOLED (ps.pa given): the gathered pre-pool value is only needed for (a) the ReLU6 mask and (b) xhat -- and both
 // follow from the pooled activated output a = relu6(scale y + shift) the forward stored: 0 < a < 6 is the same decision as
 // 0 < scale y + shift < 6 (a IS that value, clamped), and where it holds y = (a - shift) / scale.  One dense 16-byte load per 4
 // channels instead of 4 scattered 4-byte gathers out of a tensor 4x the size (the kernel sits in the exposed tail of every pass:
@@ -885,8 +885,8 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
                     const int64_t row = gbase + min(rr + u * CY, r1 - 1);          // clamped: unconditional loads
-                    d[u] = vload<VEC>(ps.dp + row * C + c0);
-                    a[u] = vload<VEC>(ps.pa + row * C + c0);
+                    d[u] = vload<VEC>(reinterpret_cast<const T*>(ps.dp) + row * C + c0);
+                    a[u] = vload<VEC>(reinterpret_cast<const T*>(ps.pa) + row * C + c0);
                 }
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
@@ -978,7 +978,8 @@ int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_
             dim3 grid(g.nb, G), block(g.cx, g.cy);
             const size_t smb = (size_t)g.cy * 4 * g.cx * sizeof(double);
             static const bool pooled_env = !(getenv("CDRL_POOLRED_POOLED") && atoi(getenv("CDRL_POOLRED_POOLED")) == 0);
-            if (at) hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<bf16_t, false>), grid, block, smb, st, ps, reinterpret_cast<const bf16_t*>(y), stats, G * C, C, Mg, g.rb, part);
+            if (at && ps.pa && pooled_env) hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<bf16_t, true>), grid, block, smb, st, ps, reinterpret_cast<const bf16_t*>(y), stats, G * C, C, Mg, g.rb, part);
+            else if (at) hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<bf16_t, false>), grid, block, smb, st, ps, reinterpret_cast<const bf16_t*>(y), stats, G * C, C, Mg, g.rb, part);
             else if (ps.pa && pooled_env) hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<float, true>), grid, block, smb, st, ps, y, stats, G * C, C, Mg, g.rb, part);
             else hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<float, false>), grid, block, smb, st, ps, y, stats, G * C, C, Mg, g.rb, part);
             CDRL_LAUNCH_CHECK();

@@ -589,10 +589,6 @@ int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stat
     const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
     hipStream_t st = S(stream);
     PoolSrc ps = make_pool_src(argmax, dp, Ho, Wo);
-    if (pooled && g_op_at) {
-        set_error("cdrl_stem_block_bwd_pooled: the pooled-output form is float32 only");
-        return -1;
-    }
     ps.pa = pooled;
     static const bool one_pass = getenv("CDRL_STEM_DIRECT") && atoi(getenv("CDRL_STEM_DIRECT")) == 1;
     if (one_pass && stem_bwd_direct_supported(Cout))        // one pass: BN sums + filter sums together (stem_bwd.hip), opt-in

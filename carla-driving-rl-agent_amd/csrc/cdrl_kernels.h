@@ -41,7 +41,7 @@ struct PoolSrc {
     const uint8_t* argmax;   // [N][Ho][Wo][C]
     const float* dp;         // [N][Ho][Wo][C]
     int H, W, Ho, Wo, pt, pl;
-    const float* pa = nullptr;   // optional (float32 tensors only): the pooled ACTIVATED output [N][Ho][Wo][C] of the forward; lets
+    const float* pa = nullptr;   // optional: the pooled ACTIVATED output [N][Ho][Wo][C] of the forward; lets
                                  // pool_bn_bwd_reduce skip the gather of the pre-pool values (see there)
 };
 // Backward: reduce (sum dz, sum dz*xhat) -> part [G][nb][2][C]

@@ -981,7 +981,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 if (stem_direct)
                     return stem_bwd_direct(in_image_, ps, y.p, stats, gamma.g, beta.g, coef, w.g, b.g, B, T, H, W, C, stem_ws, st);
                 if (stem_fused) {       // sums in scatter form over the pooled gradient; the apply happens inside the stem filter-gradient GEMM
-                    if (!at) ps.pa = pool.p;        // (float32: mask and xhat from the pooled activated output, no gather)
+                    ps.pa = pool.p;                 // mask and xhat from the pooled activated output, no gather (bf16 storage: xhat from the ROUNDED pooled value)
                     CDRL_TRY(pool_bn_bwd_reduce(ps, y.p, G, B, C, stats, scr_main_.part, st, at));
                     return bn_bwd_finalize(scr_main_.part, nb_pool, G, Mg, C, stats, gamma.g, beta.g, coef, st);
                 }

@@ -393,9 +393,10 @@ int64_t cdrl_stem_block_bwd_workspace_doubles(int B, int T, int H, int W, int Co
 int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, int B, int T,
                         int H, int W, int Cout, float* dgamma, float* dbeta, float* coef, float* dw, float* db,
                         double* workspace, void* stream);
-/* Same, with the pooled ACTIVATED output `pooled` of cdrl_maxpool_bn_fwd (float32 tensors only; null = the form above): the
+/* Same, with the pooled ACTIVATED output `pooled` of cdrl_maxpool_bn_fwd (null = the form above; element type as y / dp): the
  * BatchNorm sums then take the ReLU6 decision and xhat from it instead of gathering the pre-pool value through the argmax (a dense
- * read of a tensor a quarter the size; what the engine does in float32).  Channels with |gamma * invstd| < 0.05 keep the gather. */
+ * read of a tensor a quarter the size; what the engine does).  Channels with |gamma * invstd| < 0.05 keep the gather.  With bf16
+ * storage xhat comes from the ROUNDED pooled value: bf16-level agreement with the gather form, not bit-wise. */
 int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp,
                                const float* pooled, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta, float* coef,
                                float* dw, float* db, double* workspace, void* stream);
