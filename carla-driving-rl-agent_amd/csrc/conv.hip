@@ -254,7 +254,11 @@ struct StemBwdF {
 // 32x32 accumulator; the 4 accumulators are summed through LDS at the end and written as one
 // float partial per workgroup (deterministic two-stage reduction, no atomics).
 typedef float f32x16_c __attribute__((ext_vector_type(16)));
-#define STEM_NBLK 1024
+#define STEM_NBLK_MAX 2048                          // capacity of the partial buffer
+static int stem_nblk() {
+    static const int n = getenv("CDRL_STEM_NBLK") ? atoi(getenv("CDRL_STEM_NBLK")) : 1024;
+    return n < 64 ? 64 : (n > STEM_NBLK_MAX ? STEM_NBLK_MAX : n);
+}
 
 // FUSED: dy is not read but computed on the fly, dy = k1*(dz - k2 - xhat*k3) with dz gathered from the pooled gradient
 // through the max-pool argmax (pool_gather) and masked by ReLU6: the stem BatchNorm's backward "apply" and the 255 MB
@@ -456,7 +460,7 @@ __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restr
 
 int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    if (Cout <= 32) return ((int64_t)STEM_NBLK * 28 * Cout + 1) / 2;      // float partials inside a double buffer
+    if (Cout <= 32) return ((int64_t)STEM_NBLK_MAX * 28 * Cout + 1) / 2;      // float partials inside a double buffer
     ColGeom g = col_geom(B * T * Ho * Wo, Cout, NB_FILTER);
     return (int64_t)g.nb * 28 * Cout;
 }
@@ -467,7 +471,7 @@ int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B
     const int rows = B * T * Ho * Wo;
     if (Cout <= 32) {
         float* pf = reinterpret_cast<float*>(part);
-        int rows_per = cdiv(cdiv(rows, STEM_NBLK), 128) * 128;
+        int rows_per = cdiv(cdiv(rows, stem_nblk()), 128) * 128;
         const int nblk = cdiv(rows, rows_per);
         hipLaunchKernelGGL((stem_bwd_mfma_kernel<false, 1>), dim3(nblk), dim3(256), 0, st, x, dy, pf, B, T, H, W, Ho, Wo, Cout, rows,
                            rows_per, StemBnBwd{});
@@ -498,7 +502,7 @@ int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, con
         return -1;
     }
     float* pf = reinterpret_cast<float*>(part);
-    int rows_per = cdiv(cdiv(rows, STEM_NBLK), 128) * 128;
+    int rows_per = cdiv(cdiv(rows, stem_nblk()), 128) * 128;
     const int nblk = cdiv(rows, rows_per);
     StemBnBwd bb{ps, y, stats, coef};
     const bool n3 = ((Cout >> 2) + 1) / 2 <= 3;
