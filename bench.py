@@ -400,6 +400,12 @@ def main():
     from carla_driving_rl_agent_amd.engine import LearnerEngine, gae_returns
     from carla_driving_rl_agent_amd.parallel import DataParallelLearner
 
+    from carla_driving_rl_agent_amd import _lib as _cdrl_lib
+    # diagnostic switches that skip work or synchronisation (CDRL_DIAG_*, honoured only with CDRL_DIAG=1) give wrong results:
+    # a benchmark line measured under one is refused, and every CDRL_* override in effect is written into the line
+    if _cdrl_lib.diag_active():
+        raise SystemExit(f'[bench] refusing to benchmark: wrong-result diagnostic switches are active ({_cdrl_lib.env_overrides()})')
+    env_overrides = _cdrl_lib.env_overrides()
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -515,7 +521,7 @@ def main():
                                policy_loss='stored-actions' if args.stored_actions else 'resampled (reference-faithful)'),
                    roofline=roof, mfma=pmc_mfma(ms_per_step), dominant_kernel=dominant_kernel(B, T, H, W), kernel_rooflines=kernel_rooflines(B, T) if (world == 1 and not args.no_kernel_rooflines) else None, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3),
                    device_ms_per_step_blocks=dict(blocks=[round(x, 3) for x in block_ms], min=round(min(block_ms), 3), median=round(sorted(block_ms)[len(block_ms) // 2], 3)),
-                   host_enqueue_ms_per_step=round(host_ms, 3),
+                   host_enqueue_ms_per_step=round(host_ms, 3), env_overrides=env_overrides,
                    final_losses=dict(policy=loss_p, value=loss_v))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = run_cpu_baseline_child(args.cpu_sample_batch, T, H, W, args.cpu_threads)

@@ -57,6 +57,8 @@ _L = C.c_void_p
 PROTOTYPES = {
     'cdrl_last_error': (C.c_char_p, []),
     'cdrl_version': (_i, []),
+    'cdrl_env_overrides': (_i, [C.c_char_p, _i]),
+    'cdrl_diag_active': (_i, []),
     'cdrl_crc32c': (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     'cdrl_config_default': (None, [C.POINTER(Config)]),
     'cdrl_learner_create': (_i, [C.POINTER(Config), C.POINTER(_L)]),
@@ -172,6 +174,18 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def env_overrides():
+    """Every CDRL_* variable of the process environment as the LIBRARY sees it (cdrl_env_overrides), e.g. for a benchmark line."""
+    buf = C.create_string_buffer(8192)
+    n = load().cdrl_env_overrides(buf, len(buf))
+    return buf.value.decode().split(' ') if n else []
+
+
+def diag_active() -> int:
+    """Number of wrong-result diagnostic switches (CDRL_DIAG_* with the master CDRL_DIAG=1) in effect."""
+    return int(load().cdrl_diag_active())
 
 
 def check(rc, what=''):

@@ -11,7 +11,9 @@ import warnings
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
+from ..parallel import DataParallelLearner
 from ..rl import utils, spaces
 from ..rl.agents.ppo import PPOAgent, PPOMemory
 from ..rl.parameters import DynamicParameter
@@ -124,6 +126,73 @@ class CARLAgent(PPOAgent):
         self._augmenter = None
         self._aug_rng = np.random.default_rng(self.seed)
         self._aug_calls = 0
+        self._init_data_parallel()
+
+    # -- data parallelism (reference loop rl/agents/ppo.py:190-226 inside :464-548) ------------------------------
+    def _init_data_parallel(self):
+        """One CARLAgent per GPU under torch.distributed: every rank rolls out ITS OWN environment shard (environment and
+        rollout-sampler seeds offset by the rank), computes returns / GAE locally (per-episode quantities), runs the same
+        number of minibatch steps on its shard with gradients pre-scaled by 1 / world, and the gradient arenas are SUM-
+        all-reduced before the identical clip + Adam update (DataParallelLearner).  Parameters are broadcast from rank 0 here
+        and after load(); BatchNorm moving statistics are averaged once per update().  Without an initialised process group
+        (or at world size 1) nothing changes; CDRL_FORCE_COLLECTIVES=1 runs the collectives at world size 1 as well."""
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if on else 1
+        self.rank = dist.get_rank() if on else 0
+        force = on and os.environ.get('CDRL_FORCE_COLLECTIVES') == '1'
+        self.data_parallel = self.world > 1 or force
+        self._dp = {}
+        self._dp_force = force
+        if not self.data_parallel:
+            return
+        self._dp_for(self.network.engine).broadcast_parameters()
+        if self.rank:
+            # rank-disjoint environment shard and action-sampling stream; weights stay identical (same init seed + broadcast)
+            if self.seed is not None:
+                self.env.seed(self.seed + self.rank)
+            self._aug_rng = np.random.default_rng((self.seed or 0) + 7919 * self.rank)
+        self.network.sample_rank, self.network.sample_stride = self.rank, self.world
+
+    def _dp_for(self, eng) -> DataParallelLearner:
+        """The DataParallelLearner of an engine (the main one, or a ragged-minibatch engine over the same arenas)."""
+        dp = self._dp.get(id(eng))
+        if dp is None:
+            dp = self._dp[id(eng)] = DataParallelLearner(eng, force_collectives=self._dp_force)
+        return dp
+
+    def _all_reduce_ints(self, values, op):
+        dev = self.device if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor(list(values), dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=op)
+        return [int(x) for x in t.tolist()]
+
+    def agree_on_batches(self, policy_batches, value_batches):
+        if not self.data_parallel:
+            return policy_batches, value_batches
+        # every minibatch step is a collective: all ranks run the minimum count (episodes that ended early on one rank drop
+        # the surplus minibatches of the others for this update) -- and the ragged last minibatch only if all ranks have it
+        def rows(b):
+            t = b[1]
+            return int(t.shape[0])
+        sig = [len(policy_batches), len(value_batches),
+               rows(policy_batches[-1]) if policy_batches else 0, rows(value_batches[-1]) if value_batches else 0]
+        lo = self._all_reduce_ints(sig, dist.ReduceOp.MIN)
+        hi = self._all_reduce_ints(sig, dist.ReduceOp.MAX)
+        policy_batches, value_batches = policy_batches[:lo[0]], value_batches[:lo[1]]
+        if policy_batches and (lo[0] != hi[0] or lo[2] != hi[2]) and rows(policy_batches[-1]) != self.batch_size:
+            policy_batches = policy_batches[:-1]
+        if value_batches and (lo[1] != hi[1] or lo[3] != hi[3]) and rows(value_batches[-1]) != self.batch_size:
+            value_batches = value_batches[:-1]
+        return policy_batches, value_batches
+
+    def after_update(self):
+        if self.data_parallel:
+            self._dp_for(self.network.engine).sync_moving_statistics()
+
+    def load(self):
+        super().load()
+        if self.data_parallel:
+            self._dp_for(self.network.engine).broadcast_parameters()
 
     def hyper_parameters(self) -> dict:
         hp = super().hyper_parameters()
@@ -132,7 +201,10 @@ class CARLAgent(PPOAgent):
 
     # -- update -----------------------------------------------------------------------------------
     def update(self):
-        if len(self.memory) < self.batch_size:
+        small = len(self.memory) < self.batch_size
+        if self.data_parallel:      # a collective decision: one rank skipping alone would leave the others in an all-reduce
+            small = bool(self._all_reduce_ints([int(small)], dist.ReduceOp.MAX)[0])
+        if small:
             print('[Not updated] memory too small!')
             self.env.reset_info()
             return
@@ -164,13 +236,16 @@ class CARLAgent(PPOAgent):
                  advantages=advantages, old_log_prob=log_probabilities, speed=speed, similarity=similarity, u=actions)
         b = eng.stage(b, 'policy')           # fixed addresses -> the captured hipGraph of the step is replayed
         b.update(du_da=None, du_db=None)
+        scale = 1.0 / self.world
         if self.resample_actions:
-            # Beta(alpha, beta) of the NEW policy is sampled on the device with pathwise Jacobians
+            # Beta(alpha, beta) of the NEW policy is sampled on the device with pathwise Jacobians (rank-disjoint Philox offsets)
             self._sample_offset += 1
             eng.policy_forward_backward_resample(b, seed=self.seed if self.seed is not None else 0,
-                                                 offset=self._sample_offset)
+                                                 offset=self._sample_offset * self.world + self.rank, grad_scale=scale)
         else:
-            eng.policy_forward_backward(b)
+            eng.policy_forward_backward(b, grad_scale=scale)
+        if self.data_parallel:
+            self._dp_for(eng).reduce_policy_gradients()
         return eng.buffer(2)[0].clone(), 'policy'  # device scalar (copy of CDRL_BUF_METRICS_P[0]); gradients stay in the arena
 
     def apply_policy_gradients(self, gradients):
@@ -182,7 +257,9 @@ class CARLAgent(PPOAgent):
         eng = self._step_engine = self.network.engine_for(returns.shape[0])
         b = dict(states={k: states[k] for k in ('state_image', 'state_road', 'state_vehicle', 'state_navigation')},
                  returns=returns, speed=speed, similarity=similarity)
-        eng.value_forward_backward(eng.stage(b, 'value'))
+        eng.value_forward_backward(eng.stage(b, 'value'), grad_scale=1.0 / self.world)
+        if self.data_parallel:
+            self._dp_for(eng).reduce_value_gradients()
         return eng.buffer(3)[0].clone(), 'value'
 
     def apply_value_gradients(self, gradients):

@@ -92,6 +92,7 @@ class CARLANetwork(Network):
         self.last_value = torch.zeros((1, 2), dtype=torch.float32, device=self.device)   # (base, exp) at terminal states
         self.action_index = 0              # Philox offset of the rollout sampler: one stream per predict() call
         self.sample_seed = (agent.seed if agent.seed is not None else 0) + 0x5eed
+        self.sample_rank, self.sample_stride = 0, 1      # data-parallel agents: rank-disjoint Philox offsets (CARLAgent._init_data_parallel)
         self.update_dynamics = update_dynamics
 
     def rollout_for(self, envs: int) -> LearnerEngine:
@@ -134,7 +135,7 @@ class CARLANetwork(Network):
         self.action_index += 1
         alpha, beta = out['alpha'], out['beta']              # views of the persistent (E, 4, A) block: row stride 4A
         _lib.check(self.engine.lib.cdrl_beta_sample_logp(_lib.ptr(alpha), _lib.ptr(beta), E, A, 4 * A, int(self.sample_seed),
-                                                         int(self.action_index), _lib.ptr(action), _lib.ptr(log_prob),
+                                                         int(self.action_index * self.sample_stride + self.sample_rank), _lib.ptr(action), _lib.ptr(log_prob),
                                                          self.engine._stream()), 'cdrl_beta_sample_logp')
         return action, out['mean'].clone(), out['std'].clone(), log_prob, out['value'].clone()
 

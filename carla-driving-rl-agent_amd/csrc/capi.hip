@@ -37,6 +37,8 @@ int cdrl_set_op_activation_type(int at) {
 
 const char* cdrl_last_error(void) { return cdrl::last_error(); }
 int cdrl_version(void) { return CDRL_VERSION; }
+int cdrl_env_overrides(char* buf, int cap) { return cdrl::env_overrides(buf, cap); }
+int cdrl_diag_active(void) { return cdrl::diag_active(); }
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8 on the host: checksums of the TF-checkpoint-V2
 // writer (tf_checkpoint.py): every SSTable block and every tensor entry carries one
@@ -113,6 +115,12 @@ int cdrl_learner_create(const cdrl_config* c, cdrl_learner** out) {
         return -1;
     }
     d.compute = c->compute;
+    if (cdrl::diag_active()) {      // loud, every time: results of this learner are WRONG by request (timing diagnostics)
+        char ov[2048];
+        cdrl::env_overrides(ov, (int)sizeof(ov));
+        fprintf(stderr, "[cdrl] WARNING: CDRL_DIAG=1 with %d wrong-result diagnostic switch(es) active -- environment: %s\n",
+                cdrl::diag_active(), ov);
+    }
     cdrl_learner* l = new (std::nothrow) cdrl_learner;
     if (!l) return -3;
     l->impl = new (std::nothrow) Learner(d);
@@ -590,7 +598,7 @@ int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stat
     hipStream_t st = S(stream);
     PoolSrc ps = make_pool_src(argmax, dp, Ho, Wo);
     ps.pa = pooled;
-    static const bool one_pass = getenv("CDRL_STEM_DIRECT") && atoi(getenv("CDRL_STEM_DIRECT")) == 1;
+    static const bool one_pass = cdrl_getenv("CDRL_STEM_DIRECT") && atoi(cdrl_getenv("CDRL_STEM_DIRECT")) == 1;
     if (one_pass && stem_bwd_direct_supported(Cout))        // one pass: BN sums + filter sums together (stem_bwd.hip), opt-in
         return stem_bwd_direct(x, ps, y, stats, dgamma, dbeta, coef, dw, db, B, T, H, W, Cout, reinterpret_cast<float*>(workspace), st);
     const int nb = vcol_geom(B * Hp * Wp, Cout).nb;

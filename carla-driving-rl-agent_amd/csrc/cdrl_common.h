@@ -37,6 +37,10 @@ __host__ __device__ inline int shuffle_dst(int i, int ctot) { return (i & 1) * (
 
 void set_error(const char* fmt, ...);
 const char* last_error();
+// getenv for the library's CDRL_* switches: CDRL_DIAG_* (wrong-result timing diagnostics) only with the master CDRL_DIAG=1
+const char* cdrl_getenv(const char* name);
+int diag_active();                          // number of active CDRL_DIAG_* switches (0 unless CDRL_DIAG=1)
+int env_overrides(char* buf, int cap);      // "NAME=VALUE ..." of every CDRL_* variable in the environment; returns their count
 
 #define CDRL_HIP(expr)                                                                         \
     do {                                                                                       \

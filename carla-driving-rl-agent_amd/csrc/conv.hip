@@ -198,7 +198,7 @@ int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, 
     size_t lds = (size_t)(27 * Cout + Cout) * sizeof(float);
     const size_t red = (size_t)8 * cy * cx * sizeof(double);
     if (lds < red) lds = red;
-    static const int np = getenv("CDRL_STEM_NP") ? atoi(getenv("CDRL_STEM_NP")) : 4;
+    static const int np = cdrl_getenv("CDRL_STEM_NP") ? atoi(cdrl_getenv("CDRL_STEM_NP")) : 4;
     if (at) hipLaunchKernelGGL((stem_fwd_stats_kernel<4, bf16_t>), dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, reinterpret_cast<bf16_t*>(y), part, B, T, H, W, Ho, Wo, Cout, rb);
     else if (np >= 4) hipLaunchKernelGGL((stem_fwd_stats_kernel<4, float>), dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
     else if (np >= 2) hipLaunchKernelGGL((stem_fwd_stats_kernel<2, float>), dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
@@ -256,7 +256,7 @@ struct StemBwdF {
 typedef float f32x16_c __attribute__((ext_vector_type(16)));
 #define STEM_NBLK_MAX 2048                          // capacity of the partial buffer
 static int stem_nblk() {
-    static const int n = getenv("CDRL_STEM_NBLK") ? atoi(getenv("CDRL_STEM_NBLK")) : 1024;
+    static const int n = cdrl_getenv("CDRL_STEM_NBLK") ? atoi(cdrl_getenv("CDRL_STEM_NBLK")) : 1024;
     return n < 64 ? 64 : (n > STEM_NBLK_MAX ? STEM_NBLK_MAX : n);
 }
 

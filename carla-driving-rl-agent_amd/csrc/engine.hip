@@ -172,7 +172,7 @@ int Learner::launch(hipStream_t caller, std::vector<uint64_t> key, bool graphabl
     return 0;
 }
 
-static const int g_diag_noev = getenv("CDRL_DIAG_NOEV") ? atoi(getenv("CDRL_DIAG_NOEV")) : 0;   // timing diagnostics only (racy)
+static const int g_diag_noev = cdrl_getenv("CDRL_DIAG_NOEV") ? atoi(cdrl_getenv("CDRL_DIAG_NOEV")) : 0;   // timing diagnostics only (racy)
 
 int Learner::next_slot(hipStream_t st) {
     slot_ = (slot_ + 1) % NSLOT;
@@ -203,7 +203,7 @@ void Learner::flush_deferred() {
 }
 
 int Learner::defer_side(hipStream_t st, std::function<int(hipStream_t)> fn) {
-    static const bool on = !(getenv("CDRL_DEFER_SIDE") && atoi(getenv("CDRL_DEFER_SIDE")) == 0);
+    static const bool on = !(cdrl_getenv("CDRL_DEFER_SIDE") && atoi(cdrl_getenv("CDRL_DEFER_SIDE")) == 0);
     if (!side_enabled_ || !on || (g_diag_noev & 2)) {
         hipStream_t side = fork_side(st);
         CDRL_TRY(fn(side));
@@ -434,7 +434,7 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     if (inf_batched) note_bn_inference(gamma.p, beta.p, mm.p, mv.p, stats, G, C);
     // single-group BatchNorm over a few hundred rows (dense BNs of the trunk tail and the control branches): one launch per
     // direction instead of three
-    static const bool small_env = !(getenv("CDRL_BN_SMALL") && atoi(getenv("CDRL_BN_SMALL")) == 0);
+    static const bool small_env = !(cdrl_getenv("CDRL_BN_SMALL") && atoi(cdrl_getenv("CDRL_BN_SMALL")) == 0);
     const bool small = small_env && G == 1 && Mg <= 2048 && !bessel && act == ACT_NONE && !out_shuffle && !dout_shuffle && dx &&
                        !stats_nb && !defer_apply && !pass.fsrc.p && !pass.gsrc.p && !pass.gap_out;
     const bool gap = pass.gap_out != nullptr;
@@ -483,8 +483,8 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     PRef w = param(M_TRUNK, prefix + ".w", {1, 1, Cin, Cout}, true);
     PRef b = param(M_TRUNK, prefix + ".b", {Cout}, true);
     const int G = cfg_.T, Mg = rows / G;
-    static const bool pack_env = !(getenv("CDRL_PW_PACK") && atoi(getenv("CDRL_PW_PACK")) == 0);
-    static const bool wt_env = !(getenv("CDRL_PW_WT") && atoi(getenv("CDRL_PW_WT")) == 0);
+    static const bool pack_env = !(cdrl_getenv("CDRL_PW_PACK") && atoi(cdrl_getenv("CDRL_PW_PACK")) == 0);
+    static const bool wt_env = !(cdrl_getenv("CDRL_PW_WT") && atoi(cdrl_getenv("CDRL_PW_WT")) == 0);
     const float* wt = (wt_env && !pack_env && fuse.bwd_pw) ? pw_transposed(prefix, w.p, Cin, Cout) : nullptr;
     const float* wb = wt ? wt : w.p;                    // backward-data operand B(k = cout, n = cin)
     const int wb_sk = wt ? Cin : 1, wb_sn = wt ? 1 : Cout;
@@ -494,7 +494,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     const bool bfc = cfg_.compute >= 1;
     const int at = at_;
     // forward on the bf16 matrix pipe (exact three-way operand split, gemm_pw_x3.hip) where the shape allows it
-    static const bool x3_env = !(getenv("CDRL_PW_X3") && atoi(getenv("CDRL_PW_X3")) == 0);
+    static const bool x3_env = !(cdrl_getenv("CDRL_PW_X3") && atoi(cdrl_getenv("CDRL_PW_X3")) == 0);
     const void* w3f = (!bfc && x3_env && fuse.fwd_pw && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
     const int nb_fwd = pw_nn_plan(G, Mg, Cout, Cin).nbpg;
     // plain (unfused) wide convs -- the 464 -> 768 head conv, the 232-wide shortcut conv -- on the bf16 matrix pipe too (gemm_x3.hip)
@@ -568,7 +568,7 @@ void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, i
     PRef b = param(M_TRUNK, prefix + ".b", {C}, true);
     const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
     note_scratch(0, 0, (size_t)N * Ho * Wo * C, 0, (size_t)dw_bwd_part_elems(N, H, W, C, stride));
-    static const bool fuse_env = !(getenv("CDRL_FUSE_BNRED") && atoi(getenv("CDRL_FUSE_BNRED")) == 0);
+    static const bool fuse_env = !(cdrl_getenv("CDRL_FUSE_BNRED") && atoi(cdrl_getenv("CDRL_FUSE_BNRED")) == 0);
     const bool fuse = fuse_env && pre_bn && pre_bn->y && din_acc == 0 && pre_bn->C == C && pre_bn->Mg * pre_bn->G == N * H * W;
     BnRec pre;
     if (fuse) {
@@ -806,7 +806,7 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
 // gradient of the concat exists and run under the tower's backward.
 void Learner::add_aux_fork(std::vector<Op>& ops) {
     Op op;
-    static const int diag_skip_aux = getenv("CDRL_DIAG_SKIP_AUX") ? atoi(getenv("CDRL_DIAG_SKIP_AUX")) : 0;     // timing diagnostics only (wrong results)
+    static const int diag_skip_aux = cdrl_getenv("CDRL_DIAG_SKIP_AUX") ? atoi(cdrl_getenv("CDRL_DIAG_SKIP_AUX")) : 0;     // timing diagnostics only (wrong results)
     op.fwd = [=](hipStream_t st, int training) -> int {
         if (diag_skip_aux & 1) return 0;
         if (!side_enabled_) return run_fwd(aux_ops_, st, training);
@@ -840,7 +840,7 @@ void Learner::add_aux_join(std::vector<Op>& ops) {
         }
         return 0;
     };
-    static const int diag_skip_aux = getenv("CDRL_DIAG_SKIP_AUX") ? atoi(getenv("CDRL_DIAG_SKIP_AUX")) : 0;     // timing diagnostics only (wrong results)
+    static const int diag_skip_aux = cdrl_getenv("CDRL_DIAG_SKIP_AUX") ? atoi(cdrl_getenv("CDRL_DIAG_SKIP_AUX")) : 0;     // timing diagnostics only (wrong results)
     op.bwd = [=](hipStream_t st) -> int {
         if (diag_skip_aux & 2) return 0;
         if (!side_enabled_) return run_bwd(aux_ops_, st);
@@ -885,14 +885,14 @@ void Learner::build_trunk(std::vector<Op>& ops) {
     aux_ops_.clear();
     add_aux_fork(ops);
     {
-        const char* e = getenv("CDRL_FUSED_DW");        // 0 -> unfused bn-apply / depthwise / stats kernels
+        const char* e = cdrl_getenv("CDRL_FUSED_DW");        // 0 -> unfused bn-apply / depthwise / stats kernels
         fused_dw_ = !(e && atoi(e) == 0);
-        const char* e2 = getenv("CDRL_FUSED_PW");       // 0 -> generic tiled GEMM + separate BN passes around the 1x1 convs
+        const char* e2 = cdrl_getenv("CDRL_FUSED_PW");       // 0 -> generic tiled GEMM + separate BN passes around the 1x1 convs
         fused_pw_ = !(e2 && atoi(e2) == 0);
         fused_pw_wide_ = !(e2 && atoi(e2) == 1);        // K, N = 232 (stage-2 units) on the fused path too; 1 -> narrow layers only
         // BN-backward apply as GEMM operand prologue: bit 0 -> for the unit's first 1x1 conv (bn1), bit 1 -> for the second
         // (bn3, gathered through the shuffle map); 0 -> separate apply passes with a materialised dy
-        const char* e3 = getenv("CDRL_FUSED_BB");
+        const char* e3 = cdrl_getenv("CDRL_FUSED_BB");
         // measured at v19: 1 -> 25.5, 0 -> 25.8, 3 -> 26.0, 2 -> 26.2 ms/update-step; re-measured at v29 (buffer-load filter
         // gradient: the shuffle gather costs nothing there any more): 3 -> 20.66, 1 -> 20.80, 0 -> 21.0, 2 -> 21.3, and with
         // the wide fused pointwise path 3 -> 20.21.  Bit 2: also for the first unit's conv with 24 input channels -- slower before
@@ -911,7 +911,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         Op op;
         const int H = c.H, W = c.W, Cs = c.stem;
         // forward: BN statistics in the conv's epilogue (training only; inference uses the moving statistics)
-        const bool stem_fstats = stem_fwd_stats_supported(Cs) && !(getenv("CDRL_FUSED_STEM") && atoi(getenv("CDRL_FUSED_STEM")) == 0);
+        const bool stem_fstats = stem_fwd_stats_supported(Cs) && !(cdrl_getenv("CDRL_FUSED_STEM") && atoi(cdrl_getenv("CDRL_FUSED_STEM")) == 0);
         const int nb_stem = stem_fstats ? stem_fwd_stats_nb(B, H, W) : 0;
         if (at && !stem_fstats) build_fail("bf16 activation storage needs the fused stem forward (stem channels %d, CDRL_FUSED_STEM)", Cs);
         op.fwd = [=](hipStream_t st, int training) -> int {
@@ -919,7 +919,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             if (stem_fstats && (training || at)) return stem_fwd_stats(in_image_, w.p, b.p, y.p, scr_main_.part, B, T, H, W, Cs, st, at);
             return stem_fwd(in_image_, w.p, b.p, y.p, B, T, H, W, Cs, st);
         };
-        const bool stem_fused = stem_bwd_fused_supported(Cs) && !(getenv("CDRL_FUSED_STEM") && atoi(getenv("CDRL_FUSED_STEM")) == 0);
+        const bool stem_fused = stem_bwd_fused_supported(Cs) && !(cdrl_getenv("CDRL_FUSED_STEM") && atoi(cdrl_getenv("CDRL_FUSED_STEM")) == 0);
         // blocks of the stem BatchNorm (allocated here: the stem conv's backward consumes them in the fused form)
         float* stem_stats = alloc((size_t)4 * T * Cs);
         float* stem_coef = alloc((size_t)3 * T * Cs);
@@ -934,7 +934,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         // (CDRL_STEM_DIRECT=1): measured 747 us (three accumulator tiles, 64 KB LDS -> two workgroups per CU) against
         // 206 + 453 us for the two-pass form whose second pass overlaps on the side stream: 22.3 vs 22.0 ms/update-step.
         const bool stem_direct = !at && stem_fused && stem_bwd_direct_supported(Cs) &&
-                                 (getenv("CDRL_STEM_DIRECT") && atoi(getenv("CDRL_STEM_DIRECT")) == 1);
+                                 (cdrl_getenv("CDRL_STEM_DIRECT") && atoi(cdrl_getenv("CDRL_STEM_DIRECT")) == 1);
         float* stem_ws = stem_direct ? alloc((size_t)stem_bwd_direct_ws_floats(B, T, H, W)) : nullptr;
         op.bwd = [=](hipStream_t st) -> int {
             if (stem_direct) return 0;
@@ -1011,7 +1011,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 Tens out = tens_a(rows_out, C);
                 // stride-2 units: the shortcut branch (dw3x3/s2 -> BN -> 1x1 -> BN+ReLU6) only depends on the unit input; in the
                 // FORWARD pass (where the side stream is idle) it runs on the side stream next to the main branch
-                static const bool sc_overlap_env = !(getenv("CDRL_SC_OVERLAP") && atoi(getenv("CDRL_SC_OVERLAP")) == 0);
+                static const bool sc_overlap_env = !(cdrl_getenv("CDRL_SC_OVERLAP") && atoi(cdrl_getenv("CDRL_SC_OVERLAP")) == 0);
                 const bool sc_overlap = sc_overlap_env && stride == 2;
                 const int sc_ev = s;
                 if (sc_overlap) {
@@ -1026,7 +1026,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     ops.push_back(fk);
                 }
                 Passthrough pass;
-                static const bool fuse_pass = !(getenv("CDRL_FUSED_PASS") && atoi(getenv("CDRL_FUSED_PASS")) == 0);
+                static const bool fuse_pass = !(cdrl_getenv("CDRL_FUSED_PASS") && atoi(cdrl_getenv("CDRL_FUSED_PASS")) == 0);
                 if (stride == 1 && fuse_pass && sc_c == C - sc_c) {
                     // identity half: carried by the unit's last BatchNorm op (same channel count as the main half)
                     pass.fsrc = X.v(0);
@@ -1164,7 +1164,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         Tens yh = tens_a(rows, c.last, false);
         add_pw(ops, "img.head.conv", X.v(), rows, curC, c.last, yh.p, X.gv(), 0, bnrec(T, B * P, c.last));
         feat_ = tens(N, c.last);
-        static const bool gap_fused = !(getenv("CDRL_FUSED_GAP") && atoi(getenv("CDRL_FUSED_GAP")) == 0);
+        static const bool gap_fused = !(cdrl_getenv("CDRL_FUSED_GAP") && atoi(cdrl_getenv("CDRL_FUSED_GAP")) == 0);
         if (gap_fused) {
             // BatchNorm + ReLU6 + GlobalAveragePooling2D as one op: the 12288 x 768 activated tensor and its gradient are never
             // written -- the forward pools on the fly, the backward reads the pooled gradient broadcast over the frame's pixels
@@ -1268,7 +1268,7 @@ void Learner::build_head(std::vector<Op>& ops, int model, const std::string& pre
     int L = 0;
     for (int i = 0; i < nheads; ++i) L += head_dims[i];
     lin = tens(B, L);
-    static const bool fused_heads = !(getenv("CDRL_FUSED_HEADS") && atoi(getenv("CDRL_FUSED_HEADS")) == 0);
+    static const bool fused_heads = !(cdrl_getenv("CDRL_FUSED_HEADS") && atoi(cdrl_getenv("CDRL_FUSED_HEADS")) == 0);
     if (fused_heads && nheads <= HEADS_MAX && L <= HEADS_MAX_OUT) {
         // all linear heads of the branch in one launch per direction (heads.hip); same parameter names / order as add_dense
         HeadSet hs{};
@@ -1454,13 +1454,13 @@ int Learner::bind(const Buffers& b) {
     CDRL_TRY(upload_seg_tables());
     for (auto& z : zero_once_) CDRL_HIP(hipMemset(z.first, 0, z.second));
     if (!side_) {
-        const char* env = getenv("CDRL_SIDE_STREAM");
+        const char* env = cdrl_getenv("CDRL_SIDE_STREAM");
         side_enabled_ = !(env && atoi(env) == 0);
         // hipGraph replay is OFF by default: measured on MI355X / ROCm 7.2 at B=256 the captured update-step
         // (4 graphs of ~500-1000 kernel nodes over two streams) replays in 32.7 ms vs 31.0 ms eager, and the
         // host still spends 15 ms per step inside hipGraphLaunch (22 ms for eager launches): neither mode is
         // host-bound.  CDRL_GRAPH=1 enables it (parity suite passes in both modes).
-        const char* genv = getenv("CDRL_GRAPH");
+        const char* genv = cdrl_getenv("CDRL_GRAPH");
         graphs_enabled_ = genv && atoi(genv) != 0;
         // All three streams at the default priority.  Giving the main stream (the dependent chain) the highest and the side /
         // aux streams the lowest priority (CDRL_STREAM_PRIO=1) changes nothing for the update-step (15.98 vs 16.01 ms) but costs
@@ -1469,7 +1469,7 @@ int Learner::bind(const Buffers& b) {
         // first), the command processor comes back to the low-priority queue only after milliseconds -- predict() 5.5 ms instead
         // of 1.1 ms at E = 1 (tools/bench_rollout_rows.py).
         int prio_lo = 0, prio_hi = 0;
-        const char* penv = getenv("CDRL_STREAM_PRIO");
+        const char* penv = cdrl_getenv("CDRL_STREAM_PRIO");
         if (penv && atoi(penv) == 1) CDRL_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         CDRL_HIP(hipStreamCreateWithPriority(&main_, hipStreamNonBlocking, prio_hi));
         CDRL_HIP(hipEventCreateWithFlags(&ev_in_, hipEventDisableTiming));
@@ -1489,7 +1489,7 @@ int Learner::bind(const Buffers& b) {
         CDRL_HIP(hipStreamCreateWithPriority(&aux_, hipStreamNonBlocking, prio_lo));
         CDRL_HIP(hipEventCreateWithFlags(&ev_aux_fork_, hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_aux_done_, hipEventDisableTiming));
-        const char* tenv = getenv("CDRL_AUX_THREAD");
+        const char* tenv = cdrl_getenv("CDRL_AUX_THREAD");
         // opt-in (CDRL_AUX_THREAD=1): measured 20.76 vs 20.83 ms/update-step at B=256 -- the host is 8 ms per step ahead of
         // the GPU in steady state, so the second enqueue thread only pays off for small images (host-bound below ~45x60)
         if (side_enabled_ && !graphs_enabled_ && tenv && atoi(tenv) == 1) {

@@ -220,7 +220,7 @@ bool pw_x3_supported(View A, int N, int K) {
 }
 
 static int x3_occ() {
-    static const int v = getenv("CDRL_X3_OCC") ? atoi(getenv("CDRL_X3_OCC")) : 2;
+    static const int v = cdrl_getenv("CDRL_X3_OCC") ? atoi(cdrl_getenv("CDRL_X3_OCC")) : 2;
     return v < 1 ? 1 : (v > 8 ? 8 : v);
 }
 

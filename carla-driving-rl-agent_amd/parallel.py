@@ -49,8 +49,8 @@ class DataParallelLearner:
         self._comm = None
         if os.environ.get('CDRL_DP_OVERLAP', '1') == '0':       # one fused all-reduce per pass after the backward (round 1 form)
             overlap = False
-        if overlap and (self.world > 1 or self.force) and getattr(engine, 'device', None) and hasattr(engine, 'set_comm_stream') \
-                and engine.grads.is_cuda:
+        if self.use_comm_stream(overlap, self.world, self.force, tower_n, t_n,
+                                bool(getattr(engine, 'device', None)) and hasattr(engine, 'set_comm_stream') and engine.grads.is_cuda):
             self._comm = torch.cuda.Stream(device=engine.grads.device)
             engine.set_comm_stream(self._comm)
         # BatchNorm moving statistics = everything the replicated Adam update does not touch:
@@ -61,6 +61,21 @@ class DataParallelLearner:
         v0, vn = engine.region('value', False)
         o0, on = engine.region('old_policy', False)
         self._state_slices = [(s0, v0 + vn), (o0, o0 + on)]
+
+    @staticmethod
+    def use_comm_stream(overlap, world, force, tower_n, t_n, device_engine) -> bool:
+        """Early buckets on a communication stream only when the engine RELEASES that stream in the middle of the backward.
+        Under hipGraph replay it does not (the external stream must stay out of the capture) and reports tail_offset() == the
+        whole trunk: nothing would order an early bucket -- not even the heads' -- behind the replayed pass, so the single
+        post-pass all-reduce on the launch stream is taken instead (a premature bucket would average stale gradients)."""
+        return bool(overlap and (world > 1 or force) and device_engine and tower_n < t_n)
+
+    def reduce_policy_gradients(self):
+        """All-reduce of the policy pass's gradients [policy | trunk]; call after policy_forward_backward has been enqueued."""
+        self._reduce_gradients(self._policy_early, self._policy_slice)
+
+    def reduce_value_gradients(self):
+        self._reduce_gradients(self._value_early, self._value_slice)
 
     def _reduce_gradients(self, early, full):
         """Gradient all-reduce of one pass, issued after the pass has been ENQUEUED: early buckets on the communication

@@ -101,6 +101,7 @@ class PPOAgent(Agent):
         self.network.set_hparams(**self.hyper_parameters())
         value_batches = list(self.get_value_batches())
         policy_batches = list(self.get_policy_batches())
+        policy_batches, value_batches = self.agree_on_batches(policy_batches, value_batches)
         for _ in range(self.optimization_steps['policy']):
             for batch in policy_batches:
                 self.seed_regularization()
@@ -113,8 +114,17 @@ class PPOAgent(Agent):
                 value_loss, grads = self.get_value_gradients(batch)
                 self.update_value(grads)
                 self.log(loss_value=value_loss, lr_value=self.value_lr.value)
-        torch.cuda.synchronize()
+        self.after_update()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         print(f'Update took {round(time.time() - t0, 3)}s')
+
+    def agree_on_batches(self, policy_batches, value_batches):
+        """Hook for data-parallel agents: every rank must run the same number of minibatch steps (each one is a collective)."""
+        return policy_batches, value_batches
+
+    def after_update(self):
+        """Hook for data-parallel agents (BatchNorm moving statistics are averaged once per update())."""
 
     def update_policy(self, gradients):
         return self.apply_policy_gradients(gradients), True

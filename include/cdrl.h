@@ -92,6 +92,14 @@ typedef struct cdrl_value_batch {
 
 const char* cdrl_last_error(void);
 int cdrl_version(void);
+/* Environment switches (no reference counterpart: the reference has no native code).  The library reads its CDRL_* tuning
+ * switches from the environment; CDRL_DIAG_* switches skip work or synchronisation (WRONG RESULTS, timing diagnostics only) and
+ * are honoured only together with the master switch CDRL_DIAG=1.
+ * cdrl_env_overrides: writes "NAME=VALUE NAME=VALUE ..." of every CDRL_* variable of the process environment into buf (truncated
+ * to cap bytes, NUL-terminated) and returns their count.  cdrl_diag_active: number of wrong-result switches in effect (0 unless
+ * CDRL_DIAG=1): benchmarks must refuse to report when it is non-zero. */
+int cdrl_env_overrides(char* buf, int cap);
+int cdrl_diag_active(void);
 /* CRC-32C (Castagnoli) of `n` host bytes continued from `crc` (0 to start): block and tensor checksums of the
  * TensorFlow checkpoint-V2 files CARLANetwork.save_weights writes (reference core/networks.py:297-300). */
 uint32_t cdrl_crc32c(uint32_t crc, const void* data, size_t n);

@@ -512,6 +512,19 @@ class OracleLearner:
         aux['dynamics'] = d
         return loss, gv, gt, aux
 
+    def policy_forward(self, batch):
+        """Forward quantities of policy_grads only (loss, aux: alpha / beta / log_prob ...), no autograd graph."""
+        with torch.no_grad():
+            batch = self._cast(batch)
+            d = dynamics_forward(batch['states'], self.trunk, self.cfg, training=True)
+            return policy_objective(d, self.policy, batch, self.hp, training=True)
+
+    def value_forward(self, batch):
+        with torch.no_grad():
+            batch = self._cast(batch)
+            d = dynamics_forward(batch['states'], self.trunk, self.cfg, training=True)
+            return value_objective(d, self.value, batch, training=True)
+
     def policy_step(self, batch, grads=None):
         """`grads` lets the N-shard data-parallel emulation inject averaged gradients."""
         if grads is None:

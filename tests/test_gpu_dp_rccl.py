@@ -91,6 +91,7 @@ def _worker_world1(rank, world, port, out, graph):
             t_off, t_n = eng.region('trunk', True)
             if graph:       # hipGraph replay never releases the communication stream mid-pass: no early bucket
                 assert eng.tail_offset() == t_n and dp._tower == (t_off, t_off + t_n)
+                assert dp._comm is None          # ... and no communication stream at all: one all-reduce behind the replayed pass
             else:
                 assert dp._comm is not None and 0 < eng.tail_offset() < t_n
                 names = [e['name'] for e in eng.tables['trunk'].entries if e['trainable'] and e['offset'] >= eng.tail_offset()]
@@ -125,6 +126,54 @@ def test_world1_nccl_collective_path_is_bit_identical(tmp_path, graph):
     r = torch.load(tmp_path / 'w1.pt')
     for k in range(3):
         assert torch.equal(r['plain']['grads'][k], r['forced']['grads'][k]), k
+    for key in ('params', 'm', 'v'):
+        assert torch.equal(r['plain'][key], r['forced'][key]), key
+    assert torch.isfinite(r['plain']['params']).all()
+
+
+def _worker_agent_world1(rank, world, port, out):
+    """CARLAgent.learn() (rollout on the fake environment, GAE, update() = 3 + 3 minibatch steps with the re-sampled loss) once
+    without a process group and once as the single rank of an NCCL group with the collectives forced (CDRL_FORCE_COLLECTIVES=1):
+    broadcast at construction, all-reduce inside get_*_gradients, moving-statistics average after update()."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    from carla_driving_rl_agent_amd.core import CARLAgent, FakeCARLAEnvironment
+
+    def run():
+        env = FakeCARLAEnvironment(image_shape=(H, W, 3), time_horizon=4, num_waypoints=5, vehicle_features=4, num_actions=2,
+                                   image_range=(0.0, 1.0), seed=3)
+        agent = CARLAgent(env, batch_size=B, log_mode=None, seed=3, skip_data=0, drop_batch_remainder=False, shuffle=True,
+                          policy_lr=3e-4, value_lr=3e-4, dynamics_lr=3e-4, aug_intensity=0.0)
+        agent.learn(episodes=1, timesteps=3 * B + 3, close=False)        # 3 full minibatches + a ragged one of 3 rows
+        torch.cuda.synchronize()
+        eng = agent.network.engine
+        return agent, dict(params=eng.params.clone().cpu(), m=eng.adam_m.clone().cpu(), v=eng.adam_v.clone().cpu(),
+                           steps=eng.named_buffer('hparams', torch.int32)[10:13].tolist())
+
+    agent, plain = run()
+    assert not agent.data_parallel
+    del agent
+    os.environ['CDRL_FORCE_COLLECTIVES'] = '1'
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    agent, forced = run()
+    assert agent.data_parallel and agent.world == 1 and len(agent._dp) == 2        # main engine + the ragged-minibatch engine
+    torch.save(dict(plain=plain, forced=forced), os.path.join(out, 'agent_w1.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_agent_level_world1_nccl_is_bit_identical(tmp_path):
+    """Data parallelism through the AGENT API (CARLAgent under torch.distributed) on the one GPU of the driver's box: the forced
+    world-1 NCCL run of learn() must reproduce the plain agent bit for bit -- weights, Adam moments and step counters."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_agent_world1, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / 'agent_w1.pt')
+    assert r['plain']['steps'] == r['forced']['steps'] == [4, 4, 8]
     for key in ('params', 'm', 'v'):
         assert torch.equal(r['plain'][key], r['forced'][key]), key
     assert torch.isfinite(r['plain']['params']).all()
