@@ -439,6 +439,49 @@ int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, 
                  part, S(stream));
 }
 
+int64_t cdrl_pwconv_bwd_fused_workspace(int G, int Mg, int N, int K, int which) {
+    return which == 0 ? pw_bwd_fused_qpart_elems(G, Mg, N, K) : pw_bwd_fused_dbpart_elems(G, Mg, N, K);
+}
+
+int cdrl_pwconv_bwd_fused(const float* dz, int ld_dz, int dz_coff, int dz_shuffle, int act, const float* y, const float* stats,
+                          const float* coef, const float* a, int lda, int a_coff, const float* a_stats, const float* a_gamma,
+                          const float* a_beta, float* a_dgamma, float* a_dbeta, float* a_coef, const float* W, const void* W_packed,
+                          float* da, int ldda, int da_coff, int accumulate, float* dW, float* db, float* qpart, double* dbpart, int G,
+                          int Mg, int N, int K, void* stream) {
+    if (!dz || !y || !stats || !coef || !a || !W || !W_packed || !da || !dW || !db || !qpart || !dbpart) {
+        cdrl::set_error("cdrl_pwconv_bwd_fused: null argument");
+        return -1;
+    }
+    PwBwdFused f;
+    f.dz = make_view(const_cast<float*>(dz), ld_dz, dz_coff);
+    f.dz_shuffle = dz_shuffle;
+    f.act = act;
+    f.y = y;
+    f.stats = stats;
+    f.coef = coef;
+    f.a = make_view(const_cast<float*>(a), lda, a_coff);
+    f.a_stats = a_stats;
+    f.a_gamma = a_gamma;
+    f.a_beta = a_beta;
+    f.a_dgamma = a_dgamma;
+    f.a_dbeta = a_dbeta;
+    f.a_coef = a_coef;
+    f.W = W;
+    f.Wp = W_packed;
+    f.da = make_view(da, ldda, da_coff);
+    f.accumulate = accumulate;
+    f.dW = dW;
+    f.db = db;
+    f.qpart = qpart;
+    f.dbpart = dbpart;
+    f.G = G;
+    f.Mg = Mg;
+    f.N = N;
+    f.K = K;
+    CDRL_TRY(pw_bwd_fused(f, S(stream)));
+    return pw_bwd_fused_reduce(f, S(stream));
+}
+
 int64_t cdrl_gemm_x3_packed_bytes(int N, int K) { return gemm_x3_packed_bytes(N, K); }
 
 int cdrl_gemm_x3_pack(const float* B, int K, int N, int sbk, int sbn, void* packed, void* stream) {

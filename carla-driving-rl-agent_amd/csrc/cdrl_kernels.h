@@ -247,6 +247,41 @@ int pw_x3_pack_many(const PwX3Pack* tab_dev, int n, hipStream_t st);
 int pw_x3(View A, const float* pro_stats, const void* Wp, const float* bias, View C, int G, int Mg, int N, int K, double* part,
           hipStream_t st, int nbpg = 0);
 
+// ---------------------------------------------------------------- fused backward of a pointwise conv (gemm_pw_bwd.hip)
+// ONE pass over (dz, y, a): BatchNorm-backward apply on load, da = dy W^T, Q = a^T dy (or xhat(a)^T dy), db partials; then
+// pw_bwd_fused_reduce: dW, db and -- when a is a BatchNorm output applied on load (a_stats) -- that BatchNorm's backward sums
+// (dgamma, dbeta, coefficients) from Q, with no pass over da.  Float32 tensors, float32-accurate (three-way bf16 operand split).
+struct PwBwdFused {
+    View dz;                // gradient w.r.t. the output of the BatchNorm behind the conv
+    int dz_shuffle = 0;     // channel-shuffle gather on the dz columns (ctot), 0 = none
+    int act = 0;            // ACT_RELU6: mask from that BatchNorm's output
+    const float* y = nullptr;       // raw conv output [G*Mg][N] dense
+    const float* stats = nullptr;   // [4][G][N] of that BatchNorm
+    const float* coef = nullptr;    // [3][G][N] backward coefficients (bn_bwd_finalize)
+    View a;                 // conv input [G*Mg][K]
+    const float* a_stats = nullptr; // [4][G][K]: a = BatchNorm(a_raw) applied on load (no activation); null: plain input
+    const float* a_gamma = nullptr; // with a_stats: parameters / gradient outputs of that BatchNorm
+    const float* a_beta = nullptr;
+    float* a_dgamma = nullptr;
+    float* a_dbeta = nullptr;
+    float* a_coef = nullptr;        // [3][G][K]
+    const float* W = nullptr;       // conv weights [K][N]
+    const void* Wp = nullptr;       // pw_x3 packing of B(k = n_out, n = k_in) = W[n * N + k]  (pw_x3_pack_entry(W, wp, N, K, 1, N))
+    View da;                // gradient w.r.t. the conv input (the raw a for a_stats: gradient w.r.t. the BatchNorm OUTPUT)
+    int accumulate = 0;
+    float* dW = nullptr;    // [K][N]
+    float* db = nullptr;    // [N]
+    float* qpart = nullptr; // pw_bwd_fused_qpart_elems floats
+    double* dbpart = nullptr;       // pw_bwd_fused_dbpart_elems doubles
+    int N = 0, K = 0, G = 1, Mg = 0;
+};
+bool pw_bwd_fused_supported(View dz, View a, View da, int N, int K);
+int pw_bwd_fused_nbpg(int G, int Mg, int N, int K);
+int64_t pw_bwd_fused_qpart_elems(int G, int Mg, int N, int K);
+int64_t pw_bwd_fused_dbpart_elems(int G, int Mg, int N, int K);
+int pw_bwd_fused(const PwBwdFused& f, hipStream_t st);
+int pw_bwd_fused_reduce(const PwBwdFused& f, hipStream_t st);
+
 // general form (gemm_x3.hip): any K (multiple of 4), any N; B packed once per pass by gemm_x3_pack_many into [3][K/16][2][Npad][8]
 struct GemmX3Pack {
     const float* w;

@@ -95,6 +95,16 @@ struct PwFuse {
     View bb_dz{nullptr, 0, 0};           // gradient w.r.t. the BN output; p == nullptr: the current scratch slot (dense)
     int bb_shuffle = 0, bb_act = 0;
     bool bb_claim_slot = false;          // this op claims the rotating scratch slot (nobody upstream did)
+    // fused backward (gemm_pw_bwd.hip): when the conv input is a BatchNorm output applied on load (pro_stats; bwd_ey = its raw
+    // input), that BatchNorm's parameters / gradient outputs / coefficient block -- its backward sums come out of the conv's
+    // reduce kernel, and its own backward op does nothing (`a_bn_done`)
+    bool a_bn = false;                   // the five pointers below are set (they are null in the dry build either way)
+    const float* a_gamma = nullptr;
+    const float* a_beta = nullptr;
+    float* a_dgamma = nullptr;
+    float* a_dbeta = nullptr;
+    float* a_coef = nullptr;
+    std::shared_ptr<bool> a_bn_done;
 };
 
 class Learner {
@@ -225,9 +235,11 @@ private:
     float* add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw, const char* bn_post,
                         float* x, int H, int W, int C, int stride, float* y2, View out, View dout, View din,
                         int pre_stats_nb = 0, bool post_apply = true, int post_bwd_nb = 0, float* stats1_ext = nullptr,
-                        float* coef1_ext = nullptr, bool pre_defer_apply = false);
+                        float* coef1_ext = nullptr, bool pre_defer_apply = false, float** coef2_out = nullptr,
+                        std::shared_ptr<bool> post_bwd_done = nullptr);
     bool fused_dw_ = true, fused_pw_ = true, fused_pw_wide_ = false;
     int fused_bb_ = 1;
+    bool fused_bwd_ = true;             // backward-data + filter gradient of the unit convs as one kernel (gemm_pw_bwd.hip)
     void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
                    View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);
     void add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,
@@ -293,6 +305,10 @@ private:
     double* part2s_[NSLOT] = {};
     float* tns_[NSLOT] = {};
     double* fparts_[NSLOT] = {};
+    float* qparts_[NSLOT] = {};          // fused conv backward: per-workgroup filter-product tiles / column sums
+    double* dbparts_[NSLOT] = {};
+    size_t max_qpart_ = 0, max_dbpart_ = 0;
+    int flush_side(hipStream_t st);      // enqueue the deferred side jobs now (one event record on `st`)
     hipStream_t side_ = nullptr;
     hipStream_t aux_ = nullptr;          // feature nets + small GRUs (forward and backward)
     bool aux_pending_ = false;

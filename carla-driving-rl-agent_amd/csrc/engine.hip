@@ -213,6 +213,12 @@ int Learner::defer_side(hipStream_t st, std::function<int(hipStream_t)> fn) {
     return 0;
 }
 
+int Learner::flush_side(hipStream_t st) {
+    if (!side_enabled_ || deferred_.empty()) return 0;
+    hipStream_t side = fork_side(st);       // flushes the queue behind an event recorded on `st`
+    return done_side(side);
+}
+
 int Learner::done_side(hipStream_t side) {
     if (!side_enabled_ || side != side_) return 0;
     if (deferred_rc_ != 0) {
@@ -527,7 +533,55 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     };
     const int nbp_bwd = fuse.bb ? pw_nn_plan(G, Mg, Cin, Cout).nbpg : 0;
     if (fuse.bb) note_scratch(0, (size_t)G * nbp_bwd * Cout, 0, 0);
+    // One kernel for backward-data + filter gradient + bias gradient (+ the backward sums of the BatchNorm in front of the conv):
+    // float32 engine, both channel counts padded alike (gemm_pw_bwd.hip)
+    const View dz_probe = fuse.bb_dz.p ? fuse.bb_dz : make_view(reinterpret_cast<float*>(uintptr_t(16)), Cout);
+    const bool anorm = fuse.pro_stats != nullptr;
+    const bool fbwd = fused_bwd_ && fuse.bb && fuse.bwd_pw && !bfc && G <= 8 && pw_bwd_fused_supported(dz_probe, in, din, Cout, Cin) &&
+                      (!anorm || (fuse.bwd_ey == in.p && fuse.bwd_epi_stats == fuse.pro_stats && fuse.a_bn && in.ld == Cin && in.coff == 0)) &&
+                      (anorm || !fuse.bwd_ey);
+    const void* wpx = fbwd ? pw_x3_packed(w.p, Cout, Cin, 1, Cout) : nullptr;      // W^T planes: B(k = cout, n = cin)
+    if (fbwd) {
+        max_qpart_ = std::max(max_qpart_, (size_t)pw_bwd_fused_qpart_elems(G, Mg, Cout, Cin));
+        max_dbpart_ = std::max(max_dbpart_, (size_t)pw_bwd_fused_dbpart_elems(G, Mg, Cout, Cin));
+        if (fuse.a_bn_done) *fuse.a_bn_done = true;
+    }
     op.bwd = [=](hipStream_t st) -> int {
+        if (fbwd) {
+            if (fuse.bb_claim_slot) CDRL_TRY(next_slot(st));
+            PwBwdFused f;
+            f.dz = fuse.bb_dz.p ? fuse.bb_dz : make_view(dys_[slot_], Cout);
+            f.dz_shuffle = fuse.bb_shuffle;
+            f.act = fuse.bb_act;
+            f.y = y;
+            f.stats = fuse.bb_stats;
+            f.coef = fuse.bb_coef;
+            f.a = in;
+            f.a_stats = anorm ? fuse.pro_stats : nullptr;
+            f.a_gamma = fuse.a_gamma;
+            f.a_beta = fuse.a_beta;
+            f.a_dgamma = fuse.a_dgamma;
+            f.a_dbeta = fuse.a_dbeta;
+            f.a_coef = fuse.a_coef;
+            f.W = w.p;
+            f.Wp = wpx;
+            f.da = din;
+            f.accumulate = din_acc;
+            f.dW = w.g;
+            f.db = b.g;
+            f.qpart = qparts_[slot_];
+            f.dbpart = dbparts_[slot_];
+            f.G = G;
+            f.Mg = Mg;
+            f.N = Cout;
+            f.K = Cin;
+            CDRL_TRY(pw_bwd_fused(f, st));
+            // the reduce also finalizes the BatchNorm in front of the conv (its coefficients are the next kernel's input): critical
+            // stream; without one it only produces weight gradients -> side stream, flushed once per unit
+            if (anorm) return pw_bwd_fused_reduce(f, st);
+            CDRL_TRY(defer_side(st, [=](hipStream_t sd) -> int { return pw_bwd_fused_reduce(f, sd); }));
+            return flush_side(st);
+        }
         if (fuse.bb) {
             // BN-backward apply fused into the operand loads: dz (+ raw y, statistics, coefficients) instead of dy
             if (fuse.bb_claim_slot) CDRL_TRY(next_slot(st));
@@ -593,7 +647,7 @@ void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, i
 float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw,
                              const char* bn_post, float* x, int H, int W, int C, int stride, float* y2, View out, View dout,
                              View din, int pre_stats_nb, bool post_apply, int post_bwd_nb, float* stats1_ext, float* coef1_ext,
-                             bool pre_defer_apply) {
+                             bool pre_defer_apply, float** coef2_out, std::shared_ptr<bool> post_bwd_done) {
     const int B = cfg_.B, G = cfg_.T, N = B * G;
     const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
     const int Mi = B * H * W, Mo = B * Ho * Wo;
@@ -623,6 +677,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
     float* stats2 = alloc((size_t)4 * G * C);
     note_bn_inference(g2.p, b2.p, mm2.p, mv2.p, stats2, G, C);
     float* coef2 = alloc((size_t)3 * G * C);
+    if (coef2_out) *coef2_out = coef2;
     const int nb_in = vcol_geom(Mi, C).nb, nb_out = vcol_geom(Mo, C).nb;
     const int nbf = dwf_geom(B, G, H, W, C, stride).nb;
     const size_t nbmax = (size_t)std::max(std::max(std::max(nb_in, nb_out), nbf), std::max(pre_stats_nb, post_bwd_nb));
@@ -673,6 +728,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
             return bn_apply(y2v, G, Mo, C, stats2, ACT_NONE, out, 0, st, nullptr, nullptr, at);
         };
         op.bwd = [=](hipStream_t st) -> int {
+            if (post_bwd_done && *post_bwd_done) return 0;      // dgamma, dbeta, coefficients came out of the consumer conv's reduce kernel
             if (!post_bwd_nb) CDRL_TRY(bn_bwd_reduce(dout, 0, y2v, G, Mo, C, stats2, ACT_NONE, sc->part, st, nullptr, nullptr, nullptr, 0, at));
             return bn_bwd_finalize(sc->part, post_bwd_nb ? post_bwd_nb : nb_out, G, Mo, C, stats2, g2.g, b2.g, coef2, st);
         };
@@ -899,6 +955,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         // the accumulate variant prefetched its old output tile (248 us against 165 us for apply + plain GEMM), now 15.91 vs 15.96
         // ms/update-step and one 164 MB tensor less
         fused_bb_ = e3 ? atoi(e3) : 7;
+        const char* e4 = cdrl_getenv("CDRL_FUSED_BWD");     // 0 -> backward-data (critical stream) + filter gradient (side stream) as two kernels
+        fused_bwd_ = !(e4 && atoi(e4) == 0);
     }
 
     // ---- stem (core/architectures.py:159-161)
@@ -1076,8 +1134,10 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                            bnrec(T, Mg_in, mid), f1);
                     const int nb1 = pw_nn_plan(T, Mg_in, mid, main_in).nbpg;
                     const int nbb = pw_nn_plan(T, Mg_out, mid, main_out).nbpg;        // pw2 backward-data epilogue rows
+                    float* coef2 = nullptr;
+                    std::shared_ptr<bool> bn2_done = std::make_shared<bool>(false);
                     float* stats2 = add_dw_block(ops, pre, "bn1", "dw", "bn2", y1.p, curH, curW, mid, stride, y2.p, a2.v(), a2.gv(),
-                                                 View{nullptr, 0, 0}, nb1, false, nbb, stats1, coef1, bb1);
+                                                 View{nullptr, 0, 0}, nb1, false, nbb, stats1, coef1, bb1, &coef2, bn2_done);
                     // BN3's statistics / coefficient blocks are allocated by add_bn below; bump-allocate them here first so
                     // that pw2 (which precedes bn3 in the op list) can reference them
                     PwFuse f2;
@@ -1087,6 +1147,15 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     f2.bwd_pw = true;
                     f2.bwd_ey = y2.p;
                     f2.bwd_epi_stats = stats2;
+                    {   // BN2's blocks for the fused backward of pw2 (same arena slots as add_dw_block's lookups)
+                        PRef g2 = param(M_TRUNK, pre + ".bn2.gamma", {mid}, true), b2 = param(M_TRUNK, pre + ".bn2.beta", {mid}, true);
+                        f2.a_gamma = g2.p;
+                        f2.a_beta = b2.p;
+                        f2.a_dgamma = g2.g;
+                        f2.a_dbeta = b2.g;
+                        f2.a_coef = coef2;
+                        f2.a_bn = true;
+                    }
                     const size_t pw2_at = ops.size();
                     add_pw(ops, pre + ".pw2", y2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out), f2);
                     BnRec r3 = add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C,
@@ -1099,6 +1168,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                         f2.bb_shuffle = C;
                         f2.bb_act = ACT_RELU6;
                         f2.bb_claim_slot = true;
+                        f2.a_bn_done = bn2_done;
                         std::vector<Op> tmp;
                         add_pw(tmp, pre + ".pw2", y2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out), f2);
                         ops[pw2_at] = tmp[0];
@@ -1323,6 +1393,8 @@ void Learner::build(bool dry) {
             part2s_[i] = alloc_d(max_part2_);
             tns_[i] = alloc(max_tn_);
             fparts_[i] = alloc_d(max_fpart_);
+            qparts_[i] = alloc(max_qpart_);
+            dbparts_[i] = alloc_d(max_dbpart_);
         }
     }
     h_pwt_.clear();
@@ -1382,7 +1454,8 @@ void Learner::build(bool dry) {
                         align_up(max_tn_ * sizeof(float), 256)) +
                    align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
                    NSLOT * (align_up((max_dy_ * esz() + 3) / 4 * sizeof(float), 256) + align_up(max_part2_ * sizeof(double), 256) +
-                            align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256));
+                            align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256) +
+                            align_up(max_qpart_ * sizeof(float), 256) + align_up(max_dbpart_ * sizeof(double), 256));
         ws_bytes_ = ws_off_ + 4096;
     }
 }

@@ -1,0 +1,643 @@
+// Backward of a pointwise (1x1) convolution as ONE pass over its operands (gfx950, v_mfma_f32_32x32x16_bf16 on exact three-way
+// bf16 splits of float32 operands, see gemm_pw_x3.hip).
+//
+// Reference: the gradient of Conv2D(k=1) -> BatchNormalization (core/architectures.py:130-141) inside tape.gradient
+// (core/carla_agent.py:364-365).  For y = a W + b followed by a train-mode BatchNorm whose output gradient is dz:
+//     dy = k1 (mask dz - k2 - xhat(y) k3)          BatchNorm-backward apply (never written to HBM)
+//     da = dy W^T                                  backward-data   -> HBM
+//     dW = a^T dy,  db = column sums of dy         filter / bias gradient
+// Rounds 1-3 ran backward-data (gemm_pw.hip, critical stream) and the filter gradient (gemm_tn_direct.hip, side stream) as two
+// kernels that each load (dz, y) and apply the prologue; the side-stream kernel cost the update-step 1.6 ms of contention plus two
+// event records per unit.  Here a workgroup stages the tile ONCE: 512 threads = 8 waves, the first four load (dz, y), build dy and
+// multiply it with W^T (fragments in registers), the other four load the conv input `a` and accumulate a^T dy over all the tiles
+// of the workgroup in registers; both products read the same LDS planes.
+// When `a` is itself a BatchNorm output that is applied on load (unit conv 2: a = gamma xhat(y2) + beta, no activation), the
+// second product is taken against xhat:  Q = xhat^T dy  per time slice, and everything downstream follows from Q in the reduce
+// kernel, with no pass over da:
+//     dW[k, n]            = gamma[k] sum_g Q_g[k, n] + beta[k] db[n]
+//     sum_r da[r, k]      = sum_n W[k, n] db_g[n]                       (BatchNorm-backward sums of the BN that produced a:
+//     sum_r da[r, k] xhat = sum_n W[k, n] Q_g[k, n]                      the EPI_BNRED epilogue of gemm_pw.hip, for free)
+// Partials: one [KP][NP] float tile + [NP] doubles per workgroup, combined in fixed order by pwb_reduce_kernel (bit-wise
+// reproducible, no atomics).
+#include <stdlib.h>
+
+#include "cdrl_kernels.h"
+
+namespace cdrl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct PwbArgs {
+    View dz;                // gradient w.r.t. the BatchNorm output (columns optionally gathered through the shuffle map)
+    int dz_shuffle;         // ctot of the channel shuffle, 0 = none
+    int act;                // ACT_RELU6: mask from the BatchNorm output
+    const float* y;         // raw BatchNorm input = conv output [M][N] dense
+    const float* stats;     // [4][G][N]
+    const float* coef;      // [3][G][N]
+    View a;                 // conv input [M][K]
+    const float* a_stats;   // [4][G][K] (ANORM) or null
+    const __bf16* Wp;       // W^T as three planes of MFMA B fragments: pw_x3 packing of B(k = n_out, n = k_in)
+    View da;
+    float* qpart;           // [G][nbpg][KP][NP]
+    double* dbpart;         // [G][nbpg][NP]
+    int N, K, G, Mg, nbpg;
+    int dbg;                // timing diagnostics (CDRL_DIAG=1 CDRL_DIAG_PWB=bits, wrong results): 1 no MFMA, 2 no LDS writes, 4 no stores, 8 no loads
+};
+
+__device__ __forceinline__ void pwb_split3(float x, __bf16& h1, __bf16& h2, __bf16& h3) {
+    h1 = (__bf16)x;
+    const float r1 = x - (float)h1;
+    h2 = (__bf16)r1;
+    h3 = (__bf16)(r1 - (float)h2);
+}
+
+// KP: padded input channels (k_in), NP: padded output channels (n_out); (128, 128) -> 32-row tiles, (64, 64) -> 64-row tiles.
+// The two halves of the workgroup run DIFFERENT loops (scalar branch on the wave index: registers of one role are not live in
+// the other) with the same barrier sequence.
+template <int KP, int NP, bool SHUF, bool ANORM, bool ACC>
+__global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
+    static_assert(KP == NP && (KP == 64 || KP == 128), "instantiated for square padded shapes");
+    constexpr int BM = KP == 128 ? 32 : 64;
+    constexpr int NRG = BM / 4;                     // row groups of 4
+    constexpr int LDR = NP + 8;                     // row-major planes: bf16 per row (16-byte fragment reads, conflict-free)
+    constexpr int LDT = BM + 8;                     // transposed planes: bf16 per column ((BM + 8) / 8 odd: conflict-free b128 reads)
+    constexpr int TP = KP * LDT;                    // elements of one transposed plane (KP == NP)
+    constexpr int KS_DA = NP / 16, KS_Q = BM / 16;
+    constexpr int DA_WC = KP / 32, DA_WR = 4 / DA_WC;
+    constexpr int Q_KT = KP / 32, Q_NT = NP / 32;
+    constexpr int NTW = Q_NT / (4 / Q_KT);          // Q column tiles per wave (4 | 1)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* Rm = reinterpret_cast<__bf16*>(smem_raw);       // [3][BM][LDR]   dy, row-major
+    __bf16* Dt = Rm + 3 * BM * LDR;                         // [3][NP][LDT]   dy, transposed
+    __bf16* At = Dt + 3 * TP;                               // [3][KP][LDT]   a (or xhat(a)), transposed
+    float* cf = reinterpret_cast<float*>(At + 3 * TP);      // [7][NP] mean, invstd, scale, shift, k1, k2, k3 of the dy columns
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 8);     // 0: waves 0-3 (dy + backward-data), 1: waves 4-7 (a + filter product)
+    const int t2 = tid & 255;
+    const int rg = t2 % NRG, cg = t2 / NRG;         // micro-tile: rows 4 rg .. 4 rg + 3, columns 4 cg .. 4 cg + 3
+    const int c0 = 4 * cg;
+    const int g = blockIdx.x / a.nbpg, b = blockIdx.x % a.nbpg;
+    const int K = a.K, N = a.N;
+    const int64_t mbeg = (int64_t)g * a.Mg, mend = mbeg + a.Mg;
+    const int tiles_g = (a.Mg + BM - 1) / BM;
+    const int t0 = (int)((int64_t)b * tiles_g / a.nbpg), t1 = (int)((int64_t)(b + 1) * tiles_g / a.nbpg);
+    const int64_t Mtot = (int64_t)a.G * a.Mg;
+    const uint32_t OOR = 0x80000000u;
+
+    if (role == 0) {
+        // =========================================================== dy = BatchNorm-backward(dz, y); da = dy W^T; db partials
+        const int dwr = wave % DA_WR, dwc = wave / DA_WR;
+        bf16x8 breg[3][KS_DA];                      // W^T fragments, once
+        {
+            const int n = dwc * 32 + lrow;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int s = 0; s < KS_DA; ++s)
+                    breg[p][s] = *reinterpret_cast<const bf16x8*>(a.Wp + (((int64_t)(p * KS_DA + s) * 2 + lk) * 128 + n) * 8);
+        }
+        // the seven per-column coefficients live in LDS (28 registers otherwise: this role also holds the W^T fragments);
+        // padded columns carry 0 everywhere, so their dy is 0
+        const int GN = a.G * N;
+        for (int i = tid; i < 7 * NP; i += 256) {
+            const int q = i / NP, c = i % NP;
+            cf[i] = c < N ? (q < 4 ? a.stats[q * GN + g * N + c] : a.coef[(q - 4) * GN + g * N + c]) : 0.0f;
+        }
+        uint32_t vo[4], voy[2];                     // byte offsets of (row 4 rg, column) inside a tile, or OOR
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            const int dc = SHUF ? shuffle_dst(a.dz.coff + c, a.dz_shuffle) : a.dz.coff + c;
+            vo[e] = c < N ? (uint32_t)((4 * rg) * a.dz.ld + dc) * 4u : OOR;
+        }
+        voy[0] = c0 < N ? (uint32_t)((4 * rg) * N + c0) * 4u : OOR;
+        voy[1] = c0 + 2 < N ? (uint32_t)((4 * rg) * N + c0 + 2) * 4u : OOR;
+        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(a.dz.p, 0, (int)(Mtot * a.dz.ld * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y), 0, (int)(Mtot * N * 4), 0x00020000);
+        const uint32_t rowD = (uint32_t)a.dz.ld * 4u, rowY = (uint32_t)N * 4u;
+        const bool relu6 = a.act == ACT_RELU6;
+        float rz[4][4], ry[4][4];                   // raw tile registers: dz, y of the micro-tile
+        // Row j of tile t -> rz[j], ry[j].  The rows of the NEXT tile are requested from inside store_tile, each as soon as the
+        // prologue has consumed the registers of the current one: a load then has the LDS writes, both barriers and the whole MFMA
+        // phase to arrive (issued after the first barrier instead, ~10 of 40 us were exposed load latency).
+        auto load_row = [&](int t, int j) {
+            if (a.dbg & 8) return;
+            const int64_t m0 = mbeg + (int64_t)t * BM;
+            const uint32_t mu = (uint32_t)m0;
+            // rows of this micro-tile beyond the group (ragged last tile): read 0, zeroed again after the prologue
+            const int left = (int)(mend - (m0 + 4 * rg));
+            {
+                const uint32_t msk = j < left ? 0u : OOR;
+                if (SHUF) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        rz[j][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, (vo[e] + (uint32_t)j * rowD) | msk, mu * rowD, 0));
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsD, (vo[2 * h] + (uint32_t)j * rowD) | msk, mu * rowD, 0);
+                        rz[j][2 * h] = __uint_as_float(v[0]);
+                        rz[j][2 * h + 1] = __uint_as_float(v[1]);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsY, (voy[h] + (uint32_t)j * rowY) | msk, mu * rowY, 0);
+                    ry[j][2 * h] = __uint_as_float(v[0]);
+                    ry[j][2 * h + 1] = __uint_as_float(v[1]);
+                }
+            }
+        };
+        double cs[4] = {0.0, 0.0, 0.0, 0.0};        // column sums of dy (bias gradient)
+        auto store_tile = [&](int t) {
+            const bool more = t + 1 < t1;
+            const int left = (int)(mend - (mbeg + (int64_t)t * BM + 4 * rg));
+            float cmean[4], cinv[4], csc[4], csh[4], ck1[4], ck2[4], ck3[4];
+            {
+                const float4 q0 = *reinterpret_cast<const float4*>(&cf[0 * NP + c0]), q1 = *reinterpret_cast<const float4*>(&cf[1 * NP + c0]);
+                const float4 q2 = *reinterpret_cast<const float4*>(&cf[2 * NP + c0]), q3 = *reinterpret_cast<const float4*>(&cf[3 * NP + c0]);
+                const float4 q4 = *reinterpret_cast<const float4*>(&cf[4 * NP + c0]), q5 = *reinterpret_cast<const float4*>(&cf[5 * NP + c0]);
+                const float4 q6 = *reinterpret_cast<const float4*>(&cf[6 * NP + c0]);
+                cmean[0] = q0.x; cmean[1] = q0.y; cmean[2] = q0.z; cmean[3] = q0.w;
+                cinv[0] = q1.x; cinv[1] = q1.y; cinv[2] = q1.z; cinv[3] = q1.w;
+                csc[0] = q2.x; csc[1] = q2.y; csc[2] = q2.z; csc[3] = q2.w;
+                csh[0] = q3.x; csh[1] = q3.y; csh[2] = q3.z; csh[3] = q3.w;
+                ck1[0] = q4.x; ck1[1] = q4.y; ck1[2] = q4.z; ck1[3] = q4.w;
+                ck2[0] = q5.x; ck2[1] = q5.y; ck2[2] = q5.z; ck2[3] = q5.w;
+                ck3[0] = q6.x; ck3[1] = q6.y; ck3[2] = q6.z; ck3[3] = q6.w;
+            }
+            bf16x4 hc[3][4];                        // [plane][column e] -> 4 rows
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool rok = j < left;
+                bf16x4 hr[3];
+                float vrow[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = rz[j][e];
+                    const float yv = ry[j][e];
+                    if (relu6) {
+                        const float z = fmaf(csc[e], yv, csh[e]);
+                        if (!relu6_open(z)) d = 0.0f;
+                    }
+                    const float xh = (yv - cmean[e]) * cinv[e];
+                    float v = ck1[e] * (d - ck2[e] - xh * ck3[e]);      // padded columns: every coefficient 0 -> 0
+                    if (!rok) v = 0.0f;
+                    vrow[e] = v;
+                }
+                if (more) load_row(t + 1, j);       // rz[j] / ry[j] are free
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = vrow[e];
+                    cs[e] += (double)v;
+                    __bf16 h1, h2, h3;
+                    pwb_split3(v, h1, h2, h3);
+                    hr[0][e] = h1;
+                    hr[1][e] = h2;
+                    hr[2][e] = h3;
+                    hc[0][e][j] = h1;
+                    hc[1][e][j] = h2;
+                    hc[2][e][j] = h3;
+                }
+                if (!(a.dbg & 2)) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(&Rm[p * BM * LDR + (4 * rg + j) * LDR + c0]) = hr[p];
+                }
+            }
+            if (a.dbg & 2) {
+                if (hc[0][0][0] == (__bf16)123.0f && hc[2][3][3] == (__bf16)321.0f) Rm[0] = hc[1][1][1];      // keep the math alive
+                return;
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16x4*>(&Dt[p * TP + (c0 + e) * LDT + 4 * rg]) = hc[p][e];
+        };
+        // output tile through a buffer descriptor: the row offset of register r is wave-uniform (SGPR soffset), the lane's part
+        // (its 4 lk rows + its column) one constant voffset -- no 64-bit address per register (the flat form kept 16 of them live
+        // across the tile loop and spilled); lanes beyond K and rows beyond the group point out of range: store dropped, load 0
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.da.p, 0, (int)(Mtot * a.da.ld * 4), 0x00020000);
+        const uint32_t rowC = (uint32_t)a.da.ld * 4u;
+        const int ncol = dwc * 32 + lrow;
+        const uint32_t voC = ncol < K ? (uint32_t)((4 * lk) * a.da.ld + a.da.coff + ncol) * 4u : OOR;
+        auto compute_tile = [&](int t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const int64_t m0 = mbeg + (int64_t)t * BM + dwr * 32;
+            const uint32_t mu = (uint32_t)m0;
+            const int left = (int)(mend - m0) - 4 * lk;         // rows (r & 3) + 8 (r >> 2) of this lane below `left` are inside the group
+            float cold[ACC ? 16 : 1];
+            if (ACC) {          // old values of the output tile, fetched before the MFMA chain (gemm_pw.hip ACC_PF)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    cold[ACC ? r : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, voC | (rr < left ? 0u : OOR), (mu + (uint32_t)rr) * rowC, 0));
+                }
+            }
+            const int ao = (dwr * 32 + lrow) * LDR + 8 * lk;
+            if (!(a.dbg & 1))
+#pragma unroll
+            for (int s = 0; s < KS_DA; ++s) {
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Rm[0 * BM * LDR + ao + 16 * s]);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&Rm[1 * BM * LDR + ao + 16 * s]);
+                const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&Rm[2 * BM * LDR + ao + 16 * s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, breg[0][s], acc, 0, 0, 0);       // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[2][s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[1][s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[0][s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[1][s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[0][s], acc, 0, 0, 0);
+            }
+            if (!(a.dbg & 4))
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                const float v = ACC ? acc[r] + cold[ACC ? r : 0] : acc[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, voC | (rr < left ? 0u : OOR), (mu + (uint32_t)rr) * rowC, 0);
+            }
+        };
+        if (t0 < t1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_row(t0, j);
+        }
+        __syncthreads();            // coefficient table
+        for (int t = t0; t < t1; ++t) {
+            store_tile(t);          // (requests tile t + 1)
+            __syncthreads();
+            compute_tile(t);
+            __syncthreads();
+        }
+        double* red = reinterpret_cast<double*>(smem_raw);      // [NRG][NP]; the planes are dead
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[rg * NP + c0 + e] = cs[e];
+        __syncthreads();
+        for (int c = tid; c < NP; c += 256) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < NRG; ++r) s += red[r * NP + c];
+            a.dbpart[((int64_t)g * a.nbpg + b) * NP + c] = s;
+        }
+    } else {
+        // =========================================================== a (or xhat(a)) -> LDS; Q += a^T dy over all tiles
+        const int qw = wave & 3;
+        const int qkt = qw % Q_KT, qnt0 = (qw / Q_KT) * NTW;
+        float cmean[4], cinv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cmean[e] = cinv[e] = 0.0f;
+        if (ANORM) {
+            const int GK = a.G * K;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + e;
+                const bool on = c < K;
+                cmean[e] = on ? a.a_stats[0 * GK + g * K + (on ? c : 0)] : 0.0f;
+                cinv[e] = on ? a.a_stats[1 * GK + g * K + (on ? c : 0)] : 0.0f;
+            }
+        }
+        uint32_t vo[2];
+        vo[0] = c0 < K ? (uint32_t)((4 * rg) * a.a.ld + a.a.coff + c0) * 4u : OOR;
+        vo[1] = c0 + 2 < K ? (uint32_t)((4 * rg) * a.a.ld + a.a.coff + c0 + 2) * 4u : OOR;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a.a.p, 0, (int)(Mtot * a.a.ld * 4), 0x00020000);
+        const uint32_t rowA = (uint32_t)a.a.ld * 4u;
+        float rz[4][4];
+        auto load_row = [&](int t, int j) {
+            if (a.dbg & 8) return;
+            const int64_t m0 = mbeg + (int64_t)t * BM;
+            const uint32_t mu = (uint32_t)m0;
+            const int left = (int)(mend - (m0 + 4 * rg));
+            {
+                const uint32_t msk = j < left ? 0u : OOR;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsA, (vo[h] + (uint32_t)j * rowA) | msk, mu * rowA, 0);
+                    rz[j][2 * h] = __uint_as_float(v[0]);
+                    rz[j][2 * h + 1] = __uint_as_float(v[1]);
+                }
+            }
+        };
+        auto store_tile = [&](int t) {
+            const bool more = t + 1 < t1;
+            const int left = (int)(mend - (mbeg + (int64_t)t * BM + 4 * rg));
+            bf16x4 hc[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool rok = j < left;
+                float vrow[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = rz[j][e];
+                    if (ANORM) {
+                        v = (v - cmean[e]) * cinv[e];       // padded columns: loaded 0, mean 0, invstd 0 -> 0
+                        if (!rok) v = 0.0f;
+                    }
+                    vrow[e] = v;
+                }
+                if (more) load_row(t + 1, j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = vrow[e];
+                    __bf16 h1, h2, h3;
+                    pwb_split3(v, h1, h2, h3);
+                    hc[0][e][j] = h1;
+                    hc[1][e][j] = h2;
+                    hc[2][e][j] = h3;
+                }
+            }
+            if (a.dbg & 2) {
+                if (hc[0][0][0] == (__bf16)123.0f && hc[2][3][3] == (__bf16)321.0f) At[0] = hc[1][1][1];
+                return;
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16x4*>(&At[p * TP + (c0 + e) * LDT + 4 * rg]) = hc[p][e];
+        };
+        f32x16 qacc[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qacc[j][r] = 0.0f;
+        auto compute_tile = [&]() {
+            const int ao = (qkt * 32 + lrow) * LDT + 8 * lk;
+            if (!(a.dbg & 1))
+#pragma unroll
+            for (int s = 0; s < KS_Q; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&At[0 * TP + ao + 16 * s]);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&At[1 * TP + ao + 16 * s]);
+                const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&At[2 * TP + ao + 16 * s]);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const int bo = ((qnt0 + j) * 32 + lrow) * LDT + 8 * lk + 16 * s;
+                    const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(&Dt[0 * TP + bo]);
+                    const bf16x8 d2 = *reinterpret_cast<const bf16x8*>(&Dt[1 * TP + bo]);
+                    const bf16x8 d3 = *reinterpret_cast<const bf16x8*>(&Dt[2 * TP + bo]);
+                    qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, d1, qacc[j], 0, 0, 0);
+                    qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, d3, qacc[j], 0, 0, 0);
+                    qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, d2, qacc[j], 0, 0, 0);
+                    qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, d1, qacc[j], 0, 0, 0);
+                    qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, d2, qacc[j], 0, 0, 0);
+                    qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, d1, qacc[j], 0, 0, 0);
+                }
+            }
+        };
+        if (t0 < t1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_row(t0, j);
+        }
+        __syncthreads();            // (the other role's coefficient table)
+        for (int t = t0; t < t1; ++t) {
+            store_tile(t);
+            __syncthreads();
+            compute_tile();
+            __syncthreads();
+        }
+        float* qp = a.qpart + ((int64_t)g * a.nbpg + b) * KP * NP;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = (qnt0 + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = qkt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                qp[k * NP + n] = qacc[j][r];
+            }
+        }
+        __syncthreads();            // pairs with the barrier in front of the other role's column-sum fold
+    }
+}
+
+// One workgroup per input channel k (row of dW), one thread per output channel n.
+struct PwbReduceArgs {
+    const float* qpart;     // [G][nbpg][KP][NP]
+    const double* dbpart;   // [G][nbpg][NP]
+    const float* W;         // conv weights [K][N]
+    const float* a_stats;   // [4][G][K] or null
+    const float* a_gamma;   // ANORM: gamma / beta of the BatchNorm that produced a
+    const float* a_beta;
+    float* dW;              // [K][N]
+    float* db;              // [N]
+    float* a_dgamma;        // ANORM outputs: dgamma / dbeta [K], backward coefficients [3][G][K]
+    float* a_dbeta;
+    float* a_coef;
+    int N, K, KP, NP, G, Mg, nbpg;
+};
+
+// 512 threads = 128 output channels n x 4 slices of the partial rows: every thread sums its quarter of the nbpg partials with the
+// loads of 8 partials in flight (the first version walked all partials in one dependent loop per thread: 125 us), the four slices
+// are folded through LDS in fixed order.
+__global__ void __launch_bounds__(512) pwb_reduce_kernel(PwbReduceArgs a) {
+    __shared__ double sq[4][8][128];     // [slice][group][n]: Q partial sums
+    __shared__ double sd[4][8][128];     // db partial sums
+    __shared__ double red[2][8][2];      // [s1 | s2][group][wave]
+    const int k = blockIdx.x, n = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    const int N = a.N, K = a.K, G = a.G;
+    const bool on = n < N;
+    const int per = (a.nbpg + 3) / 4;
+    const int b0 = sl * per, b1 = min(a.nbpg, b0 + per);
+    for (int g = 0; g < G; ++g) {
+        double q = 0.0, d = 0.0;
+        if (on) {
+            const float* pq = a.qpart + ((int64_t)g * a.nbpg * a.KP + k) * a.NP + n;
+            const double* pd = a.dbpart + (int64_t)g * a.nbpg * a.NP + n;
+            int b = b0;
+            for (; b + 8 <= b1; b += 8) {
+                float v[8];
+                double u[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = pq[(int64_t)(b + i) * a.KP * a.NP];
+                    u[i] = pd[(int64_t)(b + i) * a.NP];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    q += (double)v[i];
+                    d += u[i];
+                }
+            }
+            for (; b < b1; ++b) {
+                q += (double)pq[(int64_t)b * a.KP * a.NP];
+                d += pd[(int64_t)b * a.NP];
+            }
+        }
+        sq[sl][g][n] = q;
+        sd[sl][g][n] = d;
+    }
+    __syncthreads();
+    const bool lead = sl == 0;                  // slice 0 (threads 0 .. 127 = waves 0, 1) folds and writes
+    const float w = (on && lead) ? a.W[(int64_t)k * N + n] : 0.0f;
+    double qtot = 0.0, dbtot = 0.0;
+    double s1[8], s2[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        s1[g] = s2[g] = 0.0;
+        if (g < G && lead) {
+            const double q = ((sq[0][g][n] + sq[1][g][n]) + sq[2][g][n]) + sq[3][g][n];
+            const double d = ((sd[0][g][n] + sd[1][g][n]) + sd[2][g][n]) + sd[3][g][n];
+            qtot += q;
+            dbtot += d;
+            s1[g] = (double)w * d;
+            s2[g] = (double)w * q;
+        }
+    }
+    if (on && lead) {
+        if (a.a_stats) a.dW[(int64_t)k * N + n] = (float)((double)a.a_gamma[k] * qtot + (double)a.a_beta[k] * dbtot);
+        else a.dW[(int64_t)k * N + n] = (float)qtot;
+        if (k == 0) a.db[n] = (float)dbtot;
+    }
+    if (!a.a_stats) return;
+    // BatchNorm-backward sums of the BatchNorm that produced a: fixed-order reduction over n
+    const int lane = n & 63, wave = n >> 6;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (g >= G) break;
+        double u1 = s1[g], u2 = s2[g];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            u1 += __shfl_down(u1, o);
+            u2 += __shfl_down(u2, o);
+        }
+        if (lane == 0 && lead) {
+            red[0][g][wave] = u1;
+            red[1][g][wave] = u2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int GK = G * K;
+        const double cnt = (double)a.Mg;
+        double dg = 0.0, dbt = 0.0;
+        for (int g = 0; g < G; ++g) {
+            const double u1 = red[0][g][0] + red[0][g][1], u2 = red[1][g][0] + red[1][g][1];
+            dbt += u1;
+            dg += u2;
+            a.a_coef[0 * GK + g * K + k] = a.a_stats[2 * GK + g * K + k];       // k1 = gamma * invstd
+            a.a_coef[1 * GK + g * K + k] = (float)(u1 / cnt);                   // k2 = mean(dz)
+            a.a_coef[2 * GK + g * K + k] = (float)(u2 / cnt);                   // k3 = mean(dz * xhat)
+        }
+        a.a_dgamma[k] = (float)dg;
+        a.a_dbeta[k] = (float)dbt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static inline int pwb_pad(int c) { return c <= 64 ? 64 : 128; }
+
+bool pw_bwd_fused_supported(View dz, View a, View da, int N, int K) {
+    if (N > 128 || K > 128 || N < 8 || K < 8 || (N & 1) || (K & 1)) return false;
+    if (pwb_pad(N) != pwb_pad(K)) return false;
+    auto ok = [](View v) { return (v.ld % 2 == 0) && (v.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 7) == 0); };
+    return ok(a) && ok(da) && (dz.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(dz.p) & 7) == 0);
+}
+
+int pw_bwd_fused_nbpg(int G, int Mg, int N, int K) {
+    const int bm = pwb_pad(K) == 128 ? 32 : 64;
+    const int tiles = cdiv(Mg, bm);
+    int nb = 256 / G;
+    if (nb < 1) nb = 1;
+    return nb > tiles ? tiles : nb;
+}
+
+int64_t pw_bwd_fused_qpart_elems(int G, int Mg, int N, int K) {
+    return (int64_t)G * pw_bwd_fused_nbpg(G, Mg, N, K) * pwb_pad(K) * pwb_pad(N);
+}
+
+int64_t pw_bwd_fused_dbpart_elems(int G, int Mg, int N, int K) { return (int64_t)G * pw_bwd_fused_nbpg(G, Mg, N, K) * pwb_pad(N); }
+
+template <int P, bool SHUF, bool ANORM, bool ACC>
+static int pwb_launch(const PwbArgs& a, hipStream_t st) {
+    constexpr int BM = P == 128 ? 32 : 64;
+    constexpr size_t lds = (size_t)(3 * BM * (P + 8) + 2 * 3 * P * (BM + 8)) * 2 + (size_t)7 * P * sizeof(float);
+    auto kern = pwb_kernel<P, P, SHUF, ANORM, ACC>;
+    static bool attr = false;
+    if (!attr) {
+        CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg), dim3(512), lds, st, a);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int P, bool SHUF>
+static int pwb_launch2(const PwbArgs& a, bool anorm, bool acc, hipStream_t st) {
+    if (anorm) return acc ? pwb_launch<P, SHUF, true, true>(a, st) : pwb_launch<P, SHUF, true, false>(a, st);
+    return acc ? pwb_launch<P, SHUF, false, true>(a, st) : pwb_launch<P, SHUF, false, false>(a, st);
+}
+
+int pw_bwd_fused(const PwBwdFused& f, hipStream_t st) {
+    if (!pw_bwd_fused_supported(f.dz, f.a, f.da, f.N, f.K) || !f.Wp) {
+        set_error("pw_bwd_fused: unsupported shape / alignment N=%d K=%d", f.N, f.K);
+        return -1;
+    }
+    const int64_t Mtot = (int64_t)f.G * f.Mg;
+    if (Mtot * f.dz.ld * 4 >= ((int64_t)1 << 31) || Mtot * f.a.ld * 4 >= ((int64_t)1 << 31) || Mtot * f.N * 4 >= ((int64_t)1 << 31) ||
+        Mtot * f.da.ld * 4 >= ((int64_t)1 << 31)) {
+        set_error("pw_bwd_fused: operand of 2 GB or more");
+        return -1;
+    }
+    if (f.G > 8) {
+        set_error("pw_bwd_fused: more than 8 groups");
+        return -1;
+    }
+    PwbArgs a;
+    a.dz = f.dz;
+    a.dz_shuffle = f.dz_shuffle;
+    a.act = f.act;
+    a.y = f.y;
+    a.stats = f.stats;
+    a.coef = f.coef;
+    a.a = f.a;
+    a.a_stats = f.a_stats;
+    a.Wp = reinterpret_cast<const __bf16*>(f.Wp);
+    a.da = f.da;
+    a.qpart = f.qpart;
+    a.dbpart = f.dbpart;
+    a.N = f.N;
+    a.K = f.K;
+    a.G = f.G;
+    a.Mg = f.Mg;
+    a.nbpg = pw_bwd_fused_nbpg(f.G, f.Mg, f.N, f.K);
+    static const int dbg = cdrl_getenv("CDRL_DIAG_PWB") ? atoi(cdrl_getenv("CDRL_DIAG_PWB")) : 0;
+    a.dbg = dbg;
+    const bool anorm = f.a_stats != nullptr, acc = f.accumulate != 0, shuf = f.dz_shuffle != 0;
+    if (pwb_pad(f.K) == 128) return shuf ? pwb_launch2<128, true>(a, anorm, acc, st) : pwb_launch2<128, false>(a, anorm, acc, st);
+    return shuf ? pwb_launch2<64, true>(a, anorm, acc, st) : pwb_launch2<64, false>(a, anorm, acc, st);
+}
+
+int pw_bwd_fused_reduce(const PwBwdFused& f, hipStream_t st) {
+    PwbReduceArgs r;
+    r.qpart = f.qpart;
+    r.dbpart = f.dbpart;
+    r.W = f.W;
+    r.a_stats = f.a_stats;
+    r.a_gamma = f.a_gamma;
+    r.a_beta = f.a_beta;
+    r.dW = f.dW;
+    r.db = f.db;
+    r.a_dgamma = f.a_dgamma;
+    r.a_dbeta = f.a_dbeta;
+    r.a_coef = f.a_coef;
+    r.N = f.N;
+    r.K = f.K;
+    r.KP = pwb_pad(f.K);
+    r.NP = pwb_pad(f.N);
+    r.G = f.G;
+    r.Mg = f.Mg;
+    r.nbpg = pw_bwd_fused_nbpg(f.G, f.Mg, f.N, f.K);
+    if (f.a_stats && (!f.a_gamma || !f.a_beta || !f.a_dgamma || !f.a_dbeta || !f.a_coef)) {
+        set_error("pw_bwd_fused_reduce: normalised input needs gamma / beta and the dgamma / dbeta / coef outputs");
+        return -1;
+    }
+    hipLaunchKernelGGL(pwb_reduce_kernel, dim3(f.K), dim3(512), 0, st, r);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cdrl

@@ -238,6 +238,22 @@ int cdrl_pwconv_x3_pack(const float* W, int K, int N, int sbk, int sbn, void* pa
 int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, const void* W_packed, const float* bias, float* C,
                    int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream);
 
+/* Backward of the unit's 1x1 convolution + BatchNorm (core/architectures.py:130-141 under tape.gradient, core/carla_agent.py:
+ * 364-365) as ONE pass over its operands: dy = BatchNorm-backward(dz, y) on load, da = dy W^T, dW = a^T dy, db = column sums of
+ * dy.  dz [G*Mg][ld_dz] (+ dz_coff, gathered through the channel shuffle of dz_shuffle channels when non-zero, ReLU6-masked from
+ * the BatchNorm output when act == 1), y [G*Mg][N] raw conv output, stats [4][G][N] / coef [3][G][N] of that BatchNorm.
+ * a [G*Mg][lda] (+ a_coff) conv input; a_stats ([4][G][K], or NULL): a is the raw input of a BatchNorm (no activation) applied on
+ * load, and that BatchNorm's dgamma / dbeta [K] and backward coefficients a_coef [3][G][K] are produced as well (from the filter
+ * product, no pass over da).  W [K][N]; W_packed: cdrl_pwconv_x3_pack(W, N, K, 1, N, ...) (the transposed operand).
+ * da [G*Mg][ldda] (+ da_coff; += when accumulate).  Workspaces: qpart cdrl_pwconv_bwd_fused_workspace(G, Mg, N, K, 0) floats,
+ * dbpart (..., 1) doubles.  K, N <= 128 and padded alike (both <= 64 or both > 64), even; float32-accurate. */
+int64_t cdrl_pwconv_bwd_fused_workspace(int G, int Mg, int N, int K, int which);
+int cdrl_pwconv_bwd_fused(const float* dz, int ld_dz, int dz_coff, int dz_shuffle, int act, const float* y, const float* stats,
+                          const float* coef, const float* a, int lda, int a_coff, const float* a_stats, const float* a_gamma,
+                          const float* a_beta, float* a_dgamma, float* a_dbeta, float* a_coef, const float* W, const void* W_packed,
+                          float* da, int ldda, int da_coff, int accumulate, float* dW, float* db, float* qpart, double* dbpart, int G,
+                          int Mg, int N, int K, void* stream);
+
 /* General float32 GEMM C (+)= A B + bias on the bf16 matrix pipe (three-way operand split; the 464 -> 768 head conv of
  * core/architectures.py:170 and its backward-data product).  B_packed: cdrl_gemm_x3_packed_bytes(N, K) bytes written by
  * cdrl_gemm_x3_pack from B(k, n) = B[k * sbk + n * sbn].  K, lda, a_coff multiples of 4, A 16-byte aligned. */

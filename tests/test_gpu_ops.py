@@ -723,3 +723,103 @@ def test_gemm_x3_split(lib, M, K, N):
         d = torch.ones((M, K), device=DEV)
         _lib.check(lib.cdrl_gemm_x3(P(g), N, 0, P(bt), None, P(d), K, 0, M, K, N, 1, S()))
         assert rel_err(d.cpu().numpy(), (g.double() @ b.double().t() + 1.0).cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('G,Mg,K,N,relu,shuffle,anorm,acc,generic', [
+    (4, 330, 58, 58, 1, 1, 1, 0, 0), (4, 96, 116, 116, 1, 1, 1, 0, 0), (4, 4100, 116, 116, 1, 0, 0, 1, 0), (2, 77, 58, 58, 0, 0, 0, 1, 1),
+    (4, 100, 116, 116, 1, 1, 1, 0, 1), (1, 64, 40, 60, 0, 0, 1, 0, 1), (2, 8300, 58, 58, 1, 1, 1, 0, 0), (4, 1500, 116, 116, 1, 1, 0, 0, 1),
+    (4, 12288, 116, 116, 1, 1, 1, 0, 0)])
+def test_pwconv_bwd_fused(lib, G, Mg, K, N, relu, shuffle, anorm, acc, generic):
+    """cdrl_pwconv_bwd_fused: BatchNorm-backward apply on load + backward-data + filter / bias gradient (+ the backward sums of
+    the BatchNorm in FRONT of the conv, derived from the filter product) in one pass, against a float64 numpy evaluation of
+    the same formulas (core/architectures.py:130-141 under autograd).  generic = 1: arbitrary (k2, k3) coefficients, so that
+    the bias gradient -- analytically zero behind a train-mode BatchNorm -- and every term that rides on it is exercised."""
+    rng = np.random.default_rng(G * Mg + K + 3 * N + relu + 2 * shuffle + 4 * anorm)
+    M = G * Mg
+    f64 = np.float64
+    x = rng.standard_normal((M, K)).astype(np.float32) * rng.uniform(0.5, 2.0, K).astype(np.float32) + rng.uniform(-1, 1, K).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    xg = x.astype(f64).reshape(G, Mg, K)
+    ga, ba = rng.uniform(0.5, 1.5, K).astype(np.float32), rng.uniform(-0.5, 0.5, K).astype(np.float32)
+    amean = xg.mean(axis=1).astype(np.float32)
+    ainv = (1.0 / np.sqrt(xg.var(axis=1) + 1e-3)).astype(np.float32)
+    ast = np.stack([amean, ainv, ga[None] * ainv, ba[None] - amean * (ga[None] * ainv)]).astype(np.float32)      # [4][G][K]
+    xh_a = (xg - ast[0].astype(f64)[:, None, :]) * ast[1].astype(f64)[:, None, :]
+    a = xh_a * ga.astype(f64) + ba.astype(f64) if anorm else xg
+    y64 = a @ w.astype(f64) + bias.astype(f64)
+    y = y64.astype(np.float32)                                          # the stored raw conv output
+    yg = y.astype(f64)
+    gy, by = rng.uniform(0.5, 1.5, N).astype(np.float32), rng.uniform(1.0, 3.0, N).astype(np.float32)
+    ymean = yg.mean(axis=1).astype(np.float32)
+    yinv = (1.0 / np.sqrt(yg.var(axis=1) + 1e-3)).astype(np.float32)
+    ysc = (gy[None] * yinv).astype(np.float32)
+    ysh = (by[None] - ymean * ysc).astype(np.float32)
+    yst = np.stack([ymean, yinv, ysc, ysh]).astype(np.float32)          # [4][G][N]
+    ctot, coff = (2 * N, N) if shuffle else (N, 0)
+    dout = rng.standard_normal((M, ctot)).astype(np.float32)
+    idx = [((coff + c) & 1) * (ctot // 2) + ((coff + c) >> 1) for c in range(N)] if shuffle else list(range(N))
+    dz = dout[:, idx].astype(f64).reshape(G, Mg, N)
+    if relu:
+        z = np.float32(ysc)[:, None, :] * y.reshape(G, Mg, N) + np.float32(ysh)[:, None, :]       # float32 fmaf region (ties are measure zero)
+        z64 = ysc.astype(f64)[:, None, :] * yg + ysh.astype(f64)[:, None, :]
+        safe = (np.abs(z64) > 1e-4) & (np.abs(z64 - 6.0) > 1e-4)       # elements away from the kinks decide identically
+        dz = dz * ((z64 > 0) & (z64 < 6))
+    xh_y = (yg - ymean.astype(f64)[:, None, :]) * yinv.astype(f64)[:, None, :]
+    k2 = dz.mean(axis=1)
+    k3 = (dz * xh_y).mean(axis=1)
+    if generic:
+        k2 = k2 + rng.uniform(-0.3, 0.3, k2.shape)
+        k3 = k3 + rng.uniform(-0.3, 0.3, k3.shape)
+    coef = np.stack([ysc, k2.astype(np.float32), k3.astype(np.float32)]).astype(np.float32)      # [3][G][N]
+    dy = coef[0].astype(f64)[:, None, :] * (dz - coef[1].astype(f64)[:, None, :] - xh_y * coef[2].astype(f64)[:, None, :])
+    if relu:            # kink-adjacent elements: use whatever side the float32 expression takes (both are valid float32 evaluations)
+        m32 = (z > 0) & (z < 6)
+        flip = ~safe & (m32 != ((z64 > 0) & (z64 < 6)))
+        if flip.any():
+            dzf = dout[:, idx].astype(f64).reshape(G, Mg, N) * m32
+            dy = np.where(flip, coef[0].astype(f64)[:, None, :] * (dzf - coef[1].astype(f64)[:, None, :] - xh_y * coef[2].astype(f64)[:, None, :]), dy)
+    da_ref = dy @ w.astype(f64).T                                       # (G, Mg, K)
+    dw_ref = np.einsum('gmk,gmn->kn', a, dy)
+    db_ref = dy.sum(axis=(0, 1))
+    # device
+    X, Wd, Y, YS, CF, DO = dev(x), dev(w), dev(y.reshape(M, N)), dev(yst), dev(coef), dev(dout)
+    AS, GA, BA = dev(ast), dev(ga), dev(ba)
+    wp = torch.zeros(int(lib.cdrl_pwconv_x3_packed_bytes(N)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cdrl_pwconv_x3_pack(P(Wd), N, K, 1, N, P(wp), S()))            # B(k = n_out, n = k_in) = W[n][k]
+    qpart = torch.zeros(int(lib.cdrl_pwconv_bwd_fused_workspace(G, Mg, N, K, 0)), device=DEV)
+    dbpart = torch.zeros(int(lib.cdrl_pwconv_bwd_fused_workspace(G, Mg, N, K, 1)), dtype=torch.float64, device=DEV)
+    base = rng.standard_normal((M, K + 4)).astype(np.float32)
+    dA = dev(base.copy())
+    dW, dB = torch.full((K, N), 7.0, device=DEV), torch.full((N,), 7.0, device=DEV)
+    adg, adb, acf = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV), torch.zeros(3 * G * K, device=DEV)
+    _lib.check(lib.cdrl_pwconv_bwd_fused(P(DO), ctot, coff, ctot if shuffle else 0, relu, P(Y), P(YS), P(CF), P(X), K, 0,
+                                         P(AS) if anorm else None, P(GA) if anorm else None, P(BA) if anorm else None,
+                                         P(adg) if anorm else None, P(adb) if anorm else None, P(acf) if anorm else None, P(Wd), P(wp),
+                                         P(dA), K + 4, 2, acc, P(dW), P(dB), P(qpart), P(dbpart), G, Mg, N, K, S()))
+    torch.cuda.synchronize()
+    got = dA.cpu().numpy()
+    exp = da_ref.reshape(M, K) + (base[:, 2:2 + K].astype(f64) if acc else 0.0)
+    assert rel_err(got[:, 2:2 + K], exp) < 1e-5
+    assert np.array_equal(got[:, :2], base[:, :2]) and np.array_equal(got[:, 2 + K:], base[:, 2 + K:])
+    assert rel_err(dW.cpu().numpy(), dw_ref) < 1e-5
+    scale_db = max(np.abs(db_ref).max(), 1e-4 * np.abs(dw_ref).max())
+    assert np.abs(dB.cpu().numpy() - db_ref).max() < 2e-5 * scale_db + 1e-5 * np.abs(dw_ref).max()
+    if anorm:
+        s1 = da_ref.sum(axis=1)                                         # (G, K)
+        s2 = (da_ref * xh_a).sum(axis=1)
+        cf = acf.cpu().numpy().reshape(3, G, K)
+        assert np.array_equal(cf[0], ast[2])
+        sc = max(np.abs(s2).max(), np.abs(s1).max()) / Mg
+        assert np.abs(cf[1] - s1 / Mg).max() < 2e-5 * sc
+        assert np.abs(cf[2] - s2 / Mg).max() < 2e-5 * sc
+        assert rel_err(adg.cpu().numpy(), s2.sum(axis=0)) < 2e-5
+        assert np.abs(adb.cpu().numpy() - s1.sum(axis=0)).max() < 2e-5 * np.abs(s2.sum(axis=0)).max()
+    # bit-wise reproducible (fixed-order partial sums, no atomics)
+    dW2, dB2 = torch.zeros((K, N), device=DEV), torch.zeros(N, device=DEV)
+    dA2 = dev(base.copy())
+    _lib.check(lib.cdrl_pwconv_bwd_fused(P(DO), ctot, coff, ctot if shuffle else 0, relu, P(Y), P(YS), P(CF), P(X), K, 0,
+                                         P(AS) if anorm else None, P(GA) if anorm else None, P(BA) if anorm else None,
+                                         P(adg) if anorm else None, P(adb) if anorm else None, P(acf) if anorm else None, P(Wd), P(wp),
+                                         P(dA2), K + 4, 2, acc, P(dW2), P(dB2), P(qpart), P(dbpart), G, Mg, N, K, S()))
+    assert torch.equal(dW, dW2) and torch.equal(dB, dB2) and torch.equal(dA, dA2)
