@@ -191,7 +191,7 @@ class CARLAgent(PPOAgent):
 
     def load(self):
         super().load()
-        if self.data_parallel:
+        if getattr(self, 'data_parallel', False):       # (load=True in the constructor runs before _init_data_parallel, which broadcasts itself)
             self._dp_for(self.network.engine).broadcast_parameters()
 
     def hyper_parameters(self) -> dict:

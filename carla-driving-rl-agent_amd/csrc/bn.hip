@@ -873,8 +873,12 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
         const int64_t gbase = (int64_t)g * Mg;
         bool pooled = POOLED;
         if (POOLED) {
+            // v = (a - shift) / scale recovers the pre-BatchNorm value from the pooled activation with an absolute error of
+            // eps (|a| + |shift|) / |scale|, i.e. eps (|a| + |shift|) / |gamma| in xhat: the shortcut is taken only where that stays
+            // near 3e-6 (|shift| <= 8, |gamma| >= 0.25, |scale| >= 0.05); other channels use the gather form below
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) pooled = pooled && fabsf(sc.v[i]) >= 0.05f;
+            for (int i = 0; i < VEC; ++i)
+                pooled = pooled && fabsf(sc.v[i]) >= 0.05f && fabsf(sh.v[i]) <= 8.0f && fabsf(sc.v[i]) >= 0.25f * fabsf(invstd.v[i]);
         }
         if (POOLED && pooled) {
             float isc[VEC];
@@ -898,6 +902,23 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
                             const float xh = (v - mean.v[i]) * invstd.v[i];
                             acc[0][i] += (double)d[u].v[i];
                             acc[1][i] += (double)d[u].v[i] * (double)xh;
+                        } else if (sizeof(T) == 2 && a[u].v[i] == 6.0f) {
+                            // bf16 storage: an activation in (6 - half a bf16 ulp, 6) was STORED as 6.0, but its ReLU6 is open and the
+                            // apply side (stem_bwd_filter_fused) takes the mask from the raw conv output -- decide from that here too
+                            // (rare: one gather for the element)
+                            const int64_t row = gbase + rr + u * CY;
+                            const int k = (int)ps.argmax[row * C + c0 + i];
+                            const int ox = (int)(row % ps.Wo);
+                            const int64_t q = row / ps.Wo;
+                            const int oy = (int)(q % ps.Ho);
+                            const int64_t n = q / ps.Ho;
+                            const int ky = k / 3, kx = k - 3 * ky;
+                            const float yv = ldf(y + ((n * ps.H + (2 * oy - ps.pt + ky)) * ps.W + (2 * ox - ps.pl + kx)) * C + c0 + i);
+                            if (relu6_open(fmaf(sc.v[i], yv, sh.v[i]))) {
+                                const float xh = (yv - mean.v[i]) * invstd.v[i];
+                                acc[0][i] += (double)d[u].v[i];
+                                acc[1][i] += (double)d[u].v[i] * (double)xh;
+                            }
                         }
                     }
                 }

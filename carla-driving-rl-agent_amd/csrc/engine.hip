@@ -537,7 +537,8 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     // float32 engine, both channel counts padded alike (gemm_pw_bwd.hip)
     const View dz_probe = fuse.bb_dz.p ? fuse.bb_dz : make_view(reinterpret_cast<float*>(uintptr_t(16)), Cout);
     const bool anorm = fuse.pro_stats != nullptr;
-    const bool fbwd = fused_bwd_ && fuse.bb && fuse.bwd_pw && !bfc && G <= 8 && pw_bwd_fused_supported(dz_probe, in, din, Cout, Cin) &&
+    // (24 input channels -- the first unit -- pad to 64: 158 vs 104 us for the two-kernel form; kept there)
+    const bool fbwd = fused_bwd_ && fuse.bb && fuse.bwd_pw && !bfc && G <= 8 && Cin >= 32 && pw_bwd_fused_supported(dz_probe, in, din, Cout, Cin) &&
                       (!anorm || (fuse.bwd_ey == in.p && fuse.bwd_epi_stats == fuse.pro_stats && fuse.a_bn && in.ld == Cin && in.coff == 0)) &&
                       (anorm || !fuse.bwd_ey);
     const void* wpx = fbwd ? pw_x3_packed(w.p, Cout, Cin, 1, Cout) : nullptr;      // W^T planes: B(k = cout, n = cin)

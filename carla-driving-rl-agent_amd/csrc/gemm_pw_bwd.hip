@@ -29,6 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));     // arithmetic on pairs compiles to v_pk_{add,mul,fma}_f32
 
 struct PwbArgs {
     View dz;                // gradient w.r.t. the BatchNorm output (columns optionally gathered through the shuffle map)
@@ -53,6 +54,20 @@ __device__ __forceinline__ void pwb_split3(float x, __bf16& h1, __bf16& h2, __bf
     h2 = (__bf16)r1;
     h3 = (__bf16)(r1 - (float)h2);
 }
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// the same split on a pair, results as packed dwords {lo = first element, hi = second}: three packed conversions, two packed
+// subtractions, widening by shift / mask
+__device__ __forceinline__ void pwb_split3x2(f32x2 x, uint32_t& h1, uint32_t& h2, uint32_t& h3) {
+    auto widen = [](uint32_t w) -> f32x2 { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; };
+    h1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+    const f32x2 r1 = x - widen(h1);
+    h2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+    h3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1 - widen(h2), bf16x2));
+}
+// {lo16(a), lo16(b)} and {hi16(a), hi16(b)} in one v_perm_b32 each: two rows of one column from two rows of a column pair
+__device__ __forceinline__ uint32_t pwb_lolo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t pwb_hihi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 // KP: padded input channels (k_in), NP: padded output channels (n_out); (128, 128) -> 32-row tiles, (64, 64) -> 64-row tiles.
 // The two halves of the workgroup run DIFFERENT loops (scalar branch on the wave index: registers of one role are not live in
@@ -120,7 +135,7 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
         const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y), 0, (int)(Mtot * N * 4), 0x00020000);
         const uint32_t rowD = (uint32_t)a.dz.ld * 4u, rowY = (uint32_t)N * 4u;
         const bool relu6 = a.act == ACT_RELU6;
-        float rz[4][4], ry[4][4];                   // raw tile registers: dz, y of the micro-tile
+        f32x2 rz[4][2], ry[4][2];                   // raw tile registers: dz, y of the micro-tile as column pairs
         // Row j of tile t -> rz[j], ry[j].  The rows of the NEXT tile are requested from inside store_tile, each as soon as the
         // prologue has consumed the registers of the current one: a load then has the LDS writes, both barriers and the whole MFMA
         // phase to arrive (issued after the first barrier instead, ~10 of 40 us were exposed load latency).
@@ -135,20 +150,18 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
                 if (SHUF) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        rz[j][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, (vo[e] + (uint32_t)j * rowD) | msk, mu * rowD, 0));
+                        rz[j][e >> 1][e & 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, (vo[e] + (uint32_t)j * rowD) | msk, mu * rowD, 0));
                 } else {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsD, (vo[2 * h] + (uint32_t)j * rowD) | msk, mu * rowD, 0);
-                        rz[j][2 * h] = __uint_as_float(v[0]);
-                        rz[j][2 * h + 1] = __uint_as_float(v[1]);
+                        rz[j][h] = __builtin_bit_cast(f32x2, v);
                     }
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsY, (voy[h] + (uint32_t)j * rowY) | msk, mu * rowY, 0);
-                    ry[j][2 * h] = __uint_as_float(v[0]);
-                    ry[j][2 * h + 1] = __uint_as_float(v[1]);
+                    ry[j][h] = __builtin_bit_cast(f32x2, v);
                 }
             }
         };
@@ -156,66 +169,71 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
         auto store_tile = [&](int t) {
             const bool more = t + 1 < t1;
             const int left = (int)(mend - (mbeg + (int64_t)t * BM + 4 * rg));
-            float cmean[4], cinv[4], csc[4], csh[4], ck1[4], ck2[4], ck3[4];
+            // coefficients of this thread's four columns as two pairs
+            f32x2 cmean[2], cinv[2], csc[2], csh[2], ck1[2], ck2[2], ck3[2];
             {
                 const float4 q0 = *reinterpret_cast<const float4*>(&cf[0 * NP + c0]), q1 = *reinterpret_cast<const float4*>(&cf[1 * NP + c0]);
                 const float4 q2 = *reinterpret_cast<const float4*>(&cf[2 * NP + c0]), q3 = *reinterpret_cast<const float4*>(&cf[3 * NP + c0]);
                 const float4 q4 = *reinterpret_cast<const float4*>(&cf[4 * NP + c0]), q5 = *reinterpret_cast<const float4*>(&cf[5 * NP + c0]);
                 const float4 q6 = *reinterpret_cast<const float4*>(&cf[6 * NP + c0]);
-                cmean[0] = q0.x; cmean[1] = q0.y; cmean[2] = q0.z; cmean[3] = q0.w;
-                cinv[0] = q1.x; cinv[1] = q1.y; cinv[2] = q1.z; cinv[3] = q1.w;
-                csc[0] = q2.x; csc[1] = q2.y; csc[2] = q2.z; csc[3] = q2.w;
-                csh[0] = q3.x; csh[1] = q3.y; csh[2] = q3.z; csh[3] = q3.w;
-                ck1[0] = q4.x; ck1[1] = q4.y; ck1[2] = q4.z; ck1[3] = q4.w;
-                ck2[0] = q5.x; ck2[1] = q5.y; ck2[2] = q5.z; ck2[3] = q5.w;
-                ck3[0] = q6.x; ck3[1] = q6.y; ck3[2] = q6.z; ck3[3] = q6.w;
+                cmean[0] = f32x2{q0.x, q0.y}; cmean[1] = f32x2{q0.z, q0.w};
+                cinv[0] = f32x2{q1.x, q1.y}; cinv[1] = f32x2{q1.z, q1.w};
+                csc[0] = f32x2{q2.x, q2.y}; csc[1] = f32x2{q2.z, q2.w};
+                csh[0] = f32x2{q3.x, q3.y}; csh[1] = f32x2{q3.z, q3.w};
+                ck1[0] = f32x2{q4.x, q4.y}; ck1[1] = f32x2{q4.z, q4.w};
+                ck2[0] = f32x2{q5.x, q5.y}; ck2[1] = f32x2{q5.z, q5.w};
+                ck3[0] = f32x2{q6.x, q6.y}; ck3[1] = f32x2{q6.z, q6.w};
             }
-            bf16x4 hc[3][4];                        // [plane][column e] -> 4 rows
+            uint32_t hw[3][4][2];                   // [plane][row j][column pair h]: packed bf16 pairs of the micro-tile
+            f32x2 ts[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};      // column sums of this tile's four rows (float), folded into cs below
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool rok = j < left;
-                bf16x4 hr[3];
-                float vrow[4];
+                f32x2 vrow[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float d = rz[j][e];
-                    const float yv = ry[j][e];
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 d = rz[j][h];
+                    const f32x2 yv = ry[j][h];
                     if (relu6) {
-                        const float z = fmaf(csc[e], yv, csh[e]);
-                        if (!relu6_open(z)) d = 0.0f;
+                        const f32x2 z = __builtin_elementwise_fma(csc[h], yv, csh[h]);     // = fmaf(scale, y, shift) of the forward, per element
+                        if (!relu6_open(z[0])) d[0] = 0.0f;
+                        if (!relu6_open(z[1])) d[1] = 0.0f;
                     }
-                    const float xh = (yv - cmean[e]) * cinv[e];
-                    float v = ck1[e] * (d - ck2[e] - xh * ck3[e]);      // padded columns: every coefficient 0 -> 0
-                    if (!rok) v = 0.0f;
-                    vrow[e] = v;
+                    const f32x2 xh = (yv - cmean[h]) * cinv[h];
+                    f32x2 v = ck1[h] * (d - ck2[h] - xh * ck3[h]);      // padded columns: every coefficient 0 -> 0
+                    if (!rok) v = f32x2{0.0f, 0.0f};
+                    vrow[h] = v;
                 }
                 if (more) load_row(t + 1, j);       // rz[j] / ry[j] are free
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = vrow[e];
-                    cs[e] += (double)v;
-                    __bf16 h1, h2, h3;
-                    pwb_split3(v, h1, h2, h3);
-                    hr[0][e] = h1;
-                    hr[1][e] = h2;
-                    hr[2][e] = h3;
-                    hc[0][e][j] = h1;
-                    hc[1][e][j] = h2;
-                    hc[2][e][j] = h3;
+                for (int h = 0; h < 2; ++h) {
+                    ts[h] += vrow[h];
+                    pwb_split3x2(vrow[h], hw[0][j][h], hw[1][j][h], hw[2][j][h]);
                 }
-                if (!(a.dbg & 2)) {
+                if (!(a.dbg & 2)) {                 // row-major planes: the conversion results as they are
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(&Rm[p * BM * LDR + (4 * rg + j) * LDR + c0]) = hr[p];
+                    for (int p = 0; p < 3; ++p)
+                        *reinterpret_cast<u32x2*>(&Rm[p * BM * LDR + (4 * rg + j) * LDR + c0]) = u32x2{hw[p][j][0], hw[p][j][1]};
                 }
             }
+            cs[0] += (double)ts[0][0];
+            cs[1] += (double)ts[0][1];
+            cs[2] += (double)ts[1][0];
+            cs[3] += (double)ts[1][1];
             if (a.dbg & 2) {
-                if (hc[0][0][0] == (__bf16)123.0f && hc[2][3][3] == (__bf16)321.0f) Rm[0] = hc[1][1][1];      // keep the math alive
+                if (hw[0][0][0] == 123u && hw[2][3][1] == 321u) Rm[0] = (__bf16)1.0f;      // keep the math alive
                 return;
             }
+            // transposed planes: column c0 + e, rows 4 rg .. 4 rg + 3 = one v_perm_b32 per row pair
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16x4*>(&Dt[p * TP + (c0 + e) * LDT + 4 * rg]) = hc[p][e];
+                for (int h = 0; h < 2; ++h) {
+                    *reinterpret_cast<u32x2*>(&Dt[p * TP + (c0 + 2 * h) * LDT + 4 * rg]) =
+                        u32x2{pwb_lolo(hw[p][0][h], hw[p][1][h]), pwb_lolo(hw[p][2][h], hw[p][3][h])};
+                    *reinterpret_cast<u32x2*>(&Dt[p * TP + (c0 + 2 * h + 1) * LDT + 4 * rg]) =
+                        u32x2{pwb_hihi(hw[p][0][h], hw[p][1][h]), pwb_hihi(hw[p][2][h], hw[p][3][h])};
+                }
         };
         // output tile through a buffer descriptor: the row offset of register r is wave-uniform (SGPR soffset), the lane's part
         // (its 4 lk rows + its column) one constant voffset -- no 64-bit address per register (the flat form kept 16 of them live
@@ -286,17 +304,15 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
         // =========================================================== a (or xhat(a)) -> LDS; Q += a^T dy over all tiles
         const int qw = wave & 3;
         const int qkt = qw % Q_KT, qnt0 = (qw / Q_KT) * NTW;
-        float cmean[4], cinv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cmean[e] = cinv[e] = 0.0f;
+        f32x2 cmean[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}}, cinv[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
         if (ANORM) {
             const int GK = a.G * K;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = c0 + e;
                 const bool on = c < K;
-                cmean[e] = on ? a.a_stats[0 * GK + g * K + (on ? c : 0)] : 0.0f;
-                cinv[e] = on ? a.a_stats[1 * GK + g * K + (on ? c : 0)] : 0.0f;
+                cmean[e >> 1][e & 1] = on ? a.a_stats[0 * GK + g * K + (on ? c : 0)] : 0.0f;
+                cinv[e >> 1][e & 1] = on ? a.a_stats[1 * GK + g * K + (on ? c : 0)] : 0.0f;
             }
         }
         uint32_t vo[2];
@@ -304,7 +320,7 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
         vo[1] = c0 + 2 < K ? (uint32_t)((4 * rg) * a.a.ld + a.a.coff + c0 + 2) * 4u : OOR;
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a.a.p, 0, (int)(Mtot * a.a.ld * 4), 0x00020000);
         const uint32_t rowA = (uint32_t)a.a.ld * 4u;
-        float rz[4][4];
+        f32x2 rz[4][2];
         auto load_row = [&](int t, int j) {
             if (a.dbg & 8) return;
             const int64_t m0 = mbeg + (int64_t)t * BM;
@@ -315,47 +331,44 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsA, (vo[h] + (uint32_t)j * rowA) | msk, mu * rowA, 0);
-                    rz[j][2 * h] = __uint_as_float(v[0]);
-                    rz[j][2 * h + 1] = __uint_as_float(v[1]);
+                    rz[j][h] = __builtin_bit_cast(f32x2, v);
                 }
             }
         };
         auto store_tile = [&](int t) {
             const bool more = t + 1 < t1;
             const int left = (int)(mend - (mbeg + (int64_t)t * BM + 4 * rg));
-            bf16x4 hc[3][4];
+            uint32_t hw[3][4][2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool rok = j < left;
-                float vrow[4];
+                f32x2 vrow[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = rz[j][e];
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 v = rz[j][h];
                     if (ANORM) {
-                        v = (v - cmean[e]) * cinv[e];       // padded columns: loaded 0, mean 0, invstd 0 -> 0
-                        if (!rok) v = 0.0f;
+                        v = (v - cmean[h]) * cinv[h];       // padded columns: loaded 0, mean 0, invstd 0 -> 0
+                        if (!rok) v = f32x2{0.0f, 0.0f};
                     }
-                    vrow[e] = v;
+                    vrow[h] = v;
                 }
                 if (more) load_row(t + 1, j);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = vrow[e];
-                    __bf16 h1, h2, h3;
-                    pwb_split3(v, h1, h2, h3);
-                    hc[0][e][j] = h1;
-                    hc[1][e][j] = h2;
-                    hc[2][e][j] = h3;
-                }
+                for (int h = 0; h < 2; ++h) pwb_split3x2(vrow[h], hw[0][j][h], hw[1][j][h], hw[2][j][h]);
             }
             if (a.dbg & 2) {
-                if (hc[0][0][0] == (__bf16)123.0f && hc[2][3][3] == (__bf16)321.0f) At[0] = hc[1][1][1];
+                if (hw[0][0][0] == 123u && hw[2][3][1] == 321u) At[0] = (__bf16)1.0f;
                 return;
             }
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16x4*>(&At[p * TP + (c0 + e) * LDT + 4 * rg]) = hc[p][e];
+                for (int h = 0; h < 2; ++h) {
+                    *reinterpret_cast<u32x2*>(&At[p * TP + (c0 + 2 * h) * LDT + 4 * rg]) =
+                        u32x2{pwb_lolo(hw[p][0][h], hw[p][1][h]), pwb_lolo(hw[p][2][h], hw[p][3][h])};
+                    *reinterpret_cast<u32x2*>(&At[p * TP + (c0 + 2 * h + 1) * LDT + 4 * rg]) =
+                        u32x2{pwb_hihi(hw[p][0][h], hw[p][1][h]), pwb_hihi(hw[p][2][h], hw[p][3][h])};
+                }
         };
         f32x16 qacc[NTW];
 #pragma unroll

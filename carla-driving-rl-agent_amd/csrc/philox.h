@@ -10,6 +10,11 @@
 
 namespace cdrl {
 
+// stream contract, checked by the host entry points (philox_words; beta_sample and augment_images index far below it: rows x actions
+// and pixels of one call): element index < 2^48, at most 2^16 blocks (2^18 words) per element
+constexpr uint64_t PHILOX_MAX_ELEMENTS = (uint64_t)1 << 48;
+constexpr int PHILOX_MAX_BLOCKS = 1 << 16;
+
 struct Philox {
     uint32_t c[4], k[2], out[4];
     int used;

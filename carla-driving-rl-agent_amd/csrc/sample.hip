@@ -108,6 +108,13 @@ __global__ void philox_words_kernel(uint64_t seed, uint64_t offset, uint64_t idx
 }
 
 int philox_words(uint64_t seed, uint64_t offset, uint64_t idx0, int n, int nblocks, uint32_t* out, hipStream_t st) {
+    // stream contract (philox.h): element indices below 2^48 (the top 16 bits of the index word count the element's blocks) and at
+    // most 2^16 blocks per element -- beyond either an element would silently alias another one's words
+    if (n < 0 || idx0 >= PHILOX_MAX_ELEMENTS || (uint64_t)n > PHILOX_MAX_ELEMENTS - idx0 || nblocks < 0 || nblocks > PHILOX_MAX_BLOCKS) {
+        set_error("philox_words: element range [%llu, +%d) or block count %d outside the stream contract (2^48 elements, 2^16 blocks)",
+                  (unsigned long long)idx0, n, nblocks);
+        return -1;
+    }
     if (n <= 0 || nblocks <= 0) return 0;
     hipLaunchKernelGGL(philox_words_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, seed, offset, idx0, n, nblocks, out);
     CDRL_LAUNCH_CHECK();

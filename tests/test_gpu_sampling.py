@@ -97,6 +97,13 @@ def test_philox_streams_of_consecutive_offsets_are_disjoint(lib):
     # first block = the documented counter layout (the augmentation oracle's numpy Philox reproduces it): unchanged
     from oracle.augment import _block
     assert np.array_equal(words[0][:, 0, :], _block(99, 10, np.arange(n, dtype=np.uint64)))
+    # the stream contract is enforced, not assumed: element indices >= 2^48 or more than 2^16 blocks per element would
+    # alias another element's words
+    out = torch.zeros((4, 1, 4), dtype=torch.int32, device=DEV)
+    assert lib.cdrl_philox_words(99, 10, (1 << 48) - 2, 4, 1, P(out), S()) != 0
+    assert lib.cdrl_philox_words(99, 10, 1 << 48, 1, 1, P(out), S()) != 0
+    assert lib.cdrl_philox_words(99, 10, 0, 1, (1 << 16) + 1, P(out), S()) != 0
+    assert lib.cdrl_philox_words(99, 10, (1 << 48) - 4, 4, 1, P(out), S()) == 0
 
 
 def test_beta_sample_per_sample_jacobians_match_quantile_finite_differences(lib):

@@ -86,9 +86,9 @@ def _trunk_group(name):
 
 
 # Trunk gradients of a 32-row minibatch on the engine's own decisions (same criterion as tests/test_gpu_learner.py::
-# _pinned_grad_check, there 1e-4 at 64 / 256 rows): tower and tail 2e-4 like the heads; the three tiny feature nets sit behind
+# _pinned_grad_check, there 1e-4 at 64 / 256 rows): tower 1.5e-4, tail 1e-4; the three tiny feature nets sit behind
 # BatchNorms over 32 rows per time slice, where float32 cancellation costs another factor (1.8e-4 was measured at 48 rows)
-TRUNK_TOL = dict(tower=2e-4, tail=2e-4, featnet=5e-4)
+TRUNK_TOL = dict(tower=1.5e-4, tail=1e-4, featnet=3e-4)      # measured worst over the compared steps: 5.9e-5, 4.1e-5, 1.2e-4
 
 
 def _trunk_grads_close(views, ref, seen, what):
@@ -105,12 +105,13 @@ def _trunk_grads_close(views, ref, seen, what):
         assert e < TRUNK_TOL[grp], (seen, what, name, e)
 
 
-def _head_grads_close(views, ref, seen, tol=2e-4):
+def _head_grads_close(views, ref, seen, tol=3e-4):
     """Head gradients of one minibatch step vs the FLOAT64 oracle stepping from the same state ON THE ENGINE'S OWN DISCRETE
     DECISIONS (ReLU6 regions / max-pool argmax of this very forward, tests/util.py::engine_decisions) -- both sides are then the
-    same smooth function, as in tests/test_gpu_learner.py::test_pinned_decisions_*.  Bound 2e-4 relative to each tensor's scale
+    same smooth function, as in tests/test_gpu_learner.py::test_pinned_decisions_*.  Bound 3e-4 relative to each tensor's scale
     (floored at 1e-3 of the branch's largest gradient): the minibatch here is 32 rows, where the heads' BatchNorms over 32
-    rows cost float32 a factor ~2 over the 64- and 256-row cases that are held to 1e-4 there (measured worst 1.1e-4)."""
+    rows cost float32 a factor ~2-3 over the 64- and 256-row cases that are held to 1e-4 there (measured worst 1.1e-4 .. 2.2e-4 over
+    the 14 states of the loop: the single-element bias gradients of the value heads are the worst)."""
     gmax = max(float(g.abs().max()) for g in ref.values())
     for name, g in ref.items():
         e = float((views[name].cpu().double() - g).abs().max()) / max(float(g.abs().max()), 1e-3 * gmax)
