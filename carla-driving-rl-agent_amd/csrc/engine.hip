@@ -989,6 +989,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         note_named("img.stem.bn.stats", stem_stats, (size_t)4 * T * Cs * sizeof(float));
         note_named("img.stem.bn.x", y.p, (size_t)N * Hs * Ws * Cs * esz());
         note_named("img.stem.pool.argmax", argmax, (size_t)N * Hp0 * Wp0 * Cs);
+        note_named("img.stem.pool.out", pool.p, (size_t)N * Hp0 * Wp0 * Cs * esz());
+        note_named("img.stem.pool.out.g", pool.g, (size_t)N * Hp0 * Wp0 * Cs * esz());
         // one-pass form (stem_bwd.hip): BN sums and filter sums together, everything in the BN op's backward.  Opt-in
         // (CDRL_STEM_DIRECT=1): measured 747 us (three accumulator tiles, 64 KB LDS -> two workgroups per CU) against
         // 206 + 453 us for the two-pass form whose second pass overlaps on the side stream: 22.3 vs 22.0 ms/update-step.
@@ -1068,6 +1070,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 const int Mg_in = B * curH * curW, Mg_out = B * Ho * Wo;
                 const std::string pre = "img.s" + std::to_string(s) + ".u" + std::to_string(u);
                 Tens out = tens_a(rows_out, C);
+                note_named(pre + ".out", out.p, (size_t)rows_out * C * esz());        // unit output / its gradient (per-unit parity tests)
+                note_named(pre + ".out.g", out.g, (size_t)rows_out * C * esz());
                 // stride-2 units: the shortcut branch (dw3x3/s2 -> BN -> 1x1 -> BN+ReLU6) only depends on the unit input; in the
                 // FORWARD pass (where the side stream is idle) it runs on the side stream next to the main branch
                 static const bool sc_overlap_env = !(cdrl_getenv("CDRL_SC_OVERLAP") && atoi(cdrl_getenv("CDRL_SC_OVERLAP")) == 0);

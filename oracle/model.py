@@ -201,6 +201,32 @@ class _PwBf16Operands(torch.autograd.Function):
 
 
 PW_BF16_OPERANDS = False        # set by the bf16-mode parity tests (tests/test_gpu_bf16.py); module state like DEC
+# bf16 ACTIVATION STORAGE (include/cdrl.h CDRL_COMPUTE_BF16_STORAGE, BASELINE.json configs[2]): every activation tensor of the image
+# tower that the engine keeps in HBM is rounded to bf16 where it is stored, and so is every activation GRADIENT it stores; what is
+# recomputed on load (BatchNorm apply / backward apply, ReLU6) stays in the working precision.  Set together with PW_BF16_OPERANDS.
+BF16_STORAGE = False
+
+
+class _Store(torch.autograd.Function):
+    """A storage point: forward value rounded to bf16 when `fwd`, incoming gradient rounded to bf16 when `bwd`."""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return _bf16_round(x) if fwd else x
+
+    @staticmethod
+    def backward(ctx, g):
+        return (_bf16_round(g) if ctx.bwd else g), None, None
+
+
+def _st(x, fwd, bwd):
+    """Storage point of the bf16-storage contract (no-op outside that mode).  Which tensors are stored, and which of their
+    gradients, follows the engine's workspace plan (csrc/engine.hip::build_trunk, DESIGN.md section 7):
+      fwd: raw conv / depthwise outputs (the BatchNorm inputs), the max-pool output, every unit output, the shortcut branch's BN1 output
+      bwd: gradients w.r.t. unit outputs / the pool output, w.r.t. the BN2 output (a2.g), the ReLU6-masked gradient at the BN1
+           output (dz1), the shortcut's BN1 output, and -- on the unfused paths (shortcut conv, head conv) -- w.r.t. the conv output."""
+    return _Store.apply(x, fwd, bwd) if BF16_STORAGE else x
 
 
 def conv_pw(x, p, prefix):
@@ -235,42 +261,49 @@ def channel_shuffle(x):
 # tower / trunk
 # ------------------------------------------------------------------------------------------------
 
+def shufflenet_unit(x, p, u, training: bool):
+    """shufflenet_v2_unit, core/architectures.py:120-145 (u: one entry of oracle.spec.unit_plan).  x: (T,B,C,H,W)."""
+    pre = f"img.s{u['stage']}.u{u['unit']}"
+    if u['stride'] == 1:
+        sc, m = x[:, :, :u['shortcut_c']], x[:, :, u['shortcut_c']:]               # tf.split, :87-97
+    else:
+        sc, m = _st(x, False, True), x          # (engine: the shortcut's input gradient is stored, the main branch accumulates onto it)
+    m = _st(conv_pw(m, p, f'{pre}.pw1'), True, False)
+    m = _st(bn_slices(m, p, f'{pre}.bn1', training, True), False, True)
+    m = relu6(m)
+    m = _st(conv_dw(m, p, f'{pre}.dw', u['stride']), True, False)
+    m = _st(bn_slices(m, p, f'{pre}.bn2', training, True), False, True)
+    m = _st(conv_pw(m, p, f'{pre}.pw2'), True, False)
+    m = relu6(bn_slices(m, p, f'{pre}.bn3', training, True))
+    if u['stride'] == 2:
+        sc = _st(conv_dw(sc, p, f'{pre}.sc_dw', 2), True, False)
+        sc = _st(bn_slices(sc, p, f'{pre}.sc_bn1', training, True), True, True)
+        sc = _st(conv_pw(sc, p, f'{pre}.sc_pw'), True, True)
+        sc = relu6(bn_slices(sc, p, f'{pre}.sc_bn2', training, True))
+    return _st(channel_shuffle(torch.cat([sc, m], dim=2)), True, True)               # :144-145
+
+
 def shufflenet_v2(image, p, cfg: NetConfig, training: bool, taps: Optional[dict] = None):
     """core/architectures.py:30-173.  image: (B,T,H,W,3) -> (T,B,last_channels)."""
     T = cfg.T
     x = image.permute(1, 0, 4, 2, 3)                   # (T,B,3,H,W)
     w = p['img.stem.conv.w'].permute(3, 2, 0, 1)
     x = _unfold(F.conv2d(_fold(x), w, p['img.stem.conv.b'], stride=2), T)       # valid, :159
+    x = _st(x, True, False)
     if taps is not None:
         taps['stem.y'] = x
     x = relu6(bn_slices(x, p, 'img.stem.bn', training, True))                     # :160
     ph = same_pad(x.shape[3], 3, 2)
     pw_ = same_pad(x.shape[4], 3, 2)
     xx = F.pad(_fold(x), (pw_[0], pw_[1], ph[0], ph[1]), value=float('-inf'))
-    x = _unfold(max_pool_3x3_s2(xx), T)                                        # :161
+    x = _st(_unfold(max_pool_3x3_s2(xx), T), True, True)                       # :161
     if taps is not None:
         taps['pool'] = x
     for u in unit_plan(cfg):                                                      # :164-167
-        pre = f"img.s{u['stage']}.u{u['unit']}"
-        if u['stride'] == 1:
-            sc, m = x[:, :, :u['shortcut_c']], x[:, :, u['shortcut_c']:]           # tf.split, :87-97
-        else:
-            sc, m = x, x
-        m = conv_pw(m, p, f'{pre}.pw1')
-        m = relu6(bn_slices(m, p, f'{pre}.bn1', training, True))
-        m = conv_dw(m, p, f'{pre}.dw', u['stride'])
-        m = bn_slices(m, p, f'{pre}.bn2', training, True)
-        m = conv_pw(m, p, f'{pre}.pw2')
-        m = relu6(bn_slices(m, p, f'{pre}.bn3', training, True))
-        if u['stride'] == 2:
-            sc = conv_dw(sc, p, f'{pre}.sc_dw', 2)
-            sc = bn_slices(sc, p, f'{pre}.sc_bn1', training, True)
-            sc = conv_pw(sc, p, f'{pre}.sc_pw')
-            sc = relu6(bn_slices(sc, p, f'{pre}.sc_bn2', training, True))
-        x = channel_shuffle(torch.cat([sc, m], dim=2))                            # :144-145
+        x = shufflenet_unit(x, p, u, training)
         if taps is not None:
-            taps[pre] = x
-    x = conv_pw(x, p, 'img.head.conv')                                            # :170
+            taps[f"img.s{u['stage']}.u{u['unit']}"] = x
+    x = _st(conv_pw(x, p, 'img.head.conv'), True, True)                          # :170
     x = relu6(bn_slices(x, p, 'img.head.bn', training, True))
     return x.mean(dim=(3, 4))                                                     # GAP :172
 

@@ -628,3 +628,155 @@ def test_config3_three_engines_at_batch_1024(scenario):
                 lo = gate['tower'][C3_TOWER.index(grp)] if grp in C3_TOWER else (gate['heads'] if grp.endswith('head') else gate['tail'])
                 assert g['cos'] >= lo, (compute, key, grp, g)
                 assert 0.75 <= g['ratio'] <= 1.33, (compute, key, grp, g)
+
+
+@pytest.mark.parametrize('B,H,W', [(64, 48, 64)])
+def test_bf16_storage_engine_vs_oracle_with_the_storage_rule(B, H, W):
+    """END-TO-END HIP vs ORACLE for configs[2]: the float64 oracle with the bf16-storage contract restated
+    (oracle/model.py::_st: round-to-nearest-even at every tensor the engine stores, forward and gradient; bf16 MFMA operands in the
+    1x1 convolutions), evaluated on the engine's own ReLU6 / max-pool decisions.  The rule itself is validated unit by unit at bf16
+    rounding level by test_every_unit_backward_against_the_oracle_locally.  END TO END the two cannot agree better than two bf16
+    implementations of this network do: an element whose float32 and float64 pre-rounding values straddle a bf16 rounding boundary
+    (~5e-5 of all elements) differs by one bf16 ulp, and ~50 train-mode BatchNorms amplify that a thousandfold (the float32 engine
+    meets the float64 oracle at 1e-4 = 1e-7 x 1e3).  Measured at B = 64, 48x64: loss 1e-2, alpha / beta 8-9 %, per-tensor gradient
+    error median 0.16-0.26 in every group -- the same distance as between the bf16-operand engine and ITS rule oracle (round 2:
+    4 % / 0.5 l2), i.e. rounding chaos, not wiring.  The gates only keep that level from drifting."""
+    import json
+    import os
+    from oracle import model as OM
+    from tests.util import make_pair, make_batches, to_dev, oracle_batch, rel_err, is_zero_gradient, engine_decisions
+    A = 2
+    oracle, eng = make_pair(B, H, W, seed=5, A=A, compute='bf16s', with64=True)
+    o64 = oracle.o64
+    pol, val = make_batches(B, H, W, seed=5, A=A, faithful=True)
+    dpol, dval = to_dev(pol), to_dev(val)
+
+    def ruled(fn, batch):
+        OM.DEC.items = engine_decisions(eng, oracle.cfg)
+        OM.PW_BF16_OPERANDS = OM.BF16_STORAGE = True
+        try:
+            OM.DEC.start('replay')
+            out = fn(batch)
+            assert OM.DEC.cursor == len(OM.DEC.items)
+            return out
+        finally:
+            OM.DEC.start('off')
+            OM.PW_BF16_OPERANDS = OM.BF16_STORAGE = False
+
+    report = {}
+    for kind in ('policy', 'value'):
+        if kind == 'policy':
+            eng.policy_forward_backward(dpol)
+            loss, gh, gt, aux = ruled(o64.policy_grads, oracle_batch(pol))
+            ax = eng.buffer(_lib.BUF_AUX_P, (B, 4, A)).cpu().numpy()
+            fw = dict(alpha=rel_err(ax[:, 0], aux['alpha'].detach().numpy()), beta=rel_err(ax[:, 1], aux['beta'].detach().numpy()))
+        else:
+            eng.value_forward_backward(dval)
+            loss, gh, gt, aux = ruled(o64.value_grads, oracle_batch(val))
+            fw = dict(values=rel_err(eng.buffer(_lib.BUF_AUX_V, (B, 2)).cpu().numpy(), aux['values'].detach().numpy()))
+        le = eng.metrics(kind)['loss']
+        fw['loss'] = abs(le - float(loss.detach())) / max(1.0, abs(float(loss.detach())))
+        rep = dict(forward=fw, groups={})
+        for views, ref in ((eng.grad_views('trunk'), gt), (eng.grad_views(kind), gh)):
+            gmax = max(float(g.abs().max()) for g in ref.values())
+            for name, g in ref.items():
+                if is_zero_gradient(name):
+                    continue
+                grp = _c3_group(name) if name.split('.')[0] not in ('pi', 'v') else 'head'
+                e = float((views[name].cpu().double() - g.detach()).abs().max()) / max(float(g.abs().max()), 1e-3 * gmax)
+                r = rep['groups'].setdefault(grp, dict(worst=0.0, tensor='', errs=[]))
+                r['errs'].append(e)
+                if e >= r['worst']:
+                    r['worst'], r['tensor'] = e, name
+        for r in rep['groups'].values():
+            r['median'] = float(np.median(r.pop('errs')))
+        report[kind] = rep
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(report, open(f'gpurun_out/parity_report_bf16_storage_rule_B{B}_{H}x{W}.json', 'w'), indent=1)
+    print(f'[bf16 storage engine vs storage-rule oracle, B={B} {H}x{W}]', json.dumps(report))
+    for kind, rep in report.items():
+        for k, v in rep['forward'].items():
+            assert v <= (3e-2 if k == 'loss' else 2e-1), (kind, k, v)
+        for grp, r in rep['groups'].items():
+            assert r['median'] <= 0.4, (kind, grp, r)
+
+
+@pytest.mark.parametrize('compute', ['f32', 'bf16s'])
+def test_every_unit_backward_against_the_oracle_locally(compute):
+    """Unit-by-unit HIP-vs-oracle check of the tower's backward in both storage modes (the engine-level plumbing of
+    the bf16-storage mode -- tens_a, element-sized slots, the `at` flag through ~40 call sites -- was only covered by cosine gates).
+    End to end, ~50 train-mode BatchNorms amplify a perturbation of one bf16 ulp a thousandfold (the float32 engine meets the
+    float64 oracle at 1e-4, i.e. 1e-7 rounding x 1e3), so an end-to-end comparison of two bf16 implementations can only agree in
+    direction.  LOCALLY the amplification is that of one unit: every ShuffleNet unit is replayed in the float64 oracle FROM THE
+    ENGINE'S OWN stored input X and stored output gradient G (oracle/model.py::shufflenet_unit with the storage rule `_st` and the
+    bf16-operand rule for configs[2]; the engine's own ReLU6 decisions), and the engine's stored unit output, its stored input
+    gradient and the unit's weight gradients must match per tensor: 1e-4 in float32, bf16 rounding level in bf16 storage."""
+    import json
+    import os
+    from oracle import model as OM
+    from oracle.spec import unit_plan
+    from tests.util import make_pair, make_batches, to_dev, is_zero_gradient, engine_decisions
+    B, H, W, A = 32, 48, 64, 2
+    oracle, eng = make_pair(B, H, W, seed=5, A=A, compute=compute, with64=True)
+    o64 = oracle.o64
+    pol, _ = make_batches(B, H, W, seed=5, A=A, faithful=True)
+    eng.policy_forward_backward(to_dev(pol))
+    torch.cuda.synchronize()
+    T = eng.cfg.T
+    dt = torch.bfloat16 if compute == 'bf16s' else torch.float32
+    items = engine_decisions(eng, oracle.cfg)
+    grads = eng.grad_views('trunk')
+
+    def tensor(name, h, w, c):
+        return eng.named_buffer(name, dt).view(T, B, h, w, c).permute(0, 1, 4, 2, 3).double().cpu().contiguous()
+
+    hs, ws = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    h, w = -(-hs // 2), -(-ws // 2)
+    prev, prev_c = 'img.stem.pool.out', oracle.cfg.stem_channels
+    cursor = 2
+    report = {}
+    for u in unit_plan(oracle.cfg):
+        pre = f"img.s{u['stage']}.u{u['unit']}"
+        ho, wo = (-(-h // 2), -(-w // 2)) if u['stride'] == 2 else (h, w)
+        C = oracle.cfg.stage_channels[u['stage']]
+        n_items = 3 if u['stride'] == 2 else 2
+        x = tensor(prev, h, w, prev_c).requires_grad_(True)
+        G = tensor(pre + '.out.g', ho, wo, C)
+        names = [n for n in o64.trunk if n.startswith(pre + '.') and 'moving' not in n]
+        params = [o64.trunk[n] for n in names]
+        OM.DEC.items = items[cursor:cursor + n_items]
+        OM.PW_BF16_OPERANDS = OM.BF16_STORAGE = compute == 'bf16s'
+        try:
+            OM.DEC.start('replay')
+            out = OM.shufflenet_unit(x, o64.trunk, u, True)
+            assert OM.DEC.cursor == n_items
+            gs = torch.autograd.grad(out, [x] + params, grad_outputs=G, allow_unused=True)
+        finally:
+            OM.DEC.start('off')
+            OM.PW_BF16_OPERANDS = OM.BF16_STORAGE = False
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        rep = dict(out=rel(tensor(pre + '.out', ho, wo, C), out.detach()), dx=rel(tensor(prev + '.g', h, w, prev_c), gs[0]))
+        gmax = max(float(g.abs().max()) for n, g in zip(names, gs[1:]) if not is_zero_gradient(n))
+        worst = ('', 0.0)
+        for n, g in zip(names, gs[1:]):
+            if is_zero_gradient(n):
+                continue
+            e = float((grads[n].cpu().double() - g).abs().max()) / max(float(g.abs().max()), 1e-3 * gmax)
+            if e >= worst[1]:
+                worst = (n, e)
+        rep['weights'] = worst[1]
+        rep['worst_weight'] = worst[0]
+        report[pre] = rep
+        cursor += n_items
+        prev, prev_c, h, w = pre + '.out', C, ho, wo
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump(report, open(f'gpurun_out/parity_report_units_local_{compute}_B{B}_{H}x{W}.json', 'w'), indent=1)
+    w_out, w_dx, w_w = (max(r[k] for r in report.values()) for k in ('out', 'dx', 'weights'))
+    print(f'[unit-local parity, {compute}] worst over 16 units: out {w_out:.2e}, input gradient {w_dx:.2e}, weight gradients {w_w:.2e}')
+    # measured worst over the 16 units: float32 5.6e-7 / 7.1e-7 / 5.6e-6; bf16 storage 2.8e-3 (under one bf16 ulp of the tensor maximum) /
+    # 3.3e-3 / 1.8e-2 (always bn1.gamma: the engine takes the BatchNorm-backward sums from the float32 gradient BEFORE it is rounded for
+    # storage, the oracle's autograd from the rounded one)
+    tol = dict(out=5e-6, dx=5e-6, weights=3e-5) if compute == 'f32' else dict(out=4e-3, dx=5e-3, weights=3e-2)
+    for pre, r in report.items():
+        for k in ('out', 'dx', 'weights'):
+            assert r[k] <= tol[k], (pre, k, r)

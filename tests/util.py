@@ -124,12 +124,15 @@ def engine_decisions(eng, ocfg):
     sum to float32 reproduces fmaf (up to double-rounding ties, probability ~2^-29 per element)."""
     from oracle.spec import unit_plan
     T, B = eng.cfg.T, eng.cfg.B
+    # bf16 activation storage (compute mode 2): the raw BatchNorm inputs of the image tower are bf16 in the workspace; the engine
+    # widens them exactly and evaluates the same float32 fmaf
+    tower_dtype = torch.bfloat16 if int(eng.cfg.compute) == 2 else torch.float32
 
     def bn_regions(prefix, h, w):
         stats = eng.named_buffer(prefix + '.stats')
         C = stats.numel() // (4 * T)
         st = stats.view(4, T, C).double()
-        x = eng.named_buffer(prefix + '.x').view(T, B, h, w, C).double()
+        x = eng.named_buffer(prefix + '.x', tower_dtype).view(T, B, h, w, C).double()
         z = (x * st[2].view(T, 1, 1, 1, C) + st[3].view(T, 1, 1, 1, C)).float()
         z = z.permute(0, 1, 4, 2, 3).cpu()                      # oracle layout (T, B, C, H, W)
         return ((z > 0.0) & (z < 6.0)), (z >= 6.0)
