@@ -440,19 +440,22 @@ struct PwbReduceArgs {
     int N, K, KP, NP, G, Mg, nbpg;
 };
 
-// 512 threads = 128 output channels n x 4 slices of the partial rows: every thread sums its quarter of the nbpg partials with the
-// loads of 8 partials in flight (the first version walked all partials in one dependent loop per thread: 125 us), the four slices
-// are folded through LDS in fixed order.
-__global__ void __launch_bounds__(512) pwb_reduce_kernel(PwbReduceArgs a) {
-    __shared__ double sq[4][8][128];     // [slice][group][n]: Q partial sums
-    __shared__ double sd[4][8][128];     // db partial sums
-    __shared__ double red[2][8][2];      // [s1 | s2][group][wave]
+// 1024 threads = 128 output channels n x 8 slots; a slot sums one (group, slice of the partial rows) pair with the loads of 8
+// partials in flight (the first version walked all partials in one dependent loop per thread: 125 us; 4 slices x all groups: 10-13 us),
+// the slices are folded through LDS in fixed order.
+constexpr int PWB_RS = 8;
+__global__ void __launch_bounds__(128 * PWB_RS) pwb_reduce_kernel(PwbReduceArgs a) {
+    __shared__ double sq[PWB_RS][128];        // [slice * G + group][n]: Q partial sums (G * nsl <= 8 pairs)
+    __shared__ double sd[PWB_RS][128];        // db partial sums
+    __shared__ double red[2][8][2];           // [s1 | s2][group][wave]
     const int k = blockIdx.x, n = threadIdx.x & 127, sl = threadIdx.x >> 7;
     const int N = a.N, K = a.K, G = a.G;
     const bool on = n < N;
-    const int per = (a.nbpg + 3) / 4;
-    const int b0 = sl * per, b1 = min(a.nbpg, b0 + per);
-    for (int g = 0; g < G; ++g) {
+    const int nsl = PWB_RS / G > 0 ? PWB_RS / G : 1;          // slices per group (G = 4: 2)
+    const int per = (a.nbpg + nsl - 1) / nsl;
+    for (int pair = sl; pair < G * nsl; pair += PWB_RS) {
+        const int g = pair % G, s = pair / G;
+        const int b0 = s * per, b1 = min(a.nbpg, b0 + per);
         double q = 0.0, d = 0.0;
         if (on) {
             const float* pq = a.qpart + ((int64_t)g * a.nbpg * a.KP + k) * a.NP + n;
@@ -477,8 +480,8 @@ __global__ void __launch_bounds__(512) pwb_reduce_kernel(PwbReduceArgs a) {
                 d += pd[(int64_t)b * a.NP];
             }
         }
-        sq[sl][g][n] = q;
-        sd[sl][g][n] = d;
+        sq[pair][n] = q;
+        sd[pair][n] = d;
     }
     __syncthreads();
     const bool lead = sl == 0;                  // slice 0 (threads 0 .. 127 = waves 0, 1) folds and writes
@@ -489,8 +492,11 @@ __global__ void __launch_bounds__(512) pwb_reduce_kernel(PwbReduceArgs a) {
     for (int g = 0; g < 8; ++g) {
         s1[g] = s2[g] = 0.0;
         if (g < G && lead) {
-            const double q = ((sq[0][g][n] + sq[1][g][n]) + sq[2][g][n]) + sq[3][g][n];
-            const double d = ((sd[0][g][n] + sd[1][g][n]) + sd[2][g][n]) + sd[3][g][n];
+            double q = sq[g][n], d = sd[g][n];
+            for (int s = 1; s < nsl; ++s) {
+                q += sq[s * G + g][n];
+                d += sd[s * G + g][n];
+            }
             qtot += q;
             dbtot += d;
             s1[g] = (double)w * d;
@@ -648,7 +654,7 @@ int pw_bwd_fused_reduce(const PwBwdFused& f, hipStream_t st) {
         set_error("pw_bwd_fused_reduce: normalised input needs gamma / beta and the dgamma / dbeta / coef outputs");
         return -1;
     }
-    hipLaunchKernelGGL(pwb_reduce_kernel, dim3(f.K), dim3(512), 0, st, r);
+    hipLaunchKernelGGL(pwb_reduce_kernel, dim3(f.K), dim3(128 * PWB_RS), 0, st, r);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

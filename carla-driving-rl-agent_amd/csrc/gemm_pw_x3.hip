@@ -88,22 +88,31 @@ __global__ void __launch_bounds__(256, 2) pw_x3_kernel(PwX3Args a) {
         }
     };
     auto store_tile = [&]() {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        // pairs: the arithmetic compiles to v_pk_{fma,add}_f32, the three conversions to one v_cvt_pk_bf16_f32 each, and the
+        // conversion results ARE the packed LDS words (no per-element repacking): 19.9 -> see DESIGN.md for the isolated timing
+        auto widen = [](uint32_t w) -> f32x2 { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; };
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + 256 * i, r = c / CPR, k4 = 4 * (c % CPR);
-            bf16x4 h[3];
+            uint32_t hw[3][2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = __uint_as_float(ra[i][e]);
-                if (PRO) x = (k4 + e < K) ? fmaf(pc[0][k4 + e], x, pc[1][k4 + e]) : 0.0f;
-                __bf16 h1, h2, h3;
-                split3(x, h1, h2, h3);
-                h[0][e] = h1;
-                h[1][e] = h2;
-                h[2][e] = h3;
+            for (int h = 0; h < 2; ++h) {
+                f32x2 x = f32x2{__uint_as_float(ra[i][2 * h]), __uint_as_float(ra[i][2 * h + 1])};
+                if (PRO) {
+                    // (columns beyond K carry scale 0 / shift 0 in pc)
+                    const f32x2 sc = f32x2{pc[0][k4 + 2 * h], pc[0][k4 + 2 * h + 1]}, sh = f32x2{pc[1][k4 + 2 * h], pc[1][k4 + 2 * h + 1]};
+                    x = __builtin_elementwise_fma(sc, x, sh);
+                }
+                hw[0][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+                const f32x2 r1 = x - widen(hw[0][h]);             // exact
+                hw[1][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+                hw[2][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1 - widen(hw[1][h]), bf16x2));
             }
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(&As[p][r * LDA + k4]) = h[p];
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2_t*>(&As[p][r * LDA + k4]) = u32x2_t{hw[p][0], hw[p][1]};
         }
     };
     auto compute_tile = [&](int t) {

@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_bf16_storage.py -q -s -k "unit_backward_against" 2>&1 | grep -a "passed\|failed\|unit-local\|Error\|assert" | cut -c1-1500 > gpurun_out/t8.log
-cat gpurun_out/t8.log
+out=gpurun_out/t9.log
+timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -k "pwconv_bwd_fused or pwconv_x3" 2>&1 | tail -3 > $out
+timeout 300 python tools/iso_pwb.py 2>&1 | tail -4 >> $out
+bash tools/ab_env.sh "CDRL_FUSED_BWD=0" >> $out 2>&1
+cat $out
