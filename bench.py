@@ -93,6 +93,22 @@ def dominant_kernel(B, T, H, W):
     crit = critical_stream_top_kernel()
     if crit:
         out['critical_stream_top_kernel'] = crit
+    if name.startswith('dwf_bwd_kernel<1, 2, true'):
+        # fused depthwise backward of the stride-1 units (BN2-backward apply on load -> filter / bias gradient partials + transposed
+        # conv + ReLU6 mask + BN1-backward sums): reads the output gradient, the raw depthwise output and the raw conv-1 output, writes
+        # the masked input gradient -- four tensors of frames x pixels x channels floats.  One pass: 3 stage-0 units (11x15x58), 7
+        # stage-1 units (6x8x116), 3 stage-2 units (3x4x232)
+        shapes = [(165, 58)] * 3 + [(48, 116)] * 7 + [(12, 232)] * 3
+        by = sum(4.0 * 4.0 * B * T * px * c for px, c in shapes) / len(shapes)
+        out.update(algorithmic_bytes_per_launch=by, achieved_GBs=round(by / (avg_us * 1e-6) / 1e9, 1),
+                   frac=round(by / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                   note='critical-stream kernel; average over its 13 launches per pass (three resolutions)')
+    elif name.startswith('pwb_kernel<128, 128'):
+        # fused conv backward at stage 1 (K = N = 116, M = B*T*48 rows; the stride-2 unit's first conv runs at B*T*165): reads dz, y, a,
+        # writes da
+        by = 4.0 * 4.0 * B * T * 48 * 116
+        out.update(algorithmic_bytes_per_launch=by, achieved_GBs=round(by / (avg_us * 1e-6) / 1e9, 1),
+                   frac=round(by / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), note='critical-stream kernel (stage-1 shape)')
     if name.startswith('tn_direct_tr_kernel<4'):
         if name.startswith('tn_direct_tr_kernel<4, false'):
             # pw1 filter gradients (A = the unit's input, D = dz of BN1 recomputed in the operand prologue) of the stage-1 units
@@ -206,6 +222,28 @@ def kernel_rooflines(B, T, nsets=8):
     out.append(dict(kernel='tn_direct_kernel<4> + tn_reduce (filter gradient)', shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1),
                     algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1), frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
                     cache_state=cold))
+    # round 4: the whole backward of a unit conv in one pass (backward-data + filter / bias gradient + the BatchNorm-backward sums of
+    # the BatchNorm in front): reads dz (gathered through the channel shuffle), y, a and writes da
+    dz = [torch.randn(M, 2 * Cc, device=dev) for _ in range(nsets)]
+    da = [torch.empty(M, Cc, device=dev) for _ in range(nsets)]
+    stb = torch.rand(4 * G * Cc, device=dev) + 0.5
+    cfb = torch.rand(3 * G * Cc, device=dev) * 0.1
+    ga, ba = torch.rand(Cc, device=dev) + 0.5, torch.rand(Cc, device=dev)
+    wpx = torch.zeros(int(lib.cdrl_pwconv_x3_packed_bytes(Cc)), dtype=torch.uint8, device=dev)
+    lib.cdrl_pwconv_x3_pack(P(w), Cc, Cc, 1, Cc, P(wpx), S())
+    qpart = torch.zeros(int(lib.cdrl_pwconv_bwd_fused_workspace(G, Mg, Cc, Cc, 0)), device=dev)
+    dbpart = torch.zeros(int(lib.cdrl_pwconv_bwd_fused_workspace(G, Mg, Cc, Cc, 1)), dtype=torch.float64, device=dev)
+    gW, gb = torch.empty(Cc, Cc, device=dev), torch.empty(Cc, device=dev)
+    adg, adb, acf = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev), torch.empty(3 * G * Cc, device=dev)
+    t = timeit(lambda k: lib.cdrl_pwconv_bwd_fused(P(dz[k]), 2 * Cc, Cc, 2 * Cc, 1, P(y[k]), P(stb), P(cfb), P(a[k]), Cc, 0, P(stb), P(ga), P(ba),
+                                                   P(adg), P(adb), P(acf), P(w), P(wpx), P(da[k]), Cc, 0, 0, P(gW), P(gb), P(qpart), P(dbpart),
+                                                   G, Mg, Cc, Cc, S()))
+    byb4 = 4.0 * M * 4 * Cc
+    out.append(dict(kernel='pwb_kernel<128,128,shuffle,BN-input> + pwb_reduce_kernel (fused conv backward: da, dW, db, BN2 sums)',
+                    shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1), algorithmic_bytes=byb4, achieved_GBs=round(byb4 / t / 1e9, 1),
+                    frac=round(byb4 / t / 1e9 / HBM_PEAK_GBS, 4),
+                    cache_state=f'cold: launches rotate over {nsets} buffer sets ({nsets * 5 * M * Cc * 4 / 1e6:.0f} MB > 256 MB Infinity Cache)'))
+    del dz, da
     N, Hh, Ww = G * B, 6, 8
     wd = torch.randn(3, 3, Cc, 1, device=dev)
     st = torch.rand(4 * G * Cc, device=dev) + 0.5

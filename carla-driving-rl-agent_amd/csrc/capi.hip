@@ -440,7 +440,7 @@ int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, 
 }
 
 int64_t cdrl_pwconv_bwd_fused_workspace(int G, int Mg, int N, int K, int which) {
-    return which == 0 ? pw_bwd_fused_qpart_elems(G, Mg, N, K) : pw_bwd_fused_dbpart_elems(G, Mg, N, K);
+    return which == 0 ? pw_bwd_fused_qpart_elems(G, Mg, N, K, g_op_at) : pw_bwd_fused_dbpart_elems(G, Mg, N, K, g_op_at);
 }
 
 int cdrl_pwconv_bwd_fused(const float* dz, int ld_dz, int dz_coff, int dz_shuffle, int act, const float* y, const float* stats,
@@ -478,6 +478,7 @@ int cdrl_pwconv_bwd_fused(const float* dz, int ld_dz, int dz_coff, int dz_shuffl
     f.Mg = Mg;
     f.N = N;
     f.K = K;
+    f.at = g_op_at;
     CDRL_TRY(pw_bwd_fused(f, S(stream)));
     return pw_bwd_fused_reduce(f, S(stream));
 }

@@ -274,11 +274,12 @@ struct PwBwdFused {
     float* qpart = nullptr; // pw_bwd_fused_qpart_elems floats
     double* dbpart = nullptr;       // pw_bwd_fused_dbpart_elems doubles
     int N = 0, K = 0, G = 1, Mg = 0;
+    int at = 0;             // 1: dz, y, a, da are bf16 in HBM (bf16 activation storage; one bf16 plane per MFMA operand)
 };
-bool pw_bwd_fused_supported(View dz, View a, View da, int N, int K);
-int pw_bwd_fused_nbpg(int G, int Mg, int N, int K);
-int64_t pw_bwd_fused_qpart_elems(int G, int Mg, int N, int K);
-int64_t pw_bwd_fused_dbpart_elems(int G, int Mg, int N, int K);
+bool pw_bwd_fused_supported(View dz, View a, View da, int N, int K, int at = 0);
+int pw_bwd_fused_nbpg(int G, int Mg, int N, int K, int at = 0);
+int64_t pw_bwd_fused_qpart_elems(int G, int Mg, int N, int K, int at = 0);
+int64_t pw_bwd_fused_dbpart_elems(int G, int Mg, int N, int K, int at = 0);
 int pw_bwd_fused(const PwBwdFused& f, hipStream_t st);
 int pw_bwd_fused_reduce(const PwBwdFused& f, hipStream_t st);
 

@@ -305,8 +305,15 @@ private:
     double* part2s_[NSLOT] = {};
     float* tns_[NSLOT] = {};
     double* fparts_[NSLOT] = {};
-    float* qparts_[NSLOT] = {};          // fused conv backward: per-workgroup filter-product tiles / column sums
-    double* dbparts_[NSLOT] = {};
+    // fused conv backward: per-workgroup filter-product tiles / column sums.  Their own small ring (the tiles are large: 16-21 MB per
+    // conv at B = 256), guarded by events recorded behind the side-stream reduce that reads them
+    static constexpr int NQ = 3;
+    float* qparts_[NQ] = {};
+    double* dbparts_[NQ] = {};
+    hipEvent_t ev_q_[NQ] = {};
+    bool q_used_[NQ] = {};
+    int qi_ = 0;
+    int next_q(hipStream_t st);          // main: claim the next buffer pair (waits for the side job that last read it)
     size_t max_qpart_ = 0, max_dbpart_ = 0;
     int flush_side(hipStream_t st);      // enqueue the deferred side jobs now (one event record on `st`)
     hipStream_t side_ = nullptr;

@@ -55,6 +55,8 @@ Learner::~Learner() {
     if (ev_out_) (void)hipEventDestroy(ev_out_);
     if (main_) (void)hipStreamDestroy(main_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
+    for (int i = 0; i < NQ; ++i)
+        if (ev_q_[i]) (void)hipEventDestroy(ev_q_[i]);
     if (ev_tail_main_) (void)hipEventDestroy(ev_tail_main_);
     if (ev_tail_side_) (void)hipEventDestroy(ev_tail_side_);
     for (int i = 0; i < 3; ++i) {
@@ -213,6 +215,12 @@ int Learner::defer_side(hipStream_t st, std::function<int(hipStream_t)> fn) {
     return 0;
 }
 
+int Learner::next_q(hipStream_t st) {
+    qi_ = (qi_ + 1) % NQ;
+    if (side_enabled_ && q_used_[qi_]) CDRL_HIP(hipStreamWaitEvent(st, ev_q_[qi_], 0));
+    return 0;
+}
+
 int Learner::flush_side(hipStream_t st) {
     if (!side_enabled_ || deferred_.empty()) return 0;
     hipStream_t side = fork_side(st);       // flushes the queue behind an event recorded on `st`
@@ -246,6 +254,7 @@ int Learner::join_side(hipStream_t st) {
         aux_pending_ = false;
     }
     for (int i = 0; i < NSLOT; ++i) slot_used_[i] = false;
+    for (int i = 0; i < NQ; ++i) q_used_[i] = false;
     return 0;
 }
 
@@ -534,17 +543,17 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     const int nbp_bwd = fuse.bb ? pw_nn_plan(G, Mg, Cin, Cout).nbpg : 0;
     if (fuse.bb) note_scratch(0, (size_t)G * nbp_bwd * Cout, 0, 0);
     // One kernel for backward-data + filter gradient + bias gradient (+ the backward sums of the BatchNorm in front of the conv):
-    // float32 engine, both channel counts padded alike (gemm_pw_bwd.hip)
+    // float32 engine and bf16 activation storage (not the operand-only mode), both channel counts padded alike (gemm_pw_bwd.hip)
     const View dz_probe = fuse.bb_dz.p ? fuse.bb_dz : make_view(reinterpret_cast<float*>(uintptr_t(16)), Cout);
     const bool anorm = fuse.pro_stats != nullptr;
     // (24 input channels -- the first unit -- pad to 64: 158 vs 104 us for the two-kernel form; kept there)
-    const bool fbwd = fused_bwd_ && fuse.bb && fuse.bwd_pw && !bfc && G <= 8 && Cin >= 32 && pw_bwd_fused_supported(dz_probe, in, din, Cout, Cin) &&
+    const bool fbwd = fused_bwd_ && fuse.bb && fuse.bwd_pw && (!bfc || at) && G <= 8 && Cin >= 32 && pw_bwd_fused_supported(dz_probe, in, din, Cout, Cin, at) &&
                       (!anorm || (fuse.bwd_ey == in.p && fuse.bwd_epi_stats == fuse.pro_stats && fuse.a_bn && in.ld == Cin && in.coff == 0)) &&
                       (anorm || !fuse.bwd_ey);
     const void* wpx = fbwd ? pw_x3_packed(w.p, Cout, Cin, 1, Cout) : nullptr;      // W^T planes: B(k = cout, n = cin)
     if (fbwd) {
-        max_qpart_ = std::max(max_qpart_, (size_t)pw_bwd_fused_qpart_elems(G, Mg, Cout, Cin));
-        max_dbpart_ = std::max(max_dbpart_, (size_t)pw_bwd_fused_dbpart_elems(G, Mg, Cout, Cin));
+        max_qpart_ = std::max(max_qpart_, (size_t)pw_bwd_fused_qpart_elems(G, Mg, Cout, Cin, at));
+        max_dbpart_ = std::max(max_dbpart_, (size_t)pw_bwd_fused_dbpart_elems(G, Mg, Cout, Cin, at));
         if (fuse.a_bn_done) *fuse.a_bn_done = true;
     }
     op.bwd = [=](hipStream_t st) -> int {
@@ -570,17 +579,27 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             f.accumulate = din_acc;
             f.dW = w.g;
             f.db = b.g;
-            f.qpart = qparts_[slot_];
-            f.dbpart = dbparts_[slot_];
+            CDRL_TRY(next_q(st));
+            const int qi = qi_;
+            f.qpart = qparts_[qi];
+            f.dbpart = dbparts_[qi];
             f.G = G;
             f.Mg = Mg;
             f.N = Cout;
             f.K = Cin;
+            f.at = at;
             CDRL_TRY(pw_bwd_fused(f, st));
             // the reduce also finalizes the BatchNorm in front of the conv (its coefficients are the next kernel's input): critical
             // stream; without one it only produces weight gradients -> side stream, flushed once per unit
             if (anorm) return pw_bwd_fused_reduce(f, st);
-            CDRL_TRY(defer_side(st, [=](hipStream_t sd) -> int { return pw_bwd_fused_reduce(f, sd); }));
+            CDRL_TRY(defer_side(st, [=](hipStream_t sd) -> int {
+                CDRL_TRY(pw_bwd_fused_reduce(f, sd));
+                if (side_enabled_ && sd == side_) {     // the buffer pair is free again once this reduce has run
+                    CDRL_HIP(hipEventRecord(ev_q_[qi], sd));
+                    q_used_[qi] = true;
+                }
+                return 0;
+            }));
             return flush_side(st);
         }
         if (fuse.bb) {
@@ -1398,6 +1417,8 @@ void Learner::build(bool dry) {
             part2s_[i] = alloc_d(max_part2_);
             tns_[i] = alloc(max_tn_);
             fparts_[i] = alloc_d(max_fpart_);
+        }
+        for (int i = 0; i < NQ; ++i) {
             qparts_[i] = alloc(max_qpart_);
             dbparts_[i] = alloc_d(max_dbpart_);
         }
@@ -1459,8 +1480,8 @@ void Learner::build(bool dry) {
                         align_up(max_tn_ * sizeof(float), 256)) +
                    align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
                    NSLOT * (align_up((max_dy_ * esz() + 3) / 4 * sizeof(float), 256) + align_up(max_part2_ * sizeof(double), 256) +
-                            align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256) +
-                            align_up(max_qpart_ * sizeof(float), 256) + align_up(max_dbpart_ * sizeof(double), 256));
+                            align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256)) +
+                   NQ * (align_up(max_qpart_ * sizeof(float), 256) + align_up(max_dbpart_ * sizeof(double), 256));
         ws_bytes_ = ws_off_ + 4096;
     }
 }
@@ -1558,6 +1579,7 @@ int Learner::bind(const Buffers& b) {
             CDRL_HIP(hipEventCreateWithFlags(&ev_side_[i], hipEventDisableTiming));
         }
         CDRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        for (int i = 0; i < NQ; ++i) CDRL_HIP(hipEventCreateWithFlags(&ev_q_[i], hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_tail_main_, hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_tail_side_, hipEventDisableTiming));
         for (int i = 0; i < 3; ++i) {

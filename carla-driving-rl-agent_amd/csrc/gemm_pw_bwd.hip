@@ -21,7 +21,7 @@
 // reproducible, no atomics).
 #include <stdlib.h>
 
-#include "cdrl_kernels.h"
+#include "colreduce.h"
 
 namespace cdrl {
 
@@ -44,7 +44,9 @@ struct PwbArgs {
     View da;
     float* qpart;           // [G][nbpg][KP][NP]
     double* dbpart;         // [G][nbpg][NP]
+    double* spart;          // bf16 storage + ANORM: [G][nbpg][2][KP] (sum da, sum da * xhat) taken from the accumulators in double
     int N, K, G, Mg, nbpg;
+    int at;                 // host dispatch: 1 = bf16 activation storage (pwb16_kernel)
     int dbg;                // timing diagnostics (CDRL_DIAG=1 CDRL_DIAG_PWB=bits, wrong results): 1 no MFMA, 2 no LDS writes, 4 no stores, 8 no loads
 };
 
@@ -74,21 +76,21 @@ __device__ __forceinline__ uint32_t pwb_hihi(uint32_t a, uint32_t b) { return __
 // the other) with the same barrier sequence.
 template <int KP, int NP, bool SHUF, bool ANORM, bool ACC>
 __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
-    static_assert(KP == NP && (KP == 64 || KP == 128), "instantiated for square padded shapes");
-    constexpr int BM = KP == 128 ? 32 : 64;
+    static_assert((KP == NP && (KP == 64 || KP == 128)) || (KP == 64 && NP == 128), "instantiated paddings: 64/64, 128/128, 64 -> 128");
+    constexpr int BM = (KP == 128 || NP == 128) ? 32 : 64;
     constexpr int NRG = BM / 4;                     // row groups of 4
     constexpr int LDR = NP + 8;                     // row-major planes: bf16 per row (16-byte fragment reads, conflict-free)
     constexpr int LDT = BM + 8;                     // transposed planes: bf16 per column ((BM + 8) / 8 odd: conflict-free b128 reads)
-    constexpr int TP = KP * LDT;                    // elements of one transposed plane (KP == NP)
+    constexpr int TPD = NP * LDT, TPA = KP * LDT;   // elements of one transposed plane of dy / of a
     constexpr int KS_DA = NP / 16, KS_Q = BM / 16;
-    constexpr int DA_WC = KP / 32, DA_WR = 4 / DA_WC;
+    constexpr int DA_WC = KP / 32, DA_WR = BM / 32; // backward-data tiles: DA_WC x DA_WR waves are busy (2 of 4 in the 64 -> 128 form)
     constexpr int Q_KT = KP / 32, Q_NT = NP / 32;
-    constexpr int NTW = Q_NT / (4 / Q_KT);          // Q column tiles per wave (4 | 1)
+    constexpr int NTW = Q_KT * Q_NT / 4;            // Q tiles per wave (4 | 1 | 2): wave w owns k tile w % Q_KT, column tiles from (w / Q_KT) * NTW
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* Rm = reinterpret_cast<__bf16*>(smem_raw);       // [3][BM][LDR]   dy, row-major
     __bf16* Dt = Rm + 3 * BM * LDR;                         // [3][NP][LDT]   dy, transposed
-    __bf16* At = Dt + 3 * TP;                               // [3][KP][LDT]   a (or xhat(a)), transposed
-    float* cf = reinterpret_cast<float*>(At + 3 * TP);      // [7][NP] mean, invstd, scale, shift, k1, k2, k3 of the dy columns
+    __bf16* At = Dt + 3 * TPD;                              // [3][KP][LDT]   a (or xhat(a)), transposed
+    float* cf = reinterpret_cast<float*>(At + 3 * TPA);     // [7][NP] mean, invstd, scale, shift, k1, k2, k3 of the dy columns
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lk = lane >> 5;
     const int role = __builtin_amdgcn_readfirstlane(tid >> 8);     // 0: waves 0-3 (dy + backward-data), 1: waves 4-7 (a + filter product)
@@ -229,9 +231,9 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    *reinterpret_cast<u32x2*>(&Dt[p * TP + (c0 + 2 * h) * LDT + 4 * rg]) =
+                    *reinterpret_cast<u32x2*>(&Dt[p * TPD + (c0 + 2 * h) * LDT + 4 * rg]) =
                         u32x2{pwb_lolo(hw[p][0][h], hw[p][1][h]), pwb_lolo(hw[p][2][h], hw[p][3][h])};
-                    *reinterpret_cast<u32x2*>(&Dt[p * TP + (c0 + 2 * h + 1) * LDT + 4 * rg]) =
+                    *reinterpret_cast<u32x2*>(&Dt[p * TPD + (c0 + 2 * h + 1) * LDT + 4 * rg]) =
                         u32x2{pwb_hihi(hw[p][0][h], hw[p][1][h]), pwb_hihi(hw[p][2][h], hw[p][3][h])};
                 }
         };
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
         for (int t = t0; t < t1; ++t) {
             store_tile(t);          // (requests tile t + 1)
             __syncthreads();
-            compute_tile(t);
+            if (wave < DA_WC * DA_WR) compute_tile(t);
             __syncthreads();
         }
         double* red = reinterpret_cast<double*>(smem_raw);      // [NRG][NP]; the planes are dead
@@ -315,6 +317,7 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
                 cinv[e >> 1][e & 1] = on ? a.a_stats[1 * GK + g * K + (on ? c : 0)] : 0.0f;
             }
         }
+        const bool aon = c0 < KP;                   // (64 -> 128: half of this role's threads have no column group of a)
         uint32_t vo[2];
         vo[0] = c0 < K ? (uint32_t)((4 * rg) * a.a.ld + a.a.coff + c0) * 4u : OOR;
         vo[1] = c0 + 2 < K ? (uint32_t)((4 * rg) * a.a.ld + a.a.coff + c0 + 2) * 4u : OOR;
@@ -360,15 +363,17 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
                 if (hw[0][0][0] == 123u && hw[2][3][1] == 321u) At[0] = (__bf16)1.0f;
                 return;
             }
+            if (aon) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    *reinterpret_cast<u32x2*>(&At[p * TP + (c0 + 2 * h) * LDT + 4 * rg]) =
-                        u32x2{pwb_lolo(hw[p][0][h], hw[p][1][h]), pwb_lolo(hw[p][2][h], hw[p][3][h])};
-                    *reinterpret_cast<u32x2*>(&At[p * TP + (c0 + 2 * h + 1) * LDT + 4 * rg]) =
-                        u32x2{pwb_hihi(hw[p][0][h], hw[p][1][h]), pwb_hihi(hw[p][2][h], hw[p][3][h])};
-                }
+                    for (int h = 0; h < 2; ++h) {
+                        *reinterpret_cast<u32x2*>(&At[p * TPA + (c0 + 2 * h) * LDT + 4 * rg]) =
+                            u32x2{pwb_lolo(hw[p][0][h], hw[p][1][h]), pwb_lolo(hw[p][2][h], hw[p][3][h])};
+                        *reinterpret_cast<u32x2*>(&At[p * TPA + (c0 + 2 * h + 1) * LDT + 4 * rg]) =
+                            u32x2{pwb_hihi(hw[p][0][h], hw[p][1][h]), pwb_hihi(hw[p][2][h], hw[p][3][h])};
+                    }
+            }
         };
         f32x16 qacc[NTW];
 #pragma unroll
@@ -381,15 +386,15 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
 #pragma unroll
             for (int s = 0; s < KS_Q; ++s) {
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&At[0 * TP + ao + 16 * s]);
-                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&At[1 * TP + ao + 16 * s]);
-                const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&At[2 * TP + ao + 16 * s]);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&At[0 * TPA + ao + 16 * s]);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&At[1 * TPA + ao + 16 * s]);
+                const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&At[2 * TPA + ao + 16 * s]);
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     const int bo = ((qnt0 + j) * 32 + lrow) * LDT + 8 * lk + 16 * s;
-                    const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(&Dt[0 * TP + bo]);
-                    const bf16x8 d2 = *reinterpret_cast<const bf16x8*>(&Dt[1 * TP + bo]);
-                    const bf16x8 d3 = *reinterpret_cast<const bf16x8*>(&Dt[2 * TP + bo]);
+                    const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(&Dt[0 * TPD + bo]);
+                    const bf16x8 d2 = *reinterpret_cast<const bf16x8*>(&Dt[1 * TPD + bo]);
+                    const bf16x8 d3 = *reinterpret_cast<const bf16x8*>(&Dt[2 * TPD + bo]);
                     qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, d1, qacc[j], 0, 0, 0);
                     qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, d3, qacc[j], 0, 0, 0);
                     qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, d2, qacc[j], 0, 0, 0);
@@ -424,10 +429,367 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// bf16 ACTIVATION STORAGE (configuration 3, Config::compute == 2): the same skeleton on bf16 tensors.  dz, y, a are read and da is
+// written as bf16 (paired 4-byte accesses: a thread's four columns are two bf16 pairs; 4-byte accesses at 2-byte alignment are
+// fine on gfx950, 8-byte ones that straddle the end of a buffer are dropped as a whole, hence pairs), the BatchNorm-backward
+// prologue runs in float32, both MFMA operands are ONE bf16 plane (dy and xhat / a rounded to nearest even, W^T = plane 0 of the
+// packed fragments = bf16(W)), accumulation / partials / the reduce kernel in float32 / double as above.  A third of the LDS and a
+// sixth of the matrix work of the float32 form: two workgroups per CU.
+template <int KP, int NP, bool SHUF, bool ANORM, bool ACC>
+__global__ void __launch_bounds__(512, 4) pwb16_kernel(PwbArgs a) {
+    static_assert(KP == NP && (KP == 64 || KP == 128), "instantiated for square padded shapes");
+    constexpr int BM = KP == 128 ? 32 : 64;
+    constexpr int NRG = BM / 4;
+    constexpr int LDR = NP + 8;
+    constexpr int LDT = BM + 8;
+    constexpr int TP = KP * LDT;
+    constexpr int KS_DA = NP / 16, KS_Q = BM / 16;
+    constexpr int DA_WC = KP / 32, DA_WR = 4 / DA_WC;
+    constexpr int Q_KT = KP / 32, Q_NT = NP / 32;
+    constexpr int NTW = Q_NT / (4 / Q_KT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* Rm = reinterpret_cast<__bf16*>(smem_raw);       // [BM][LDR]   dy, row-major
+    __bf16* Dt = Rm + BM * LDR;                             // [NP][LDT]   dy, transposed
+    __bf16* At = Dt + TP;                                   // [KP][LDT]   a (or xhat(a)), transposed
+    float* cf = reinterpret_cast<float*>(At + TP);          // [7][NP]
+    __bf16* Wl = reinterpret_cast<__bf16*>(cf + 7 * NP);    // [NP/16][2][128][8] W^T fragments (plane 0): LDS, not registers -- at two
+                                                            // workgroups per CU a wave has 128 VGPRs, and 32 of them went to these
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int t2 = tid & 255;
+    const int rg = t2 % NRG, cg = t2 / NRG;
+    const int c0 = 4 * cg;
+    const int g = blockIdx.x / a.nbpg, b = blockIdx.x % a.nbpg;
+    const int K = a.K, N = a.N;
+    const int64_t mbeg = (int64_t)g * a.Mg, mend = mbeg + a.Mg;
+    const int tiles_g = (a.Mg + BM - 1) / BM;
+    const int t0 = (int)((int64_t)b * tiles_g / a.nbpg), t1 = (int)((int64_t)(b + 1) * tiles_g / a.nbpg);
+    const int64_t Mtot = (int64_t)a.G * a.Mg;
+    const uint32_t OOR = 0x80000000u;
+    auto widen = [](uint32_t w) -> f32x2 { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; };
+    auto pack = [](f32x2 v) -> uint32_t { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); };
+
+    if (role == 0) {
+        const int dwr = wave % DA_WR, dwc = wave / DA_WR;
+        for (int i = tid; i < KS_DA * 2 * 128; i += 256)       // W^T fragments (plane 0 of the packed operand) -> LDS, once
+            *reinterpret_cast<bf16x8*>(&Wl[i * 8]) = *reinterpret_cast<const bf16x8*>(a.Wp + (int64_t)i * 8);
+        const int GN = a.G * N;
+        for (int i = tid; i < 7 * NP; i += 256) {
+            const int q = i / NP, c = i % NP;
+            cf[i] = c < N ? (q < 4 ? a.stats[q * GN + g * N + c] : a.coef[(q - 4) * GN + g * N + c]) : 0.0f;
+        }
+        // byte offsets of the two bf16 pairs of (row 4 rg) inside a tile.  Dense: pairs (c0, c0 + 1), (c0 + 2, c0 + 3).  Through the
+        // shuffle gather destination columns c and c + 2 are ADJACENT in the source: pairs (c0, c0 + 2), (c0 + 1, c0 + 3).
+        uint32_t vo[2], voy[2];
+        bool cok[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cok[e] = c0 + e < N;
+        // (a pair whose second half would lie beyond the END OF THE ROW -- N = 58: destination column 57 is the row's last source
+        //  element -- is fetched one element lower and taken from the high half: a 4-byte access that straddles the end of the buffer
+        //  in the tensor's last row is dropped as a whole)
+        bool hi_half[2] = {false, false};
+        if (SHUF) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int dc = shuffle_dst(a.dz.coff + c0 + h, a.dz_shuffle);
+                if (dc + 1 >= a.dz.ld) {
+                    dc -= 1;
+                    hi_half[h] = true;
+                }
+                vo[h] = cok[h] ? (uint32_t)((4 * rg) * a.dz.ld + dc) * 2u : OOR;
+            }
+        } else {
+            vo[0] = cok[0] ? (uint32_t)((4 * rg) * a.dz.ld + a.dz.coff + c0) * 2u : OOR;
+            vo[1] = cok[2] ? (uint32_t)((4 * rg) * a.dz.ld + a.dz.coff + c0 + 2) * 2u : OOR;
+        }
+        voy[0] = cok[0] ? (uint32_t)((4 * rg) * N + c0) * 2u : OOR;
+        voy[1] = cok[2] ? (uint32_t)((4 * rg) * N + c0 + 2) * 2u : OOR;
+        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(a.dz.p, 0, (int)(Mtot * a.dz.ld * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y), 0, (int)(Mtot * N * 2), 0x00020000);
+        const uint32_t rowD = (uint32_t)a.dz.ld * 2u, rowY = (uint32_t)N * 2u;
+        const bool relu6 = a.act == ACT_RELU6;
+        uint32_t rz[4][2], ry[4][2];                // raw words (widened where they are used, not where they are loaded)
+        auto load_row = [&](int t, int j) {
+            const int64_t m0 = mbeg + (int64_t)t * BM;
+            const uint32_t mu = (uint32_t)m0;
+            const int left = (int)(mend - (m0 + 4 * rg));
+            const uint32_t msk = j < left ? 0u : OOR;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                rz[j][h] = __builtin_amdgcn_raw_buffer_load_b32(rsD, (vo[h] + (uint32_t)j * rowD) | msk, mu * rowD, 0);
+                ry[j][h] = __builtin_amdgcn_raw_buffer_load_b32(rsY, (voy[h] + (uint32_t)j * rowY) | msk, mu * rowY, 0);
+            }
+        };
+        double cs[4] = {0.0, 0.0, 0.0, 0.0};
+        auto store_tile = [&](int t) {
+            const bool more = t + 1 < t1;
+            const int left = (int)(mend - (mbeg + (int64_t)t * BM + 4 * rg));
+            f32x2 cmean[2], cinv[2], csc[2], csh[2], ck1[2], ck2[2], ck3[2];
+            {
+                const float4 q0 = *reinterpret_cast<const float4*>(&cf[0 * NP + c0]), q1 = *reinterpret_cast<const float4*>(&cf[1 * NP + c0]);
+                const float4 q2 = *reinterpret_cast<const float4*>(&cf[2 * NP + c0]), q3 = *reinterpret_cast<const float4*>(&cf[3 * NP + c0]);
+                const float4 q4 = *reinterpret_cast<const float4*>(&cf[4 * NP + c0]), q5 = *reinterpret_cast<const float4*>(&cf[5 * NP + c0]);
+                const float4 q6 = *reinterpret_cast<const float4*>(&cf[6 * NP + c0]);
+                cmean[0] = f32x2{q0.x, q0.y}; cmean[1] = f32x2{q0.z, q0.w};
+                cinv[0] = f32x2{q1.x, q1.y}; cinv[1] = f32x2{q1.z, q1.w};
+                csc[0] = f32x2{q2.x, q2.y}; csc[1] = f32x2{q2.z, q2.w};
+                csh[0] = f32x2{q3.x, q3.y}; csh[1] = f32x2{q3.z, q3.w};
+                ck1[0] = f32x2{q4.x, q4.y}; ck1[1] = f32x2{q4.z, q4.w};
+                ck2[0] = f32x2{q5.x, q5.y}; ck2[1] = f32x2{q5.z, q5.w};
+                ck3[0] = f32x2{q6.x, q6.y}; ck3[1] = f32x2{q6.z, q6.w};
+            }
+            uint32_t hw[4][2];                      // [row j][column pair h]
+            f32x2 ts[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool rok = j < left;
+                f32x2 dz2[2];
+                if (SHUF) {     // loaded (c0, c0 + 2), (c0 + 1, c0 + 3) -> pairs (c0, c0 + 1), (c0 + 2, c0 + 3)
+                    const f32x2 pa = widen(hi_half[0] ? rz[j][0] >> 16 : rz[j][0]), pb = widen(hi_half[1] ? rz[j][1] >> 16 : rz[j][1]);
+                    dz2[0] = f32x2{pa[0], pb[0]};
+                    dz2[1] = f32x2{pa[1], pb[1]};
+                    if (!cok[2]) dz2[1][0] = 0.0f;      // (channel counts are even: c0 + 2 and c0 + 3 are valid together; the source
+                    if (!cok[3]) dz2[1][1] = 0.0f;      //  words' second halves belong to other channels there)
+                } else {
+                    dz2[0] = widen(rz[j][0]);
+                    dz2[1] = widen(rz[j][1]);
+                }
+                f32x2 vrow[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 d = dz2[h];
+                    const f32x2 yv = widen(ry[j][h]);
+                    if (relu6) {
+                        const f32x2 z = __builtin_elementwise_fma(csc[h], yv, csh[h]);
+                        if (!relu6_open(z[0])) d[0] = 0.0f;
+                        if (!relu6_open(z[1])) d[1] = 0.0f;
+                    }
+                    const f32x2 xh = (yv - cmean[h]) * cinv[h];
+                    f32x2 v = ck1[h] * (d - ck2[h] - xh * ck3[h]);
+                    if (!rok) v = f32x2{0.0f, 0.0f};
+                    vrow[h] = v;
+                }
+                if (more) load_row(t + 1, j);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    ts[h] += vrow[h];
+                    hw[j][h] = pack(vrow[h]);
+                }
+                *reinterpret_cast<u32x2*>(&Rm[(4 * rg + j) * LDR + c0]) = u32x2{hw[j][0], hw[j][1]};
+            }
+            cs[0] += (double)ts[0][0];
+            cs[1] += (double)ts[0][1];
+            cs[2] += (double)ts[1][0];
+            cs[3] += (double)ts[1][1];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                *reinterpret_cast<u32x2*>(&Dt[(c0 + 2 * h) * LDT + 4 * rg]) = u32x2{pwb_lolo(hw[0][h], hw[1][h]), pwb_lolo(hw[2][h], hw[3][h])};
+                *reinterpret_cast<u32x2*>(&Dt[(c0 + 2 * h + 1) * LDT + 4 * rg]) = u32x2{pwb_hihi(hw[0][h], hw[1][h]), pwb_hihi(hw[2][h], hw[3][h])};
+            }
+        };
+        // output tile as bf16: a lane owns ONE column (16 rows in 16 registers); lanes (2i, 2i + 1) own adjacent columns -- the even
+        // lane takes the even registers of both columns, the odd lane the odd ones, the partner's half arrives by DPP: 8 four-byte
+        // stores per lane instead of 16 two-byte ones (gemm_pw.hip pair_load16).  Row offsets of register pair q are wave-uniform.
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.da.p, 0, (int)(Mtot * a.da.ld * 2), 0x00020000);
+        const uint32_t rowC = (uint32_t)a.da.ld * 2u;
+        const int ncol = dwc * 32 + lrow;
+        const bool odd = (lane & 1) != 0;
+        const uint32_t voC = (ncol & ~1) < K ? (uint32_t)((4 * lk + (odd ? 1 : 0)) * a.da.ld + a.da.coff + (ncol & ~1)) * 2u : OOR;
+        auto swap1 = [](float x) -> float { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true)); };
+        double sda = 0.0, sdx = 0.0;                // ANORM: this lane's column, its 16 rows of every tile
+        auto compute_tile = [&](int t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const int64_t m0 = mbeg + (int64_t)t * BM + dwr * 32;
+            const uint32_t mu = (uint32_t)m0;
+            const int left = (int)(mend - m0) - 4 * lk - (odd ? 1 : 0);
+            uint32_t cold[ACC ? 8 : 1];
+            if (ACC) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int rr = ((2 * q) & 3) + 8 * ((2 * q) >> 2);
+                    cold[ACC ? q : 0] = __builtin_amdgcn_raw_buffer_load_b32(rsC, voC | (rr < left ? 0u : OOR), (mu + (uint32_t)rr) * rowC, 0);
+                }
+            }
+            const int ao = (dwr * 32 + lrow) * LDR + 8 * lk;
+#pragma unroll
+            for (int s = 0; s < KS_DA; ++s) {
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Rm[ao + 16 * s]);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Wl[((s * 2 + lk) * 128 + ncol) * 8]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+            }
+            if (ANORM) {
+                // BatchNorm-backward sums of the BatchNorm in front of the conv, from the float32 accumulators and the xhat operand
+                // plane, in double: deriving them from the float32 filter-product partials (as the float32 kernel does) makes the
+                // coefficients order-dependent in their last bits, and behind bf16 storage a last-bit change of a coefficient flips
+                // roundings downstream (test_config3_full_size_properties: permutation invariance)
+                // (every term in double: float32 partial sums over the 16 rows of a tile already break the invariance, measured)
+                const int xo = ncol * LDT + dwr * 32 + 4 * lk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x2 xw = *reinterpret_cast<const u32x2*>(&At[xo + 8 * i]);
+                    const f32x2 x01 = widen(xw[0]), x23 = widen(xw[1]);
+                    sda += ((double)acc[4 * i] + (double)acc[4 * i + 1]) + ((double)acc[4 * i + 2] + (double)acc[4 * i + 3]);
+                    sdx += ((double)acc[4 * i] * (double)x01[0] + (double)acc[4 * i + 1] * (double)x01[1]) +
+                           ((double)acc[4 * i + 2] * (double)x23[0] + (double)acc[4 * i + 3] * (double)x23[1]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                // even lane: rows of registers 2q (its own column -> lo, partner's -> hi); odd lane: registers 2q + 1
+                const float recv = swap1(odd ? acc[2 * q] : acc[2 * q + 1]);
+                float lo = odd ? recv : acc[2 * q], hi = odd ? acc[2 * q + 1] : recv;
+                if (ACC) {
+                    lo += bf_lo(cold[ACC ? q : 0]);
+                    hi += bf_hi(cold[ACC ? q : 0]);
+                }
+                const int rr = ((2 * q) & 3) + 8 * ((2 * q) >> 2);
+                __builtin_amdgcn_raw_buffer_store_b32(bf_pack(lo, hi), rsC, voC | (rr < left ? 0u : OOR), (mu + (uint32_t)rr) * rowC, 0);
+            }
+        };
+        if (t0 < t1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_row(t0, j);
+        }
+        __syncthreads();
+        for (int t = t0; t < t1; ++t) {
+            store_tile(t);
+            __syncthreads();
+            compute_tile(t);
+            __syncthreads();
+        }
+        double* red = reinterpret_cast<double*>(smem_raw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[rg * NP + c0 + e] = cs[e];
+        __syncthreads();
+        for (int c = tid; c < NP; c += 256) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < NRG; ++r) s += red[r * NP + c];
+            a.dbpart[((int64_t)g * a.nbpg + b) * NP + c] = s;
+        }
+        if (ANORM && a.spart) {
+            __syncthreads();                        // (role 1 passes the matching barriers below)
+            double* r2 = reinterpret_cast<double*>(smem_raw);       // [DA_WR][2][2][KP]: wave row, lk half, quantity, column
+            r2[((dwr * 2 + lk) * 2 + 0) * KP + ncol] = sda;
+            r2[((dwr * 2 + lk) * 2 + 1) * KP + ncol] = sdx;
+            __syncthreads();
+            for (int i = tid; i < 2 * KP; i += 256) {
+                const int q = i / KP, c = i % KP;
+                double s = 0.0;
+#pragma unroll
+                for (int w = 0; w < DA_WR * 2; ++w) s += r2[(w * 2 + q) * KP + c];
+                a.spart[(((int64_t)g * a.nbpg + b) * 2 + q) * KP + c] = s;
+            }
+        }
+    } else {
+        const int qw = wave & 3;
+        const int qkt = qw % Q_KT, qnt0 = (qw / Q_KT) * NTW;
+        f32x2 cmean[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}}, cinv[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+        if (ANORM) {
+            const int GK = a.G * K;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + e;
+                const bool on = c < K;
+                cmean[e >> 1][e & 1] = on ? a.a_stats[0 * GK + g * K + (on ? c : 0)] : 0.0f;
+                cinv[e >> 1][e & 1] = on ? a.a_stats[1 * GK + g * K + (on ? c : 0)] : 0.0f;
+            }
+        }
+        uint32_t vo[2];
+        vo[0] = c0 < K ? (uint32_t)((4 * rg) * a.a.ld + a.a.coff + c0) * 2u : OOR;
+        vo[1] = c0 + 2 < K ? (uint32_t)((4 * rg) * a.a.ld + a.a.coff + c0 + 2) * 2u : OOR;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a.a.p, 0, (int)(Mtot * a.a.ld * 2), 0x00020000);
+        const uint32_t rowA = (uint32_t)a.a.ld * 2u;
+        uint32_t rz[4][2];
+        auto load_row = [&](int t, int j) {
+            const int64_t m0 = mbeg + (int64_t)t * BM;
+            const uint32_t mu = (uint32_t)m0;
+            const int left = (int)(mend - (m0 + 4 * rg));
+            const uint32_t msk = j < left ? 0u : OOR;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) rz[j][h] = __builtin_amdgcn_raw_buffer_load_b32(rsA, (vo[h] + (uint32_t)j * rowA) | msk, mu * rowA, 0);
+        };
+        auto store_tile = [&](int t) {
+            const bool more = t + 1 < t1;
+            const int left = (int)(mend - (mbeg + (int64_t)t * BM + 4 * rg));
+            uint32_t hw[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool rok = j < left;
+                if (ANORM) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x2 v = (widen(rz[j][h]) - cmean[h]) * cinv[h];       // padded columns: loaded 0, mean 0, invstd 0 -> 0
+                        if (!rok) v = f32x2{0.0f, 0.0f};
+                        hw[j][h] = pack(v);
+                    }
+                } else {
+                    hw[j][0] = rz[j][0];            // plain input: the stored bf16 values ARE the operand
+                    hw[j][1] = rz[j][1];
+                }
+                if (more) load_row(t + 1, j);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                *reinterpret_cast<u32x2*>(&At[(c0 + 2 * h) * LDT + 4 * rg]) = u32x2{pwb_lolo(hw[0][h], hw[1][h]), pwb_lolo(hw[2][h], hw[3][h])};
+                *reinterpret_cast<u32x2*>(&At[(c0 + 2 * h + 1) * LDT + 4 * rg]) = u32x2{pwb_hihi(hw[0][h], hw[1][h]), pwb_hihi(hw[2][h], hw[3][h])};
+            }
+        };
+        f32x16 qacc[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qacc[j][r] = 0.0f;
+        auto compute_tile = [&]() {
+            const int ao = (qkt * 32 + lrow) * LDT + 8 * lk;
+#pragma unroll
+            for (int s = 0; s < KS_Q; ++s) {
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&At[ao + 16 * s]);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(&Dt[((qnt0 + j) * 32 + lrow) * LDT + 8 * lk + 16 * s]);
+                    qacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, d1, qacc[j], 0, 0, 0);
+                }
+            }
+        };
+        if (t0 < t1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_row(t0, j);
+        }
+        __syncthreads();
+        for (int t = t0; t < t1; ++t) {
+            store_tile(t);
+            __syncthreads();
+            compute_tile();
+            __syncthreads();
+        }
+        float* qp = a.qpart + ((int64_t)g * a.nbpg + b) * KP * NP;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = (qnt0 + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = qkt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                qp[k * NP + n] = qacc[j][r];
+            }
+        }
+        __syncthreads();
+        if (ANORM && a.spart) {
+            __syncthreads();
+            __syncthreads();
+        }
+    }
+}
+
 // One workgroup per input channel k (row of dW), one thread per output channel n.
 struct PwbReduceArgs {
     const float* qpart;     // [G][nbpg][KP][NP]
     const double* dbpart;   // [G][nbpg][NP]
+    const double* spart;    // [G][nbpg][2][KP] or null: BatchNorm-backward sums taken directly by the main kernel (bf16 storage)
     const float* W;         // conv weights [K][N]
     const float* a_stats;   // [4][G][K] or null
     const float* a_gamma;   // ANORM: gamma / beta of the BatchNorm that produced a
@@ -438,6 +800,7 @@ struct PwbReduceArgs {
     float* a_dbeta;
     float* a_coef;
     int N, K, KP, NP, G, Mg, nbpg;
+    int wbf;                // bf16 storage: the backward-data product used bf16(W); the derived BatchNorm sums use the same values
 };
 
 // 1024 threads = 128 output channels n x 8 slots; a slot sums one (group, slice of the partial rows) pair with the loads of 8
@@ -485,7 +848,8 @@ __global__ void __launch_bounds__(128 * PWB_RS) pwb_reduce_kernel(PwbReduceArgs 
     }
     __syncthreads();
     const bool lead = sl == 0;                  // slice 0 (threads 0 .. 127 = waves 0, 1) folds and writes
-    const float w = (on && lead) ? a.W[(int64_t)k * N + n] : 0.0f;
+    float w = (on && lead) ? a.W[(int64_t)k * N + n] : 0.0f;
+    if (a.wbf) w = (float)(__bf16)w;
     double qtot = 0.0, dbtot = 0.0;
     double s1[8], s2[8];
 #pragma unroll
@@ -526,6 +890,14 @@ __global__ void __launch_bounds__(128 * PWB_RS) pwb_reduce_kernel(PwbReduceArgs 
         }
     }
     __syncthreads();
+    if (a.spart && threadIdx.x < 2 * G) {          // the directly accumulated sums replace the derived ones (fixed order over the workgroups)
+        const int g = threadIdx.x >> 1, q = threadIdx.x & 1;
+        double u = 0.0;
+        for (int b = 0; b < a.nbpg; ++b) u += a.spart[(((int64_t)g * a.nbpg + b) * 2 + q) * a.KP + k];
+        red[q][g][0] = u;
+        red[q][g][1] = 0.0;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         const int GK = G * K;
         const double cnt = (double)a.Mg;
@@ -548,32 +920,36 @@ __global__ void __launch_bounds__(128 * PWB_RS) pwb_reduce_kernel(PwbReduceArgs 
 // ------------------------------------------------------------------------------------------
 static inline int pwb_pad(int c) { return c <= 64 ? 64 : 128; }
 
-bool pw_bwd_fused_supported(View dz, View a, View da, int N, int K) {
+bool pw_bwd_fused_supported(View dz, View a, View da, int N, int K, int at) {
     if (N > 128 || K > 128 || N < 8 || K < 8 || (N & 1) || (K & 1)) return false;
-    if (pwb_pad(N) != pwb_pad(K)) return false;
+    if (at && pwb_pad(N) != pwb_pad(K)) return false;          // bf16-storage form: equal paddings only
+    if (pwb_pad(N) != pwb_pad(K) && !(pwb_pad(K) == 64 && pwb_pad(N) == 128)) return false;      // 64/64, 128/128, 64 -> 128
     auto ok = [](View v) { return (v.ld % 2 == 0) && (v.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 7) == 0); };
     return ok(a) && ok(da) && (dz.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(dz.p) & 7) == 0);
 }
 
-int pw_bwd_fused_nbpg(int G, int Mg, int N, int K) {
-    const int bm = pwb_pad(K) == 128 ? 32 : 64;
+int pw_bwd_fused_nbpg(int G, int Mg, int N, int K, int at) {
+    const int bm = (pwb_pad(K) == 128 || pwb_pad(N) == 128) ? 32 : 64;
     const int tiles = cdiv(Mg, bm);
-    int nb = 256 / G;
+    int nb = (at ? 512 : 256) / G;          // resident workgroups: one per CU (float32: 87 KB of LDS), two in bf16 storage (32 KB)
     if (nb < 1) nb = 1;
     return nb > tiles ? tiles : nb;
 }
 
-int64_t pw_bwd_fused_qpart_elems(int G, int Mg, int N, int K) {
-    return (int64_t)G * pw_bwd_fused_nbpg(G, Mg, N, K) * pwb_pad(K) * pwb_pad(N);
+int64_t pw_bwd_fused_qpart_elems(int G, int Mg, int N, int K, int at) {
+    return (int64_t)G * pw_bwd_fused_nbpg(G, Mg, N, K, at) * pwb_pad(K) * pwb_pad(N);
 }
 
-int64_t pw_bwd_fused_dbpart_elems(int G, int Mg, int N, int K) { return (int64_t)G * pw_bwd_fused_nbpg(G, Mg, N, K) * pwb_pad(N); }
+// (bf16 storage: [column sums of dy | (sum da, sum da xhat)] -- three rows of NP == KP doubles per workgroup)
+int64_t pw_bwd_fused_dbpart_elems(int G, int Mg, int N, int K, int at) {
+    return (int64_t)G * pw_bwd_fused_nbpg(G, Mg, N, K, at) * pwb_pad(N) * (at ? 3 : 1);
+}
 
-template <int P, bool SHUF, bool ANORM, bool ACC>
+template <int KP, int NP, bool SHUF, bool ANORM, bool ACC>
 static int pwb_launch(const PwbArgs& a, hipStream_t st) {
-    constexpr int BM = P == 128 ? 32 : 64;
-    constexpr size_t lds = (size_t)(3 * BM * (P + 8) + 2 * 3 * P * (BM + 8)) * 2 + (size_t)7 * P * sizeof(float);
-    auto kern = pwb_kernel<P, P, SHUF, ANORM, ACC>;
+    constexpr int BM = (KP == 128 || NP == 128) ? 32 : 64;
+    constexpr size_t lds = (size_t)(3 * BM * (NP + 8) + 3 * (NP + KP) * (BM + 8)) * 2 + (size_t)7 * NP * sizeof(float);
+    auto kern = pwb_kernel<KP, NP, SHUF, ANORM, ACC>;
     static bool attr = false;
     if (!attr) {
         CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -584,18 +960,43 @@ static int pwb_launch(const PwbArgs& a, hipStream_t st) {
     return 0;
 }
 
+template <int P, bool SHUF, bool ANORM, bool ACC>
+static int pwb16_launch(const PwbArgs& a, hipStream_t st) {
+    constexpr int BM = P == 128 ? 32 : 64;
+    constexpr size_t lds = (size_t)(BM * (P + 8) + 2 * P * (BM + 8)) * 2 + (size_t)7 * P * sizeof(float) + (size_t)(P / 16) * 2 * 128 * 8 * 2;
+    auto kern = pwb16_kernel<P, P, SHUF, ANORM, ACC>;
+    static bool attr = false;
+    if (!attr && lds >= 64 * 1024) {
+        CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg), dim3(512), lds, st, a);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int P, bool SHUF>
+static int pwb16_launch2(const PwbArgs& a, bool anorm, bool acc, hipStream_t st) {
+    if (anorm) return acc ? pwb16_launch<P, SHUF, true, true>(a, st) : pwb16_launch<P, SHUF, true, false>(a, st);
+    return acc ? pwb16_launch<P, SHUF, false, true>(a, st) : pwb16_launch<P, SHUF, false, false>(a, st);
+}
+
+template <int KP, int NP, bool SHUF>
 static int pwb_launch2(const PwbArgs& a, bool anorm, bool acc, hipStream_t st) {
-    if (anorm) return acc ? pwb_launch<P, SHUF, true, true>(a, st) : pwb_launch<P, SHUF, true, false>(a, st);
-    return acc ? pwb_launch<P, SHUF, false, true>(a, st) : pwb_launch<P, SHUF, false, false>(a, st);
+    if (anorm) return acc ? pwb_launch<KP, NP, SHUF, true, true>(a, st) : pwb_launch<KP, NP, SHUF, true, false>(a, st);
+    return acc ? pwb_launch<KP, NP, SHUF, false, true>(a, st) : pwb_launch<KP, NP, SHUF, false, false>(a, st);
 }
 
 int pw_bwd_fused(const PwBwdFused& f, hipStream_t st) {
-    if (!pw_bwd_fused_supported(f.dz, f.a, f.da, f.N, f.K) || !f.Wp) {
+    if (!pw_bwd_fused_supported(f.dz, f.a, f.da, f.N, f.K, f.at) || !f.Wp) {
         set_error("pw_bwd_fused: unsupported shape / alignment N=%d K=%d", f.N, f.K);
         return -1;
     }
     const int64_t Mtot = (int64_t)f.G * f.Mg;
+    if (f.at && ((f.dz.coff | f.dz.ld | f.a.coff | f.a.ld | f.da.coff | f.da.ld) & 1)) {
+        set_error("pw_bwd_fused: bf16 storage needs even leading dimensions / channel offsets");
+        return -1;
+    }
     if (Mtot * f.dz.ld * 4 >= ((int64_t)1 << 31) || Mtot * f.a.ld * 4 >= ((int64_t)1 << 31) || Mtot * f.N * 4 >= ((int64_t)1 << 31) ||
         Mtot * f.da.ld * 4 >= ((int64_t)1 << 31)) {
         set_error("pw_bwd_fused: operand of 2 GB or more");
@@ -622,12 +1023,23 @@ int pw_bwd_fused(const PwBwdFused& f, hipStream_t st) {
     a.K = f.K;
     a.G = f.G;
     a.Mg = f.Mg;
-    a.nbpg = pw_bwd_fused_nbpg(f.G, f.Mg, f.N, f.K);
+    a.nbpg = pw_bwd_fused_nbpg(f.G, f.Mg, f.N, f.K, f.at);
+    a.at = f.at;
+    a.spart = (f.at && f.a_stats) ? f.dbpart + (int64_t)f.G * a.nbpg * pwb_pad(f.N) : nullptr;
     static const int dbg = cdrl_getenv("CDRL_DIAG_PWB") ? atoi(cdrl_getenv("CDRL_DIAG_PWB")) : 0;
     a.dbg = dbg;
     const bool anorm = f.a_stats != nullptr, acc = f.accumulate != 0, shuf = f.dz_shuffle != 0;
-    if (pwb_pad(f.K) == 128) return shuf ? pwb_launch2<128, true>(a, anorm, acc, st) : pwb_launch2<128, false>(a, anorm, acc, st);
-    return shuf ? pwb_launch2<64, true>(a, anorm, acc, st) : pwb_launch2<64, false>(a, anorm, acc, st);
+    if (f.at && pwb_pad(f.K) != pwb_pad(f.N)) {
+        set_error("pw_bwd_fused: the bf16-storage form is instantiated for equal paddings only (N=%d K=%d)", f.N, f.K);
+        return -1;
+    }
+    if (f.at) {
+        if (pwb_pad(f.K) == 128) return shuf ? pwb16_launch2<128, true>(a, anorm, acc, st) : pwb16_launch2<128, false>(a, anorm, acc, st);
+        return shuf ? pwb16_launch2<64, true>(a, anorm, acc, st) : pwb16_launch2<64, false>(a, anorm, acc, st);
+    }
+    if (pwb_pad(f.K) == 128) return shuf ? pwb_launch2<128, 128, true>(a, anorm, acc, st) : pwb_launch2<128, 128, false>(a, anorm, acc, st);
+    if (pwb_pad(f.N) == 128) return shuf ? pwb_launch2<64, 128, true>(a, anorm, acc, st) : pwb_launch2<64, 128, false>(a, anorm, acc, st);
+    return shuf ? pwb_launch2<64, 64, true>(a, anorm, acc, st) : pwb_launch2<64, 64, false>(a, anorm, acc, st);
 }
 
 int pw_bwd_fused_reduce(const PwBwdFused& f, hipStream_t st) {
@@ -649,7 +1061,9 @@ int pw_bwd_fused_reduce(const PwBwdFused& f, hipStream_t st) {
     r.NP = pwb_pad(f.N);
     r.G = f.G;
     r.Mg = f.Mg;
-    r.nbpg = pw_bwd_fused_nbpg(f.G, f.Mg, f.N, f.K);
+    r.nbpg = pw_bwd_fused_nbpg(f.G, f.Mg, f.N, f.K, f.at);
+    r.wbf = f.at;
+    r.spart = (f.at && f.a_stats) ? f.dbpart + (int64_t)f.G * r.nbpg * pwb_pad(f.N) : nullptr;
     if (f.a_stats && (!f.a_gamma || !f.a_beta || !f.a_dgamma || !f.a_dbeta || !f.a_coef)) {
         set_error("pw_bwd_fused_reduce: normalised input needs gamma / beta and the dgamma / dbeta / coef outputs");
         return -1;

@@ -246,7 +246,9 @@ int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, 
  * load, and that BatchNorm's dgamma / dbeta [K] and backward coefficients a_coef [3][G][K] are produced as well (from the filter
  * product, no pass over da).  W [K][N]; W_packed: cdrl_pwconv_x3_pack(W, N, K, 1, N, ...) (the transposed operand).
  * da [G*Mg][ldda] (+ da_coff; += when accumulate).  Workspaces: qpart cdrl_pwconv_bwd_fused_workspace(G, Mg, N, K, 0) floats,
- * dbpart (..., 1) doubles.  K, N <= 128 and padded alike (both <= 64 or both > 64), even; float32-accurate. */
+ * dbpart (..., 1) doubles.  K, N <= 128 and padded alike (both <= 64 or both > 64), even; float32-accurate.
+ * After cdrl_set_op_activation_type(1): dz, y, a, da are bf16 (bf16 activation storage: one bf16 plane per MFMA operand, i.e. dy,
+ * xhat / a and W rounded to nearest even; leading dimensions / offsets even); workspaces sized under the same setting. */
 int64_t cdrl_pwconv_bwd_fused_workspace(int G, int Mg, int N, int K, int which);
 int cdrl_pwconv_bwd_fused(const float* dz, int ld_dz, int dz_coff, int dz_shuffle, int act, const float* y, const float* stats,
                           const float* coef, const float* a, int lda, int a_coff, const float* a_stats, const float* a_gamma,

@@ -774,9 +774,9 @@ def test_every_unit_backward_against_the_oracle_locally(compute):
     w_out, w_dx, w_w = (max(r[k] for r in report.values()) for k in ('out', 'dx', 'weights'))
     print(f'[unit-local parity, {compute}] worst over 16 units: out {w_out:.2e}, input gradient {w_dx:.2e}, weight gradients {w_w:.2e}')
     # measured worst over the 16 units: float32 5.6e-7 / 7.1e-7 / 5.6e-6; bf16 storage 2.8e-3 (under one bf16 ulp of the tensor maximum) /
-    # 3.3e-3 / 1.8e-2 (always bn1.gamma: the engine takes the BatchNorm-backward sums from the float32 gradient BEFORE it is rounded for
+    # 3.5e-3 / 2.7e-2 (always bn1.gamma, every other tensor <= 1e-2: the engine takes the BatchNorm-backward sums from the float32 gradient BEFORE it is rounded for
     # storage, the oracle's autograd from the rounded one)
-    tol = dict(out=5e-6, dx=5e-6, weights=3e-5) if compute == 'f32' else dict(out=4e-3, dx=5e-3, weights=3e-2)
+    tol = dict(out=5e-6, dx=5e-6, weights=3e-5) if compute == 'f32' else dict(out=4e-3, dx=5e-3, weights=4e-2)
     for pre, r in report.items():
         for k in ('out', 'dx', 'weights'):
             assert r[k] <= tol[k], (pre, k, r)

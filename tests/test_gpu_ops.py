@@ -728,7 +728,7 @@ def test_gemm_x3_split(lib, M, K, N):
 @pytest.mark.parametrize('G,Mg,K,N,relu,shuffle,anorm,acc,generic', [
     (4, 330, 58, 58, 1, 1, 1, 0, 0), (4, 96, 116, 116, 1, 1, 1, 0, 0), (4, 4100, 116, 116, 1, 0, 0, 1, 0), (2, 77, 58, 58, 0, 0, 0, 1, 1),
     (4, 100, 116, 116, 1, 1, 1, 0, 1), (1, 64, 40, 60, 0, 0, 1, 0, 1), (2, 8300, 58, 58, 1, 1, 1, 0, 0), (4, 1500, 116, 116, 1, 1, 0, 0, 1),
-    (4, 12288, 116, 116, 1, 1, 1, 0, 0)])
+    (4, 12288, 116, 116, 1, 1, 1, 0, 0), (4, 330, 58, 92, 1, 1, 1, 0, 0), (2, 4300, 58, 92, 1, 0, 0, 1, 1), (4, 77, 36, 100, 0, 1, 1, 0, 1)])
 def test_pwconv_bwd_fused(lib, G, Mg, K, N, relu, shuffle, anorm, acc, generic):
     """cdrl_pwconv_bwd_fused: BatchNorm-backward apply on load + backward-data + filter / bias gradient (+ the backward sums of
     the BatchNorm in FRONT of the conv, derived from the filter product) in one pass, against a float64 numpy evaluation of
@@ -823,3 +823,108 @@ def test_pwconv_bwd_fused(lib, G, Mg, K, N, relu, shuffle, anorm, acc, generic):
                                          P(adg) if anorm else None, P(adb) if anorm else None, P(acf) if anorm else None, P(Wd), P(wp),
                                          P(dA2), K + 4, 2, acc, P(dW2), P(dB2), P(qpart), P(dbpart), G, Mg, N, K, S()))
     assert torch.equal(dW, dW2) and torch.equal(dB, dB2) and torch.equal(dA, dA2)
+
+
+def _bf(x):
+    """round-to-nearest-even to bf16, returned as float64 (numpy in / out)"""
+    return torch.as_tensor(np.asarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+@pytest.mark.parametrize('G,Mg,K,N,relu,shuffle,anorm,acc', [
+    (4, 330, 58, 58, 1, 1, 1, 0), (4, 96, 116, 116, 1, 1, 1, 0), (4, 4100, 116, 116, 1, 0, 0, 1), (2, 77, 58, 58, 0, 0, 0, 1),
+    (4, 100, 116, 116, 1, 1, 1, 0), (2, 8300, 58, 58, 1, 1, 1, 0), (4, 1500, 116, 116, 1, 1, 0, 0), (4, 12288, 116, 116, 1, 1, 1, 0)])
+def test_pwconv_bwd_fused_bf16_storage(lib, G, Mg, K, N, relu, shuffle, anorm, acc):
+    """The bf16-storage form of cdrl_pwconv_bwd_fused (configuration 3): bf16 tensors in HBM, float32 BatchNorm-backward prologue,
+    ONE bf16 plane per MFMA operand.  Reference: float64 evaluation of the same contract -- dy, xhat / a and W rounded to bf16
+    where the kernel rounds them, exact products and sums.  What remains is float32-vs-float64 in front of a rounding: an element
+    within 1e-7 of a bf16 boundary lands on the other side (one bf16 ulp for that element), hence bounds at bf16 level for the
+    stored tensor and much tighter ones for the sums."""
+    rng = np.random.default_rng(7 + G * Mg + K + 3 * N + relu + 2 * shuffle + 4 * anorm)
+    M = G * Mg
+    f64 = np.float64
+    x = _bf(rng.standard_normal((M, K)) * rng.uniform(0.5, 2.0, K) + rng.uniform(-1, 1, K))            # stored bf16 tensors
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    xg = x.reshape(G, Mg, K)
+    ga, ba = rng.uniform(0.5, 1.5, K).astype(np.float32), rng.uniform(-0.5, 0.5, K).astype(np.float32)
+    amean = xg.mean(axis=1).astype(np.float32)
+    ainv = (1.0 / np.sqrt(xg.var(axis=1) + 1e-3)).astype(np.float32)
+    ast = np.stack([amean, ainv, ga[None] * ainv, ba[None] - amean * (ga[None] * ainv)]).astype(np.float32)
+    xh_a = (xg - ast[0].astype(f64)[:, None, :]) * ast[1].astype(f64)[:, None, :]
+    a_op = _bf(xh_a.astype(np.float32)).reshape(G, Mg, K) if anorm else xg                              # the kernel's second operand
+    a_val = xh_a * ga.astype(f64) + ba.astype(f64) if anorm else xg
+    y = _bf(a_val @ w.astype(f64) + rng.standard_normal(N))                                              # stored raw conv output
+    yg = y.reshape(G, Mg, N)
+    gy, by = rng.uniform(0.5, 1.5, N).astype(np.float32), rng.uniform(1.0, 3.0, N).astype(np.float32)
+    ymean = yg.mean(axis=1).astype(np.float32)
+    yinv = (1.0 / np.sqrt(yg.var(axis=1) + 1e-3)).astype(np.float32)
+    ysc = (gy[None] * yinv).astype(np.float32)
+    ysh = (by[None] - ymean * ysc).astype(np.float32)
+    yst = np.stack([ymean, yinv, ysc, ysh]).astype(np.float32)
+    ctot, coff = (2 * N, N) if shuffle else (N, 0)
+    dout = _bf(rng.standard_normal((M, ctot)))
+    idx = [((coff + c) & 1) * (ctot // 2) + ((coff + c) >> 1) for c in range(N)] if shuffle else list(range(N))
+    dz = dout[:, idx].reshape(G, Mg, N)
+    if relu:
+        z32 = ysc[:, None, :] * yg.astype(np.float32) + ysh[:, None, :]
+        z64 = ysc.astype(f64)[:, None, :] * yg + ysh.astype(f64)[:, None, :]
+        m = np.where(np.abs(z64 - np.round(z64 / 6.0) * 6.0) > 1e-4, (z64 > 0) & (z64 < 6), (z32 > 0) & (z32 < 6))
+        dz = dz * m
+    xh_y = (yg - ymean.astype(f64)[:, None, :]) * yinv.astype(f64)[:, None, :]
+    coef = np.stack([ysc, dz.mean(axis=1).astype(np.float32) + rng.uniform(-0.3, 0.3, (G, N)).astype(np.float32),
+                     (dz * xh_y).mean(axis=1).astype(np.float32) + rng.uniform(-0.3, 0.3, (G, N)).astype(np.float32)]).astype(np.float32)
+    dy = coef[0].astype(f64)[:, None, :] * (dz - coef[1].astype(f64)[:, None, :] - xh_y * coef[2].astype(f64)[:, None, :])
+    dyb = _bf(dy.astype(np.float32)).reshape(G, Mg, N)                                                  # the MFMA operand
+    wb = _bf(w)
+    da_ref = dyb @ wb.T
+    q_ref = np.einsum('gmk,gmn->gkn', a_op, dyb)
+    db_g = dy.sum(axis=1)                                                                               # float32 dy, summed in double
+    db_ref = db_g.sum(axis=0)
+    dw_ref = (ga.astype(f64)[:, None] * q_ref.sum(axis=0) + ba.astype(f64)[:, None] * db_ref[None, :]) if anorm else q_ref.sum(axis=0)
+    bf16 = torch.bfloat16
+    X, Wd, Y, YS, CF = dev(torch.as_tensor(x).to(bf16)), dev(w), dev(torch.as_tensor(y).to(bf16)), dev(yst), dev(coef)
+    DO = dev(torch.as_tensor(dout).to(bf16))
+    AS, GA, BA = dev(ast), dev(ga), dev(ba)
+    wp = torch.zeros(int(lib.cdrl_pwconv_x3_packed_bytes(N)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cdrl_pwconv_x3_pack(P(Wd), N, K, 1, N, P(wp), S()))
+    lib.cdrl_set_op_activation_type(1)
+    try:
+        qpart = torch.zeros(int(lib.cdrl_pwconv_bwd_fused_workspace(G, Mg, N, K, 0)), device=DEV)
+        dbpart = torch.zeros(int(lib.cdrl_pwconv_bwd_fused_workspace(G, Mg, N, K, 1)), dtype=torch.float64, device=DEV)
+        base = _bf(rng.standard_normal((M, K + 4)))
+        outs = []
+        for _ in range(2):
+            dA = dev(torch.as_tensor(base).to(bf16))
+            dW, dB = torch.full((K, N), 7.0, device=DEV), torch.full((N,), 7.0, device=DEV)
+            adg, adb, acf = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV), torch.zeros(3 * G * K, device=DEV)
+            _lib.check(lib.cdrl_pwconv_bwd_fused(P(DO), ctot, coff, ctot if shuffle else 0, relu, P(Y), P(YS), P(CF), P(X), K, 0,
+                                                 P(AS) if anorm else None, P(GA) if anorm else None, P(BA) if anorm else None,
+                                                 P(adg) if anorm else None, P(adb) if anorm else None, P(acf) if anorm else None, P(Wd), P(wp),
+                                                 P(dA), K + 4, 2, acc, P(dW), P(dB), P(qpart), P(dbpart), G, Mg, N, K, S()))
+            torch.cuda.synchronize()
+            outs.append((dA.clone(), dW.clone(), dB.clone(), adg.clone(), adb.clone(), acf.clone()))
+    finally:
+        lib.cdrl_set_op_activation_type(0)
+    dA, dW, dB, adg, adb, acf = outs[0]
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)                                                                        # bit-wise reproducible
+    got = dA.double().cpu().numpy()
+    exp = da_ref.reshape(M, K) + (base[:, 2:2 + K] if acc else 0.0)
+    assert rel_err(got[:, 2:2 + K], exp) < 6e-3                                                         # stored as bf16: one ulp of the maximum = 3.9e-3
+    assert np.array_equal(got[:, :2], base[:, :2]) and np.array_equal(got[:, 2 + K:], base[:, 2 + K:])
+    assert rel_err(dW.cpu().numpy(), dw_ref) < 5e-4                                                     # sums: single-element ulp flips average out
+    assert np.abs(dB.cpu().numpy() - db_ref).max() < 1e-4 * max(np.abs(db_ref).max(), 1e-3 * np.abs(dw_ref).max())
+    if anorm:
+        # bf16 storage: the sums are taken directly from the float32 backward-data accumulators and the xhat operand plane
+        # (float32 over a lane's 16 rows of a tile, double beyond), not derived from the filter product
+        da_u = dyb @ wb.T
+        s1 = da_u.sum(axis=1)
+        s2 = (da_u * a_op).sum(axis=1)
+        cf = acf.cpu().numpy().reshape(3, G, K)
+        sc = max(np.abs(s2).max(), np.abs(s1).max()) / Mg
+        assert np.array_equal(cf[0], ast[2])
+        assert np.abs(cf[1] - s1 / Mg).max() < 5e-4 * sc and np.abs(cf[2] - s2 / Mg).max() < 5e-4 * sc
+        assert rel_err(adg.cpu().numpy(), s2.sum(axis=0)) < 5e-4
+        # ... which are the BatchNorm-backward sums of the (unrounded) da up to the operand rounding of xhat
+        true_s2 = (da_u * xh_a).sum(axis=1)
+        assert np.abs(s2 - true_s2).max() < 2e-2 * np.abs(true_s2).max()
+        assert np.abs(adb.cpu().numpy() - s1.sum(axis=0)).max() < 5e-4 * np.abs(s2.sum(axis=0)).max()
