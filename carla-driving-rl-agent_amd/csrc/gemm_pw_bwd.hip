@@ -824,6 +824,20 @@ __global__ void __launch_bounds__(128 * PWB_RS) pwb_reduce_kernel(PwbReduceArgs 
             const float* pq = a.qpart + ((int64_t)g * a.nbpg * a.KP + k) * a.NP + n;
             const double* pd = a.dbpart + (int64_t)g * a.nbpg * a.NP + n;
             int b = b0;
+            for (; b + 16 <= b1; b += 16) {         // 32 loads in flight per thread (a slot's 32 partials are two rounds)
+                float v[16];
+                double u[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    v[i] = pq[(int64_t)(b + i) * a.KP * a.NP];
+                    u[i] = pd[(int64_t)(b + i) * a.NP];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    q += (double)v[i];
+                    d += u[i];
+                }
+            }
             for (; b + 8 <= b1; b += 8) {
                 float v[8];
                 double u[8];
