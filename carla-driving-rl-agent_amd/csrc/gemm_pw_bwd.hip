@@ -945,7 +945,9 @@ bool pw_bwd_fused_supported(View dz, View a, View da, int N, int K, int at) {
 int pw_bwd_fused_nbpg(int G, int Mg, int N, int K, int at) {
     const int bm = (pwb_pad(K) == 128 || pwb_pad(N) == 128) ? 32 : 64;
     const int tiles = cdiv(Mg, bm);
-    int nb = (at ? 512 : 256) / G;          // resident workgroups: one per CU (float32: 87 KB of LDS), two in bf16 storage (32 KB)
+    // resident workgroups: one per CU (float32: 87 KB of LDS); bf16 storage (32 KB) fits two, taken while a workgroup still gets >= 6 tiles
+    int nb = 256 / G;
+    if (at && tiles >= 6 * (512 / G)) nb = 512 / G;
     if (nb < 1) nb = 1;
     return nb > tiles ? tiles : nb;
 }

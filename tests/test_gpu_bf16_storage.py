@@ -701,8 +701,8 @@ def test_bf16_storage_engine_vs_oracle_with_the_storage_rule(B, H, W):
             assert r['median'] <= 0.4, (kind, grp, r)
 
 
-@pytest.mark.parametrize('compute', ['f32', 'bf16s'])
-def test_every_unit_backward_against_the_oracle_locally(compute):
+@pytest.mark.parametrize('compute', ['f32', 'bf16s', 'bf16s_fused'])
+def test_every_unit_backward_against_the_oracle_locally(compute, monkeypatch):
     """Unit-by-unit HIP-vs-oracle check of the tower's backward in both storage modes (the engine-level plumbing of
     the bf16-storage mode -- tens_a, element-sized slots, the `at` flag through ~40 call sites -- was only covered by cosine gates).
     End to end, ~50 train-mode BatchNorms amplify a perturbation of one bf16 ulp a thousandfold (the float32 engine meets the
@@ -717,6 +717,10 @@ def test_every_unit_backward_against_the_oracle_locally(compute):
     from oracle.spec import unit_plan
     from tests.util import make_pair, make_batches, to_dev, is_zero_gradient, engine_decisions
     B, H, W, A = 32, 48, 64, 2
+    label = compute
+    if compute == 'bf16s_fused':        # the engine takes the fused backward in bf16 storage from B = 512 on its own: forced here
+        monkeypatch.setenv('CDRL_FUSED_BWD', '1')
+        compute = 'bf16s'
     oracle, eng = make_pair(B, H, W, seed=5, A=A, compute=compute, with64=True)
     o64 = oracle.o64
     pol, _ = make_batches(B, H, W, seed=5, A=A, faithful=True)
@@ -770,9 +774,9 @@ def test_every_unit_backward_against_the_oracle_locally(compute):
         cursor += n_items
         prev, prev_c, h, w = pre + '.out', C, ho, wo
     os.makedirs('gpurun_out', exist_ok=True)
-    json.dump(report, open(f'gpurun_out/parity_report_units_local_{compute}_B{B}_{H}x{W}.json', 'w'), indent=1)
+    json.dump(report, open(f'gpurun_out/parity_report_units_local_{label}_B{B}_{H}x{W}.json', 'w'), indent=1)
     w_out, w_dx, w_w = (max(r[k] for r in report.values()) for k in ('out', 'dx', 'weights'))
-    print(f'[unit-local parity, {compute}] worst over 16 units: out {w_out:.2e}, input gradient {w_dx:.2e}, weight gradients {w_w:.2e}')
+    print(f'[unit-local parity, {label}] worst over 16 units: out {w_out:.2e}, input gradient {w_dx:.2e}, weight gradients {w_w:.2e}')
     # measured worst over the 16 units: float32 5.6e-7 / 7.1e-7 / 5.6e-6; bf16 storage 2.8e-3 (under one bf16 ulp of the tensor maximum) /
     # 3.5e-3 / 2.7e-2 (always bn1.gamma, every other tensor <= 1e-2: the engine takes the BatchNorm-backward sums from the float32 gradient BEFORE it is rounded for
     # storage, the oracle's autograd from the rounded one)
