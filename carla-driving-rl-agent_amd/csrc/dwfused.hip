@@ -342,6 +342,19 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
         k2 = vload<VEC>(post_coef + 1 * GC + g * C + c);
         k3 = vload<VEC>(post_coef + 2 * GC + g * C + c);
     }
+    // xhat1 = (v - bt1) * rg1 with v = the activated value of tile A (bt1 = beta, rg1 = 1 / gamma) or, for a thread holding a channel
+    // with |gamma| < 0.05, v = y1 re-read from memory (bt1 = mean, rg1 = invstd); see the input-gradient phase
+    VecF<VEC> bt1, rg1;
+    bool slow1 = false;
+    if (PRE && on) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) slow1 |= !(fabsf(sc.v[i]) >= 0.05f * fabsf(inv1.v[i]));
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            bt1.v[i] = slow1 ? mean1.v[i] : fmaf(mean1.v[i], sc.v[i], sh.v[i]);
+            rg1.v[i] = slow1 ? inv1.v[i] : inv1.v[i] / sc.v[i];
+        }
+    }
     // filter / bias gradient accumulators: float over the (<= 8) frames of this workgroup (a few hundred fmaf per lane),
     // double from the block reduction on -- 40 fewer VGPRs than double accumulators, one more wave per SIMD
     float gf[10][VEC];
@@ -418,13 +431,10 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) gf[9][i] += d.v[i];
             }
-            // gradient w.r.t. the depthwise input (transposed conv), masked by ReLU6 of the pre BN.
-            // Batches of DXU pixels: the L2-resident re-reads of y1 (for xhat1) of the NEXT batch are issued before the
-            // stores of this one and consumed after the next batch's taps.  gfx9 counts loads and stores in one in-order
-            // counter: with "load, taps, store, use" per pixel every iteration waited for its own store to complete
-            // (s_waitcnt vmcnt(0): ~21 exposed round trips per frame, 266 us for the 22x30 stride-2 block).
+            // gradient w.r.t. the depthwise input (transposed conv), masked by ReLU6 of the pre BN, in batches of DXU pixels
+            // (stores of a batch issued together).
             constexpr int DXU = (S == 2 && PRE) ? 4 : 1;      // (stride 1: deeper batches cost a wave of occupancy, measured slower)
-            auto taps = [&](int p) {
+            auto taps = [&](int p, VecF<VEC>& av) {
                 const int iy = (int)(((float)p + 0.5f) * invW), ix = p - iy * W;
                 VecF<VEC> acc;
 #pragma unroll
@@ -471,42 +481,41 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
                     }
                 }
                 if (PRE) {      // ReLU6 mask of BN1's output (the activated value is in tile A)
-                    const VecF<VEC> av = vload<VEC>(&tile[((iy + 1) * Wp + ix + 1) * cchunk + tx * VEC]);
+                    av = vload<VEC>(&tile[((iy + 1) * Wp + ix + 1) * cchunk + tx * VEC]);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i)
                         if (!relu6_open(av.v[i])) acc.v[i] = 0.0f;
                 }
                 return acc;
             };
-            VecF<VEC> yb[DXU];
-            if (PRE) {
-#pragma unroll
-                for (int u = 0; u < DXU; ++u) yb[u] = vload_raw<VEC>(xp + (int64_t)min(ty + u * CY, P - 1) * C);
-            }
+            // xhat1 for BN1's backward sums comes from the ACTIVATED value in tile A: where the ReLU6 mask is open a = scale y1 + shift,
+            // so xhat1 = (a - beta) / gamma (beta = shift + mean scale, 1 / gamma = invstd / scale); where it is closed the gradient is
+            // zero and xhat1 is not needed.  No global re-read of y1 in this phase (it was an L2 round trip per pixel batch in front of
+            // the stores, both on gfx9's single in-order memory counter).  Channels with |gamma| < 0.05 (the division would amplify
+            // the rounding of a) re-read y1, thread by thread.
             for (int p0 = ty; p0 < P; p0 += CY * DXU) {
-                VecF<VEC> acc[DXU];
+                VecF<VEC> acc[DXU], av[DXU];
 #pragma unroll
                 for (int u = 0; u < DXU; ++u) {
                     const int p = p0 + u * CY;
-                    if (p < P) acc[u] = taps(p);
+                    if (p < P) acc[u] = taps(p, av[u]);
                 }
                 if (PRE) {
 #pragma unroll
                     for (int u = 0; u < DXU; ++u) {
                         const int p = p0 + u * CY;
                         if (p >= P) continue;
-                        vdecode<VEC>(yb[u], xp);
+                        if (slow1) {
+                            av[u] = vload_raw<VEC>(xp + (int64_t)p * C);
+                            vdecode<VEC>(av[u], xp);
+                        }
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) {
-                            const float xh = (yb[u].v[i] - mean1.v[i]) * inv1.v[i];
+                            const float xh = (av[u].v[i] - bt1.v[i]) * rg1.v[i];
                             gb1[i] += (double)acc[u].v[i];
                             gb2[i] += (double)acc[u].v[i] * (double)xh;
                         }
                     }
-                    // next batch's y1 (clamped addresses: unconditional loads), ahead of this batch's stores
-#pragma unroll
-                    for (int u = 0; u < DXU; ++u) yb[u] = vload_raw<VEC>(xp + (int64_t)min(p0 + (DXU + u) * CY, P - 1) * C);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int u = 0; u < DXU; ++u) {

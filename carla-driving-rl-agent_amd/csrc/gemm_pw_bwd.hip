@@ -904,12 +904,18 @@ __global__ void __launch_bounds__(128 * PWB_RS) pwb_reduce_kernel(PwbReduceArgs 
         }
     }
     __syncthreads();
-    if (a.spart && threadIdx.x < 2 * G) {          // the directly accumulated sums replace the derived ones (fixed order over the workgroups)
-        const int g = threadIdx.x >> 1, q = threadIdx.x & 1;
+    if (a.spart && (int)(threadIdx.x >> 6) < 2 * G) {   // the directly accumulated sums replace the derived ones: one wave per (group, sum)
+        // pair, lane l takes the workgroups l, l + 64, ... and the lanes fold in a fixed tree (one thread walking all 128 partials was a
+        // chain of dependent loads: 53 us per launch at B = 1024 against 14 us for the rest of the kernel)
+        const int pr = threadIdx.x >> 6, g = pr >> 1, q = pr & 1, l = threadIdx.x & 63;
         double u = 0.0;
-        for (int b = 0; b < a.nbpg; ++b) u += a.spart[(((int64_t)g * a.nbpg + b) * 2 + q) * a.KP + k];
-        red[q][g][0] = u;
-        red[q][g][1] = 0.0;
+        for (int b = l; b < a.nbpg; b += 64) u += a.spart[(((int64_t)g * a.nbpg + b) * 2 + q) * a.KP + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) u += __shfl_down(u, o);
+        if (l == 0) {
+            red[q][g][0] = u;
+            red[q][g][1] = 0.0;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
