@@ -3,8 +3,8 @@ cover): the same policy pass at the benchmark shape (B=256, T=4, 90x120x3) throu
 depthwise block, persistent pointwise GEMMs with BatchNorm prologues / epilogues, BN-backward operand prologue, fused stem
 block, identity half riding on the BatchNorm ops, side / aux streams -- and (b) the engine with every fusion and the side
 stream switched off, in two subprocesses (the switches are per process).  Every reduction on the path accumulates in
-double over float data and every GEMM is a k-ordered fmaf chain, so the two paths agree to float rounding -- in practice
-bit for bit -- everywhere except on the analytically-zero bias gradients (pure rounding noise, tests/util.py)."""
+double over float data and every GEMM is a k-ordered fmaf chain, so the two paths agree to float rounding everywhere except on
+the analytically-zero gradients (pure rounding noise, tests/util.py)."""
 import os
 import subprocess
 import sys
@@ -46,13 +46,21 @@ def _worst(a, b, floor=0.0, skip_zero_gradients=False):
 
 def test_fused_and_unfused_paths_agree_at_full_size(tmp_path):
     """(a0) every fusion on, float32-MFMA GEMMs  vs  (b) everything off: same arithmetic (k-ordered fmaf chains, double
-    reductions), different kernels -> 1e-5 on every tensor, in practice bit for bit."""
+    reductions) except the fused depthwise backward's xhat1, different kernels -> 5e-5 of every tensor's scale (measured worst
+    1.3e-5: the stem BatchNorm's beta, the end of the backward chain; bit for bit until round 3)."""
     a0 = _run(str(tmp_path / 'fused.pt'), CDRL_PW_X3=0, CDRL_FUSED_BWD=0)
     b = _run(str(tmp_path / 'plain.pt'), CDRL_FUSED_DW=0, CDRL_FUSED_PW=0, CDRL_FUSED_STEM=0, CDRL_FUSED_PASS=0, CDRL_FUSED_BB=0,
              CDRL_SIDE_STREAM=0, CDRL_PW_X3=0)
     assert abs(a0['loss'].item() - b['loss'].item()) <= 1e-6 * max(1.0, abs(b['loss'].item()))
-    bad = {k: v for k, v in _worst(a0, b).items() if v > 1e-5}
+    # (the analytically-zero gradients are rounding residue of the others: since the fused depthwise backward takes xhat1 from the
+    #  activated tile -- (a - beta) / gamma instead of (y1 - mean) invstd -- they are no longer bit-identical between the paths; they
+    #  are held to "negligible next to the real gradients" instead)
+    bad = {k: v for k, v in _worst(a0, b, skip_zero_gradients=True).items() if v > 5e-5}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    gmax = max(v.abs().max().item() for k, v in b.items() if k.startswith('trunk/'))
+    for k in a0:
+        if k.startswith('trunk/') and _zero_gradient(k.split('/', 1)[-1]):
+            assert a0[k].abs().max().item() < 1e-5 * gmax and b[k].abs().max().item() < 1e-5 * gmax, k
 
 
 def test_fused_conv_backward_agrees_with_the_two_kernel_backward_at_full_size(tmp_path):
