@@ -198,9 +198,20 @@ def kernel_rooflines(B, T, nsets=8):
     t = timeit(lambda k: lib.cdrl_pwconv_fused(P(a[k]), Cc, 0, None, P(w), Cc, 1, P(bias), P(y[k]), Cc, 0, 0, G, Mg, Cc, Cc, 1, None,
                                                None, P(part), S()))
     by = 4.0 * M * 2 * Cc
-    out.append(dict(kernel='pw_nn_kernel<64,4,0,1> (1x1 conv + BN statistics epilogue)', shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1),
+    out.append(dict(kernel='pw_nn_kernel<64,4,0,1> (1x1 conv on float32 MFMA + BN statistics epilogue; the stage-2 / first-unit form)', shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1),
                     algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1), frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
                     cache_state=cold))
+    # the form the step runs for the stage-0 / stage-1 forward convs since round 3: the same conv on the bf16 matrix pipe by exact
+    # three-way operand splitting (gemm_pw_x3.hip), BatchNorm-apply prologue + statistics epilogue
+    stx = torch.rand(4 * G * Cc, device=dev) + 0.5
+    wpf = torch.zeros(int(lib.cdrl_pwconv_x3_packed_bytes(Cc)), dtype=torch.uint8, device=dev)
+    lib.cdrl_pwconv_x3_pack(P(w), Cc, Cc, Cc, 1, P(wpf), S())
+    nbx = int(lib.cdrl_pwconv_x3_partial_rows(G, Mg, Cc, Cc))
+    partx = torch.zeros(G * nbx * 2 * Cc, dtype=torch.float64, device=dev)
+    t = timeit(lambda k: lib.cdrl_pwconv_x3(P(a[k]), Cc, 0, P(stx), P(wpf), P(bias), P(y[k]), Cc, 0, G, Mg, Cc, Cc, P(partx), S()))
+    out.append(dict(kernel='pw_x3_kernel<128,4,BN-apply prologue,statistics epilogue> (1x1 conv, three-way bf16 operand split, v_mfma_f32_32x32x16_bf16)',
+                    shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1), algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1),
+                    frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4), cache_state=cold))
     # bf16 path (configuration 3), kernel level: the same conv with bf16 activations + bf16 MFMA (half the bytes)
     ab = [x.to(torch.bfloat16) for x in a]
     yb = [torch.empty(M, Cc, dtype=torch.bfloat16, device=dev) for _ in range(nsets)]

@@ -388,6 +388,15 @@ const void* Learner::pw_x3_packed(const float* w, int K, int N, int sbk, int sbn
     return wp;
 }
 
+// (shape-only decision: the views of the 232-channel convs are 16-byte aligned by construction; add_pw fails the build otherwise)
+bool Learner::pw_fwd_wide(int N, int K) const {
+    return wide_pw_ && cfg_.compute == 0 && N > 128 && N <= 256 && K > 224 && K <= 256 && K % 4 == 0;
+}
+
+int Learner::pw_fwd_nbpg(int G, int Mg, int N, int K) const {
+    return pw_fwd_wide(N, K) ? pw_wide_nbpg(G, Mg, N, K) : pw_nn_plan(G, Mg, N, K).nbpg;
+}
+
 const void* Learner::gemm_x3_packed(const float* w, int K, int N, int sbk, int sbn) {
     void* wp = alloc((size_t)gemm_x3_packed_bytes(N, K) / sizeof(float));
     h_gpack_.push_back(gemm_x3_pack_entry(w, wp, K, N, sbk, sbn));
@@ -511,7 +520,12 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     // forward on the bf16 matrix pipe (exact three-way operand split, gemm_pw_x3.hip) where the shape allows it
     static const bool x3_env = !(cdrl_getenv("CDRL_PW_X3") && atoi(cdrl_getenv("CDRL_PW_X3")) == 0);
     const void* w3f = (!bfc && x3_env && fuse.fwd_pw && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
-    const int nb_fwd = pw_nn_plan(G, Mg, Cout, Cin).nbpg;
+    const int nb_fwd = pw_fwd_nbpg(G, Mg, Cout, Cin);
+    // stage 2 (232 channels): panels resident in LDS, W fragments streamed from L2 (gemm_pw_wide.hip) -- 18 vs 26 us per launch
+    const bool wide_f = fuse.fwd_pw && !w3f && pw_fwd_wide(Cout, Cin);
+    if (wide_f && !pw_wide_supported(in, make_view(y, Cout), Cout, Cin))
+        build_fail("wide pointwise conv %s (%d -> %d): input view ld %d coff %d is not 16-byte aligned", prefix.c_str(), Cin, Cout, in.ld, in.coff);
+    const void* wwf = wide_f ? gemm_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
     // plain (unfused) wide convs -- the 464 -> 768 head conv, the 232-wide shortcut conv -- on the bf16 matrix pipe too (gemm_x3.hip)
     const bool wide = Cin >= 128 || Cout > 128;
     const bool g3 = bfc || (x3_env && wide);
@@ -523,17 +537,19 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         build_fail("bf16-operand mode: 1x1 convolution %s (%d -> %d, fwd %d bwd %d bb %d; input ld %d coff %d) has no bf16 kernel",
                    prefix.c_str(), Cin, Cout, (int)fuse.fwd_pw, (int)fuse.bwd_pw, (int)fuse.bb, in.ld, in.coff);
     if (bfc && !pack_env) build_fail("bf16-operand mode needs the packed-weight path (CDRL_PW_PACK=0 is set)");
-    const float* wpf = (pack_env && fuse.fwd_pw && !w3f) ? pw_packed(w.p, Cin, Cout, Cout, 1, bfc) : nullptr;      // forward: B(k = cin, n = cout)
+    const float* wpf = (pack_env && fuse.fwd_pw && !w3f && !wide_f) ? pw_packed(w.p, Cin, Cout, Cout, 1, bfc) : nullptr;      // forward: B(k = cin, n = cout)
     const float* wpb = (pack_env && fuse.bwd_pw) ? pw_packed(w.p, Cout, Cin, 1, Cout, bfc) : nullptr;      // backward-data: W^T
     const int tn_groups = (fuse.pro_stats || fuse.bb) ? G : 1;
     note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin, tn_groups));
-    if (fuse.epi_stats) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cout, Cin).nbpg * 2 * Cout, 0, 0, 0);
+    if (fuse.epi_stats) note_scratch((size_t)G * nb_fwd * 2 * Cout, 0, 0, 0);
     if (fuse.bwd_ey) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cin, Cout).nbpg * 2 * Cin, 0, 0, 0);
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
         if (w3f)
             return pw_x3(in, fuse.pro_stats, w3f, b.p, make_view(y, Cout), G, Mg, Cout, Cin, fuse.epi_stats ? scr_main_.part : nullptr, st,
                          nb_fwd);
+        if (wwf)
+            return pw_wide(in, fuse.pro_stats, wwf, b.p, make_view(y, Cout), G, Mg, Cout, Cin, fuse.epi_stats ? scr_main_.part : nullptr, st);
         if (fuse.fwd_pw)
             return pw_nn(in, fuse.pro_stats, w.p, Cout, 1, b.p, make_view(y, Cout), 0, G, Mg, Cout, Cin, fuse.epi_stats ? 1 : 0,
                          nullptr, nullptr, scr_main_.part, st, nullptr, wpf, bfc, at);
@@ -975,6 +991,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         // the accumulate variant prefetched its old output tile (248 us against 165 us for apply + plain GEMM), now 15.91 vs 15.96
         // ms/update-step and one 164 MB tensor less
         fused_bb_ = e3 ? atoi(e3) : 7;
+        const char* e5 = cdrl_getenv("CDRL_PW_WIDE");        // 0 -> the 232-channel forward convs on the register-resident-W kernel (rounds 1-3)
+        wide_pw_ = !(e5 && atoi(e5) == 0);
         const char* e4 = cdrl_getenv("CDRL_FUSED_BWD");     // 0 -> backward-data (critical stream) + filter gradient (side stream) as two kernels
         fused_bwd_ = !(e4 && atoi(e4) == 0);
         // bf16 storage: its two-kernel form is cheap already (one plane, half the bytes); fused-on vs fused-off measured
@@ -1159,7 +1177,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     }
                     add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off), stride == 2 ? 1 : 0,
                            bnrec(T, Mg_in, mid), f1);
-                    const int nb1 = pw_nn_plan(T, Mg_in, mid, main_in).nbpg;
+                    const int nb1 = pw_fwd_nbpg(T, Mg_in, mid, main_in);
                     const int nbb = pw_nn_plan(T, Mg_out, mid, main_out).nbpg;        // pw2 backward-data epilogue rows
                     float* coef2 = nullptr;
                     std::shared_ptr<bool> bn2_done = std::make_shared<bool>(false);
@@ -1186,7 +1204,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     const size_t pw2_at = ops.size();
                     add_pw(ops, pre + ".pw2", y2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out), f2);
                     BnRec r3 = add_bn(ops, M_TRUNK, pre + ".bn3", y3.v(), T, Mg_out, main_out, true, ACT_RELU6, out.v(sc_c), C,
-                                      out.gv(sc_c), C, nullptr, pw_nn_plan(T, Mg_out, main_out, mid).nbpg, bb3, pass);
+                                      out.gv(sc_c), C, nullptr, pw_fwd_nbpg(T, Mg_out, main_out, mid), bb3, pass);
                     if (bb3) {      // rebuild pw2 with the BN3 blocks known (same parameters -> same arena slots)
                         f2.bb = true;
                         f2.bb_stats = r3.stats;

@@ -15,7 +15,10 @@ def main():
         g = lambda k: int(re.search(k + r': (\d+)', b).group(1))
         names.append(name)
         rows.append((g('VGPRs'), g('AGPRs'), g('VGPRs Spill'), g(r'ScratchSize \[bytes/lane\]'), g(r'Occupancy \[waves/SIMD\]')))
-    dem = subprocess.run(['c++filt'] + names, capture_output=True, text=True).stdout.splitlines()
+    if not names:
+        print('no kernel-resource remarks in', sys.argv[1])
+        return
+    dem = subprocess.run(['c++filt'] + names, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=60).stdout.splitlines()
     for n, r in zip(dem, rows):
         if filt in n:
             print(f'{n[:90]:90s} vgpr {r[0]:3d} agpr {r[1]:3d} spill {r[2]:3d} scratch {r[3]:4d} occ {r[4]}')
