@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
                                                       const float* __restrict__ post_coef, const float* __restrict__ w,
                                                       View dx, double* __restrict__ part_bn, double* __restrict__ part_w,
                                                       int Bf, int H, int W, int Ho, int Wo, int C, int GC, int pt, int pl,
-                                                      int fpb, int nb, int cchunk, bool dx_al, int nfb) {
+                                                      int fpb, int nb, int cchunk, bool dx_al, int nfb, bool reload_y1) {
     extern __shared__ __attribute__((aligned(16))) float tile[];     // A [H*W][cc] | D [Ho*Wo][cc]
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int CX = blockDim.x, CY = blockDim.y;
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
     // xhat1 = (v - bt1) * rg1 with v = the activated value of tile A (bt1 = beta, rg1 = 1 / gamma) or, for a thread holding a channel
     // with |gamma| < 0.05, v = y1 re-read from memory (bt1 = mean, rg1 = invstd); see the input-gradient phase
     VecF<VEC> bt1, rg1;
-    bool slow1 = false;
+    bool slow1 = reload_y1;
     if (PRE && on) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) slow1 |= !(fabsf(sc.v[i]) >= 0.05f * fabsf(inv1.v[i]));
@@ -608,11 +608,13 @@ static int launch_dwf_bwd(const DwfGeom& g, hipStream_t st, const float* x, cons
                           const float* y2, const float* post_stats, const float* post_coef, const float* w, View dx,
                           double* part_bn, double* part_w, int G, int B, int H, int W, int C) {
     const int Ho = same_out(H, S), Wo = same_out(W, S);
+    // CDRL_DWF_XHAT_RELOAD=1: xhat1 from a re-read of y1 for every channel (the form of rounds 1-3) instead of the activated tile
+    static const bool reload_y1 = cdrl_getenv("CDRL_DWF_XHAT_RELOAD") && atoi(cdrl_getenv("CDRL_DWF_XHAT_RELOAD")) == 1;
     CDRL_TRY((allow_lds<dwf_bwd_kernel<S, VEC, PRE, T>>(g.lds_bwd)));
     hipLaunchKernelGGL((dwf_bwd_kernel<S, VEC, PRE, T>), dim3(cdiv(G * g.nb, 8) * 8 * g.nch), dim3(g.cx_bwd, g.cy_bwd), g.lds_bwd, st,
                        reinterpret_cast<const T*>(x), pre_stats, reinterpret_cast<const T*>(dout), reinterpret_cast<const T*>(y2),
                        post_stats, post_coef, w, dx, part_bn, part_w, B, H, W, Ho, Wo, C, G * C, same_pad_before(H, S),
-                       same_pad_before(W, S), g.fpb, g.nb, g.cchunk, view_aligned(dx, g.vec_bwd), G * g.nb);
+                       same_pad_before(W, S), g.fpb, g.nb, g.cchunk, view_aligned(dx, g.vec_bwd), G * g.nb, reload_y1);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

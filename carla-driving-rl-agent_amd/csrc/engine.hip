@@ -991,8 +991,12 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         // the accumulate variant prefetched its old output tile (248 us against 165 us for apply + plain GEMM), now 15.91 vs 15.96
         // ms/update-step and one 164 MB tensor less
         fused_bb_ = e3 ? atoi(e3) : 7;
-        const char* e5 = cdrl_getenv("CDRL_PW_WIDE");        // 0 -> the 232-channel forward convs on the register-resident-W kernel (rounds 1-3)
-        wide_pw_ = !(e5 && atoi(e5) == 0);
+        // 1 -> the 232-channel forward convs of stage 2 on gemm_pw_wide.hip (18 vs 26 us per launch isolated, 14.84 vs 14.91 ms per
+        // update-step, kernel-level error 5.1e-7 vs 6.3e-7 of the float32-MFMA form).  Opt-in: a different float32 forward re-draws
+        // the ReLU6 / max-pool decisions, and smoke()'s worst tensor (a stage-0 BatchNorm gamma at 4e-3 of the largest gradient) moved
+        // from 6.8e-5 to 9.6e-5 of north_star's 1e-4 with it -- half a percent is not worth a gate without margin
+        const char* e5 = cdrl_getenv("CDRL_PW_WIDE");
+        wide_pw_ = e5 && atoi(e5) == 1;
         const char* e4 = cdrl_getenv("CDRL_FUSED_BWD");     // 0 -> backward-data (critical stream) + filter gradient (side stream) as two kernels
         fused_bwd_ = !(e4 && atoi(e4) == 0);
         // bf16 storage: its two-kernel form is cheap already (one plane, half the bytes); fused-on vs fused-off measured
