@@ -282,6 +282,13 @@ struct PwBwdFused {
     double* dbpart = nullptr;       // pw_bwd_fused_dbpart_elems doubles
     int N = 0, K = 0, G = 1, Mg = 0;
     int at = 0;             // 1: dz, y, a, da are bf16 in HBM (bf16 activation storage; one bf16 plane per MFMA operand)
+    // float32 form, optional: the finalize of the BatchNorm behind the conv on load (no bn_bwd_finalize launch in front, `coef` unused):
+    // fin_part = its [G][fin_nb][2][N] backward sums, fin_tot = [G][2][N] doubles of scratch, o_dgamma / o_dbeta [N] written by the reduce
+    const double* fin_part = nullptr;
+    double* fin_tot = nullptr;
+    int fin_nb = 0;
+    float* o_dgamma = nullptr;
+    float* o_dbeta = nullptr;
 };
 bool pw_bwd_fused_supported(View dz, View a, View da, int N, int K, int at = 0);
 int pw_bwd_fused_nbpg(int G, int Mg, int N, int K, int at = 0);

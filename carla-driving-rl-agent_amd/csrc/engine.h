@@ -105,6 +105,14 @@ struct PwFuse {
     float* a_dbeta = nullptr;
     float* a_coef = nullptr;
     std::shared_ptr<bool> a_bn_done;
+    // finalize of the BatchNorm BEHIND the conv on load (gemm_pw_bwd.hip, float32): its backward sums sit in *bb_fin_part
+    // (bb_fin_nb rows per group); dgamma / dbeta come out of the conv's reduce kernel; `bb_fin_done` tells the BatchNorm's backward op
+    bool bb_fin = false;
+    double** bb_fin_part = nullptr;      // &scratch.part
+    int bb_fin_nb = 0;
+    float* bb_dgamma = nullptr;
+    float* bb_dbeta = nullptr;
+    std::shared_ptr<bool> bb_fin_done;
 };
 
 class Learner {
@@ -200,6 +208,13 @@ private:
         // set by the op that produces this BN's incoming gradient when it also accumulates the BN-backward
         // sums (sum dz, sum dz*xhat) in its own pass: the BN backward then skips its reduce kernel
         std::shared_ptr<bool> reduce_fused;
+        // the fused backward of the conv in front (float32) folds this BatchNorm's backward sums itself (finalize on load): the
+        // BatchNorm backward then skips bn_bwd_finalize.  What that kernel needs: the scratch block the sums are left in, their row
+        // count, the gradient slots of gamma / beta.
+        std::shared_ptr<bool> fin_by_consumer;
+        double** part_ptr = nullptr;        // &scratch.part of the stream the BatchNorm runs on (filled at the end of the build)
+        float* dgamma = nullptr;
+        float* dbeta = nullptr;
     };
 
     // --- building
@@ -236,7 +251,7 @@ private:
                         float* x, int H, int W, int C, int stride, float* y2, View out, View dout, View din,
                         int pre_stats_nb = 0, bool post_apply = true, int post_bwd_nb = 0, float* stats1_ext = nullptr,
                         float* coef1_ext = nullptr, bool pre_defer_apply = false, float** coef2_out = nullptr,
-                        std::shared_ptr<bool> post_bwd_done = nullptr);
+                        std::shared_ptr<bool> post_bwd_done = nullptr, std::shared_ptr<bool> pre_fin_done = nullptr);
     bool fused_dw_ = true, fused_pw_ = true, fused_pw_wide_ = false;
     int fused_bb_ = 1;
     bool fused_bwd_ = true;             // backward-data + filter gradient of the unit convs as one kernel (gemm_pw_bwd.hip)
@@ -313,6 +328,8 @@ private:
     static constexpr int NQ = 3;
     float* qparts_[NQ] = {};
     double* dbparts_[NQ] = {};
+    double* fintots_[NQ] = {};           // [8][2][128] group totals of a finalize-on-load BatchNorm (gemm_pw_bwd.hip)
+    bool fin_on_load_ = false;           // CDRL_FIN_ON_LOAD=1: the fused conv backward finalizes the BatchNorm behind it on load (measured neutral)
     hipEvent_t ev_q_[NQ] = {};
     bool q_used_[NQ] = {};
     int qi_ = 0;

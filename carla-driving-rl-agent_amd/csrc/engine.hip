@@ -450,7 +450,11 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     rec.y = (x.ld == C && x.coff == 0) ? x.p : nullptr;
     rec.act = act;
     rec.reduce_fused = std::make_shared<bool>(false);
-    std::shared_ptr<bool> fused = rec.reduce_fused;
+    rec.fin_by_consumer = std::make_shared<bool>(false);
+    rec.part_ptr = &build_scr_->part;
+    rec.dgamma = gamma.g;
+    rec.dbeta = beta.g;
+    std::shared_ptr<bool> fused = rec.reduce_fused, finc = rec.fin_by_consumer;
     const int bes = bessel ? 1 : 0;
     Scratch* sc = build_scr_;
     // trunk layers: the inference-mode statistics block comes from the batched launch at the start of the forward
@@ -492,6 +496,7 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
         const int bc = gap ? pass.gap_rows : 0;
         if (pass.gsrc.p) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, &pass.gsrc, &pass.gdst, 0, at));
         else if (!*fused) CDRL_TRY(bn_bwd_reduce(dsrc, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, nullptr, nullptr, bc, at));
+        if (*finc) return 0;            // sums folded, applied and turned into dgamma / dbeta by the fused conv backward that follows
         CDRL_TRY(bn_bwd_finalize(sc->part, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
         if (defer_apply) return 0;      // applied by the consumer GEMMs on load (PwFuse::bb)
         if (dx) return bn_bwd_apply(dsrc, dout_shuffle, x, G, Mg, C, stats, coef, act, dx, sc->part2, st, nullptr, bc, at);
@@ -572,6 +577,10 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         max_dbpart_ = std::max(max_dbpart_, (size_t)pw_bwd_fused_dbpart_elems(G, Mg, Cout, Cin, at));
         if (fuse.a_bn_done) *fuse.a_bn_done = true;
     }
+    // float32: the finalize of the BatchNorm behind the conv inside the fused kernel (no bn_bwd_finalize launch in front of it)
+    const bool fin = fbwd && !at && fin_on_load_ && fuse.bb_fin;
+    if (fin && fuse.bb_fin_done) *fuse.bb_fin_done = true;
+    if (fin && !dry_ && (!fuse.bb_fin_part || fuse.bb_fin_nb <= 0)) build_fail("%s: finalize on load without the BatchNorm's scratch block", prefix.c_str());
     op.bwd = [=](hipStream_t st) -> int {
         if (fbwd) {
             if (fuse.bb_claim_slot) CDRL_TRY(next_slot(st));
@@ -599,6 +608,13 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             const int qi = qi_;
             f.qpart = qparts_[qi];
             f.dbpart = dbparts_[qi];
+            if (fin) {
+                f.fin_part = *fuse.bb_fin_part;
+                f.fin_nb = fuse.bb_fin_nb;
+                f.fin_tot = fintots_[qi];
+                f.o_dgamma = fuse.bb_dgamma;
+                f.o_dbeta = fuse.bb_dbeta;
+            }
             f.G = G;
             f.Mg = Mg;
             f.N = Cout;
@@ -683,7 +699,8 @@ void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, i
 float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, const char* bn_pre, const char* dw,
                              const char* bn_post, float* x, int H, int W, int C, int stride, float* y2, View out, View dout,
                              View din, int pre_stats_nb, bool post_apply, int post_bwd_nb, float* stats1_ext, float* coef1_ext,
-                             bool pre_defer_apply, float** coef2_out, std::shared_ptr<bool> post_bwd_done) {
+                             bool pre_defer_apply, float** coef2_out, std::shared_ptr<bool> post_bwd_done,
+                             std::shared_ptr<bool> pre_fin_done) {
     const int B = cfg_.B, G = cfg_.T, N = B * G;
     const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
     const int Mi = B * H * W, Mo = B * Ho * Wo;
@@ -731,6 +748,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
                                stats1, st);
         };
         op.bwd = [=](hipStream_t st) -> int {
+            if (pre_fin_done && *pre_fin_done) return 0;   // folded by the fused backward of the 1x1 conv in front (finalize on load)
             CDRL_TRY(bn_bwd_finalize(sc->part, nbf, G, Mi, C, stats1, g1.g, b1.g, coef1, st));
             if (pre_defer_apply) return 0;                 // the 1x1 conv in front applies it on load (PwFuse::bb)
             const float* dz = dys_[slot_];                 // masked gradient left there by the depthwise op
@@ -997,6 +1015,12 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         // from 6.8e-5 to 9.6e-5 of north_star's 1e-4 with it -- half a percent is not worth a gate without margin
         const char* e5 = cdrl_getenv("CDRL_PW_WIDE");
         wide_pw_ = e5 && atoi(e5) == 1;
+        // 1 -> the fused conv backward folds the backward sums of the BatchNorm behind it itself (no bn_bwd_finalize launch in front:
+        // 70 fewer critical-stream launches per update-step).  Measured neutral (15.23 vs 15.25 ms, same box): the sums arrive as
+        // 128-256 partial rows per time slice, and every one of the 64 workgroups of a slice reads all of them (240-475 KB from L2,
+        // 2.5-5 us) where the finalize kernel spreads them over 15 workgroups.  Opt-in.
+        const char* e6 = cdrl_getenv("CDRL_FIN_ON_LOAD");
+        fin_on_load_ = e6 && atoi(e6) == 1;
         const char* e4 = cdrl_getenv("CDRL_FUSED_BWD");     // 0 -> backward-data (critical stream) + filter gradient (side stream) as two kernels
         fused_bwd_ = !(e4 && atoi(e4) == 0);
         // bf16 storage: its two-kernel form is cheap already (one plane, half the bytes); fused-on vs fused-off measured
@@ -1179,6 +1203,16 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                         f1.bb_stats = stats1;
                         f1.bb_coef = coef1;          // dz = masked gradient in the current scratch slot (written by the dw op)
                     }
+                    std::shared_ptr<bool> bn1_fin = std::make_shared<bool>(false);
+                    if (bb1 && fused_dw_) {     // BN1's backward sums come out of the depthwise backward: sc->part, dwf_geom rows
+                        PRef g1 = param(M_TRUNK, pre + ".bn1.gamma", {mid}, true), b1 = param(M_TRUNK, pre + ".bn1.beta", {mid}, true);
+                        f1.bb_fin = true;
+                        f1.bb_fin_part = &build_scr_->part;
+                        f1.bb_fin_nb = dwf_geom(B, T, curH, curW, mid, stride).nb;
+                        f1.bb_dgamma = g1.g;
+                        f1.bb_dbeta = b1.g;
+                        f1.bb_fin_done = bn1_fin;
+                    }
                     add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off), stride == 2 ? 1 : 0,
                            bnrec(T, Mg_in, mid), f1);
                     const int nb1 = pw_fwd_nbpg(T, Mg_in, mid, main_in);
@@ -1186,7 +1220,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     float* coef2 = nullptr;
                     std::shared_ptr<bool> bn2_done = std::make_shared<bool>(false);
                     float* stats2 = add_dw_block(ops, pre, "bn1", "dw", "bn2", y1.p, curH, curW, mid, stride, y2.p, a2.v(), a2.gv(),
-                                                 View{nullptr, 0, 0}, nb1, false, nbb, stats1, coef1, bb1, &coef2, bn2_done);
+                                                 View{nullptr, 0, 0}, nb1, false, nbb, stats1, coef1, bb1, &coef2, bn2_done, bn1_fin);
                     // BN3's statistics / coefficient blocks are allocated by add_bn below; bump-allocate them here first so
                     // that pw2 (which precedes bn3 in the op list) can reference them
                     PwFuse f2;
@@ -1218,6 +1252,12 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                         f2.bb_act = ACT_RELU6;
                         f2.bb_claim_slot = true;
                         f2.a_bn_done = bn2_done;
+                        f2.bb_fin = true;               // BN3's sums: bn_bwd_reduce(_shuf) into *r3.part_ptr, r3.nb rows per group
+                        f2.bb_fin_part = r3.part_ptr;
+                        f2.bb_fin_nb = r3.nb;
+                        f2.bb_dgamma = r3.dgamma;
+                        f2.bb_dbeta = r3.dbeta;
+                        f2.bb_fin_done = r3.fin_by_consumer;
                         std::vector<Op> tmp;
                         add_pw(tmp, pre + ".pw2", y2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out), f2);
                         ops[pw2_at] = tmp[0];
@@ -1446,6 +1486,7 @@ void Learner::build(bool dry) {
         for (int i = 0; i < NQ; ++i) {
             qparts_[i] = alloc(max_qpart_);
             dbparts_[i] = alloc_d(max_dbpart_);
+            fintots_[i] = alloc_d((size_t)8 * 2 * 128);
         }
     }
     h_pwt_.clear();

@@ -46,6 +46,13 @@ struct PwbArgs {
     double* dbpart;         // [G][nbpg][NP]
     double* spart;          // bf16 storage + ANORM: [G][nbpg][2][KP] (sum da, sum da * xhat) taken from the accumulators in double
     int N, K, G, Mg, nbpg;
+    // float32 form: the BatchNorm-backward FINALIZE of the BatchNorm behind the conv done here instead of by bn_bwd_finalize in front of
+    // this launch -- fin_part = that BatchNorm's [G][fin_nb][2][N] sums (sum dz, sum dz xhat); every workgroup folds the rows of its group
+    // into k2 = mean(dz), k3 = mean(dz xhat) (k1 = gamma invstd is the statistics block's scale row); the first workgroup of a group
+    // leaves the group totals in fin_tot [G][2][N] for the reduce kernel (dgamma / dbeta)
+    const double* fin_part;
+    double* fin_tot;
+    int fin_nb;
     int at;                 // host dispatch: 1 = bf16 activation storage (pwb16_kernel)
     int dbg;                // timing diagnostics (CDRL_DIAG=1 CDRL_DIAG_PWB=bits, wrong results): 1 no MFMA, 2 no LDS writes, 4 no stores, 8 no loads
 };
@@ -105,6 +112,47 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
     const int64_t Mtot = (int64_t)a.G * a.Mg;
     const uint32_t OOR = 0x80000000u;
 
+    if (a.fin_part) {
+        // BatchNorm-backward finalize of this group's columns, by all eight waves before they part: wave w takes columns 16 w .. 16 w + 15,
+        // lane bits 4-5 a quarter of the partial rows each (16 loads in flight), folded by two shuffles in a fixed order
+        const int c = wave * 16 + (lane & 15), sl = lane >> 4;
+        const int per = (a.fin_nb + 3) >> 2, b0 = sl * per, b1 = min(a.fin_nb, b0 + per);
+        double s = 0.0, q = 0.0;
+        if (c < N) {
+            const double* ps = a.fin_part + ((int64_t)g * a.fin_nb * 2) * N + c;
+            int bb = b0;
+            for (; bb + 8 <= b1; bb += 8) {
+                double u[8], v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    u[i] = ps[(int64_t)(bb + i) * 2 * N];
+                    v[i] = ps[(int64_t)(bb + i) * 2 * N + N];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s += u[i];
+                    q += v[i];
+                }
+            }
+            for (; bb < b1; ++bb) {
+                s += ps[(int64_t)bb * 2 * N];
+                q += ps[(int64_t)bb * 2 * N + N];
+            }
+        }
+        s += __shfl_xor(s, 16);
+        q += __shfl_xor(q, 16);
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (sl == 0 && c < NP) {
+            const double cnt = (double)a.Mg;
+            cf[5 * NP + c] = c < N ? (float)(s / cnt) : 0.0f;
+            cf[6 * NP + c] = c < N ? (float)(q / cnt) : 0.0f;
+            if (b == 0 && c < N) {
+                a.fin_tot[((int64_t)g * 2 + 0) * N + c] = s;
+                a.fin_tot[((int64_t)g * 2 + 1) * N + c] = q;
+            }
+        }
+    }
     if (role == 0) {
         // =========================================================== dy = BatchNorm-backward(dz, y); da = dy W^T; db partials
         const int dwr = wave % DA_WR, dwc = wave / DA_WR;
@@ -120,9 +168,10 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
         // the seven per-column coefficients live in LDS (28 registers otherwise: this role also holds the W^T fragments);
         // padded columns carry 0 everywhere, so their dy is 0
         const int GN = a.G * N;
-        for (int i = tid; i < 7 * NP; i += 256) {
+        for (int i = tid; i < (a.fin_part ? 5 : 7) * NP; i += 256) {
             const int q = i / NP, c = i % NP;
-            cf[i] = c < N ? (q < 4 ? a.stats[q * GN + g * N + c] : a.coef[(q - 4) * GN + g * N + c]) : 0.0f;
+            // (fin_part: k1 = the scale row of the statistics block, k2 / k3 were written above)
+            cf[i] = c < N ? (q < 4 ? a.stats[q * GN + g * N + c] : (a.fin_part ? a.stats[2 * GN + g * N + c] : a.coef[(q - 4) * GN + g * N + c])) : 0.0f;
         }
         uint32_t vo[4], voy[2];                     // byte offsets of (row 4 rg, column) inside a tile, or OOR
 #pragma unroll
@@ -799,6 +848,9 @@ struct PwbReduceArgs {
     float* a_dgamma;        // ANORM outputs: dgamma / dbeta [K], backward coefficients [3][G][K]
     float* a_dbeta;
     float* a_coef;
+    const double* fin_tot;  // [G][2][N] (or null): group totals of the BatchNorm BEHIND the conv -> its dgamma / dbeta
+    float* o_dgamma;
+    float* o_dbeta;
     int N, K, KP, NP, G, Mg, nbpg;
     int wbf;                // bf16 storage: the backward-data product used bf16(W); the derived BatchNorm sums use the same values
 };
@@ -885,6 +937,15 @@ __global__ void __launch_bounds__(128 * PWB_RS) pwb_reduce_kernel(PwbReduceArgs 
         if (a.a_stats) a.dW[(int64_t)k * N + n] = (float)((double)a.a_gamma[k] * qtot + (double)a.a_beta[k] * dbtot);
         else a.dW[(int64_t)k * N + n] = (float)qtot;
         if (k == 0) a.db[n] = (float)dbtot;
+        if (k == 0 && a.fin_tot) {      // shared gamma / beta: summed over the T applications, t ascending (as bn_bwd_finalize)
+            double dg = 0.0, dbt = 0.0;
+            for (int g = 0; g < G; ++g) {
+                dbt += a.fin_tot[((int64_t)g * 2 + 0) * N + n];
+                dg += a.fin_tot[((int64_t)g * 2 + 1) * N + n];
+            }
+            a.o_dgamma[n] = (float)dg;
+            a.o_dbeta[n] = (float)dbt;
+        }
     }
     if (!a.a_stats) return;
     // BatchNorm-backward sums of the BatchNorm that produced a: fixed-order reduction over n
@@ -1047,6 +1108,13 @@ int pw_bwd_fused(const PwBwdFused& f, hipStream_t st) {
     a.Mg = f.Mg;
     a.nbpg = pw_bwd_fused_nbpg(f.G, f.Mg, f.N, f.K, f.at);
     a.at = f.at;
+    a.fin_part = f.at ? nullptr : f.fin_part;
+    a.fin_tot = f.fin_tot;
+    a.fin_nb = f.fin_nb;
+    if (f.fin_part && (f.at || !f.fin_tot || f.fin_nb <= 0)) {
+        set_error("pw_bwd_fused: finalize-on-load needs the float32 form, fin_tot and fin_nb");
+        return -1;
+    }
     a.spart = (f.at && f.a_stats) ? f.dbpart + (int64_t)f.G * a.nbpg * pwb_pad(f.N) : nullptr;
     static const int dbg = cdrl_getenv("CDRL_DIAG_PWB") ? atoi(cdrl_getenv("CDRL_DIAG_PWB")) : 0;
     a.dbg = dbg;
@@ -1085,6 +1153,13 @@ int pw_bwd_fused_reduce(const PwBwdFused& f, hipStream_t st) {
     r.Mg = f.Mg;
     r.nbpg = pw_bwd_fused_nbpg(f.G, f.Mg, f.N, f.K, f.at);
     r.wbf = f.at;
+    r.fin_tot = (f.fin_part && !f.at) ? f.fin_tot : nullptr;
+    r.o_dgamma = f.o_dgamma;
+    r.o_dbeta = f.o_dbeta;
+    if (r.fin_tot && (!f.o_dgamma || !f.o_dbeta)) {
+        set_error("pw_bwd_fused_reduce: finalize-on-load needs the dgamma / dbeta outputs of the BatchNorm behind the conv");
+        return -1;
+    }
     r.spart = (f.at && f.a_stats) ? f.dbpart + (int64_t)f.G * r.nbpg * pwb_pad(f.N) : nullptr;
     if (f.a_stats && (!f.a_gamma || !f.a_beta || !f.a_dgamma || !f.a_dbeta || !f.a_coef)) {
         set_error("pw_bwd_fused_reduce: normalised input needs gamma / beta and the dgamma / dbeta / coef outputs");
