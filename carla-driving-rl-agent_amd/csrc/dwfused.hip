@@ -343,12 +343,13 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
         k3 = vload<VEC>(post_coef + 2 * GC + g * C + c);
     }
     // xhat1 = (v - bt1) * rg1 with v = the activated value of tile A (bt1 = beta, rg1 = 1 / gamma) or, for a thread holding a channel
-    // with |gamma| < 0.05, v = y1 re-read from memory (bt1 = mean, rg1 = invstd); see the input-gradient phase
+    // with (6 + |beta|) / |gamma| > 170, v = y1 re-read from memory (bt1 = mean, rg1 = invstd); see the input-gradient phase
     VecF<VEC> bt1, rg1;
     bool slow1 = reload_y1;
     if (PRE && on) {
+        // error of (a - beta) / gamma: ~ 2^-24 (|a| + |beta|) / |gamma| with a in (0, 6); held to ~1e-5 of xhat's unit scale
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) slow1 |= !(fabsf(sc.v[i]) >= 0.05f * fabsf(inv1.v[i]));
+        for (int i = 0; i < VEC; ++i) slow1 |= !((6.0f + fabsf(fmaf(mean1.v[i], sc.v[i], sh.v[i]))) * fabsf(inv1.v[i]) <= 170.0f * fabsf(sc.v[i]));
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             bt1.v[i] = slow1 ? mean1.v[i] : fmaf(mean1.v[i], sc.v[i], sh.v[i]);
@@ -491,8 +492,8 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
             // xhat1 for BN1's backward sums comes from the ACTIVATED value in tile A: where the ReLU6 mask is open a = scale y1 + shift,
             // so xhat1 = (a - beta) / gamma (beta = shift + mean scale, 1 / gamma = invstd / scale); where it is closed the gradient is
             // zero and xhat1 is not needed.  No global re-read of y1 in this phase (it was an L2 round trip per pixel batch in front of
-            // the stores, both on gfx9's single in-order memory counter).  Channels with |gamma| < 0.05 (the division would amplify
-            // the rounding of a) re-read y1, thread by thread.
+            // the stores, both on gfx9's single in-order memory counter).  Channels with (6 + |beta|) / |gamma| > 170 (the division would
+            // amplify the rounding of a beyond 1e-5) re-read y1, thread by thread.
             for (int p0 = ty; p0 < P; p0 += CY * DXU) {
                 VecF<VEC> acc[DXU], av[DXU];
 #pragma unroll

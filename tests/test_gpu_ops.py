@@ -237,7 +237,7 @@ def test_dwconv(lib, N, H, W, Cc, stride):
 
 @pytest.mark.parametrize('T,B,H,W,Cc,stride,pre', [(4, 2, 11, 15, 58, 1, 1), (2, 4, 22, 30, 58, 2, 1), (4, 8, 3, 4, 232, 1, 1),
                                                   (2, 3, 6, 8, 116, 1, 1), (2, 2, 22, 30, 24, 2, 0), (4, 2, 11, 15, 116, 2, 0),
-                                                  (2, 2, 6, 23, 232, 2, 1), (1, 2, 22, 90, 58, 2, 1)])
+                                                  (2, 2, 6, 23, 232, 2, 1), (1, 2, 22, 90, 58, 2, 1), (2, 3, 6, 8, 116, 1, 2), (2, 4, 22, 30, 58, 2, 2)])
 def test_dwconv_bn_fused(lib, T, B, H, W, Cc, stride, pre):
     """Fused depthwise block (frames in LDS): [BN+ReLU6 prologue] -> dw3x3 -> following BN statistics, and its
     backward (BN-backward prologue, filter/bias gradients, input gradient, ReLU6 mask, previous BN backward):
@@ -256,6 +256,14 @@ def test_dwconv_bn_fused(lib, T, B, H, W, Cc, stride, pre):
                 f'{name}.moving_var': torch.tensor(rng.uniform(0.5, 1.5, Cc), dtype=torch.float64)}
     p = {'c.w': torch.tensor(w, dtype=torch.float64).requires_grad_(True),
          'c.b': torch.tensor(b, dtype=torch.float64).requires_grad_(True), **bnp('pre'), **bnp('post')}
+    if pre == 2:
+        # channels the backward must NOT take xhat1 = (a - beta) / gamma for (tiny |gamma|, large |beta| / |gamma|: it re-reads y1 there),
+        # mixed with ordinary ones inside a thread's channel pair
+        with torch.no_grad():
+            p['pre.gamma'][::5] = torch.tensor(rng.choice([-1.0, 1.0], len(p['pre.gamma'][::5])) * 0.01, dtype=torch.float64)
+            p['pre.beta'][::5] = torch.tensor(rng.uniform(0.5, 2.5, len(p['pre.beta'][::5])), dtype=torch.float64)
+            p['pre.gamma'][3::7] = 0.2
+            p['pre.beta'][3::7] = 3.0 + 0.0 * p['pre.beta'][3::7]
     f32 = {k: v.detach().clone().float() for k, v in p.items()}
     xt = torch.tensor(x, dtype=torch.float64).permute(0, 1, 4, 2, 3).requires_grad_(True)        # (T,B,C,H,W)
     a = OM.relu6(OM.bn_slices(xt, p, 'pre', True, True)) if pre else xt
@@ -304,8 +312,10 @@ def test_dwconv_bn_fused(lib, T, B, H, W, Cc, stride, pre):
     assert rel_err(vecs[0].cpu().numpy(), p['post.gamma'].grad.numpy()) < 2e-5
     assert rel_err(vecs[1].cpu().numpy(), p['post.beta'].grad.numpy()) < 2e-5
     if pre:
-        assert rel_err(vecs[2].cpu().numpy(), p['pre.gamma'].grad.numpy()) < 2e-5
-        assert rel_err(vecs[3].cpu().numpy(), p['pre.beta'].grad.numpy()) < 2e-5
+        eg = np.abs(vecs[2].cpu().numpy() - p['pre.gamma'].grad.numpy()) / np.abs(p['pre.gamma'].grad.numpy()).max()
+        assert eg.max() < 2e-5, (eg.max(), int(eg.argmax()), p['pre.gamma'][int(eg.argmax())].item(), p['pre.beta'][int(eg.argmax())].item())
+        # (pre == 2: 2.4e-5 measured on the stride-2 case, with and without the xhat shortcut -- the tiny-gamma channels put 1 / gamma = 100 in front of the float32 dz)
+        assert rel_err(vecs[3].cpu().numpy(), p['pre.beta'].grad.numpy()) < (5e-5 if pre == 2 else 2e-5)
 
 
 @pytest.mark.parametrize('N,H,W', [(3, 44, 59), (2, 19, 27), (2, 20, 28)])
