@@ -1205,6 +1205,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     }
                     std::shared_ptr<bool> bn1_fin = std::make_shared<bool>(false);
                     if (bb1 && fused_dw_) {     // BN1's backward sums come out of the depthwise backward: sc->part, dwf_geom rows
+                        // (parameter order = the reference's variable order: pw1's own parameters are registered first, as add_pw would)
+                        (void)param(M_TRUNK, pre + ".pw1.w", {1, 1, main_in, mid}, true);
+                        (void)param(M_TRUNK, pre + ".pw1.b", {mid}, true);
                         PRef g1 = param(M_TRUNK, pre + ".bn1.gamma", {mid}, true), b1 = param(M_TRUNK, pre + ".bn1.beta", {mid}, true);
                         f1.bb_fin = true;
                         f1.bb_fin_part = &build_scr_->part;
