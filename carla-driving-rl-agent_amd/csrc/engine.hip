@@ -1550,7 +1550,8 @@ void Learner::build(bool dry) {
                    align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
                    NSLOT * (align_up((max_dy_ * esz() + 3) / 4 * sizeof(float), 256) + align_up(max_part2_ * sizeof(double), 256) +
                             align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256)) +
-                   NQ * (align_up(max_qpart_ * sizeof(float), 256) + align_up(max_dbpart_ * sizeof(double), 256));
+                   NQ * (align_up(max_qpart_ * sizeof(float), 256) + align_up(max_dbpart_ * sizeof(double), 256) +
+                         align_up((size_t)8 * 2 * 128 * sizeof(double), 256));
         ws_bytes_ = ws_off_ + 4096;
     }
 }
