@@ -12,13 +12,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B, H, W = 8, 48, 64
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend='nccl'):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
-    dev = f'cuda:{rank}'
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+    if backend == 'nccl':
+        torch.cuda.set_device(rank)
+        dev = f'cuda:{rank}'
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+    else:       # both ranks on device 0, collectives of device tensors through gloo (RCCL refuses two ranks on one device)
+        torch.cuda.set_device(0)
+        dev = 'cuda:0'
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     from carla_driving_rl_agent_amd.engine import LearnerEngine
     from carla_driving_rl_agent_amd.init import init_engine_parameters
     from carla_driving_rl_agent_amd.parallel import DataParallelLearner
@@ -58,6 +63,31 @@ def test_two_rank_rccl_data_parallel(tmp_path):
     r0, r1 = torch.load(tmp_path / 'r0.pt'), torch.load(tmp_path / 'r1.pt')
     assert torch.equal(r0['params'], r1['params']) and torch.equal(r0['m'], r1['m'])         # replicas identical
     assert torch.equal(r0['reduced'], r1['reduced'])
+    from carla_driving_rl_agent_amd.engine import LearnerEngine
+    lay = LearnerEngine(B, device=None, H=H, W=W)
+    p_off, p_n = lay.region('policy', True)
+    t_off, t_n = lay.region('trunk', True)
+    lo, hi = p_off, t_off + t_n
+    mean = 0.5 * (r0['local'][lo:hi] + r1['local'][lo:hi])
+    scale = float(mean.abs().max())
+    assert float((r0['reduced'][lo:hi] - mean).abs().max()) <= 2e-6 * scale
+
+
+def test_two_ranks_on_one_gpu_data_parallel_over_gloo(tmp_path):
+    """The same two-rank check on a ONE-GPU box: both ranks run their HIP engines on device 0 and all-reduce the device tensors
+    through gloo (RCCL needs one device per rank).  What it exercises that the world-1 NCCL tests cannot: a SUM over two DIFFERENT
+    shards -- replicas identical after broadcast + policy step + value step + moving-statistics average, all-reduced arena = mean of
+    the two local gradients -- with the real kernels, the communication stream released in the middle of the backward and the
+    early buckets (/root/reference has no multi-GPU code: north_star's data-parallel contract)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), 'gloo'), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'r0.pt'), torch.load(tmp_path / 'r1.pt')
+    assert torch.equal(r0['params'], r1['params']) and torch.equal(r0['m'], r1['m'])         # replicas identical
+    assert torch.equal(r0['reduced'], r1['reduced'])
+    assert not torch.equal(r0['local'], r1['local'])                                        # the shards really differ
     from carla_driving_rl_agent_amd.engine import LearnerEngine
     lay = LearnerEngine(B, device=None, H=H, W=W)
     p_off, p_n = lay.region('policy', True)
@@ -177,3 +207,52 @@ def test_agent_level_world1_nccl_is_bit_identical(tmp_path):
     for key in ('params', 'm', 'v'):
         assert torch.equal(r['plain'][key], r['forced'][key]), key
     assert torch.isfinite(r['plain']['params']).all()
+
+
+def _worker_agent_world2_gloo(rank, world, port, out):
+    """Two CARLAgents, one GPU, gloo: rank-own environment shards (seed + rank inside the agent), local GAE, update() with the
+    gradient all-reduce inside get_*_gradients, moving statistics averaged once per update()."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from carla_driving_rl_agent_amd.core import CARLAgent, FakeCARLAEnvironment
+    env = FakeCARLAEnvironment(image_shape=(H, W, 3), time_horizon=4, num_waypoints=5, vehicle_features=4, num_actions=2,
+                               image_range=(0.0, 1.0), seed=3)
+    agent = CARLAgent(env, batch_size=B, log_mode=None, seed=3, skip_data=0, drop_batch_remainder=False, shuffle=True,
+                      policy_lr=3e-4, value_lr=3e-4, dynamics_lr=3e-4, aug_intensity=0.0)
+    assert agent.data_parallel and agent.world == 2 and agent.rank == rank
+    first = {}
+    orig_update = agent.update
+
+    def update():
+        first['image'] = agent.memory.states['state_image'][0].clone().cpu()
+        orig_update()
+
+    agent.update = update
+    agent.learn(episodes=1, timesteps=2 * B + 3, close=False)        # 2 full minibatches + a ragged one of 3 rows, on both ranks
+    torch.cuda.synchronize()
+    eng = agent.network.engine
+    torch.save(dict(params=eng.params.clone().cpu(), m=eng.adam_m.clone().cpu(), v=eng.adam_v.clone().cpu(), first=first['image'],
+                    steps=eng.named_buffer('hparams', torch.int32)[10:13].tolist()), os.path.join(out, f'agent_w2_{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_agent_level_world2_on_one_gpu_over_gloo(tmp_path):
+    """Data parallelism through the AGENT API with TWO ranks and the real engines (both on device 0, collectives through gloo):
+    after learn() -- rollouts on different environment shards, 3 + 3 minibatch steps incl. the ragged one -- the replicas hold
+    bit-identical weights, Adam moments, BatchNorm moving statistics and step counters (reference loop rl/agents/ppo.py:190-226
+    inside :464-548; the sharding contract is north_star's)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_agent_world2_gloo, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'agent_w2_0.pt'), torch.load(tmp_path / 'agent_w2_1.pt')
+    assert not torch.equal(r0['first'], r1['first'])                 # rank-own environment shards
+    assert r0['steps'] == r1['steps'] == [3, 3, 6]
+    for key in ('params', 'm', 'v'):
+        assert torch.equal(r0[key], r1[key]), key
+    assert torch.isfinite(r0['params']).all()
