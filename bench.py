@@ -517,13 +517,22 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
         raise SystemExit(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}: start one rank per GPU')
+    # Functional check of the N > 1 path on a ONE-GPU box (tests/test_gpu_dp_rccl.py): CDRL_BENCH_SHARE_DEVICE=1 puts every rank on
+    # device 0 and routes the collectives of the device tensors through gloo (RCCL refuses two ranks on one device).  The line it
+    # prints is marked `shared_device` and is NOT a scaling figure.
+    share_device = world > 1 and os.environ.get('CDRL_BENCH_SHARE_DEVICE') == '1'
+    if share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f'cuda:{local_rank}'
     use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('CDRL_FORCE_COLLECTIVES') == '1')
     if use_dist:      # launched by torchrun: RCCL over xGMI (CDRL_FORCE_COLLECTIVES=1 exercises it on 1 GPU too)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+        if share_device:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
 
     B, T, H, W = args.batch, 4, args.height, args.width
     eng = LearnerEngine(B, device=dev, T=T, H=H, W=W, compute=args.dtype)
@@ -628,6 +637,7 @@ def main():
                    roofline=roof, mfma=pmc_mfma(ms_per_step), dominant_kernel=dominant_kernel(B, T, H, W), kernel_rooflines=kernel_rooflines(B, T) if (world == 1 and not args.no_kernel_rooflines) else None, gae_ms=round(gae_ms, 3), device_ms_per_step=round(dev_ms / args.steps, 3),
                    device_ms_per_step_blocks=dict(blocks=[round(x, 3) for x in block_ms], min=round(min(block_ms), 3), median=round(sorted(block_ms)[len(block_ms) // 2], 3)),
                    host_enqueue_ms_per_step=round(host_ms, 3), env_overrides=env_overrides,
+                   **(dict(shared_device='all ranks on cuda:0, collectives through gloo: a functional check of the N > 1 path, not a scaling figure') if share_device else {}),
                    final_losses=dict(policy=loss_p, value=loss_v))
         # (--no-kernel-rooflines marks a profiling pass: PMC totals and trace call counts must contain only the headline update-steps)
         if world == 1 and not args.no_secondary and not args.no_kernel_rooflines and (B, H, W, args.dtype) == (256, 90, 120, 'f32'):

@@ -256,3 +256,26 @@ def test_agent_level_world2_on_one_gpu_over_gloo(tmp_path):
     for key in ('params', 'm', 'v'):
         assert torch.equal(r0[key], r1[key]), key
     assert torch.isfinite(r0['params']).all()
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """`bench.py --gpus 2` end to end on the one GPU of the box: the plain-process form spawns the two ranks through
+    torch.distributed.run, every rank builds its engine, broadcasts, runs the timed update-steps between barriers, the elapsed time is
+    MAX-reduced and rank 0 prints ONE line with the whole-job figure (CDRL_BENCH_SHARE_DEVICE=1: both ranks on device 0, gloo instead of
+    RCCL -- the line is marked `shared_device`; it checks the N > 1 plumbing, not the scaling)."""
+    import json
+    import subprocess
+    env = dict(os.environ, CDRL_BENCH_SHARE_DEVICE='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--batch', '32',
+                        '--height', '48', '--width', '64', '--no-cpu-baseline', '--no-kernel-rooflines'], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 64 and d['scaling'] == 'weak'
+    assert d['steps'] == 4 and d['value'] > 0 and abs(d['value'] - 2 * 4 / (d['ms_per_step'] * 4e-3)) < 1e-2 * d['value']
+    assert 'shared_device' in d and r.stdout.rstrip().splitlines()[-1] == lines[0]          # the JSON line is the last line of the job
+    assert all(map(lambda v: v == v, d['final_losses'].values()))
