@@ -102,7 +102,10 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     g.nb = B / fpb;
     // backward: 12 double accumulators per channel lane -> at 4 channels per thread the kernel needs > 256 VGPRs (one
     // workgroup per CU); 2 channels per thread keep it at ~150 (3 waves / SIMD)
-    g.vec_bwd = g.vec > 2 ? 2 : g.vec;
+    // (CDRL_DWF_BWD_VEC4=1: 4 channels per thread in the backward too -- half the load / LDS / address instructions per element at
+    //  two waves per SIMD instead of three or four)
+    static const bool bwd4 = cdrl_getenv("CDRL_DWF_BWD_VEC4") && atoi(cdrl_getenv("CDRL_DWF_BWD_VEC4")) == 1;
+    g.vec_bwd = (g.vec > 2 && !bwd4) ? 2 : g.vec;
     g.cx_bwd = g.cchunk / g.vec_bwd;
     g.cy_bwd = t_bwd / g.cx_bwd;
     if (g.cy_bwd > Po_) g.cy_bwd = Po_;
@@ -653,9 +656,11 @@ int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const flo
 #define CDRL_DWF_BWD(S, V) \
     return launch_dwf_bwd_pre<S, V>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C, at)
     if (stride == 1) {
+        if (g.vec_bwd == 4) CDRL_DWF_BWD(1, 4);
         if (g.vec_bwd == 2) CDRL_DWF_BWD(1, 2);
         CDRL_DWF_BWD(1, 1);
     }
+    if (g.vec_bwd == 4) CDRL_DWF_BWD(2, 4);
     if (g.vec_bwd == 2) CDRL_DWF_BWD(2, 2);
     CDRL_DWF_BWD(2, 1);
 #undef CDRL_DWF_BWD
