@@ -117,3 +117,17 @@ def test_wide_stage2_convs_agree_with_the_register_resident_form_at_full_size(tm
     tail = {k: v for k, v in w.items() if not k.startswith('trunk/img.') and not k.startswith('mv/') and k != 'dyn'}
     assert max(tail.values()) < 1e-4, sorted(tail.items(), key=lambda kv: -kv[1])[:4]
     assert any(not torch.equal(a[k], a0[k]) for k in a if k.startswith('trunk/img.s2.'))        # the switch really changed the path
+
+
+def test_depthwise_backward_with_four_channels_per_thread_agrees_at_full_size(tmp_path):
+    """Opt-in variant CDRL_DWF_BWD_VEC4=1 (four channels per thread in the fused depthwise backward): same forward, hence the same
+    decisions; every gradient tensor within 5e-5 of the default's (other thread -> pixel map, other float32 summation order of the
+    filter-gradient partials)."""
+    a1 = _run(str(tmp_path / 'vec4.pt'), CDRL_DWF_BWD_VEC4=1)
+    a0 = _run(str(tmp_path / 'default.pt'))
+    assert a1['loss'].item() == a0['loss'].item()
+    assert torch.equal(a1['dyn'], a0['dyn'])
+    w = _worst(a1, a0, skip_zero_gradients=True)
+    worst = sorted(w.items(), key=lambda kv: -kv[1])[:4]
+    assert worst[0][1] < 5e-5, worst
+    assert any(not torch.equal(a1[k], a0[k]) for k in a1 if k.startswith('trunk/img.') and k.endswith('.dw.w'))     # the switch took effect
