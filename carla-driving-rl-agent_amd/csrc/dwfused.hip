@@ -39,6 +39,7 @@ static constexpr size_t DWF_LDS_BUDGET = 38 * 1024;
 #define DWF_T_BWD 512
 #define DWF_T_FWD_DEFAULT 256                            // (tunable: CDRL_DWF_TF / CDRL_DWF_TB, <= the maxima above; 256 vs 512 forward: -0.1 ms/update-step at v39)
 #define DWF_T_BWD_DEFAULT 256
+#define DWF_BWD_VEC4_DEFAULT 0                           // CDRL_DWF_BWD_VEC4 (dwf_bwd)
 #define DWF_UF 8                                         // forward: loads in flight per thread (one tensor)
 #define DWF_U 4                                          // global loads in flight per thread in the tile loads
 
@@ -102,10 +103,7 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     g.nb = B / fpb;
     // backward: 12 double accumulators per channel lane -> at 4 channels per thread the kernel needs > 256 VGPRs (one
     // workgroup per CU); 2 channels per thread keep it at ~150 (3 waves / SIMD)
-    // (CDRL_DWF_BWD_VEC4=1: 4 channels per thread in the backward too -- half the load / LDS / address instructions per element at
-    //  two waves per SIMD instead of three or four)
-    static const bool bwd4 = cdrl_getenv("CDRL_DWF_BWD_VEC4") && atoi(cdrl_getenv("CDRL_DWF_BWD_VEC4")) == 1;
-    g.vec_bwd = (g.vec > 2 && !bwd4) ? 2 : g.vec;
+    g.vec_bwd = g.vec > 2 ? 2 : g.vec;      // (dwf_bwd may widen it: dwf_bwd_lanes)
     g.cx_bwd = g.cchunk / g.vec_bwd;
     g.cy_bwd = t_bwd / g.cx_bwd;
     if (g.cy_bwd > Po_) g.cy_bwd = Po_;
@@ -648,7 +646,28 @@ int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const flo
         set_error("dwf_bwd: part_bn is required with a pre-BN prologue");
         return -1;
     }
-    const DwfGeom g = dwf_geom(B, G, H, W, C, stride);
+    DwfGeom g = dwf_geom(B, G, H, W, C, stride);
+    // Four channels per thread -- half the load / LDS / address instructions per element, 214-256 VGPRs, two waves per SIMD instead of
+    // three or four.  CDRL_DWF_BWD_VEC4 = bit mask: 1 float32 stride 1, 2 float32 stride 2, 4 bf16 storage stride 1, 8 bf16 storage
+    // stride 2.  Measured on one box each: mask 1 -> 14.77 vs 14.83 ms per update-step (float32; two boxes), mask 2 -> +-0.0, mask 4 -> 30.4
+    // vs 29.9 ms (bf16 storage, B = 1024; stride 2 spills 4-12 VGPRs).  Default 0: the float32 and the bf16-storage form of this kernel share
+    // one thread -> pixel map, which is what lets tests/test_gpu_bf16_storage.py hold the bf16 form to the float32 form BIT FOR BIT;
+    // -0.45 % for float32 alone is not worth that property
+    {
+        static const int mask4 = cdrl_getenv("CDRL_DWF_BWD_VEC4") ? atoi(cdrl_getenv("CDRL_DWF_BWD_VEC4")) : DWF_BWD_VEC4_DEFAULT;
+        const int bit = (at ? 4 : 1) << (stride == 2 ? 1 : 0);
+        if (g.vec == 4 && (mask4 & bit)) {
+            static const int t_bwd = cdrl_getenv("CDRL_DWF_TB") ? atoi(cdrl_getenv("CDRL_DWF_TB")) : DWF_T_BWD_DEFAULT;
+            const int Po_ = same_out(H, stride) * same_out(W, stride);
+            g.vec_bwd = 4;
+            g.cx_bwd = g.cchunk / 4;
+            g.cy_bwd = t_bwd / g.cx_bwd;
+            if (g.cy_bwd > Po_) g.cy_bwd = Po_;
+            if (g.cy_bwd < 1) g.cy_bwd = 1;
+            const size_t red_b = (size_t)10 * g.cy_bwd * g.vec_bwd * g.cx_bwd * sizeof(double);
+            if (g.lds_bwd < red_b) g.lds_bwd = red_b;
+        }
+    }
     if (g.lds_bwd > 150 * 1024) {
         set_error("dwf_bwd: frame %dx%d does not fit LDS even at %d channels", H, W, g.cchunk);
         return -1;

@@ -120,11 +120,11 @@ def test_wide_stage2_convs_agree_with_the_register_resident_form_at_full_size(tm
 
 
 def test_depthwise_backward_with_four_channels_per_thread_agrees_at_full_size(tmp_path):
-    """Opt-in variant CDRL_DWF_BWD_VEC4=1 (four channels per thread in the fused depthwise backward): same forward, hence the same
-    decisions; every gradient tensor within 5e-5 of the default's (other thread -> pixel map, other float32 summation order of the
-    filter-gradient partials)."""
-    a1 = _run(str(tmp_path / 'vec4.pt'), CDRL_DWF_BWD_VEC4=1)
-    a0 = _run(str(tmp_path / 'default.pt'))
+    """Four channels per thread in the fused depthwise backward (opt-in bit mask CDRL_DWF_BWD_VEC4; here in every float32 block) vs two
+    everywhere (the default): same forward, hence the same decisions; every gradient tensor within 5e-5 (other thread -> pixel map, other
+    float32 summation order of the filter-gradient partials)."""
+    a1 = _run(str(tmp_path / 'vec4.pt'), CDRL_DWF_BWD_VEC4=3)
+    a0 = _run(str(tmp_path / 'vec2.pt'), CDRL_DWF_BWD_VEC4=0)
     assert a1['loss'].item() == a0['loss'].item()
     assert torch.equal(a1['dyn'], a0['dyn'])
     w = _worst(a1, a0, skip_zero_gradients=True)
