@@ -701,7 +701,7 @@ def test_bf16_storage_engine_vs_oracle_with_the_storage_rule(B, H, W):
             assert r['median'] <= 0.4, (kind, grp, r)
 
 
-@pytest.mark.parametrize('compute', ['f32', 'f32_fin', 'bf16s', 'bf16s_fused'])
+@pytest.mark.parametrize('compute', ['f32', 'f32_fin', 'f32_fold', 'bf16s', 'bf16s_fused'])
 def test_every_unit_backward_against_the_oracle_locally(compute, monkeypatch):
     """Unit-by-unit HIP-vs-oracle check of the tower's backward in both storage modes (the engine-level plumbing of
     the bf16-storage mode -- tens_a, element-sized slots, the `at` flag through ~40 call sites -- was only covered by cosine gates).
@@ -718,8 +718,9 @@ def test_every_unit_backward_against_the_oracle_locally(compute, monkeypatch):
     from tests.util import make_pair, make_batches, to_dev, is_zero_gradient, engine_decisions
     B, H, W, A = 32, 48, 64, 2
     label = compute
-    if compute == 'f32_fin':            # opt-in: the fused conv backward finalizes the BatchNorm behind it on load (no bn_bwd_finalize launch)
-        monkeypatch.setenv('CDRL_FIN_ON_LOAD', '1')
+    if compute in ('f32_fin', 'f32_fold'):      # opt-in: the fused conv backward finalizes the BatchNorm behind it on load (no bn_bwd_finalize
+        # launch); 'fold': the reduce kernel in front also folds its partial rows in clusters of 4 in-launch (agent-scope hand-off)
+        monkeypatch.setenv('CDRL_FIN_ON_LOAD', '2' if compute == 'f32_fold' else '1')
         compute = 'f32'
     if compute == 'bf16s_fused':        # the engine takes the fused backward in bf16 storage from B = 512 on its own: forced here
         monkeypatch.setenv('CDRL_FUSED_BWD', '1')
