@@ -126,6 +126,7 @@ class CARLAgent(PPOAgent):
         self._augmenter = None
         self._aug_rng = np.random.default_rng(self.seed)
         self._aug_calls = 0
+        self._shard, self._info_segments = [self.env], []
         self._init_data_parallel()
 
     # -- data parallelism (reference loop rl/agents/ppo.py:190-226 inside :464-548) ------------------------------
@@ -167,27 +168,40 @@ class CARLAgent(PPOAgent):
         return [int(x) for x in t.tolist()]
 
     def agree_on_batches(self, policy_batches, value_batches):
+        """Every minibatch step is a collective (the gradient all-reduce), so the NUMBER of steps is decided collectively and
+        never from a rank's own list: all ranks run the minimum count of FULL minibatches (episodes that ended early on one rank
+        drop the surplus minibatches of the others for this update), followed by ONE ragged step only if every rank holds exactly
+        one ragged minibatch with the same row count.  The ragged minibatch is found by its row count, not by its position
+        (with shuffle_batches it is not the last one), and is moved to the end of the list."""
         if not self.data_parallel:
             return policy_batches, value_batches
-        # every minibatch step is a collective: all ranks run the minimum count (episodes that ended early on one rank drop
-        # the surplus minibatches of the others for this update) -- and the ragged last minibatch only if all ranks have it
-        def rows(b):
-            t = b[1]
-            return int(t.shape[0])
-        sig = [len(policy_batches), len(value_batches),
-               rows(policy_batches[-1]) if policy_batches else 0, rows(value_batches[-1]) if value_batches else 0]
+
+        def split(batches):
+            full = [b for b in batches if int(b[1].shape[0]) == self.batch_size]
+            ragged = [b for b in batches if int(b[1].shape[0]) != self.batch_size]
+            # rows of THE ragged minibatch; 0 = none (or several: a pipeline this agent does not produce, never agreed on)
+            return full, ragged, (int(ragged[0][1].shape[0]) if len(ragged) == 1 else 0)
+
+        pf, pr, prow = split(policy_batches)
+        vf, vr, vrow = split(value_batches)
+        sig = [len(pf), len(vf), prow, vrow]
         lo = self._all_reduce_ints(sig, dist.ReduceOp.MIN)
         hi = self._all_reduce_ints(sig, dist.ReduceOp.MAX)
-        policy_batches, value_batches = policy_batches[:lo[0]], value_batches[:lo[1]]
-        if policy_batches and (lo[0] != hi[0] or lo[2] != hi[2]) and rows(policy_batches[-1]) != self.batch_size:
-            policy_batches = policy_batches[:-1]
-        if value_batches and (lo[1] != hi[1] or lo[3] != hi[3]) and rows(value_batches[-1]) != self.batch_size:
-            value_batches = value_batches[:-1]
+        policy_batches = pf[:lo[0]] + (pr if lo[2] > 0 and lo[2] == hi[2] else [])
+        value_batches = vf[:lo[1]] + (vr if lo[3] > 0 and lo[3] == hi[3] else [])
         return policy_batches, value_batches
 
     def after_update(self):
         if self.data_parallel:
             self._dp_for(self.network.engine).sync_moving_statistics()
+
+    def is_writer(self) -> bool:
+        # every rank runs learn() to its end: checkpoints, summaries and traces are written by rank 0 alone (ADVICE r4)
+        return not self.data_parallel or self.rank == 0
+
+    def rank_barrier(self):
+        if self.data_parallel:
+            dist.barrier()
 
     def load(self):
         super().load()
@@ -206,14 +220,43 @@ class CARLAgent(PPOAgent):
             small = bool(self._all_reduce_ints([int(small)], dist.ReduceOp.MAX)[0])
         if small:
             print('[Not updated] memory too small!')
-            self.env.reset_info()
+            self._reset_info()
             return
         super().update()
-        self.env.reset_info()
+        self._reset_info()
+
+    def _reset_info(self):
+        for env in self._shard:
+            env.reset_info()
+        self._info_segments = []
+
+    def collect(self, shard, *args, **kwargs):
+        self._shard = shard
+        return super().collect(shard, *args, **kwargs)
+
+    def trajectory_stored(self, env_index, rollout):
+        # several environments: remember which slice of WHICH environment's info buffer belongs to the rows just appended
+        if len(self._shard) > 1:
+            have = len(self._shard[env_index].info_buffer['speed'])
+            self._info_segments.append((env_index, have - rollout.env_steps[env_index], rollout.length[env_index]))
 
     def _info(self, n):
-        speed = torch.as_tensor(np.asarray(self.env.info_buffer['speed'], dtype=np.float32), device=self.device) / 100.0
-        sim = torch.as_tensor(np.asarray(self.env.info_buffer['similarity'], dtype=np.float32), device=self.device)
+        """speed / similarity targets of the auxiliary heads, one per memory row, from the environments' info buffers
+        (reference core/carla_agent.py:328-329,341-347: padded / truncated to the number of rows).  With an environment shard
+        the buffers are cut per trajectory, in the order the trajectories were appended."""
+        if self._info_segments:
+            sp, si = [], []
+            for e, start, rows in self._info_segments:
+                buf = self._shard[e].info_buffer
+                for dst, key in ((sp, 'speed'), (si, 'similarity')):
+                    piece = np.asarray(buf[key][start:start + rows], dtype=np.float32)
+                    dst.append(np.pad(piece, (0, rows - piece.shape[0])))
+            speed_h, sim_h = np.concatenate(sp), np.concatenate(si)
+        else:
+            speed_h = np.asarray(self.env.info_buffer['speed'], dtype=np.float32)
+            sim_h = np.asarray(self.env.info_buffer['similarity'], dtype=np.float32)
+        speed = torch.as_tensor(speed_h, device=self.device) / 100.0
+        sim = torch.as_tensor(sim_h, device=self.device)
         if speed.shape[0] >= n:
             return speed[:n].contiguous(), sim[:n].contiguous()
         pad = torch.zeros(n - speed.shape[0], device=self.device)

@@ -6,7 +6,7 @@ update() = all policy minibatches then all value minibatches (:190-226), learn()
 (:464-568), end_episode (:574-585), PPOMemory (:629-733)."""
 import os
 import time
-from typing import Union
+from typing import Optional, Sequence, Union
 
 import numpy as np
 import torch
@@ -79,7 +79,9 @@ class PPOAgent(Agent):
         self.action_low = np.asarray(space.low, dtype=np.float32)
         self.action_high = np.asarray(space.high, dtype=np.float32)
         self.action_range = self.action_high - self.action_low
-        self.convert_action = lambda a: (a[0].detach().cpu().numpy() * self.action_range + self.action_low)
+        # (E, A) device sample in [0, 1] -> environment actions; one row (the reference's single environment) comes back as (A,)
+        self.convert_action = lambda a: np.squeeze(a.detach().cpu().numpy() * self.action_range + self.action_low, axis=0) \
+            if a.shape[0] == 1 else a.detach().cpu().numpy() * self.action_range + self.action_low
 
     # -- acting -----------------------------------------------------------------------------------
     def predict(self, state, *args, **kwargs):
@@ -162,75 +164,152 @@ class PPOAgent(Agent):
         return self._batches(self.policy_batch_tensors(), self.shuffle, self.shuffle_batches)
 
     # -- learning loop ------------------------------------------------------------------------------
+    @staticmethod
+    def _period(every, episodes: int, end_keyword=False) -> int:
+        """`save_every` / `render_every` of the reference's learn() as a period in episodes: False / None -> never,
+        True -> every episode, 'end' (saving only) -> the last episode, an int -> that period (must divide `episodes`)."""
+        if every is False or every is None:
+            return episodes + 1
+        if every is True:
+            return 1
+        if end_keyword and every == 'end':
+            return episodes
+        assert not isinstance(every, str) and episodes % every == 0
+        return int(every)
+
     def learn(self, episodes: int, timesteps: int, save_every: Union[bool, str, int] = False,
-              render_every: Union[bool, str, int] = False, close=True):
+              render_every: Union[bool, str, int] = False, close=True, envs: Optional[Sequence] = None):
+        """The reference's training loop (rl/agents/ppo.py:464-568: roll out up to `timesteps` steps per episode, close the
+        trajectory with the bootstrap value, update() every `update_frequency` episodes, then the host side effects) built around
+        an ENVIRONMENT SHARD: `envs` (default `[self.env]`, the reference's case) are stepped in lockstep, one batched
+        `predict` per step for all of them, their rows stay on the device, and at the end of the episode every environment's
+        trajectory is appended to the memory with its own bootstrap value and its own returns / GAE(lambda).  With one environment
+        the sequence of environment, sampler and memory operations is the reference's."""
         assert episodes % self.update_frequency == 0
-        if save_every in (False, None):
-            save_every = episodes + 1
-        elif save_every is True:
-            save_every = 1
-        elif save_every == 'end':
-            save_every = episodes
-        else:
-            assert episodes % save_every == 0
-        if render_every is False:
-            render_every = episodes + 1
-        elif render_every is True:
-            render_every = 1
+        save_period = self._period(save_every, episodes, end_keyword=True)
+        render_period = self._period(render_every, episodes)
+        shard = list(envs) if envs is not None else [self.env]
         try:
             self.memory = self.get_memory()
             for episode in range(1, episodes + 1):
                 self.seed_regularization()
                 self.on_episode_start()
-                preprocess_fn = self.preprocess()
                 self.reset()
-                state = self.env.reset()
-                episode_reward = 0.0
-                t0 = time.time()
-                render = episode % render_every == 0
-                for t in range(1, timesteps + 1):
-                    if render:
-                        self.env.render()
-                    if isinstance(state, dict):
-                        state = {f'state_{k}': v for k, v in state.items()}
-                    state = utils.to_tensor(preprocess_fn(state), device=self.device)
-                    action, mean, std, log_prob, value = self.predict(state)
-                    action_env = self.convert_action(action)
-                    reward, done = 0.0, False
-                    for _ in range(self.repeat_action):
-                        next_state, reward, done, _ = self.env.step(action_env)
-                        episode_reward += reward
-                        if done:
-                            break
-                    self.log(actions=action, rewards=reward, distribution_mean=mean, distribution_std=std)
-                    self.memory.append(state, action, reward, value, log_prob)
-                    state = next_state
-                    if done or (t == timesteps):
-                        print(f'Episode {episode} terminated after {t} timesteps in {round(time.time() - t0, 3)}s '
-                              f'with reward {round(episode_reward, 3)}.')
-                        self.log(timestep=t)
-                        if isinstance(state, dict):
-                            state = {f'state_{k}': v for k, v in state.items()}
-                        state = utils.to_tensor(preprocess_fn(state), device=self.device)
-                        last_value = self.network.predict_last_value(state, timestep=(t + 1) / timesteps, is_terminal=done)
-                        self.end_episode(last_value, append=self.update_frequency > 1)
-                        break
-                if episode % self.update_frequency == 0:
+                rollout = self.collect(shard, timesteps, render=episode % render_period == 0, episode=episode)
+                updating = episode % self.update_frequency == 0
+                self.store(rollout, timesteps, keep_open=not updating)
+                if updating:
                     self.update()
                     self.memory.delete()
                     self.memory = self.get_memory()
-                elif self.update_frequency > 1:
-                    self.memory.drop_bootstrap()
-                self.log(episode_rewards=episode_reward)
-                self.write_summaries()
-                if self.should_record:
-                    self.record(episode)
+                self.log(episode_rewards=rollout.episode_reward if len(shard) > 1 else rollout.episode_reward[0])
+                # host side effects: ONE writer under data parallelism (N ranks writing the same checkpoint / summary files
+                # concurrently leave torn files), everyone waits for it
+                if self.is_writer():
+                    self.write_summaries()
+                    if self.should_record:
+                        self.record(episode)
+                else:
+                    self.statistics.stats = {}
                 self.on_episode_end()
-                if episode % save_every == 0:
-                    self.save()
+                if episode % save_period == 0:
+                    if self.is_writer():
+                        self.save()
+                    self.rank_barrier()
         finally:
             if close:
-                self.env.close()
+                for env in shard:
+                    env.close()
+
+    def is_writer(self) -> bool:
+        """Hook for data-parallel agents: the rank that writes checkpoints, summaries and traces."""
+        return True
+
+    def rank_barrier(self):
+        """Hook for data-parallel agents: all ranks meet here after the writer has written."""
+
+    def observe(self, observations: list, preprocess_fn) -> dict:
+        """Per-environment observations -> one dict of (E, ...) device tensors: keys get the reference's `state_` prefix, the
+        agent's preprocess function runs per environment (it may return device tensors: the augmentation kernels), host arrays
+        cross PCIe as ONE copy per key."""
+        prepared = []
+        for obs in observations:
+            if isinstance(obs, dict):
+                obs = {f'state_{k}': v for k, v in obs.items()}
+            prepared.append(preprocess_fn(obs))
+        if not isinstance(prepared[0], dict):
+            prepared = [dict(state=p) for p in prepared]
+        out = {}
+        for key in prepared[0]:
+            vals = [p[key] for p in prepared]
+            if any(isinstance(v, torch.Tensor) for v in vals):
+                vals = [v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, dtype=np.float32)) for v in vals]
+                out[key] = torch.stack([v.to(device=self.device, dtype=torch.float32) for v in vals], dim=0)
+            else:
+                out[key] = torch.as_tensor(np.stack([np.asarray(v, dtype=np.float32) for v in vals], axis=0)).to(self.device)
+        return out
+
+    def collect(self, shard: list, timesteps: int, render=False, episode=0) -> 'Rollout':
+        """One episode of every environment of the shard, in lockstep.  An environment that terminates early keeps its last
+        observation in the batch (its rows are not recorded any more), so the inference engine sees one shape throughout."""
+        E = len(shard)
+        preprocess_fn = self.preprocess()
+        observations = [env.reset() for env in shard]
+        rollout = Rollout(E, timesteps, self.device)
+        running = list(range(E))
+        t0 = time.time()
+        batch = self.observe(observations, preprocess_fn)
+        for t in range(1, timesteps + 1):
+            if render:
+                for e in running:
+                    shard[e].render()
+            action, mean, std, log_prob, value = self.predict(batch)
+            rollout.record(batch, action, log_prob, value, running)
+            env_actions = np.atleast_2d(self.convert_action(action))
+            rewards = []
+            for e in list(running):
+                reward, done = 0.0, False
+                for _ in range(self.repeat_action):
+                    observations[e], reward, done, _ = shard[e].step(env_actions[e])
+                    rollout.episode_reward[e] += reward
+                    rollout.env_steps[e] += 1
+                    if done:
+                        break
+                rollout.rewards[e].append(float(reward))
+                rewards.append(reward)
+                if done or t == timesteps:
+                    rollout.terminal[e] = done
+                    running.remove(e)
+                    print(f'Episode {episode}{f" [env {e}]" if E > 1 else ""} terminated after {t} timesteps in '
+                          f'{round(time.time() - t0, 3)}s with reward {round(rollout.episode_reward[e], 3)}.')
+                    self.log(timestep=t)
+            self.log(actions=action, rewards=rewards if E > 1 else rewards[0], distribution_mean=mean, distribution_std=std)
+            batch = self.observe(observations, preprocess_fn)
+            if not running:
+                break
+        rollout.final = batch               # the observation behind every environment's last recorded step
+        return rollout
+
+    def store(self, rollout: 'Rollout', timesteps: int, keep_open: bool):
+        """Appends every environment's trajectory to the memory: rows, bootstrap value (zero at a terminal state, the value
+        head's estimate of the final observation otherwise), returns and GAE(lambda) of THAT trajectory (end_episode).
+        `keep_open`: more rows follow before the next update() (update_frequency > 1) -- the bootstrap entry is removed again."""
+        E = rollout.envs
+        estimate = None
+        if not all(rollout.terminal):
+            t_last = max(rollout.length)
+            estimate = self.network.predict_last_value(rollout.final, timestep=(t_last + 1) / timesteps, is_terminal=False)
+        for e in range(E):
+            first = e == 0 and self.update_frequency == 1
+            self.memory.extend(*rollout.trajectory(e))
+            last_value = (self.network.predict_last_value(None, is_terminal=True) if rollout.terminal[e] else estimate[e:e + 1])
+            self.end_episode(last_value, append=not first)
+            self.trajectory_stored(e, rollout)
+            if keep_open or e < E - 1:
+                self.memory.drop_bootstrap()
+
+    def trajectory_stored(self, env_index: int, rollout: 'Rollout'):
+        """Hook: environment `env_index`'s trajectory of this rollout now sits at the end of the memory."""
 
     def get_memory(self):
         return PPOMemory(state_spec=self.state_spec, num_actions=self.num_actions, device=self.device)
@@ -274,9 +353,46 @@ class PPOAgent(Agent):
         self.adv_scale.on_episode()
 
 
+class Rollout:
+    """What an environment shard stepped in lockstep leaves behind: (steps, E, ...) device blocks written in place, one per
+    state component / action / log-probability / value, plus the host-side bookkeeping per environment (rewards, number of
+    recorded steps, terminal flag).  `trajectory(e)` hands environment e's rows to the memory as contiguous blocks."""
+
+    def __init__(self, envs: int, timesteps: int, device):
+        self.envs, self.timesteps, self.device = envs, timesteps, device
+        self.blocks = None                                  # name -> (timesteps, E, ...) tensor, allocated by the first record()
+        self.rewards = [[] for _ in range(envs)]
+        self.length = [0] * envs
+        self.env_steps = [0] * envs                         # environment steps incl. repeated actions (info-buffer entries)
+        self.terminal = [False] * envs
+        self.episode_reward = [0.0] * envs
+        self.final = None
+        self.step = 0
+
+    def record(self, states: dict, action, log_prob, value, running):
+        rows = dict(states)
+        rows.update({'/action': action, '/log_prob': log_prob, '/value': value})
+        if self.blocks is None:
+            self.blocks = {k: torch.empty((self.timesteps,) + tuple(v.shape), dtype=torch.float32, device=self.device)
+                           for k, v in rows.items()}
+        for k, v in rows.items():
+            self.blocks[k][self.step].copy_(v)
+        self.step += 1
+        for e in running:
+            self.length[e] += 1
+
+    def trajectory(self, e: int):
+        """-> (states, actions, rewards, values, log_probs) of environment e: its first `length[e]` steps."""
+        n = self.length[e]
+        take = lambda k: self.blocks[k][:n, e].contiguous()
+        states = {k: take(k) for k in self.blocks if not k.startswith('/')}
+        return states, take('/action'), self.rewards[e][:n], take('/value'), take('/log_prob')
+
+
 class PPOMemory:
-    """Rollout buffer resident in HBM.  Rows are appended as (1, ...) device tensors and stacked on
-    demand; returns / advantages come from the cdrl_gae_returns kernel."""
+    """Rollout buffer resident in HBM.  Rows arrive one at a time (`append`, (1, ...) device tensors) or as whole
+    trajectories (`extend`, (n, ...) blocks) and are concatenated on demand; returns / advantages come from the
+    cdrl_gae_returns kernel."""
 
     def __init__(self, state_spec: dict, num_actions: int, device='cuda:0'):
         self.device = device
@@ -289,15 +405,17 @@ class PPOMemory:
         self.returns = None
         self.advantages = None
         self._cache = {}
+        self._n = 0
 
     def __len__(self):
-        return len(self._actions)
+        return self._n
 
     def delete(self):
         self._states = None
         self._rewards = self._values = self._actions = self._log_probs = None
         self.returns = self.advantages = None
         self._cache = {}
+        self._n = 0
 
     @staticmethod
     def _row(x, device, width=None):
@@ -318,6 +436,26 @@ class PPOMemory:
         self._rewards.append(float(reward))
         self._values.append(self._row(value, self.device, True))
         self._log_probs.append(self._row(log_prob, self.device, True))
+        self._n += 1
+
+    def extend(self, states, actions, rewards, values, log_probs):
+        """A whole trajectory of n rows: (n, ...) device blocks (state dict or tensor, actions (n, A), values (n, 2),
+        log-probabilities (n, A)) and n host rewards."""
+        n = int(actions.shape[0])
+        if n == 0:
+            return
+        self._cache = {}
+        if self.simple_state:
+            self._states.append(states['state'] if isinstance(states, dict) else states)
+        else:
+            for k, v in states.items():
+                if k in self._states:
+                    self._states[k].append(v)
+        self._actions.append(actions.reshape(n, -1))
+        self._rewards.extend(float(r) for r in rewards)
+        self._values.append(values.reshape(n, -1))
+        self._log_probs.append(log_probs.reshape(n, -1))
+        self._n += n
 
     def _cat(self, key, rows):
         if key not in self._cache:

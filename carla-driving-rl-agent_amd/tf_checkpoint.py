@@ -293,12 +293,13 @@ def save_checkpoint(prefix: str, tensors: Dict[str, np.ndarray], full_names: Dic
     index += with_trailer(index_block)
     footer = _put_varint(meta_off) + _put_varint(len(meta_block)) + _put_varint(index_off) + _put_varint(len(index_block))
     index += footer + b'\x00' * (40 - len(footer)) + struct.pack('<Q', _MAGIC)
-    with open(prefix + '.index', 'wb') as f:
-        f.write(bytes(index))
-    with open(prefix + '.data-00000-of-00002', 'wb') as f:
-        f.write(shard0)
-    with open(prefix + '.data-00001-of-00002', 'wb') as f:
-        f.write(bytes(shard1))
+    # data shards first, the index last, each through a temporary file + rename: a reader (or a second writer) never sees
+    # a torn file, and an index never points at shards that are not there yet
+    for suffix, blob in (('.data-00000-of-00002', shard0), ('.data-00001-of-00002', bytes(shard1)), ('.index', bytes(index))):
+        tmp = f'{prefix}{suffix}.tmp{os.getpid()}'
+        with open(tmp, 'wb') as f:
+            f.write(blob)
+        os.replace(tmp, prefix + suffix)
 
 
 def keras_full_names(model: str, stage_n=(4, 8, 4)) -> Dict[str, str]:

@@ -204,3 +204,57 @@ def test_comm_stream_is_not_used_when_the_engine_never_releases_it():
     assert DP.use_comm_stream(True, 1, True, 400, t_n, True)
     assert not DP.use_comm_stream(False, 2, False, 400, t_n, True)
     assert not DP.use_comm_stream(True, 2, False, 400, t_n, False)          # host engine stand-ins
+
+
+# ---- the number of minibatch steps is a COLLECTIVE decision, also with unequal shards -------------------------
+_AGREE_CASES = [
+    # (rows of rank 0's policy minibatches, rank 1's) -> the same for value; expected (full steps, ragged rows or 0)
+    ([4, 4, 4, 4, 1], [4, 4, 2], 2, 0),         # the advisor's first replay: A ran 3 steps and B 2 before the fix
+    ([4, 4], [4, 3], 1, 0),                     # the second: A 2, B 1
+    ([4, 4, 3], [4, 1], 1, 0),                  # 2B+3 against B+1 rows: ragged minibatches of different size are dropped
+    ([4, 4], [4, 4, 4], 2, 0),                  # exact multiples, different counts
+    ([4, 4, 2], [4, 4, 2], 2, 2),               # equal shards keep the ragged step
+    ([4, 2, 4], [2, 4, 4], 2, 2),               # shuffle_batches: the ragged minibatch is found by row count and run last
+    ([4, 4, 2], [4, 4], 2, 0),                  # one rank without a ragged minibatch
+    ([2], [2], 0, 2),
+]
+
+
+def _agree_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from carla_driving_rl_agent_amd.core import CARLAgent
+
+    class Stub:
+        data_parallel, batch_size, device = True, 4, 'cpu'
+        _all_reduce_ints = CARLAgent._all_reduce_ints
+        agree_on_batches = CARLAgent.agree_on_batches
+
+    stub, got = Stub(), []
+    for case in _AGREE_CASES:
+        mine = case[rank]
+        mk = lambda rows, tag: [((tag, i), torch.zeros(r)) for i, r in enumerate(rows)]
+        # value minibatches of the case in REVERSE role (rank 0 takes rank 1's list): both lists are agreed on independently
+        p, v = stub.agree_on_batches(mk(mine, 'p'), mk(case[1 - rank], 'v'))
+        got.append(([int(b[1].shape[0]) for b in p], [int(b[1].shape[0]) for b in v], [b[0][1] for b in p]))
+    torch.save(got, os.path.join(out, f'agree{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_minibatch_count_is_agreed_collectively_with_unequal_shards(tmp_path):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = torch.load(tmp_path / 'agree0.pt'), torch.load(tmp_path / 'agree1.pt')
+    for case, a, b in zip(_AGREE_CASES, g0, g1):
+        want = [4] * case[2] + ([case[3]] if case[3] else [])
+        # the same row sequence on both ranks, for the policy AND the value list: every all-reduce pairs like with like
+        assert a[0] == b[0] == want and a[1] == b[1] == want, (case, a, b)
+        # full minibatches keep the rank's own order (the first `min` of them), the ragged one comes last
+        full_idx = [i for i, r in enumerate(case[0]) if r == 4][:case[2]]
+        rag_idx = [i for i, r in enumerate(case[0]) if r != 4] if case[3] else []
+        assert a[2] == full_idx + rag_idx, (case, a)

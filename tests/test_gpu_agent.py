@@ -73,3 +73,58 @@ def test_learn_cycle_bf16_compute_mode(tmp_path):
     assert np.isfinite(agent.network.engine.metrics('policy')['loss'])
     with pytest.raises(Exception):
         CARLAgent(_env(), batch_size=8, log_mode=None, compute='fp8')
+
+
+def test_learn_with_an_environment_shard(tmp_path):
+    """learn(envs=[E environments]): the shard is stepped in lockstep through ONE batched predict per step
+    (rollout_for(E)), the rows stay on the device, and every environment's trajectory enters the memory with its own bootstrap
+    value and its own returns / GAE -- incl. an environment that terminates early.  Contract: reference rl/agents/ppo.py:464-568
+    per environment."""
+    from carla_driving_rl_agent_amd.rl import utils
+    E, steps = 3, 12
+    envs = [_env(seed=10 + e, episode_length=(7 if e == 1 else None)) for e in range(E)]
+    agent = CARLAgent(envs[0], batch_size=8, log_mode=None, seed=5, skip_data=0, shuffle=True, policy_lr=3e-4, value_lr=3e-4,
+                      dynamics_lr=3e-4, gamma=0.99, lambda_=0.95, aug_intensity=0.0, weights_dir=str(tmp_path), name='shard')
+    seen = {}
+    orig_update = agent.update
+
+    def update():
+        m = agent.memory
+        seen.update(n=len(m), returns=m.returns.clone(), adv=m.advantages.clone(), values=m.values.clone(), rewards=m.rewards.clone(),
+                    image=m.states['state_image'].clone(), info=[x.clone() for x in agent._info(len(m))],
+                    segments=list(agent._info_segments))
+        orig_update()
+
+    agent.update = update
+    calls = agent.network.action_index
+    before = agent.network.engine.params.clone()
+    agent.learn(episodes=1, timesteps=steps, close=False, envs=envs)
+    lengths = [steps, 7, steps]
+    assert agent.network.action_index - calls == steps             # one predict per step for the whole shard
+    assert E in agent.network._rollouts                             # ... on the E-environment inference engine
+    assert seen['n'] == sum(lengths) and seen['image'].shape[0] == sum(lengths)
+    assert seen['returns'].shape == (sum(lengths), 2) and seen['adv'].shape[0] == sum(lengths)
+    # rewards / values hold the rows of all trajectories + the LAST trajectory's bootstrap entry
+    assert seen['rewards'].shape[0] == sum(lengths) + 1
+    # every trajectory's returns / advantages are those of the device kernel run on that trajectory alone
+    r, v = seen['rewards'], seen['values']
+    for e, n in enumerate(lengths):
+        off = sum(lengths[:e])
+        if e == 1:      # terminal: bootstrap (0, 0)
+            re, ve = torch.cat([r[off:off + n], r.new_zeros(1)]), torch.cat([v[off:off + n], v.new_zeros((1, 2))])
+        elif e == E - 1:
+            re, ve = r[off:off + n + 1], v[off:off + n + 1]
+        else:
+            continue    # (its bootstrap entry was dropped again; covered by the shape checks and by trajectory 2)
+        out = utils.returns_and_advantages(re, ve, 0.99, 0.0, 1.0)
+        assert torch.equal(out['returns_be'], seen['returns'][off:off + n]), e
+        out = utils.returns_and_advantages(re, ve, 0.99, 0.95, agent.adv_scale())
+        assert torch.equal(out['advantages'], seen['adv'][off:off + n]), e
+    # rows of different environments differ (rank-own observation streams), info targets are cut per trajectory
+    assert not torch.equal(seen['image'][0], seen['image'][steps])
+    assert seen['segments'] == [(0, 0, steps), (1, 0, 7), (2, 0, steps)]
+    sp = np.concatenate([np.asarray(envs[e].info_buffer['speed'][:n], dtype=np.float32) for e, n in enumerate(lengths)]) \
+        if envs[0].info_buffer['speed'] else None
+    assert sp is None                                               # update() reset every environment's info buffer
+    assert seen['info'][0].shape[0] == sum(lengths)
+    assert torch.isfinite(agent.network.engine.params).all() and not torch.equal(before, agent.network.engine.params)
