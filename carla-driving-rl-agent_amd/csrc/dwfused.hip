@@ -26,6 +26,8 @@
 // The `pre` prologue is optional (shortcut branch: the depthwise reads an activation tensor directly).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "colreduce.h"
 
 namespace cdrl {
@@ -559,6 +561,350 @@ static int allow_lds(size_t bytes) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Stride-1 backward in STRIP form (round 5).  SQ counters of the pixel-mapped kernel above (profiles/r05_pmc_sq.json): 3266 VALU and
+// 435 LDS instructions per wave for 12 channel-pixels per thread and frame (~68 VALU per channel-pixel: three p -> (y, x) conversions,
+// 20 LDS addresses and 2 x 4 double-precision operations per pixel around 38 useful FMAs), VALU busy 0.34, waves parked 52 % of
+// their cycles at 1.6 waves per SIMD -- an instruction- and latency-chain per workgroup, not a bandwidth limit (2.5 TB/s at 6x8,
+// 1.1 TB/s at 3x4 pixels).  Here a thread owns a channel PAIR and a row strip of SW pixels:
+//   * both products of the backward come from the SAME 3x3 window of D around the strip's own pixels --
+//       da[i]   = sum_k D[i + 1 - k] w[k]            (transposed conv)
+//       dW[k]  += a[i] D[i + 1 - k]                  (filter gradient in scatter form: own input pixel x neighbouring D)
+//     so only D goes to LDS (half the tile, half the LDS stores); the activated input strip stays in registers across the barrier;
+//   * the window slides along the strip in registers: 3 x (SW + 2) LDS reads per SW pixels (3.75 per pixel at SW = 8; 20 before);
+//   * strip coordinates are computed once per strip, every LDS / global offset inside a strip is a compile-time constant;
+//   * BN1's backward sums are accumulated in float32 along a strip (<= 8 terms, fixed order) and in double across strips;
+//   * F frames share one tile batch when the frames are small (one barrier pair per F frames), all 3 x SW global loads of a strip
+//     are issued before the first one is consumed (unconditional, clamped addresses).
+// Partial-row layout, frames per workgroup and the block -> (frame block, channel chunk) map are those of dwf_bwd_kernel.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int NF, int ND>
+__device__ __forceinline__ void block_colsum_mixed(float* smf, float (&a)[NF][2], double (&d)[ND][2], int tx, int ty, int CX, int CY, bool on,
+                                                   double* outf, double* outd, int qstride) {
+    // [NF][CY][2][CX] floats, then [ND][CY][2][CX] doubles: every (quantity, channel) column is summed over the strip lanes by ONE
+    // thread in lane order (deterministic); float32 accumulators are widened when they are read (exact)
+    double* smd = reinterpret_cast<double*>(smf + (size_t)NF * CY * 2 * CX);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) smf[((q * CY + ty) * 2 + i) * CX + tx] = a[q][i];
+#pragma unroll
+    for (int q = 0; q < ND; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) smd[((q * CY + ty) * 2 + i) * CX + tx] = d[q][i];
+    __syncthreads();
+    for (int j = ty; j < (NF + ND) * 2; j += CY) {
+        const int q = j >> 1, i = j & 1;
+        double s = 0.0;
+        if (q < NF) {
+            for (int y = 0; y < CY; ++y) s += (double)smf[((q * CY + y) * 2 + i) * CX + tx];
+            if (on) outf[(int64_t)q * qstride + i] = s;
+        } else {
+            for (int y = 0; y < CY; ++y) s += smd[(((q - NF) * CY + y) * 2 + i) * CX + tx];
+            if (on) outd[(int64_t)(q - NF) * qstride + i] = s;
+        }
+    }
+}
+
+#ifndef DWS_LB
+#define DWS_LB 640
+#endif
+template <int SW, int R, class T>
+__global__ void __launch_bounds__(DWS_LB) dws_bwd_kernel(const T* __restrict__ x, const float* __restrict__ pre_stats, const T* __restrict__ dout,
+                                                      const T* __restrict__ y2, const float* __restrict__ post_stats,
+                                                      const float* __restrict__ post_coef, const float* __restrict__ w, View dx,
+                                                      double* __restrict__ part_bn, double* __restrict__ part_w, int Bf, int H, int W, int C,
+                                                      int GC, int fpb, int nb, int cchunk, bool dx_al, int nfb, bool reload_y1, int F, int S,
+                                                      int tile_floats) {
+    // D: [F][H + 2][S * SW + 2][cchunk], zero border and right padding | coefficient table [16][cchunk]
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int nch_ = (C + cchunk - 1) / cchunk;
+    const int q_ = blockIdx.x >> 3;
+    const int fb_ = (q_ / nch_) * 8 + (blockIdx.x & 7);
+    if (fb_ >= nfb) return;
+    const int g = fb_ / nb, b = fb_ % nb;
+    const int cbase = (q_ % nch_) * cchunk;
+    const int cc = min(cchunk, C - cbase);
+    const bool on = tx * 2 < cc;
+    const int c = cbase + (on ? tx * 2 : 0);          // (idle lanes load channel pair 0 of the chunk: unconditional loads)
+    const int P = H * W, Wp = S * SW + 2, Hp = H + 2;
+    const int NS1 = H * S, NSB = F * NS1;
+    for (int i = (ty * CX + tx) * 2; i < tile_floats; i += CX * CY * 2) *reinterpret_cast<float2*>(&tile[i]) = make_float2(0.0f, 0.0f);
+    // Per-channel constants live in LDS, not in registers: the load phase needs 7 pairs (BN1 scale / shift, BN2 mean / invstd / k1..k3),
+    // the window phase the 9 filter taps -- read where they are used, they are not live across the other phase (~30 VGPRs)
+    const int ctab = tile_floats + tx * 2;             // entry e of this lane's channel pair: tile[ctab + e * cchunk]
+    VecF<2> bt1, rg1;
+    bool slow1 = reload_y1;
+    {
+        const VecF<2> mean1 = vload<2>(pre_stats + 0 * GC + g * C + c), inv1 = vload<2>(pre_stats + 1 * GC + g * C + c);
+        const VecF<2> sc = vload<2>(pre_stats + 2 * GC + g * C + c), sh = vload<2>(pre_stats + 3 * GC + g * C + c);
+        if (ty == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) vstore<2>(&tile[ctab + k * cchunk], vload<2>(w + k * C + c));
+            vstore<2>(&tile[ctab + 9 * cchunk], sc);
+            vstore<2>(&tile[ctab + 10 * cchunk], sh);
+            vstore<2>(&tile[ctab + 11 * cchunk], vload<2>(post_stats + 0 * GC + g * C + c));
+            vstore<2>(&tile[ctab + 12 * cchunk], vload<2>(post_stats + 1 * GC + g * C + c));
+            vstore<2>(&tile[ctab + 13 * cchunk], vload<2>(post_coef + 0 * GC + g * C + c));
+            vstore<2>(&tile[ctab + 14 * cchunk], vload<2>(post_coef + 1 * GC + g * C + c));
+            vstore<2>(&tile[ctab + 15 * cchunk], vload<2>(post_coef + 2 * GC + g * C + c));
+        }
+        // xhat1 = (a - beta) / gamma from the activated value (see dwf_bwd_kernel); channels beyond the amplification bound re-read y1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) slow1 |= !((6.0f + fabsf(fmaf(mean1.v[i], sc.v[i], sh.v[i]))) * fabsf(inv1.v[i]) <= 170.0f * fabsf(sc.v[i]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bt1.v[i] = slow1 ? mean1.v[i] : fmaf(mean1.v[i], sc.v[i], sh.v[i]);
+            rg1.v[i] = slow1 ? inv1.v[i] : inv1.v[i] / sc.v[i];
+        }
+    }
+    float gf[10][2];
+    double gb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        gb[0][i] = gb[1][i] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) gf[k][i] = 0.0f;
+    }
+    // Buffer descriptors: a strip's pixels sit at voffset (one VGPR per tensor) + j * C * sizeof(T) (a scalar / immediate), so the 3 x SW
+    // loads and SW stores of a strip carry no 64-bit address registers (48 + 16 VGPRs in the flat form); an offset beyond the tensor
+    // (idle lanes: OOR) reads 0 and drops stores, the pixels of a partial strip that lie beyond its row are loaded and ignored
+    constexpr uint32_t OOR = 0x80000000u;
+    constexpr int ESZ = (int)sizeof(T);
+    const int tot_bytes = (int)((int64_t)nfb * fpb * P * C * ESZ);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, tot_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dout), 0, tot_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(y2), 0, tot_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(vptr<T>(dx), 0, (int)((int64_t)nfb * fpb * P * dx.ld * ESZ), 0x00020000);
+    auto ldp = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t vo, uint32_t so) -> VecF<2> {
+        VecF<2> r;
+        if (ESZ == 2) {
+            r.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+            r.v[1] = 0.0f;
+        } else {
+            const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+            r.v[0] = __uint_as_float(t[0]);
+            r.v[1] = __uint_as_float(t[1]);
+        }
+        return r;
+    };
+    const float invNS1 = 1.0f / (float)NS1, invS = 1.0f / (float)S;
+    for (int f0 = 0; f0 < fpb; f0 += F) {
+        VecF<2> A[R][SW];
+        int pix0[R], lbase[R], nx[R];          // first pixel of the strip (global pixel index), its LDS offset, pixels in range
+        __syncthreads();                          // the previous batch's windows have been read (first pass: table + zeros written)
+        {
+            const VecF<2> sc = vload<2>(&tile[ctab + 9 * cchunk]), sh = vload<2>(&tile[ctab + 10 * cchunk]);
+            const VecF<2> mean2 = vload<2>(&tile[ctab + 11 * cchunk]), inv2 = vload<2>(&tile[ctab + 12 * cchunk]);
+            const VecF<2> k1 = vload<2>(&tile[ctab + 13 * cchunk]), k2 = vload<2>(&tile[ctab + 14 * cchunk]), k3 = vload<2>(&tile[ctab + 15 * cchunk]);
+#pragma unroll
+            for (int rd = 0; rd < R; ++rd) {
+                const int s = ty + rd * CY;
+                const bool valid = on && s < NSB;
+                const int sv = s < NSB ? s : 0;
+                const int fl = (int)(((float)sv + 0.5f) * invNS1);
+                const int rem = sv - fl * NS1;
+                const int r = (int)(((float)rem + 0.5f) * invS);
+                const int x0 = (rem - r * S) * SW;
+                const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f0 + fl;
+                nx[rd] = valid ? min(SW, W - x0) : 0;
+                pix0[rd] = (int)(n * P) + r * W + x0;            // (byte offsets fit 31 bits: checked by the launcher)
+                lbase[rd] = ((fl * Hp + r + 1) * Wp + x0 + 1) * cchunk + tx * 2;
+                const uint32_t vo = valid ? (uint32_t)(pix0[rd] * C + c) * ESZ : OOR;
+                VecF<2> xa[SW], d[SW], v[SW];
+#pragma unroll
+                for (int j = 0; j < SW; ++j) {
+                    xa[j] = ldp(rsX, vo, (uint32_t)(j * C * ESZ));
+                    d[j] = ldp(rsD, vo, (uint32_t)(j * C * ESZ));
+                    v[j] = ldp(rsY, vo, (uint32_t)(j * C * ESZ));
+                }
+#pragma unroll
+                for (int j = 0; j < SW; ++j) {
+                    vdecode<2>(xa[j], x);
+                    vdecode<2>(d[j], x);
+                    vdecode<2>(v[j], x);
+                    VecF<2> o;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float a = fminf(fmaxf(fmaf(sc.v[i], xa[j].v[i], sh.v[i]), 0.0f), 6.0f);
+                        A[rd][j].v[i] = j < nx[rd] ? a : 0.0f;
+                        const float xh = (v[j].v[i] - mean2.v[i]) * inv2.v[i];
+                        o.v[i] = k1.v[i] * (d[j].v[i] - k2.v[i] - xh * k3.v[i]);
+                    }
+                    if (j < nx[rd]) vstore<2>(&tile[lbase[rd] + j * cchunk], o);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            VecF<2> wk[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = vload<2>(&tile[ctab + k * cchunk]);
+#pragma unroll
+            for (int rd = 0; rd < R; ++rd) {
+                if (nx[rd] == 0) continue;
+                VecF<2> da[SW];
+#pragma unroll
+                for (int j = 0; j < SW; ++j) da[j].v[0] = da[j].v[1] = 0.0f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    // row r + 1 - ky of D, columns x0 - 1 .. x0 + SW (padded coordinates: + 1 each); one row in registers at a time
+                    const int rb = lbase[rd] + ((1 - ky) * Wp - 1) * cchunk;
+                    VecF<2> dr[SW + 2];
+#pragma unroll
+                    for (int m = 0; m < SW + 2; ++m) dr[m] = vload<2>(&tile[rb + m * cchunk]);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int j = 0; j < SW; ++j)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                da[j].v[i] = fmaf(dr[j + 2 - kx].v[i], wk[ky * 3 + kx].v[i], da[j].v[i]);
+                                gf[ky * 3 + kx][i] = fmaf(A[rd][j].v[i], dr[j + 2 - kx].v[i], gf[ky * 3 + kx][i]);
+                            }
+                    if (ky == 1) {
+#pragma unroll
+                        for (int j = 0; j < SW; ++j)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) gf[9][i] += dr[j + 1].v[i];       // (columns beyond W hold zeros)
+                    }
+                    // One row of D in registers at a time (20 VGPRs, not 60): the accumulators are pinned here, so this row's FMAs are
+                    // complete before the next row's LDS reads are issued (pure arithmetic is otherwise sunk below all 30 reads)
+#pragma unroll
+                    for (int j = 0; j < SW; ++j) asm volatile("" : "+v"(da[j].v[0]), "+v"(da[j].v[1]));
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) asm volatile("" : "+v"(gf[ky * 3 + kx][0]), "+v"(gf[ky * 3 + kx][1]));
+                    asm volatile("" ::: "memory");
+                }
+                VecF<2> av[SW];
+#pragma unroll
+                for (int j = 0; j < SW; ++j) {
+                    av[j] = A[rd][j];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        if (!relu6_open(av[j].v[i])) da[j].v[i] = 0.0f;
+                }
+                if (slow1) {        // (rare: a channel whose |beta| / |gamma| would amplify the rounding of a beyond 1e-5 -- xhat1 from y1 itself)
+                    const uint32_t vo = (uint32_t)(pix0[rd] * C + c) * ESZ;
+#pragma unroll
+                    for (int j = 0; j < SW; ++j) av[j] = ldp(rsX, vo, (uint32_t)(j * C * ESZ));
+#pragma unroll
+                    for (int j = 0; j < SW; ++j) vdecode<2>(av[j], x);
+                }
+                float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < SW; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float xh = (av[j].v[i] - bt1.v[i]) * rg1.v[i];
+                        s1[i] += da[j].v[i];              // (masked / out-of-row pixels carry da = 0)
+                        s2[i] = fmaf(da[j].v[i], xh, s2[i]);
+                    }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    gb[0][i] += (double)s1[i];
+                    gb[1][i] += (double)s2[i];
+                }
+                if (dx_al) {
+                    const uint32_t vo = (uint32_t)(pix0[rd] * dx.ld + dx.coff + c) * ESZ;
+#pragma unroll
+                    for (int j = 0; j < SW; ++j) {
+                        const uint32_t voj = j < nx[rd] ? vo : OOR;
+                        if (ESZ == 2) __builtin_amdgcn_raw_buffer_store_b32(bf_pack(da[j].v[0], da[j].v[1]), rsO, voj, (uint32_t)(j * dx.ld * ESZ), 0);
+                        else {
+                            u32x2_t t;
+                            t[0] = __float_as_uint(da[j].v[0]);
+                            t[1] = __float_as_uint(da[j].v[1]);
+                            __builtin_amdgcn_raw_buffer_store_b64(t, rsO, voj, (uint32_t)(j * dx.ld * ESZ), 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < SW; ++j)
+                        if (j < nx[rd]) vstore_view<2, T>(dx, (int64_t)pix0[rd] + j, c, 0, false, da[j]);
+                }
+            }
+        }
+    }
+    block_colsum_mixed<10, 2>(tile, gf, gb, tx, ty, CX, CY, on, part_w + ((int64_t)g * nb + b) * 10 * C + c, part_bn + ((int64_t)g * nb + b) * 2 * C + c, C);
+}
+
+struct DwsGeom {
+    bool ok;
+    int sw, S, R, F, cchunk, nch, cx, cy, tile_floats;
+    size_t lds;
+};
+
+// strip geometry of the stride-1 backward; ok == false -> the pixel-mapped kernel runs
+static DwsGeom dws_geom(const DwfGeom& g, int H, int W, int C) {
+    DwsGeom d;
+    d.ok = false;
+    if (C % 2 != 0) return d;
+    static const int lds_kb = cdrl_getenv("CDRL_DWS_LDS_KB") ? atoi(cdrl_getenv("CDRL_DWS_LDS_KB")) : 56;
+    static const int max_thr = cdrl_getenv("CDRL_DWS_THREADS") ? atoi(cdrl_getenv("CDRL_DWS_THREADS")) : 384;
+    const size_t budget = (size_t)lds_kb * 1024;
+    // strips of 8 pixels when every thread then has ONE strip per tile batch (the activated strips live in registers across the
+    // barrier: 16 VGPRs per strip of 8), strips of 4 with up to 3 per thread otherwise
+    struct Try {
+        int sw, thr, rmax;
+    };
+    // strips of 8 pixels with ONE strip per thread and tile batch (the activated strip lives in registers across the barrier: 16 VGPRs),
+    // in workgroups of up to 384 threads, then up to 640 (11x15 frames: 22 strips x 29 channel pairs); strips of 4 with up to 3 per thread
+    // (whole pixel rows -- one channel chunk -- first: 232-byte accesses instead of 120-byte ones)
+    for (int nch = 1; nch <= 16; ++nch) {
+        const int cchunk = cdiv(C / 2, nch) * 2;
+        if (cchunk < 8 && nch > 1) break;
+        for (const Try t : {Try{8, max_thr, 1}, Try{8, 640, 1}, Try{4, max_thr, 3}}) {
+            const int sw = t.sw;
+            if (sw == 8 && W <= 4) continue;
+            const int S = cdiv(W, sw);
+            const int Wp = S * sw + 2, Hp = H + 2, NS1 = H * S;
+            const int cx = cchunk / 2;
+            const int maxcy = t.thr / cx;
+            if (maxcy < 1) continue;
+            const size_t lds1 = (size_t)Hp * Wp * cchunk * sizeof(float);
+            if (lds1 > budget) continue;
+            const int R = cdiv(NS1, maxcy);
+            if (R > t.rmax) continue;
+            int F = 1;
+            if (R == 1)
+                while (F * 2 <= g.fpb && g.fpb % (F * 2) == 0 && (size_t)(F * 2) * lds1 <= budget && F * 2 * NS1 <= maxcy) F *= 2;
+            d.ok = true;
+            d.sw = sw;
+            d.S = S;
+            d.R = R;
+            d.F = F;
+            d.cchunk = cchunk;
+            d.nch = cdiv(C, cchunk);
+            d.cx = cx;
+            d.cy = cdiv(F * NS1, R);
+            d.tile_floats = F * Hp * Wp * cchunk;
+            const size_t red = (size_t)d.cx * d.cy * (10 * 2 * sizeof(float) + 2 * 2 * sizeof(double));
+            d.lds = std::max((size_t)(d.tile_floats + 16 * cchunk) * sizeof(float), red);
+            return d;
+        }
+    }
+    return d;
+}
+
+template <int SW, int R, class T>
+static int launch_dws_bwd(const DwfGeom& g, const DwsGeom& d, hipStream_t st, const float* x, const float* pre_stats, const float* dout,
+                          const float* y2, const float* post_stats, const float* post_coef, const float* w, View dx, double* part_bn,
+                          double* part_w, int G, int B, int H, int W, int C) {
+    static const bool reload_y1 = cdrl_getenv("CDRL_DWF_XHAT_RELOAD") && atoi(cdrl_getenv("CDRL_DWF_XHAT_RELOAD")) == 1;
+    CDRL_TRY((allow_lds<dws_bwd_kernel<SW, R, T>>(d.lds)));
+    hipLaunchKernelGGL((dws_bwd_kernel<SW, R, T>), dim3(cdiv(G * g.nb, 8) * 8 * d.nch), dim3(d.cx, d.cy), d.lds, st,
+                       reinterpret_cast<const T*>(x), pre_stats, reinterpret_cast<const T*>(dout), reinterpret_cast<const T*>(y2), post_stats,
+                       post_coef, w, dx, part_bn, part_w, B, H, W, C, G * C, g.fpb, g.nb, d.cchunk, view_aligned(dx, 2), G * g.nb, reload_y1,
+                       d.F, d.S, d.tile_floats);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int S, int VEC, bool PRE, class T>
 static int launch_dwf_fwd(const DwfGeom& g, hipStream_t st, const float* x, const float* pre_stats, const float* w,
                           const float* bias, float* y, double* part, int G, int B, int H, int W, int C) {
@@ -647,6 +993,23 @@ int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const flo
         return -1;
     }
     DwfGeom g = dwf_geom(B, G, H, W, C, stride);
+    // stride 1 behind a pre-BN (every stride-1 unit of the tower): the strip form
+    static const bool strips = !(cdrl_getenv("CDRL_DWS") && atoi(cdrl_getenv("CDRL_DWS")) == 0);
+    if (strips && stride == 1 && pre_stats && (int64_t)G * B * H * W * std::max(C, dx.ld) * 4 < (int64_t)1 << 31) {
+        const DwsGeom d = dws_geom(g, H, W, C);
+        if (d.ok) {
+#define CDRL_DWS(SWV, RV)                                                                                                                         \
+    return at ? launch_dws_bwd<SWV, RV, bf16_t>(g, d, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C) \
+              : launch_dws_bwd<SWV, RV, float>(g, d, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C)
+            if (d.sw == 4) {
+                if (d.R == 1) CDRL_DWS(4, 1);
+                if (d.R == 2) CDRL_DWS(4, 2);
+                CDRL_DWS(4, 3);
+            }
+            CDRL_DWS(8, 1);
+#undef CDRL_DWS
+        }
+    }
     // Four channels per thread -- half the load / LDS / address instructions per element, 214-256 VGPRs, two waves per SIMD instead of
     // three or four.  CDRL_DWF_BWD_VEC4 = bit mask: 1 float32 stride 1, 2 float32 stride 2, 4 bf16 storage stride 1, 8 bf16 storage
     // stride 2.  Measured on one box each: mask 1 -> 14.77 vs 14.83 ms per update-step (float32; two boxes), mask 2 -> +-0.0, mask 4 -> 30.4

@@ -299,11 +299,13 @@ class PPOAgent(Agent):
         if not all(rollout.terminal):
             t_last = max(rollout.length)
             estimate = self.network.predict_last_value(rollout.final, timestep=(t_last + 1) / timesteps, is_terminal=False)
+        # `append` (reference: update_frequency > 1) = the memory's row index advances PAST rows only, because the bootstrap entry of
+        # this trajectory is removed again before the next one arrives -- also the case between the trajectories of a shard
+        append = self.update_frequency > 1 or E > 1
         for e in range(E):
-            first = e == 0 and self.update_frequency == 1
             self.memory.extend(*rollout.trajectory(e))
             last_value = (self.network.predict_last_value(None, is_terminal=True) if rollout.terminal[e] else estimate[e:e + 1])
-            self.end_episode(last_value, append=not first)
+            self.end_episode(last_value, append=append)
             self.trajectory_stored(e, rollout)
             if keep_open or e < E - 1:
                 self.memory.drop_bootstrap()
