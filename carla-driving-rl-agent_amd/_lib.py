@@ -114,6 +114,7 @@ PROTOTYPES = {
     'cdrl_learner_trunk_forward_train': (_i, [_L, _fp, _fp, _fp, _fp, _fp]),
     'cdrl_learner_get_buffer': (_i, [_L, _i, C.POINTER(_fp), C.POINTER(_i64)]),
     'cdrl_learner_named_buffer': (_i, [_L, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
+    'cdrl_learner_check_guards': (_i, [_L, _fp, C.POINTER(_i64), C.POINTER(_i64)]),
     'cdrl_gae_returns': (_i, [_fp, _fp, _i, _d, _d, _f, _fp, _fp, _fp, _fp, _fp, _fp]),
     'cdrl_gather_rows': (_i, [_fp, _fp, _fp, _i, _i64, _fp]),
     'cdrl_gemm_nn': (_i, [_fp, _i, _i, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),

@@ -405,6 +405,11 @@ int cdrl_learner_named_buffer(const cdrl_learner* l, const char* name, void** pt
     return 0;
 }
 
+int cdrl_learner_check_guards(cdrl_learner* l, void* stream, int64_t* bad_bands, int64_t* first_bad_offset) {
+    CHECK_L(l);
+    return l->impl->check_guards(S(stream), bad_bands, first_bad_offset);
+}
+
 int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double gamma, double lambda, float scale,
                      float* returns, float* returns_be, float* adv_raw, float* adv, double* scratch, void* stream) {
     if (!rewards || !values_be || !returns || !returns_be || !adv_raw || !adv || !scratch) {
@@ -786,10 +791,10 @@ int cdrl_dwconv_bn_bwd(const float* x, const float* pre_stats, const float* dout
     CDRL_TRY(bn_bwd_reduce(vd, 0, vy, G, Mo, C, post_stats, ACT_NONE, part_r, st, nullptr, nullptr, nullptr, 0, g_op_at));
     CDRL_TRY(bn_bwd_finalize(part_r, vcol_geom(Mo, C).nb, G, Mo, C, post_stats, dgamma_post, dbeta_post, coef_post, st));
     CDRL_TRY(dwf_bwd(x, pre_stats, dout, y, post_stats, coef_post, w, make_view(dx, C), part_bn, part_w, G, B, H, W, C, stride, st, g_op_at));
-    CDRL_TRY(reduce_partials(part_w, G * g.nb, 9 * C, (int64_t)10 * C, dw, 0, st));
-    CDRL_TRY(reduce_partials(part_w + 9 * C, G * g.nb, C, (int64_t)10 * C, db, 0, st));
+    CDRL_TRY(reduce_partials(part_w, G * g.nb_bwd, 9 * C, (int64_t)10 * C, dw, 0, st));
+    CDRL_TRY(reduce_partials(part_w + 9 * C, G * g.nb_bwd, C, (int64_t)10 * C, db, 0, st));
     if (pre_stats) {
-        CDRL_TRY(bn_bwd_finalize(part_bn, g.nb, G, Mi, C, pre_stats, dgamma_pre, dbeta_pre, coef_pre, st));
+        CDRL_TRY(bn_bwd_finalize(part_bn, g.nb_bwd, G, Mi, C, pre_stats, dgamma_pre, dbeta_pre, coef_pre, st));
         View vx = make_view(const_cast<float*>(x), C);
         CDRL_TRY(bn_bwd_apply(make_view(dx, C), 0, vx, G, Mi, C, pre_stats, coef_pre, ACT_NONE, dx, part_r, st, nullptr, 0, g_op_at));
     }

@@ -192,10 +192,18 @@ int64_t dw_bwd_part_elems(int N, int H, int W, int C, int stride);
 int dw_bwd_filter(View a, const float* dy, float* dw, float* db, int N, int H, int W, int C, int stride,
                   double* part, hipStream_t st);
 // ---- fused depthwise block (dwfused.hip): whole frames staged in LDS.  G groups x B frames per group.
+// strip form of the backward (round 5): thread = channel pair x row strip of `sw` pixels; ok == false -> the pixel-mapped kernel runs
+struct DwsGeom {
+    bool ok;
+    int sw, S, R, F, cchunk, nch, cx, cy, wdp, tile_floats;    // S strips per row, R strips per thread and tile batch (stride 1), F frames
+    size_t lds;                                                // per tile batch, wdp padded tile width (stride 2)
+};
 struct DwfGeom {
-    int vec, nch, cchunk, cx, cy, fpb, nb;     // nb: partial blocks per group (B / frames-per-block)
+    int vec, nch, cchunk, cx, cy, fpb, nb;     // nb: partial blocks per group (B / frames-per-block) of the FORWARD kernel
     int vec_bwd, cx_bwd, cy_bwd;               // backward lane shape (fewer channels per thread: register budget)
     size_t lds_fwd, lds_bwd;
+    int fpb_bwd, nb_bwd;                       // frames per workgroup / partial rows per group of the BACKWARD kernel
+    DwsGeom strip;
 };
 DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride);
 int64_t dwf_stats_part_elems(int B, int G, int H, int W, int C, int stride);      // doubles: [G][nb][2][C]

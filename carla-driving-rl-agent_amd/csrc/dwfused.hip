@@ -41,9 +41,11 @@ static constexpr size_t DWF_LDS_BUDGET = 38 * 1024;
 #define DWF_T_BWD 512
 #define DWF_T_FWD_DEFAULT 256                            // (tunable: CDRL_DWF_TF / CDRL_DWF_TB, <= the maxima above; 256 vs 512 forward: -0.1 ms/update-step at v39)
 #define DWF_T_BWD_DEFAULT 256
-#define DWF_BWD_VEC4_DEFAULT 0                           // CDRL_DWF_BWD_VEC4 (dwf_bwd)
 #define DWF_UF 8                                         // forward: loads in flight per thread (one tensor)
 #define DWF_U 4                                          // global loads in flight per thread in the tile loads
+
+static DwsGeom dws_geom(int B, int G, int fpb, int H, int W, int C);
+static DwsGeom dws2_geom(int B, int G, int fpb, int H, int W, int C);
 
 DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     DwfGeom g;
@@ -105,7 +107,7 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     g.nb = B / fpb;
     // backward: 12 double accumulators per channel lane -> at 4 channels per thread the kernel needs > 256 VGPRs (one
     // workgroup per CU); 2 channels per thread keep it at ~150 (3 waves / SIMD)
-    g.vec_bwd = g.vec > 2 ? 2 : g.vec;      // (dwf_bwd may widen it: dwf_bwd_lanes)
+    g.vec_bwd = g.vec > 2 ? 2 : g.vec;
     g.cx_bwd = g.cchunk / g.vec_bwd;
     g.cy_bwd = t_bwd / g.cx_bwd;
     if (g.cy_bwd > Po_) g.cy_bwd = Po_;
@@ -116,14 +118,38 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     g.lds_bwd = (a_px + d_px) * g.cchunk * sizeof(float);
     if (g.lds_fwd < red_f) g.lds_fwd = red_f;
     if (g.lds_bwd < red_b) g.lds_bwd = red_b;
+    // Backward in strip form (whole pixel rows per workgroup where LDS allows): its own frames-per-workgroup count -- the largest
+    // power of two (<= 8) that still leaves CDRL_DWS_WGS workgroups.  Measured on the seven shapes of the 90x120 tower at B = 256
+    // (isolated, cold; 128 | 256 | 512 | 1024 workgroups): ONE workgroup of 6-10 waves per CU is the optimum -- 11x15x58 - | 38.5 | 43.3 |
+    // 52.1 us, 6x8x116 35.7 | 26.7 | 31.0 | 39.6, stride 2: 22x30x58 141 | 83.6 | 86.4 | 93.8, 11x15x116 79.2 | 48.9 | 52.8 | 61.1 -- except
+    // for the 3x4 frames (18.0 | 16.2 at 256 | 512): frames of <= 16 pixels take two per CU
+    g.fpb_bwd = g.fpb;
+    g.nb_bwd = g.nb;
+    g.strip.ok = false;
+    static const bool strips = !(cdrl_getenv("CDRL_DWS") && atoi(cdrl_getenv("CDRL_DWS")) == 0);
+    static const int want_env = cdrl_getenv("CDRL_DWS_WGS") ? atoi(cdrl_getenv("CDRL_DWS_WGS")) : 0;
+    const int want_wgs = want_env ? want_env : (H * W <= 16 ? 512 : 256);
+    if (strips && (stride == 1 || stride == 2) && (int64_t)G * B * H * W * C * 8 < (int64_t)1 << 31) {
+        // (the channel-chunk count of the plan does not depend on fpb: plan with 1 first)
+        DwsGeom d = stride == 1 ? dws_geom(B, G, 1, H, W, C) : dws2_geom(B, G, 1, H, W, C);
+        if (d.ok) {
+            int fb = 1;
+            while (fb < 8 && B % (fb * 2) == 0 && (int64_t)G * (B / (fb * 2)) * d.nch >= want_wgs) fb *= 2;
+            g.strip = stride == 1 ? dws_geom(B, G, fb, H, W, C) : dws2_geom(B, G, fb, H, W, C);
+            g.fpb_bwd = fb;
+            g.nb_bwd = B / fb;
+        }
+    }
     return g;
 }
 
 int64_t dwf_stats_part_elems(int B, int G, int H, int W, int C, int stride) {
-    return (int64_t)G * dwf_geom(B, G, H, W, C, stride).nb * 2 * C;
+    const DwfGeom g = dwf_geom(B, G, H, W, C, stride);
+    return (int64_t)G * std::max(g.nb, g.nb_bwd) * 2 * C;
 }
 int64_t dwf_filter_part_elems(int B, int G, int H, int W, int C, int stride) {
-    return (int64_t)G * dwf_geom(B, G, H, W, C, stride).nb * 10 * C;
+    const DwfGeom g = dwf_geom(B, G, H, W, C, stride);
+    return (int64_t)G * std::max(g.nb, g.nb_bwd) * 10 * C;
 }
 
 // reduce one double per (channel lane, vec) over the pixel lanes through LDS; result valid on ty == 0
@@ -603,7 +629,7 @@ __device__ __forceinline__ void block_colsum_mixed(float* smf, float (&a)[NF][2]
             if (on) outf[(int64_t)q * qstride + i] = s;
         } else {
             for (int y = 0; y < CY; ++y) s += smd[(((q - NF) * CY + y) * 2 + i) * CX + tx];
-            if (on) outd[(int64_t)(q - NF) * qstride + i] = s;
+            if (on && outd) outd[(int64_t)(q - NF) * qstride + i] = s;
         }
     }
 }
@@ -611,7 +637,7 @@ __device__ __forceinline__ void block_colsum_mixed(float* smf, float (&a)[NF][2]
 #ifndef DWS_LB
 #define DWS_LB 640
 #endif
-template <int SW, int R, class T>
+template <int SW, int R, bool PRE, class T>
 __global__ void __launch_bounds__(DWS_LB) dws_bwd_kernel(const T* __restrict__ x, const float* __restrict__ pre_stats, const T* __restrict__ dout,
                                                       const T* __restrict__ y2, const float* __restrict__ post_stats,
                                                       const float* __restrict__ post_coef, const float* __restrict__ w, View dx,
@@ -638,10 +664,20 @@ __global__ void __launch_bounds__(DWS_LB) dws_bwd_kernel(const T* __restrict__ x
     // the window phase the 9 filter taps -- read where they are used, they are not live across the other phase (~30 VGPRs)
     const int ctab = tile_floats + tx * 2;             // entry e of this lane's channel pair: tile[ctab + e * cchunk]
     VecF<2> bt1, rg1;
-    bool slow1 = reload_y1;
+    bool slow1 = PRE && reload_y1;
     {
-        const VecF<2> mean1 = vload<2>(pre_stats + 0 * GC + g * C + c), inv1 = vload<2>(pre_stats + 1 * GC + g * C + c);
-        const VecF<2> sc = vload<2>(pre_stats + 2 * GC + g * C + c), sh = vload<2>(pre_stats + 3 * GC + g * C + c);
+        VecF<2> mean1, inv1, sc, sh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            mean1.v[i] = sh.v[i] = 0.0f;        // (no pre-BN: the identity, never used)
+            inv1.v[i] = sc.v[i] = 1.0f;
+        }
+        if (PRE) {
+            mean1 = vload<2>(pre_stats + 0 * GC + g * C + c);
+            inv1 = vload<2>(pre_stats + 1 * GC + g * C + c);
+            sc = vload<2>(pre_stats + 2 * GC + g * C + c);
+            sh = vload<2>(pre_stats + 3 * GC + g * C + c);
+        }
         if (ty == 0) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) vstore<2>(&tile[ctab + k * cchunk], vload<2>(w + k * C + c));
@@ -730,7 +766,7 @@ __global__ void __launch_bounds__(DWS_LB) dws_bwd_kernel(const T* __restrict__ x
                     VecF<2> o;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const float a = fminf(fmaxf(fmaf(sc.v[i], xa[j].v[i], sh.v[i]), 0.0f), 6.0f);
+                        const float a = PRE ? fminf(fmaxf(fmaf(sc.v[i], xa[j].v[i], sh.v[i]), 0.0f), 6.0f) : xa[j].v[i];
                         A[rd][j].v[i] = j < nx[rd] ? a : 0.0f;
                         const float xh = (v[j].v[i] - mean2.v[i]) * inv2.v[i];
                         o.v[i] = k1.v[i] * (d[j].v[i] - k2.v[i] - xh * k3.v[i]);
@@ -780,6 +816,7 @@ __global__ void __launch_bounds__(DWS_LB) dws_bwd_kernel(const T* __restrict__ x
                     for (int kx = 0; kx < 3; ++kx) asm volatile("" : "+v"(gf[ky * 3 + kx][0]), "+v"(gf[ky * 3 + kx][1]));
                     asm volatile("" ::: "memory");
                 }
+                if (PRE) {
                 VecF<2> av[SW];
 #pragma unroll
                 for (int j = 0; j < SW; ++j) {
@@ -809,6 +846,7 @@ __global__ void __launch_bounds__(DWS_LB) dws_bwd_kernel(const T* __restrict__ x
                     gb[0][i] += (double)s1[i];
                     gb[1][i] += (double)s2[i];
                 }
+                }
                 if (dx_al) {
                     const uint32_t vo = (uint32_t)(pix0[rd] * dx.ld + dx.coff + c) * ESZ;
 #pragma unroll
@@ -830,17 +868,288 @@ __global__ void __launch_bounds__(DWS_LB) dws_bwd_kernel(const T* __restrict__ x
             }
         }
     }
-    block_colsum_mixed<10, 2>(tile, gf, gb, tx, ty, CX, CY, on, part_w + ((int64_t)g * nb + b) * 10 * C + c, part_bn + ((int64_t)g * nb + b) * 2 * C + c, C);
+    block_colsum_mixed<10, 2>(tile, gf, gb, tx, ty, CX, CY, on, part_w + ((int64_t)g * nb + b) * 10 * C + c,
+                              PRE ? part_bn + ((int64_t)g * nb + b) * 2 * C + c : nullptr, C);
 }
 
-struct DwsGeom {
-    bool ok;
-    int sw, S, R, F, cchunk, nch, cx, cy, tile_floats;
-    size_t lds;
-};
+// Stride-2 backward in strip form.  An input pixel (iy, ix) meets the taps k with ky = (iy + pt) mod 2 (+ 2), kx = (ix + pl) mod 2 (+ 2):
+// 1, 2 or 4 of the 9, at D[(iy + pt - ky) / 2][(ix + pl - kx) / 2].  A thread owns a channel pair and walks input-row strips of 8
+// pixels: the column parities inside a strip are compile-time constants (PL = pl), the row parity is a per-strip select between filter
+// rows (no divergent code), and a strip reads 2 rows x 5 columns of D from LDS for its 8 pixels.  The D tile (BatchNorm-backward applied
+// on load, bias gradient summed by the producing thread) is built first from the output-sized tensors; the 4x larger input is streamed
+// through registers only: load strip -> [BN1 apply + ReLU6] -> da, dW += a (x) D -> mask -> BN1 sums -> store.
+template <int PL, bool PRE, class T>
+__global__ void __launch_bounds__(512) dws2_bwd_kernel(const T* __restrict__ x, const float* __restrict__ pre_stats, const T* __restrict__ dout,
+                                                       const T* __restrict__ y2, const float* __restrict__ post_stats,
+                                                       const float* __restrict__ post_coef, const float* __restrict__ w, View dx,
+                                                       double* __restrict__ part_bn, double* __restrict__ part_w, int Bf, int H, int W, int Ho,
+                                                       int Wo, int C, int GC, int pt, int fpb, int nb, int cchunk, bool dx_al, int nfb,
+                                                       bool reload_y1, int F, int S, int Wdp, int tile_floats) {
+    constexpr int SW = 8, ND = SW / 2 + 1 + PL;     // D columns a strip touches per row
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // D: [F][Ho + 2][Wdp][cchunk] (zero frame) | coefficient table [16][cchunk]
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int CX = blockDim.x, CY = blockDim.y;
+    const int nch_ = (C + cchunk - 1) / cchunk;
+    const int q_ = blockIdx.x >> 3;
+    const int fb_ = (q_ / nch_) * 8 + (blockIdx.x & 7);
+    if (fb_ >= nfb) return;
+    const int g = fb_ / nb, b = fb_ % nb;
+    const int cbase = (q_ % nch_) * cchunk;
+    const int cc = min(cchunk, C - cbase);
+    const bool on = tx * 2 < cc;
+    const int c = cbase + (on ? tx * 2 : 0);
+    const int P = H * W, Po = Ho * Wo, Hdp = Ho + 2;
+    for (int i = (ty * CX + tx) * 2; i < tile_floats; i += CX * CY * 2) *reinterpret_cast<float2*>(&tile[i]) = make_float2(0.0f, 0.0f);
+    const int ctab = tile_floats + tx * 2;
+    VecF<2> bt1, rg1, sc, sh;
+    bool slow1 = reload_y1;
+    if (PRE) {
+        const VecF<2> mean1 = vload<2>(pre_stats + 0 * GC + g * C + c), inv1 = vload<2>(pre_stats + 1 * GC + g * C + c);
+        sc = vload<2>(pre_stats + 2 * GC + g * C + c);
+        sh = vload<2>(pre_stats + 3 * GC + g * C + c);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) slow1 |= !((6.0f + fabsf(fmaf(mean1.v[i], sc.v[i], sh.v[i]))) * fabsf(inv1.v[i]) <= 170.0f * fabsf(sc.v[i]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bt1.v[i] = slow1 ? mean1.v[i] : fmaf(mean1.v[i], sc.v[i], sh.v[i]);
+            rg1.v[i] = slow1 ? inv1.v[i] : inv1.v[i] / sc.v[i];
+        }
+    }
+    if (ty == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) vstore<2>(&tile[ctab + k * cchunk], vload<2>(w + k * C + c));
+        vstore<2>(&tile[ctab + 11 * cchunk], vload<2>(post_stats + 0 * GC + g * C + c));
+        vstore<2>(&tile[ctab + 12 * cchunk], vload<2>(post_stats + 1 * GC + g * C + c));
+        vstore<2>(&tile[ctab + 13 * cchunk], vload<2>(post_coef + 0 * GC + g * C + c));
+        vstore<2>(&tile[ctab + 14 * cchunk], vload<2>(post_coef + 1 * GC + g * C + c));
+        vstore<2>(&tile[ctab + 15 * cchunk], vload<2>(post_coef + 2 * GC + g * C + c));
+    }
+    float gf[10][2];
+    double gb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        gb[0][i] = gb[1][i] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) gf[k][i] = 0.0f;
+    }
+    constexpr uint32_t OOR = 0x80000000u;
+    constexpr int ESZ = (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)((int64_t)nfb * fpb * P * C * ESZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dout), 0, (int)((int64_t)nfb * fpb * Po * C * ESZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(y2), 0, (int)((int64_t)nfb * fpb * Po * C * ESZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(vptr<T>(dx), 0, (int)((int64_t)nfb * fpb * P * dx.ld * ESZ), 0x00020000);
+    auto ldp = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t vo, uint32_t so) -> VecF<2> {
+        VecF<2> r;
+        if (ESZ == 2) {
+            r.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+            r.v[1] = 0.0f;
+        } else {
+            const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+            r.v[0] = __uint_as_float(t[0]);
+            r.v[1] = __uint_as_float(t[1]);
+        }
+        return r;
+    };
+    const int So = (Wo + 3) >> 2;                       // output strips of 4 pixels (tile construction)
+    const int NO1 = Ho * So, NS1 = H * S;
+    const float invNO1 = 1.0f / (float)NO1, invSo = 1.0f / (float)So, invNS1 = 1.0f / (float)NS1, invS = 1.0f / (float)S;
+    for (int f0 = 0; f0 < fpb; f0 += F) {
+        __syncthreads();                                 // the previous batch's windows have been read (first pass: table + zeros written)
+        {
+            const VecF<2> mean2 = vload<2>(&tile[ctab + 11 * cchunk]), inv2 = vload<2>(&tile[ctab + 12 * cchunk]);
+            const VecF<2> k1 = vload<2>(&tile[ctab + 13 * cchunk]), k2 = vload<2>(&tile[ctab + 14 * cchunk]), k3 = vload<2>(&tile[ctab + 15 * cchunk]);
+            for (int s = ty; s < F * NO1; s += CY) {
+                const int fl = (int)(((float)s + 0.5f) * invNO1);
+                const int rem = s - fl * NO1;
+                const int r = (int)(((float)rem + 0.5f) * invSo);
+                const int x0 = (rem - r * So) * 4;
+                const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f0 + fl;
+                const int nxo = min(4, Wo - x0);
+                const uint32_t vo = on ? (uint32_t)(((int)(n * Po) + r * Wo + x0) * C + c) * ESZ : OOR;
+                VecF<2> d[4], v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    d[j] = ldp(rsD, vo, (uint32_t)(j * C * ESZ));
+                    v[j] = ldp(rsY, vo, (uint32_t)(j * C * ESZ));
+                }
+                const int lb = ((fl * Hdp + r + 1) * Wdp + x0 + 1) * cchunk + tx * 2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vdecode<2>(d[j], x);
+                    vdecode<2>(v[j], x);
+                    VecF<2> o;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float xh = (v[j].v[i] - mean2.v[i]) * inv2.v[i];
+                        o.v[i] = k1.v[i] * (d[j].v[i] - k2.v[i] - xh * k3.v[i]);
+                    }
+                    if (on && j < nxo) {
+                        vstore<2>(&tile[lb + j * cchunk], o);
+                        gf[9][0] += o.v[0];
+                        gf[9][1] += o.v[1];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            // strips of the input, streamed through registers; the NEXT strip's 8 loads are in flight while this one is computed
+            const int NSB = F * NS1;
+            auto coords = [&](int s, int& fl, int& r, int& x0, int& pix0) {
+                fl = (int)(((float)s + 0.5f) * invNS1);
+                const int rem = s - fl * NS1;
+                r = (int)(((float)rem + 0.5f) * invS);
+                x0 = (rem - r * S) * SW;
+                const int64_t n = (int64_t)g * Bf + (int64_t)b * fpb + f0 + fl;
+                pix0 = (int)(n * P) + r * W + x0;
+            };
+            VecF<2> nxt[SW];
+            {
+                int fl, r, x0, pix0;
+                coords(min(ty, NSB - 1), fl, r, x0, pix0);
+                const uint32_t vo = (on && ty < NSB) ? (uint32_t)(pix0 * C + c) * ESZ : OOR;
+#pragma unroll
+                for (int j = 0; j < SW; ++j) nxt[j] = ldp(rsX, vo, (uint32_t)(j * C * ESZ));
+            }
+            for (int s = ty; s < NSB; s += CY) {
+                int fl, r, x0, pix0;
+                coords(s, fl, r, x0, pix0);
+                const int nx = on ? min(SW, W - x0) : 0;
+                const uint32_t vo = on ? (uint32_t)(pix0 * C + c) * ESZ : OOR;
+                VecF<2> A[SW], av[SW];
+#pragma unroll
+                for (int j = 0; j < SW; ++j) av[j] = nxt[j];
+                {
+                    int fl2, r2, x02, pix02;
+                    const int s2 = s + CY;
+                    coords(min(s2, NSB - 1), fl2, r2, x02, pix02);
+                    const uint32_t vo2 = (on && s2 < NSB) ? (uint32_t)(pix02 * C + c) * ESZ : OOR;
+#pragma unroll
+                    for (int j = 0; j < SW; ++j) nxt[j] = ldp(rsX, vo2, (uint32_t)(j * C * ESZ));
+                }
+                const int ny = r + pt;
+                const bool odd = ny & 1;
+                const int oyA = ny >> 1;                                 // D row of tap row kyA = odd ? 1 : 0; row B = oyA - 1 (tap row 2, even only)
+                // (filter rows from the LDS table, selected by address: row kyA = odd ? 1 : 0 against D row A, row 2 -- even strips only -- against row B)
+                VecF<2> wa[3], wb[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    wa[kx] = vload<2>(&tile[ctab + ((odd ? 3 : 0) + kx) * cchunk]);
+                    wb[kx] = vload<2>(&tile[ctab + (6 + kx) * cchunk]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) wb[kx].v[i] = odd ? 0.0f : wb[kx].v[i];
+                }
+                // D columns (x0 + PL) / 2 - 1 + m, m = 0 .. ND - 1 (padded coordinates: + 1)
+                const int lb = ((fl * Hdp + oyA + 1) * Wdp + ((x0 + PL) >> 1)) * cchunk + tx * 2;
+                VecF<2> da_[2][ND];
+#pragma unroll
+                for (int m = 0; m < ND; ++m) {
+                    da_[0][m] = vload<2>(&tile[lb + m * cchunk]);
+                    da_[1][m] = vload<2>(&tile[lb + (m - Wdp) * cchunk]);
+                }
+#pragma unroll
+                for (int j = 0; j < SW; ++j) {
+                    vdecode<2>(av[j], x);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float a = PRE ? fminf(fmaxf(fmaf(sc.v[i], av[j].v[i], sh.v[i]), 0.0f), 6.0f) : av[j].v[i];
+                        A[j].v[i] = j < nx ? a : 0.0f;
+                    }
+                }
+                VecF<2> da[SW];
+                float ca[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}}, cb[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma unroll
+                for (int j = 0; j < SW; ++j) {
+                    // nx_j = x0 + j + PL; column index into the 5-wide window: (j + PL') with PL' = (x0 + PL) & 1 = PL (x0 is even)
+                    const int e = j + PL;                  // nx - (first window column's nx) ... the window starts at ox = (x0 + PL) / 2 - 1
+                    da[j].v[0] = da[j].v[1] = 0.0f;
+                    if ((e & 1) == 0) {                    // even column parity: taps kx = 0 (ox = e / 2) and kx = 2 (ox = e / 2 - 1)
+                        const int m0 = (e >> 1) + 1, m2 = (e >> 1);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            da[j].v[i] = fmaf(da_[0][m0].v[i], wa[0].v[i], da[j].v[i]);
+                            da[j].v[i] = fmaf(da_[0][m2].v[i], wa[2].v[i], da[j].v[i]);
+                            da[j].v[i] = fmaf(da_[1][m0].v[i], wb[0].v[i], da[j].v[i]);
+                            da[j].v[i] = fmaf(da_[1][m2].v[i], wb[2].v[i], da[j].v[i]);
+                            ca[0][i] = fmaf(A[j].v[i], da_[0][m0].v[i], ca[0][i]);
+                            ca[2][i] = fmaf(A[j].v[i], da_[0][m2].v[i], ca[2][i]);
+                            cb[0][i] = fmaf(A[j].v[i], da_[1][m0].v[i], cb[0][i]);
+                            cb[2][i] = fmaf(A[j].v[i], da_[1][m2].v[i], cb[2][i]);
+                        }
+                    } else {                               // odd: tap kx = 1 at ox = (e - 1) / 2
+                        const int m1 = ((e - 1) >> 1) + 1;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            da[j].v[i] = fmaf(da_[0][m1].v[i], wa[1].v[i], da[j].v[i]);
+                            da[j].v[i] = fmaf(da_[1][m1].v[i], wb[1].v[i], da[j].v[i]);
+                            ca[1][i] = fmaf(A[j].v[i], da_[0][m1].v[i], ca[1][i]);
+                            cb[1][i] = fmaf(A[j].v[i], da_[1][m1].v[i], cb[1][i]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        gf[kx][i] += odd ? 0.0f : ca[kx][i];
+                        gf[3 + kx][i] += odd ? ca[kx][i] : 0.0f;
+                        gf[6 + kx][i] += odd ? 0.0f : cb[kx][i];
+                    }
+                if (PRE) {
+#pragma unroll
+                    for (int j = 0; j < SW; ++j)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (!relu6_open(A[j].v[i])) da[j].v[i] = 0.0f;
+                    if (slow1) {
+#pragma unroll
+                        for (int j = 0; j < SW; ++j) A[j] = ldp(rsX, vo, (uint32_t)(j * C * ESZ));
+#pragma unroll
+                        for (int j = 0; j < SW; ++j) vdecode<2>(A[j], x);
+                    }
+                    float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < SW; ++j)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const float xh = (A[j].v[i] - bt1.v[i]) * rg1.v[i];
+                            const float dv = j < nx ? da[j].v[i] : 0.0f;
+                            s1[i] += dv;
+                            s2[i] = fmaf(dv, xh, s2[i]);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        gb[0][i] += (double)s1[i];
+                        gb[1][i] += (double)s2[i];
+                    }
+                }
+                if (dx_al) {
+                    const uint32_t vd = (uint32_t)(pix0 * dx.ld + dx.coff + c) * ESZ;
+#pragma unroll
+                    for (int j = 0; j < SW; ++j) {
+                        const uint32_t voj = j < nx ? vd : OOR;
+                        if (ESZ == 2) __builtin_amdgcn_raw_buffer_store_b32(bf_pack(da[j].v[0], da[j].v[1]), rsO, voj, (uint32_t)(j * dx.ld * ESZ), 0);
+                        else {
+                            u32x2_t t;
+                            t[0] = __float_as_uint(da[j].v[0]);
+                            t[1] = __float_as_uint(da[j].v[1]);
+                            __builtin_amdgcn_raw_buffer_store_b64(t, rsO, voj, (uint32_t)(j * dx.ld * ESZ), 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < SW; ++j)
+                        if (j < nx) vstore_view<2, T>(dx, (int64_t)pix0 + j, c, 0, false, da[j]);
+                }
+            }
+        }
+    }
+    block_colsum_mixed<10, 2>(tile, gf, gb, tx, ty, CX, CY, on, part_w + ((int64_t)g * nb + b) * 10 * C + c,
+                              PRE ? part_bn + ((int64_t)g * nb + b) * 2 * C + c : nullptr, C);
+}
 
 // strip geometry of the stride-1 backward; ok == false -> the pixel-mapped kernel runs
-static DwsGeom dws_geom(const DwfGeom& g, int H, int W, int C) {
+static DwsGeom dws_geom(int B, int G, int fpb, int H, int W, int C) {
     DwsGeom d;
     d.ok = false;
     if (C % 2 != 0) return d;
@@ -872,7 +1181,7 @@ static DwsGeom dws_geom(const DwfGeom& g, int H, int W, int C) {
             if (R > t.rmax) continue;
             int F = 1;
             if (R == 1)
-                while (F * 2 <= g.fpb && g.fpb % (F * 2) == 0 && (size_t)(F * 2) * lds1 <= budget && F * 2 * NS1 <= maxcy) F *= 2;
+                while (F * 2 <= fpb && fpb % (F * 2) == 0 && (size_t)(F * 2) * lds1 <= budget && F * 2 * NS1 <= maxcy) F *= 2;
             d.ok = true;
             d.sw = sw;
             d.S = S;
@@ -891,15 +1200,66 @@ static DwsGeom dws_geom(const DwfGeom& g, int H, int W, int C) {
     return d;
 }
 
-template <int SW, int R, class T>
+static DwsGeom dws2_geom(int B, int G, int fpb, int H, int W, int C) {
+    DwsGeom d;
+    d.ok = false;
+    if (C % 2 != 0) return d;
+    static const int lds_kb = cdrl_getenv("CDRL_DWS_LDS_KB") ? atoi(cdrl_getenv("CDRL_DWS_LDS_KB")) : 60;
+    static const int max_thr = cdrl_getenv("CDRL_DWS2_THREADS") ? atoi(cdrl_getenv("CDRL_DWS2_THREADS")) : 384;
+    const int Ho = same_out(H, 2), Wo = same_out(W, 2);
+    const int S = cdiv(W, 8), NS1 = H * S;
+    const int Wdp = std::max(4 * S + 2, Wo + 2), Hdp = Ho + 2;
+    for (int nch = 1; nch <= 16; ++nch) {
+        const int cchunk = cdiv(C / 2, nch) * 2;
+        if (cchunk < 8 && nch > 1) break;
+        const int cx = cchunk / 2;
+        const int maxcy = max_thr / cx;
+        if (maxcy < 1) continue;
+        const size_t lds1 = (size_t)Hdp * Wdp * cchunk * sizeof(float);
+        if (lds1 > (size_t)lds_kb * 1024) continue;
+        int F = 1;
+        while (F * 2 <= fpb && fpb % (F * 2) == 0 && (size_t)(F * 2) * lds1 <= (size_t)lds_kb * 1024 && F * NS1 < maxcy) F *= 2;
+        d.ok = true;
+        d.sw = 8;
+        d.S = S;
+        d.R = 1;
+        d.wdp = Wdp;
+        d.F = F;
+        d.cchunk = cchunk;
+        d.nch = cdiv(C, cchunk);
+        d.cx = cx;
+        d.cy = std::min(maxcy, F * NS1);
+        d.tile_floats = F * Hdp * Wdp * cchunk;
+        const size_t red = (size_t)d.cx * d.cy * (10 * 2 * sizeof(float) + 2 * 2 * sizeof(double));
+        d.lds = std::max((size_t)(d.tile_floats + 16 * cchunk) * sizeof(float), red);
+        return d;
+    }
+    return d;
+}
+
+template <int PL, bool PRE, class T>
+static int launch_dws2_bwd(const DwfGeom& g, const DwsGeom& d, hipStream_t st, const float* x, const float* pre_stats, const float* dout,
+                           const float* y2, const float* post_stats, const float* post_coef, const float* w, View dx, double* part_bn,
+                           double* part_w, int G, int B, int H, int W, int C) {
+    static const bool reload_y1 = cdrl_getenv("CDRL_DWF_XHAT_RELOAD") && atoi(cdrl_getenv("CDRL_DWF_XHAT_RELOAD")) == 1;
+    CDRL_TRY((allow_lds<dws2_bwd_kernel<PL, PRE, T>>(d.lds)));
+    hipLaunchKernelGGL((dws2_bwd_kernel<PL, PRE, T>), dim3(cdiv(G * g.nb_bwd, 8) * 8 * d.nch), dim3(d.cx, d.cy), d.lds, st,
+                       reinterpret_cast<const T*>(x), pre_stats, reinterpret_cast<const T*>(dout), reinterpret_cast<const T*>(y2), post_stats,
+                       post_coef, w, dx, part_bn, part_w, B, H, W, same_out(H, 2), same_out(W, 2), C, G * C, same_pad_before(H, 2), g.fpb_bwd,
+                       g.nb_bwd, d.cchunk, view_aligned(dx, 2), G * g.nb_bwd, reload_y1, d.F, d.S, d.wdp, d.tile_floats);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int SW, int R, bool PRE, class T>
 static int launch_dws_bwd(const DwfGeom& g, const DwsGeom& d, hipStream_t st, const float* x, const float* pre_stats, const float* dout,
                           const float* y2, const float* post_stats, const float* post_coef, const float* w, View dx, double* part_bn,
                           double* part_w, int G, int B, int H, int W, int C) {
     static const bool reload_y1 = cdrl_getenv("CDRL_DWF_XHAT_RELOAD") && atoi(cdrl_getenv("CDRL_DWF_XHAT_RELOAD")) == 1;
-    CDRL_TRY((allow_lds<dws_bwd_kernel<SW, R, T>>(d.lds)));
-    hipLaunchKernelGGL((dws_bwd_kernel<SW, R, T>), dim3(cdiv(G * g.nb, 8) * 8 * d.nch), dim3(d.cx, d.cy), d.lds, st,
+    CDRL_TRY((allow_lds<dws_bwd_kernel<SW, R, PRE, T>>(d.lds)));
+    hipLaunchKernelGGL((dws_bwd_kernel<SW, R, PRE, T>), dim3(cdiv(G * g.nb_bwd, 8) * 8 * d.nch), dim3(d.cx, d.cy), d.lds, st,
                        reinterpret_cast<const T*>(x), pre_stats, reinterpret_cast<const T*>(dout), reinterpret_cast<const T*>(y2), post_stats,
-                       post_coef, w, dx, part_bn, part_w, B, H, W, C, G * C, g.fpb, g.nb, d.cchunk, view_aligned(dx, 2), G * g.nb, reload_y1,
+                       post_coef, w, dx, part_bn, part_w, B, H, W, C, G * C, g.fpb_bwd, g.nb_bwd, d.cchunk, view_aligned(dx, 2), G * g.nb_bwd, reload_y1,
                        d.F, d.S, d.tile_floats);
     CDRL_LAUNCH_CHECK();
     return 0;
@@ -992,15 +1352,23 @@ int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const flo
         set_error("dwf_bwd: part_bn is required with a pre-BN prologue");
         return -1;
     }
-    DwfGeom g = dwf_geom(B, G, H, W, C, stride);
-    // stride 1 behind a pre-BN (every stride-1 unit of the tower): the strip form
-    static const bool strips = !(cdrl_getenv("CDRL_DWS") && atoi(cdrl_getenv("CDRL_DWS")) == 0);
-    if (strips && stride == 1 && pre_stats && (int64_t)G * B * H * W * std::max(C, dx.ld) * 4 < (int64_t)1 << 31) {
-        const DwsGeom d = dws_geom(g, H, W, C);
-        if (d.ok) {
-#define CDRL_DWS(SWV, RV)                                                                                                                         \
-    return at ? launch_dws_bwd<SWV, RV, bf16_t>(g, d, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C) \
-              : launch_dws_bwd<SWV, RV, float>(g, d, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C)
+    const DwfGeom g = dwf_geom(B, G, H, W, C, stride);
+    // strip form (planned by dwf_geom: the partial-row count nb_bwd the caller finalizes with belongs to it)
+    if (g.strip.ok) {
+        const DwsGeom& d = g.strip;
+        if ((int64_t)G * B * H * W * std::max(C, dx.ld) * 4 >= (int64_t)1 << 31) {
+            set_error("dwf_bwd: gradient view too large for the strip kernels' 32-bit buffer offsets");
+            return -1;
+        }
+        if (stride == 1) {
+#define CDRL_DWS(SWV, RV)                                                                                                                                  \
+    do {                                                                                                                                                   \
+        if (pre_stats)                                                                                                                                     \
+            return at ? launch_dws_bwd<SWV, RV, true, bf16_t>(g, d, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C) \
+                      : launch_dws_bwd<SWV, RV, true, float>(g, d, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C); \
+        return at ? launch_dws_bwd<SWV, RV, false, bf16_t>(g, d, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C)   \
+                  : launch_dws_bwd<SWV, RV, false, float>(g, d, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C);  \
+    } while (0)
             if (d.sw == 4) {
                 if (d.R == 1) CDRL_DWS(4, 1);
                 if (d.R == 2) CDRL_DWS(4, 2);
@@ -1009,27 +1377,17 @@ int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const flo
             CDRL_DWS(8, 1);
 #undef CDRL_DWS
         }
-    }
-    // Four channels per thread -- half the load / LDS / address instructions per element, 214-256 VGPRs, two waves per SIMD instead of
-    // three or four.  CDRL_DWF_BWD_VEC4 = bit mask: 1 float32 stride 1, 2 float32 stride 2, 4 bf16 storage stride 1, 8 bf16 storage
-    // stride 2.  Measured on one box each: mask 1 -> 14.77 vs 14.83 ms per update-step (float32; two boxes), mask 2 -> +-0.0, mask 4 -> 30.4
-    // vs 29.9 ms (bf16 storage, B = 1024; stride 2 spills 4-12 VGPRs).  Default 0: the float32 and the bf16-storage form of this kernel share
-    // one thread -> pixel map, which is what lets tests/test_gpu_bf16_storage.py hold the bf16 form to the float32 form BIT FOR BIT;
-    // -0.45 % for float32 alone is not worth that property
-    {
-        static const int mask4 = cdrl_getenv("CDRL_DWF_BWD_VEC4") ? atoi(cdrl_getenv("CDRL_DWF_BWD_VEC4")) : DWF_BWD_VEC4_DEFAULT;
-        const int bit = (at ? 4 : 1) << (stride == 2 ? 1 : 0);
-        if (g.vec == 4 && (mask4 & bit)) {
-            static const int t_bwd = cdrl_getenv("CDRL_DWF_TB") ? atoi(cdrl_getenv("CDRL_DWF_TB")) : DWF_T_BWD_DEFAULT;
-            const int Po_ = same_out(H, stride) * same_out(W, stride);
-            g.vec_bwd = 4;
-            g.cx_bwd = g.cchunk / 4;
-            g.cy_bwd = t_bwd / g.cx_bwd;
-            if (g.cy_bwd > Po_) g.cy_bwd = Po_;
-            if (g.cy_bwd < 1) g.cy_bwd = 1;
-            const size_t red_b = (size_t)10 * g.cy_bwd * g.vec_bwd * g.cx_bwd * sizeof(double);
-            if (g.lds_bwd < red_b) g.lds_bwd = red_b;
+        const int pl = same_pad_before(W, 2);
+#define CDRL_DWS2(PLV, PREV)                                                                                                                             \
+    return at ? launch_dws2_bwd<PLV, PREV, bf16_t>(g, d, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C) \
+              : launch_dws2_bwd<PLV, PREV, float>(g, d, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C)
+        if (pre_stats) {
+            if (pl) CDRL_DWS2(1, true);
+            CDRL_DWS2(0, true);
         }
+        if (pl) CDRL_DWS2(1, false);
+        CDRL_DWS2(0, false);
+#undef CDRL_DWS2
     }
     if (g.lds_bwd > 150 * 1024) {
         set_error("dwf_bwd: frame %dx%d does not fit LDS even at %d channels", H, W, g.cchunk);
@@ -1038,11 +1396,9 @@ int dwf_bwd(const float* x, const float* pre_stats, const float* dout, const flo
 #define CDRL_DWF_BWD(S, V) \
     return launch_dwf_bwd_pre<S, V>(g, st, x, pre_stats, dout, y2, post_stats, post_coef, w, dx, part_bn, part_w, G, B, H, W, C, at)
     if (stride == 1) {
-        if (g.vec_bwd == 4) CDRL_DWF_BWD(1, 4);
         if (g.vec_bwd == 2) CDRL_DWF_BWD(1, 2);
         CDRL_DWF_BWD(1, 1);
     }
-    if (g.vec_bwd == 4) CDRL_DWF_BWD(2, 4);
     if (g.vec_bwd == 2) CDRL_DWF_BWD(2, 2);
     CDRL_DWF_BWD(2, 1);
 #undef CDRL_DWF_BWD

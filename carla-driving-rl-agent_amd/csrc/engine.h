@@ -187,6 +187,8 @@ public:
     bool graphs_enabled() const { return graphs_enabled_; }
     // Named internal tensors (parity tests: the raw BatchNorm inputs, statistics blocks, max-pool argmax codes and dense
     // pre-activations from which the discrete ReLU6 / max-pool decisions of the last forward are reconstructed)
+    // CDRL_GUARD=1: 64 KB canary bands behind every workspace tensor (filled at bind); counts the bands that lost their pattern
+    int check_guards(hipStream_t st, int64_t* bad, int64_t* first_off);
     bool named_buffer(const std::string& name, void** p, int64_t* bytes) const {
         auto it = named_.find(name);
         if (it == named_.end()) return false;
@@ -307,6 +309,11 @@ private:
     bool dry_ = true;
     char* ws_base_ = nullptr;
     size_t ws_off_ = 0, ws_bytes_ = 0;
+    static constexpr size_t GUARD_BYTES = 65536, GUARD_TABLE_MAX = 131072;
+    bool guard_ = false;
+    std::vector<int64_t> guard_off_;        // byte offsets of the bands (real build)
+    int64_t* guard_tab_ = nullptr;          // device copy + [GUARD_TABLE_MAX]: bad count, [+1]: first bad band
+    void add_guard();
     // scratch maxima (from the dry build) and pointers
     size_t max_part_ = 0, max_part2_ = 0, max_dy_ = 0, max_tn_ = 0, max_fpart_ = 0;
     // reduction scratch of the ops on the main stream / of the auxiliary ops (feature nets + small GRUs),

@@ -38,6 +38,7 @@ Learner::Learner(const Config& cfg) : cfg_(cfg) {
     hp_host_.beta2 = 0.999f;
     hp_host_.eps = 1e-7f;
     at_ = cfg_.compute == 2 ? 1 : 0;
+    guard_ = cdrl_getenv("CDRL_GUARD") && atoi(cdrl_getenv("CDRL_GUARD")) == 1;
     build(true);
     table_frozen_ = true;
     build_seg_tables();
@@ -282,10 +283,19 @@ int64_t Learner::params_total() const { return st_offset(M_OLD_POLICY) + st_size
 // ------------------------------------------------------------------------------------------
 // allocation helpers
 // ------------------------------------------------------------------------------------------
+// CDRL_GUARD=1: a canary band behind every bump allocation (the only out-of-bounds detector this stack has for kernels that address
+// the workspace through raw buffer descriptors: an overrun into the neighbour tensor is otherwise seen only if a parity test reads it)
+void Learner::add_guard() {
+    if (!guard_) return;
+    if (!dry_) guard_off_.push_back((int64_t)ws_off_);
+    ws_off_ += GUARD_BYTES;
+}
+
 float* Learner::alloc(size_t n) {
     const size_t bytes = align_up(n * sizeof(float), 256);
     float* p = dry_ ? nullptr : reinterpret_cast<float*>(ws_base_ + ws_off_);
     ws_off_ += bytes;
+    add_guard();
     return p;
 }
 
@@ -293,7 +303,48 @@ double* Learner::alloc_d(size_t n) {
     const size_t bytes = align_up(n * sizeof(double), 256);
     double* p = dry_ ? nullptr : reinterpret_cast<double*>(ws_base_ + ws_off_);
     ws_off_ += bytes;
+    add_guard();
     return p;
+}
+
+static constexpr uint32_t GUARD_PATTERN = 0xA5C3961Eu;
+
+__global__ void __launch_bounds__(256) guard_fill_kernel(char* base, const int64_t* __restrict__ offs, int words) {
+    uint32_t* p = reinterpret_cast<uint32_t*>(base + offs[blockIdx.x]);
+    for (int i = threadIdx.x; i < words; i += 256) p[i] = GUARD_PATTERN ^ (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) guard_check_kernel(const char* base, const int64_t* __restrict__ offs, int words, int64_t* out) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(base + offs[blockIdx.x]);
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    int b = 0;
+    for (int i = threadIdx.x; i < words; i += 256) b |= p[i] != (GUARD_PATTERN ^ (uint32_t)i);
+    if (b) bad = 1;          // (benign race: every writer stores 1)
+    __syncthreads();
+    if (threadIdx.x == 0 && bad) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(out), 1ull);
+        atomicMin(reinterpret_cast<long long*>(out + 1), (long long)blockIdx.x);
+    }
+}
+
+int Learner::check_guards(hipStream_t st, int64_t* bad, int64_t* first_off) {
+    if (!guard_ || !guard_tab_) {
+        set_error("check_guards: the learner was not created with CDRL_GUARD=1 (or is not bound)");
+        return -1;
+    }
+    const int n = (int)guard_off_.size();
+    int64_t init[2] = {0, (int64_t)1 << 40};
+    CDRL_HIP(hipMemcpyAsync(guard_tab_ + GUARD_TABLE_MAX, init, sizeof(init), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(guard_check_kernel, dim3(n), dim3(256), 0, st, ws_base_, guard_tab_, (int)(GUARD_BYTES / 4), guard_tab_ + GUARD_TABLE_MAX);
+    CDRL_LAUNCH_CHECK();
+    int64_t out[2];
+    CDRL_HIP(hipMemcpyAsync(out, guard_tab_ + GUARD_TABLE_MAX, sizeof(out), hipMemcpyDeviceToHost, st));
+    CDRL_HIP(hipStreamSynchronize(st));
+    if (bad) *bad = out[0];
+    if (first_off) *first_off = out[0] ? guard_off_[(size_t)out[1]] : -1;
+    return 0;
 }
 
 Learner::Tens Learner::tens(int rows, int C, bool grad) {
@@ -741,8 +792,9 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
     float* coef2 = alloc((size_t)3 * G * C);
     if (coef2_out) *coef2_out = coef2;
     const int nb_in = vcol_geom(Mi, C).nb, nb_out = vcol_geom(Mo, C).nb;
-    const int nbf = dwf_geom(B, G, H, W, C, stride).nb;
-    const size_t nbmax = (size_t)std::max(std::max(std::max(nb_in, nb_out), nbf), std::max(pre_stats_nb, post_bwd_nb));
+    const int nbf = dwf_geom(B, G, H, W, C, stride).nb;              // partial rows of the forward kernel (BN2 statistics) ...
+    const int nbb = dwf_geom(B, G, H, W, C, stride).nb_bwd;          // ... and of the backward (BN1 sums, filter partials)
+    const size_t nbmax = (size_t)std::max(std::max(std::max(nb_in, nb_out), std::max(nbf, nbb)), std::max(pre_stats_nb, post_bwd_nb));
     note_scratch((size_t)G * nbmax * 2 * C, (size_t)G * nbmax * C, (size_t)N * H * W * C, 0,
                  (size_t)dwf_filter_part_elems(B, G, H, W, C, stride));
     const View xv = make_view(x, C), y2v = make_view(y2, C);
@@ -758,7 +810,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
         };
         op.bwd = [=](hipStream_t st) -> int {
             if (pre_fin_done && *pre_fin_done) return 0;   // folded by the fused backward of the 1x1 conv in front (finalize on load)
-            CDRL_TRY(bn_bwd_finalize(sc->part, nbf, G, Mi, C, stats1, g1.g, b1.g, coef1, st));
+            CDRL_TRY(bn_bwd_finalize(sc->part, nbb, G, Mi, C, stats1, g1.g, b1.g, coef1, st));
             if (pre_defer_apply) return 0;                 // the 1x1 conv in front applies it on load (PwFuse::bb)
             const float* dz = dys_[slot_];                 // masked gradient left there by the depthwise op
             CDRL_TRY(next_slot(st));
@@ -778,7 +830,7 @@ float* Learner::add_dw_block(std::vector<Op>& ops, const std::string& unit, cons
             const View dx = pre ? make_view(dys_[slot_], C) : din;
             CDRL_TRY(dwf_bwd(x, stats1, dout.p, y2, stats2, coef2, w.p, dx, sc->part, pw, G, B, H, W, C, stride, st, at));
             return defer_side(st, [=](hipStream_t sd) -> int {
-                return reduce_partials2(pw, G * nbf, 9 * C, C, (int64_t)10 * C, w.g, b.g, 0, sd);
+                return reduce_partials2(pw, G * nbb, 9 * C, C, (int64_t)10 * C, w.g, b.g, 0, sd);
             });
         };
         ops.push_back(op);
@@ -1224,7 +1276,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                         PRef g1 = param(M_TRUNK, pre + ".bn1.gamma", {mid}, true), b1 = param(M_TRUNK, pre + ".bn1.beta", {mid}, true);
                         f1.bb_fin = true;
                         f1.bb_fin_part = &build_scr_->part;
-                        f1.bb_fin_nb = dwf_geom(B, T, curH, curW, mid, stride).nb;
+                        f1.bb_fin_nb = dwf_geom(B, T, curH, curW, mid, stride).nb_bwd;
                         f1.bb_dgamma = g1.g;
                         f1.bb_dbeta = b1.g;
                         f1.bb_fin_done = bn1_fin;
@@ -1410,7 +1462,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             CDRL_HIP(hipEventRecord(ev_tail_main_, st));
             CDRL_HIP(hipStreamWaitEvent(comm_, ev_tail_main_, 0));
             if (side_enabled_) {
-                flush_deferred();
+                CDRL_TRY(flush_side(st));       // (queued side jobs go out BEHIND an event of the critical stream, as everywhere else)
                 CDRL_HIP(hipEventRecord(ev_tail_side_, side_));
                 CDRL_HIP(hipStreamWaitEvent(comm_, ev_tail_side_, 0));
                 if (aux_pending_) CDRL_HIP(hipStreamWaitEvent(comm_, ev_aux_done_, 0));
@@ -1480,6 +1532,7 @@ void Learner::build_head(std::vector<Op>& ops, int model, const std::string& pre
 void Learner::build(bool dry) {
     dry_ = dry;
     ws_off_ = 0;
+    guard_off_.clear();
     trunk_ops_.clear();
     policy_ops_.clear();
     value_ops_.clear();
@@ -1558,6 +1611,13 @@ void Learner::build(bool dry) {
         s.chunk_part = alloc_d((size_t)nch);
         s.sqnorms = alloc((size_t)nt);
     }
+    if (guard_) {       // band table (device) behind everything else; no band behind it
+        const bool g = guard_;
+        guard_ = false;
+        guard_tab_ = reinterpret_cast<int64_t*>(alloc_d(GUARD_TABLE_MAX + 2));
+        guard_ = g;
+        if (!dry && guard_off_.size() > GUARD_TABLE_MAX) build_fail("CDRL_GUARD: %zu bands exceed the table", guard_off_.size());
+    }
     if (dry) {
         // scratch goes first in the real layout; account for it here
         ws_off_ += align_up((max_part_ / 4 + 64) * sizeof(double), 256) + align_up(1024 * sizeof(float), 256) + 512 +
@@ -1568,6 +1628,7 @@ void Learner::build(bool dry) {
                             align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256)) +
                    NQ * (align_up(max_qpart_ * sizeof(float), 256) + align_up(max_dbpart_ * sizeof(double), 256) +
                          align_up((size_t)8 * 2 * 128 * sizeof(double), 256));
+        if (guard_) ws_off_ += (size_t)(9 + 4 * NSLOT + 3 * NQ) * GUARD_BYTES;      // one band per scratch allocation above
         ws_bytes_ = ws_off_ + 4096;
     }
 }
@@ -1639,6 +1700,16 @@ int Learner::bind(const Buffers& b) {
     }
     CDRL_TRY(upload_seg_tables());
     for (auto& z : zero_once_) CDRL_HIP(hipMemset(z.first, 0, z.second));
+    if (guard_) {
+        if (!build_err_.empty()) {
+            set_error("bind: %s", build_err_.c_str());
+            return -1;
+        }
+        CDRL_HIP(hipMemcpy(guard_tab_, guard_off_.data(), guard_off_.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(guard_fill_kernel, dim3((unsigned)guard_off_.size()), dim3(256), 0, nullptr, ws_base_, guard_tab_, (int)(GUARD_BYTES / 4));
+        CDRL_LAUNCH_CHECK();
+        CDRL_HIP(hipDeviceSynchronize());
+    }
     if (!side_) {
         const char* env = cdrl_getenv("CDRL_SIDE_STREAM");
         side_enabled_ = !(env && atoi(env) == 0);

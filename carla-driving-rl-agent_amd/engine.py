@@ -182,6 +182,13 @@ class LearnerEngine:
         t = self.workspace[off: off + 4 * n.value].view(torch.float32)
         return t.view(shape) if shape is not None else t
 
+    def check_guards(self):
+        """(bands that lost their pattern, workspace byte offset of the first one or -1): the out-of-bounds canaries behind every
+        workspace tensor of a learner created with CDRL_GUARD=1 in the environment (cdrl_learner_check_guards)."""
+        bad, first = C.c_int64(0), C.c_int64(-1)
+        _lib.check(self.lib.cdrl_learner_check_guards(self.h, self._stream(), C.byref(bad), C.byref(first)), 'check_guards')
+        return int(bad.value), int(first.value)
+
     def named_buffer(self, name: str, dtype=torch.float32, shape=None) -> torch.Tensor:
         """Zero-copy view of a named internal tensor (cdrl_learner_named_buffer; parity tests)."""
         p = C.c_void_p()

@@ -192,6 +192,12 @@ int cdrl_learner_get_buffer(const cdrl_learner* l, int which, float** ptr, int64
  * (ReLU6 region = region of fmaf(scale, x, shift); max-pool argmax) are reconstructed from them, so that the float64 oracle
  * can be evaluated on the SAME decisions (reference core/architectures.py:47,161 are the sites). */
 int cdrl_learner_named_buffer(const cdrl_learner* l, const char* name, void** ptr, int64_t* bytes);
+/* Out-of-bounds canaries of the workspace (sanitizer row; there is no GPU AddressSanitizer on this pool and the
+ * kernels address the workspace through raw buffer descriptors).  A learner created with CDRL_GUARD=1 in the environment plans its
+ * workspace with a 64 KB band behind EVERY tensor (cdrl_learner_workspace_bytes grows accordingly) and cdrl_learner_bind fills the
+ * bands with a pattern; this call checks them on `stream` (synchronises): *bad_bands = number of bands that no longer hold the pattern,
+ * *first_bad_offset = byte offset (inside the workspace) of the first one, -1 if none.  Without CDRL_GUARD=1 it fails with -1. */
+int cdrl_learner_check_guards(cdrl_learner* l, void* stream, int64_t* bad_bands, int64_t* first_bad_offset);
 
 /* ---- rollout-buffer post-processing ---------------------------------------------------------
  * PPOMemory.compute_returns + compute_advantages (rl/agents/ppo.py:699-727), utils.gae /

@@ -119,12 +119,12 @@ def test_wide_stage2_convs_agree_with_the_register_resident_form_at_full_size(tm
     assert any(not torch.equal(a[k], a0[k]) for k in a if k.startswith('trunk/img.s2.'))        # the switch really changed the path
 
 
-def test_depthwise_backward_with_four_channels_per_thread_agrees_at_full_size(tmp_path):
-    """Four channels per thread in the fused depthwise backward (opt-in bit mask CDRL_DWF_BWD_VEC4; here in every float32 block) vs two
-    everywhere (the default): same forward, hence the same decisions; every gradient tensor within 5e-5 (other thread -> pixel map, other
-    float32 summation order of the filter-gradient partials)."""
-    a1 = _run(str(tmp_path / 'vec4.pt'), CDRL_DWF_BWD_VEC4=3)
-    a0 = _run(str(tmp_path / 'vec2.pt'), CDRL_DWF_BWD_VEC4=0)
+def test_depthwise_backward_in_strip_form_agrees_with_the_pixel_mapped_form_at_full_size(tmp_path):
+    """Round 5: the depthwise backward in strip form (dws_bwd_kernel / dws2_bwd_kernel: thread = channel pair x row strip, filter
+    gradient in scatter form from the window of D, BN1 sums in float32 along a strip; the default) vs the pixel-mapped kernel of rounds
+    1-4 (CDRL_DWS=0): same forward, hence the same decisions; every gradient tensor within 5e-5 (other summation orders)."""
+    a1 = _run(str(tmp_path / 'strips.pt'))
+    a0 = _run(str(tmp_path / 'pixels.pt'), CDRL_DWS=0)
     assert a1['loss'].item() == a0['loss'].item()
     assert torch.equal(a1['dyn'], a0['dyn'])
     w = _worst(a1, a0, skip_zero_gradients=True)
