@@ -632,8 +632,7 @@ struct BnBwdReduceF {
 template <int VEC, bool PASS, class T>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ctot, const T* __restrict__ y,
                                                                  const float* __restrict__ stats, int GC, int C, int Mg, int rb,
-                                                                 View pgs, View pgd, double* __restrict__ part, unsigned* tickets,
-                                                                 double* __restrict__ partf) {
+                                                                 View pgs, View pgd, double* __restrict__ part) {
     extern __shared__ double sm[];   // [CY][VEC][CX]
     constexpr int RU = 4;
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -746,67 +745,29 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_shuf_kernel(View da, int ct
             __syncthreads();
         }
     }
-    if (!tickets) {
-        if (ty == 0 && on) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) part[(((int64_t)g * nb + blockIdx.x) * 2 + q) * C + c0 + i] = acc[q][i];
-        }
-        return;
-    }
-    // In-launch fold of clusters of 4 workgroups (CDRL_FIN_ON_LOAD=2: the consumer that finalizes on load then reads nb / 4 rows).
-    // Hand-off in the counter form of the guide's recipe: rows published with 8-byte agent-scope stores (write-through), every wave
-    // drains its stores, one relaxed agent-scope ticket per workgroup; the last arriver of a cluster reads the cluster's rows with
-    // agent-scope loads and adds them in ROW order (not arrival order: bit-wise reproducible), and re-arms the ticket.
-    const int cl = blockIdx.x >> 2, nbf = (nb + 3) >> 2, csize = min(4, nb - 4 * cl);
     if (ty == 0 && on) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int i = 0; i < VEC; ++i)
-                __hip_atomic_store(&part[(((int64_t)g * nb + blockIdx.x) * 2 + q) * C + c0 + i], acc[q][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < VEC; ++i) part[(((int64_t)g * nb + blockIdx.x) * 2 + q) * C + c0 + i] = acc[q][i];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned* tk = tickets + g * nbf + cl;
-    if (tx == 0 && ty == 0) {
-        const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        reinterpret_cast<int*>(sm)[0] = (t == (unsigned)(csize - 1)) ? 1 : 0;
-    }
-    __syncthreads();
-    if (reinterpret_cast<int*>(sm)[0] == 0) return;
-    if (ty == 0 && on) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                double u = 0.0;
-                for (int j = 0; j < csize; ++j)
-                    u += __hip_atomic_load(&part[(((int64_t)g * nb + 4 * cl + j) * 2 + q) * C + c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                partf[(((int64_t)g * nbf + cl) * 2 + q) * C + c0 + i] = u;
-            }
-    }
-    if (tx == 0 && ty == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int VEC, class T>
 static void launch_bbr_shuf(const VColGeom& g, int G, hipStream_t st, View da, int ctot, const float* y, const float* stats, int C,
-                            int Mg, View pgs, View pgd, double* part, unsigned* tickets, double* partf) {
+                            int Mg, View pgs, View pgd, double* part) {
     dim3 grid(g.nb, G), block(g.cx, g.cy);
     size_t sm = (size_t)g.cy * VEC * g.cx * sizeof(double);
     if (sm < 16) sm = 16;
     const T* yt = reinterpret_cast<const T*>(y);
     if (pgs.p)
-        hipLaunchKernelGGL((bn_bwd_reduce_shuf_kernel<VEC, true, T>), grid, block, sm, st, da, ctot, yt, stats, G * C, C, Mg, g.rb, pgs, pgd, part, tickets, partf);
+        hipLaunchKernelGGL((bn_bwd_reduce_shuf_kernel<VEC, true, T>), grid, block, sm, st, da, ctot, yt, stats, G * C, C, Mg, g.rb, pgs, pgd, part);
     else
-        hipLaunchKernelGGL((bn_bwd_reduce_shuf_kernel<VEC, false, T>), grid, block, sm, st, da, ctot, yt, stats, G * C, C, Mg, g.rb, pgs, pgd, part, tickets, partf);
+        hipLaunchKernelGGL((bn_bwd_reduce_shuf_kernel<VEC, false, T>), grid, block, sm, st, da, ctot, yt, stats, G * C, C, Mg, g.rb, pgs, pgd, part);
 }
 
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
-                  double* part, hipStream_t st, const PoolSrc* pool, const View* pass_gsrc, const View* pass_gdst, int bcast_rows, int at,
-                  unsigned* fold_tickets, double** fold_part_out, int* fold_nb_out) {
-    if (fold_nb_out) *fold_nb_out = 0;
+                  double* part, hipStream_t st, const PoolSrc* pool, const View* pass_gsrc, const View* pass_gdst, int bcast_rows, int at) {
     {
         static const bool fast = !(cdrl_getenv("CDRL_BBR_FAST") && atoi(cdrl_getenv("CDRL_BBR_FAST")) == 0);
         const VColGeom g = vcol_geom(Mg, C, NB_STATS);
@@ -818,19 +779,12 @@ int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const
         const bool ydense = y.ld == C && y.coff == 0 && view_aligned(y, g.vec);
         const bool pok = !pgs.p || (pgd.p && view_aligned(pgd, g.vec));
         if (fast && !pool && !bcast_rows && shuffle_ctot && act == ACT_RELU6 && g.nloop == 1 && ydense && pok && g.vec >= 2) {
-            // fold (fold_tickets: zeroed, >= G * ceil(nb / 4) counters): the folded rows go BEHIND the G * nb unfolded ones in `part`
-            unsigned* tk = (fold_tickets && fold_part_out && fold_nb_out && g.nb >= 8 && G * cdiv(g.nb, 4) <= 1024) ? fold_tickets : nullptr;
-            double* partf = tk ? part + (int64_t)G * g.nb * 2 * C : nullptr;
-            if (tk) {
-                *fold_part_out = partf;
-                *fold_nb_out = cdiv(g.nb, 4);
-            }
             if (at) {
-                if (g.vec == 4) launch_bbr_shuf<4, bf16_t>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part, tk, partf);
-                else launch_bbr_shuf<2, bf16_t>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part, tk, partf);
+                if (g.vec == 4) launch_bbr_shuf<4, bf16_t>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
+                else launch_bbr_shuf<2, bf16_t>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
             } else {
-                if (g.vec == 4) launch_bbr_shuf<4, float>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part, tk, partf);
-                else launch_bbr_shuf<2, float>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part, tk, partf);
+                if (g.vec == 4) launch_bbr_shuf<4, float>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
+                else launch_bbr_shuf<2, float>(g, G, st, da, shuffle_ctot, y.p, stats, C, Mg, pgs, pgd, part);
             }
             CDRL_LAUNCH_CHECK();
             return 0;

@@ -47,10 +47,7 @@ struct PoolSrc {
 // Backward: reduce (sum dz, sum dz*xhat) -> part [G][nb][2][C]
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
                   double* part, hipStream_t st, const PoolSrc* pool = nullptr, const View* pass_gsrc = nullptr,
-                  const View* pass_gdst = nullptr, int bcast_rows = 0, int at = 0, unsigned* fold_tickets = nullptr,
-                  double** fold_part_out = nullptr, int* fold_nb_out = nullptr);
-// fold_*: in-launch fold of clusters of 4 partial rows (fast path only; *fold_nb_out == 0: not folded); `part` must then hold
-// 5/4 of its usual size and fold_tickets >= 1024 zeroed counters
+                  const View* pass_gdst = nullptr, int bcast_rows = 0, int at = 0);
 // bcast_rows > 0 (here and in bn_bwd_apply): `da` holds ONE row per bcast_rows rows of y and is divided by bcast_rows on load --
 // the gradient of a global average pool over bcast_rows pixels, never materialised (head of the tower)     // pass_*: gradient of the identity half gathered in the same pass
 // Same sums for a BN+ReLU6 that feeds a 3x3/s2 max-pool, in scatter form over the POOLED gradient (ps.dp, ps.argmax);

@@ -80,13 +80,6 @@ struct Passthrough {
 };
 
 // BatchNorm work folded into a pointwise conv (gemm_pw.hip); all optional
-// run-time hand-over from a BatchNorm's backward op to the fused conv backward that finalizes it on load: where the (possibly
-// in-launch folded) partial rows are and how many per group (nb == 0: not folded, the consumer takes the unfolded block)
-struct FoldInfo {
-    double* part = nullptr;
-    int nb = 0;
-};
-
 struct PwFuse {
     bool fwd_pw = false;                 // forward through the persistent skinny GEMM
     const float* pro_stats = nullptr;    // input = BN-apply(in) with these statistics (in = raw previous conv output)
@@ -120,7 +113,6 @@ struct PwFuse {
     float* bb_dgamma = nullptr;
     float* bb_dbeta = nullptr;
     std::shared_ptr<bool> bb_fin_done;
-    std::shared_ptr<FoldInfo> bb_fold;    // CDRL_FIN_ON_LOAD=2: rows folded in-launch by the BatchNorm's reduce kernel
 };
 
 class Learner {
@@ -223,7 +215,6 @@ private:
         // count, the gradient slots of gamma / beta.
         std::shared_ptr<bool> fin_by_consumer;
         double** part_ptr = nullptr;        // &scratch.part of the stream the BatchNorm runs on (filled at the end of the build)
-        std::shared_ptr<FoldInfo> fold;
         float* dgamma = nullptr;
         float* dbeta = nullptr;
     };
@@ -345,9 +336,7 @@ private:
     float* qparts_[NQ] = {};
     double* dbparts_[NQ] = {};
     double* fintots_[NQ] = {};           // [8][2][128] group totals of a finalize-on-load BatchNorm (gemm_pw_bwd.hip)
-    bool fin_fold_ = false;              // CDRL_FIN_ON_LOAD=2: + in-launch fold of the partial rows in clusters of 4 (bn_bwd_reduce_shuf)
-    unsigned* fold_tickets_ = nullptr;   // 1024 zeroed counters
-    bool fin_on_load_ = false;           // CDRL_FIN_ON_LOAD=1: the fused conv backward finalizes the BatchNorm behind it on load (measured neutral)
+    bool fin_on_load_ = true;            // the fused conv backward finalizes the BatchNorm behind it on load (CDRL_FIN_ON_LOAD=0: stand-alone launches)
     hipEvent_t ev_q_[NQ] = {};
     bool q_used_[NQ] = {};
     int qi_ = 0;

@@ -503,8 +503,6 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     rec.reduce_fused = std::make_shared<bool>(false);
     rec.fin_by_consumer = std::make_shared<bool>(false);
     rec.part_ptr = &build_scr_->part;
-    rec.fold = std::make_shared<FoldInfo>();
-    std::shared_ptr<FoldInfo> foldi = rec.fold;
     rec.dgamma = gamma.g;
     rec.dbeta = beta.g;
     std::shared_ptr<bool> fused = rec.reduce_fused, finc = rec.fin_by_consumer;
@@ -547,11 +545,8 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
         // fused global average pool: the gradient source is the pooled gradient, one row per gap_rows rows of x
         const View dsrc = gap ? make_view(const_cast<float*>(pass.gap_dout), C) : dout;
         const int bc = gap ? pass.gap_rows : 0;
-        // (finalize on load + CDRL_FIN_ON_LOAD=2: the reduce kernel folds its rows in clusters of 4 for the consumer)
-        unsigned* ftk = (*finc && fin_fold_ && sc == &scr_main_) ? fold_tickets_ : nullptr;
-        foldi->nb = 0;
-        if (pass.gsrc.p) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, &pass.gsrc, &pass.gdst, 0, at, ftk, &foldi->part, &foldi->nb));
-        else if (!*fused) CDRL_TRY(bn_bwd_reduce(dsrc, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, nullptr, nullptr, bc, at, ftk, &foldi->part, &foldi->nb));
+        if (pass.gsrc.p) CDRL_TRY(bn_bwd_reduce(dout, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, &pass.gsrc, &pass.gdst, 0, at));
+        else if (!*fused) CDRL_TRY(bn_bwd_reduce(dsrc, dout_shuffle, x, G, Mg, C, stats, act, sc->part, st, nullptr, nullptr, nullptr, bc, at));
         if (*finc) return 0;            // sums folded, applied and turned into dgamma / dbeta by the fused conv backward that follows
         CDRL_TRY(bn_bwd_finalize(sc->part, nb, G, Mg, C, stats, gamma.g, beta.g, coef, st));
         if (defer_apply) return 0;      // applied by the consumer GEMMs on load (PwFuse::bb)
@@ -667,10 +662,6 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             if (fin) {
                 f.fin_part = *fuse.bb_fin_part;
                 f.fin_nb = fuse.bb_fin_nb;
-                if (fuse.bb_fold && fuse.bb_fold->nb > 0) {
-                    f.fin_part = fuse.bb_fold->part;
-                    f.fin_nb = fuse.bb_fold->nb;
-                }
                 f.fin_tot = fintots_[qi];
                 f.o_dgamma = fuse.bb_dgamma;
                 f.o_dbeta = fuse.bb_dbeta;
@@ -1076,16 +1067,14 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         // from 6.8e-5 to 9.6e-5 of north_star's 1e-4 with it -- half a percent is not worth a gate without margin
         const char* e5 = cdrl_getenv("CDRL_PW_WIDE");
         wide_pw_ = e5 && atoi(e5) == 1;
-        // 1 -> the fused conv backward folds the backward sums of the BatchNorm behind it itself (no bn_bwd_finalize launch in front: 46
-        // fewer critical-stream launches per update-step, 614 -> 568).  The sums arrive as 128-256 partial rows per time slice and every
-        // one of the 64 workgroups of a slice reads all of them (240-475 KB from L2): same-box A/B -0.02 / -0.10 / -0.08 ms per update-step
-        // on three boxes with bit-identical losses over 155 update-steps, but the fused kernels grow by 3-11 us (critical-stream busy
-        // time 13.3 vs 13.1-13.2 ms in the serialised profile) and the redundant reads count as traffic: 38.86 vs 38.61 GB per
-        // update-step.  Opt-in.  2 -> additionally the reduce kernel folds its rows in clusters of 4 in-launch (agent-scope hand-off):
-        // slower than 1 (15.03 vs 14.98 ms).
+        // The fused conv backward folds the backward sums of the BatchNorm behind it in its own prologue (no bn_bwd_finalize launch in
+        // front: 46 fewer critical-stream launches per update-step, 614 -> 568; losses bit-identical over 155 update-steps).  Round 4
+        // measured it neutral (-0.07 ms) with 128-256 partial rows per time slice -- every one of the 64 workgroups of a slice reads all
+        // of them from L2 -- and kept it opt-in; with 64 rows from the strip-form depthwise backward and 128 from the BatchNorm reductions
+        // (NB_STATS) it is worth 0.16 ms per update-step (14.15 vs 14.31 ms, same box) and is the default.  CDRL_FIN_ON_LOAD=0 -> stand-alone
+        // finalize launches.
         const char* e6 = cdrl_getenv("CDRL_FIN_ON_LOAD");
-        fin_on_load_ = e6 && atoi(e6) >= 1;
-        fin_fold_ = e6 && atoi(e6) == 2;
+        fin_on_load_ = !(e6 && atoi(e6) == 0);
         const char* e4 = cdrl_getenv("CDRL_FUSED_BWD");     // 0 -> backward-data (critical stream) + filter gradient (side stream) as two kernels
         fused_bwd_ = !(e4 && atoi(e4) == 0);
         // bf16 storage: its two-kernel form is cheap already (one plane, half the bytes); fused-on vs fused-off measured
@@ -1326,7 +1315,6 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                         f2.bb_dgamma = r3.dgamma;
                         f2.bb_dbeta = r3.dbeta;
                         f2.bb_fin_done = r3.fin_by_consumer;
-                        f2.bb_fold = r3.fold;
                         std::vector<Op> tmp;
                         add_pw(tmp, pre + ".pw2", y2.v(), rows_out, mid, main_out, y3.p, a2.gv(), 0, bnrec(T, Mg_out, main_out), f2);
                         ops[pw2_at] = tmp[0];
@@ -1538,8 +1526,7 @@ void Learner::build(bool dry) {
     value_ops_.clear();
     old_policy_ops_.clear();
     if (!dry) {
-        scr_main_.part = alloc_d(max_part_ + max_part_ / 4 + 64);       // (+ 1/4: in-launch folded rows, CDRL_FIN_ON_LOAD=2)
-        fold_tickets_ = reinterpret_cast<unsigned*>(alloc(1024));
+        scr_main_.part = alloc_d(max_part_);
         scr_main_.part2 = alloc_d(max_part2_);
         scr_main_.tn = alloc(max_tn_);
         scr_aux_.part = alloc_d(max_part_);
@@ -1620,15 +1607,14 @@ void Learner::build(bool dry) {
     }
     if (dry) {
         // scratch goes first in the real layout; account for it here
-        ws_off_ += align_up((max_part_ / 4 + 64) * sizeof(double), 256) + align_up(1024 * sizeof(float), 256) + 512 +
-                   2 * (align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
+        ws_off_ += 512 + 2 * (align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
                         align_up(max_tn_ * sizeof(float), 256)) +
                    align_up(max_part_ * sizeof(double), 256) + align_up(max_part2_ * sizeof(double), 256) +
                    NSLOT * (align_up((max_dy_ * esz() + 3) / 4 * sizeof(float), 256) + align_up(max_part2_ * sizeof(double), 256) +
                             align_up(max_tn_ * sizeof(float), 256) + align_up(max_fpart_ * sizeof(double), 256)) +
                    NQ * (align_up(max_qpart_ * sizeof(float), 256) + align_up(max_dbpart_ * sizeof(double), 256) +
                          align_up((size_t)8 * 2 * 128 * sizeof(double), 256));
-        if (guard_) ws_off_ += (size_t)(9 + 4 * NSLOT + 3 * NQ) * GUARD_BYTES;      // one band per scratch allocation above
+        if (guard_) ws_off_ += (size_t)(8 + 4 * NSLOT + 3 * NQ) * GUARD_BYTES;      // one band per scratch allocation above
         ws_bytes_ = ws_off_ + 4096;
     }
 }
@@ -1693,7 +1679,6 @@ int Learner::bind(const Buffers& b) {
     buf_ = b;
     ws_base_ = reinterpret_cast<char*>(b.workspace);
     build(false);
-    if (fold_tickets_) CDRL_HIP(hipMemset(fold_tickets_, 0, 1024 * sizeof(unsigned)));
     if (ws_off_ > b.workspace_bytes) {
         set_error("bind: internal workspace overflow");
         return -1;

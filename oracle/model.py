@@ -205,6 +205,10 @@ PW_BF16_OPERANDS = False        # set by the bf16-mode parity tests (tests/test_
 # tower that the engine keeps in HBM is rounded to bf16 where it is stored, and so is every activation GRADIENT it stores; what is
 # recomputed on load (BatchNorm apply / backward apply, ReLU6) stays in the working precision.  Set together with PW_BF16_OPERANDS.
 BF16_STORAGE = False
+# ablation switches of the storage rule (tests/test_oracle_bf16_ablation.py): round only the stored ACTIVATIONS, or only the stored
+# activation GRADIENTS
+BF16_STORE_FWD = True
+BF16_STORE_BWD = True
 
 
 class _Store(torch.autograd.Function):
@@ -226,7 +230,7 @@ def _st(x, fwd, bwd):
       fwd: raw conv / depthwise outputs (the BatchNorm inputs), the max-pool output, every unit output, the shortcut branch's BN1 output
       bwd: gradients w.r.t. unit outputs / the pool output, w.r.t. the BN2 output (a2.g), the ReLU6-masked gradient at the BN1
            output (dz1), the shortcut's BN1 output, and -- on the unfused paths (shortcut conv, head conv) -- w.r.t. the conv output."""
-    return _Store.apply(x, fwd, bwd) if BF16_STORAGE else x
+    return _Store.apply(x, fwd and BF16_STORE_FWD, bwd and BF16_STORE_BWD) if BF16_STORAGE else x
 
 
 def conv_pw(x, p, prefix):
