@@ -444,18 +444,6 @@ int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, 
                  part, S(stream));
 }
 
-int cdrl_pwconv_wide_partial_rows(int G, int Mg, int N, int K) { return pw_wide_nbpg(G, Mg, N, K); }
-
-int cdrl_pwconv_wide(const float* A, int lda, int a_coff, const float* pro_stats, const void* B_packed, const float* bias, float* C,
-                     int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream) {
-    if (!A || !B_packed || !C) {
-        cdrl::set_error("cdrl_pwconv_wide: null argument");
-        return -1;
-    }
-    return pw_wide(make_view(const_cast<float*>(A), lda, a_coff), pro_stats, B_packed, bias, make_view(C, ldc, c_coff), G, Mg, N, K,
-                   part, S(stream));
-}
-
 int64_t cdrl_pwconv_bwd_fused_workspace(int G, int Mg, int N, int K, int which) {
     return which == 0 ? pw_bwd_fused_qpart_elems(G, Mg, N, K, g_op_at) : pw_bwd_fused_dbpart_elems(G, Mg, N, K, g_op_at);
 }

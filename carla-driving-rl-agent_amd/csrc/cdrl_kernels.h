@@ -255,12 +255,6 @@ int pw_x3_pack_many(const PwX3Pack* tab_dev, int n, hipStream_t st);
 int pw_x3(View A, const float* pro_stats, const void* Wp, const float* bias, View C, int G, int Mg, int N, int K, double* part,
           hipStream_t st, int nbpg = 0);
 
-// ---------------------------------------------------------------- wide pointwise conv, 128 < K, N <= 256 (gemm_pw_wide.hip)
-// 64-row panels resident in LDS as three bf16 planes, W fragments (gemm_x3_pack) streamed from L2, BatchNorm prologue / epilogue
-bool pw_wide_supported(View A, View C, int N, int K);
-int pw_wide_nbpg(int G, int Mg, int N, int K);
-int pw_wide(View A, const float* pro_stats, const void* Wp, const float* bias, View C, int G, int Mg, int N, int K, double* part,
-            hipStream_t st);
 
 // ---------------------------------------------------------------- fused backward of a pointwise conv (gemm_pw_bwd.hip)
 // ONE pass over (dz, y, a): BatchNorm-backward apply on load, da = dy W^T, Q = a^T dy (or xhat(a)^T dy), db partials; then

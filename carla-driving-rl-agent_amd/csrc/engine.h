@@ -257,8 +257,6 @@ private:
     bool fused_dw_ = true, fused_pw_ = true, fused_pw_wide_ = false;
     int fused_bb_ = 1;
     bool fused_bwd_ = true;             // backward-data + filter gradient of the unit convs as one kernel (gemm_pw_bwd.hip)
-    bool wide_pw_ = false;              // forward 232-channel convs (stage 2) as LDS-resident 64-row panels (gemm_pw_wide.hip); CDRL_PW_WIDE=1
-    bool pw_fwd_wide(int N, int K) const;
     int pw_fwd_nbpg(int G, int Mg, int N, int K) const;    // statistics partial rows per group written by a unit conv's forward
     void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
                    View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);

@@ -439,13 +439,8 @@ const void* Learner::pw_x3_packed(const float* w, int K, int N, int sbk, int sbn
     return wp;
 }
 
-// (shape-only decision: the views of the 232-channel convs are 16-byte aligned by construction; add_pw fails the build otherwise)
-bool Learner::pw_fwd_wide(int N, int K) const {
-    return wide_pw_ && cfg_.compute == 0 && N > 128 && N <= 256 && K > 224 && K <= 256 && K % 4 == 0;
-}
-
 int Learner::pw_fwd_nbpg(int G, int Mg, int N, int K) const {
-    return pw_fwd_wide(N, K) ? pw_wide_nbpg(G, Mg, N, K) : pw_nn_plan(G, Mg, N, K).nbpg;
+    return pw_nn_plan(G, Mg, N, K).nbpg;
 }
 
 const void* Learner::gemm_x3_packed(const float* w, int K, int N, int sbk, int sbn) {
@@ -577,11 +572,6 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     static const bool x3_env = !(cdrl_getenv("CDRL_PW_X3") && atoi(cdrl_getenv("CDRL_PW_X3")) == 0);
     const void* w3f = (!bfc && x3_env && fuse.fwd_pw && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
     const int nb_fwd = pw_fwd_nbpg(G, Mg, Cout, Cin);
-    // stage 2 (232 channels): panels resident in LDS, W fragments streamed from L2 (gemm_pw_wide.hip) -- 18 vs 26 us per launch
-    const bool wide_f = fuse.fwd_pw && !w3f && pw_fwd_wide(Cout, Cin);
-    if (wide_f && !pw_wide_supported(in, make_view(y, Cout), Cout, Cin))
-        build_fail("wide pointwise conv %s (%d -> %d): input view ld %d coff %d is not 16-byte aligned", prefix.c_str(), Cin, Cout, in.ld, in.coff);
-    const void* wwf = wide_f ? gemm_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
     // plain (unfused) wide convs -- the 464 -> 768 head conv, the 232-wide shortcut conv -- on the bf16 matrix pipe too (gemm_x3.hip)
     const bool wide = Cin >= 128 || Cout > 128;
     const bool g3 = bfc || (x3_env && wide);
@@ -593,7 +583,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         build_fail("bf16-operand mode: 1x1 convolution %s (%d -> %d, fwd %d bwd %d bb %d; input ld %d coff %d) has no bf16 kernel",
                    prefix.c_str(), Cin, Cout, (int)fuse.fwd_pw, (int)fuse.bwd_pw, (int)fuse.bb, in.ld, in.coff);
     if (bfc && !pack_env) build_fail("bf16-operand mode needs the packed-weight path (CDRL_PW_PACK=0 is set)");
-    const float* wpf = (pack_env && fuse.fwd_pw && !w3f && !wide_f) ? pw_packed(w.p, Cin, Cout, Cout, 1, bfc) : nullptr;      // forward: B(k = cin, n = cout)
+    const float* wpf = (pack_env && fuse.fwd_pw && !w3f) ? pw_packed(w.p, Cin, Cout, Cout, 1, bfc) : nullptr;      // forward: B(k = cin, n = cout)
     const float* wpb = (pack_env && fuse.bwd_pw) ? pw_packed(w.p, Cout, Cin, 1, Cout, bfc) : nullptr;      // backward-data: W^T
     const int tn_groups = (fuse.pro_stats || fuse.bb) ? G : 1;
     note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin, tn_groups));
@@ -604,8 +594,6 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         if (w3f)
             return pw_x3(in, fuse.pro_stats, w3f, b.p, make_view(y, Cout), G, Mg, Cout, Cin, fuse.epi_stats ? scr_main_.part : nullptr, st,
                          nb_fwd);
-        if (wwf)
-            return pw_wide(in, fuse.pro_stats, wwf, b.p, make_view(y, Cout), G, Mg, Cout, Cin, fuse.epi_stats ? scr_main_.part : nullptr, st);
         if (fuse.fwd_pw)
             return pw_nn(in, fuse.pro_stats, w.p, Cout, 1, b.p, make_view(y, Cout), 0, G, Mg, Cout, Cin, fuse.epi_stats ? 1 : 0,
                          nullptr, nullptr, scr_main_.part, st, nullptr, wpf, bfc, at);
@@ -1061,12 +1049,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         // the accumulate variant prefetched its old output tile (248 us against 165 us for apply + plain GEMM), now 15.91 vs 15.96
         // ms/update-step and one 164 MB tensor less
         fused_bb_ = e3 ? atoi(e3) : 7;
-        // 1 -> the 232-channel forward convs of stage 2 on gemm_pw_wide.hip (18 vs 26 us per launch isolated, 14.84 vs 14.91 ms per
-        // update-step, kernel-level error 5.1e-7 vs 6.3e-7 of the float32-MFMA form).  Opt-in: a different float32 forward re-draws
-        // the ReLU6 / max-pool decisions, and smoke()'s worst tensor (a stage-0 BatchNorm gamma at 4e-3 of the largest gradient) moved
-        // from 6.8e-5 to 9.6e-5 of north_star's 1e-4 with it -- half a percent is not worth a gate without margin
-        const char* e5 = cdrl_getenv("CDRL_PW_WIDE");
-        wide_pw_ = e5 && atoi(e5) == 1;
+        // (round 4's LDS-resident 64-row panel form of the 232-channel forward convs, gemm_pw_wide.hip, is gone: 18 vs 26 us per launch
+        //  isolated but 14.43 vs 14.48 ms per update-step, and -- like any change of a float32 forward -- it re-drew the ReLU6 decisions
+        //  and moved smoke()'s worst tensor from 6.9e-5 to 9.5e-5 of the 1e-4 gate, both times it was measured: DESIGN.md section 3)
         // The fused conv backward folds the backward sums of the BatchNorm behind it in its own prologue (no bn_bwd_finalize launch in
         // front: 46 fewer critical-stream launches per update-step, 614 -> 568; losses bit-identical over 155 update-steps).  Round 4
         // measured it neutral (-0.07 ms) with 128-256 partial rows per time slice -- every one of the 64 workgroups of a slice reads all

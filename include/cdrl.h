@@ -244,12 +244,6 @@ int cdrl_pwconv_x3_pack(const float* W, int K, int N, int sbk, int sbn, void* pa
 int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, const void* W_packed, const float* bias, float* C,
                    int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream);
 
-/* The same convolution for 128 < K, N <= 256 (the 232-channel convs of stage 2, core/architectures.py:130,140): 64-row panels of A
- * resident in LDS as three bf16 planes, W fragments streamed from L2.  B_packed: cdrl_gemm_x3_pack of B(k, n) = W (K x N),
- * cdrl_gemm_x3_packed_bytes(N, K) bytes.  pro_stats / part as above, cdrl_pwconv_wide_partial_rows rows per group. */
-int cdrl_pwconv_wide_partial_rows(int G, int Mg, int N, int K);
-int cdrl_pwconv_wide(const float* A, int lda, int a_coff, const float* pro_stats, const void* B_packed, const float* bias, float* C,
-                     int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream);
 
 /* Backward of the unit's 1x1 convolution + BatchNorm (core/architectures.py:130-141 under tape.gradient, core/carla_agent.py:
  * 364-365) as ONE pass over its operands: dy = BatchNorm-backward(dz, y) on load, da = dy W^T, dW = a^T dy, db = column sums of

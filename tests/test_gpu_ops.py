@@ -709,46 +709,6 @@ def test_pwconv_x3_split(lib, G, Mg, K, N, pro):
         assert rel_err(d.cpu().numpy(), (gc.double() @ w.double().t()).cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('G,Mg,K,N,pro,stats_epi', [(4, 3072, 232, 232, True, True), (4, 3072, 232, 232, False, True), (3, 100, 232, 232, True, False),
-                                                    (2, 130, 256, 200, True, True), (1, 65, 228, 132, False, True), (4, 12288, 232, 232, True, True)])
-def test_pwconv_wide(lib, G, Mg, K, N, pro, stats_epi):
-    """Round 4: the 232-channel 1x1 convs of stage 2 (core/architectures.py:130,140) as 64-row panels resident in LDS (three bf16 planes)
-    with the W fragments streamed from L2 (gemm_pw_wide.hip): float32 accuracy against float64, BatchNorm-apply prologue, statistics
-    epilogue (exact double sums of the stored values), ragged group ends, strided views, untouched padding, bit-wise reproducible."""
-    rng = np.random.default_rng(G + Mg + K + N)
-    M = G * Mg
-    lda, a_coff, ldc, c_coff = K + 12, 4, N + 8, 4
-    a = dev(rng.standard_normal((M, lda)).astype(np.float32))
-    w = dev((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32))
-    bias = dev((rng.standard_normal(N) * 0.1).astype(np.float32))
-    stats = None
-    if pro:
-        stats = dev(rng.uniform(0.5, 1.5, (4, G, K)).astype(np.float32))
-        stats[3] = dev(rng.uniform(-0.3, 0.3, (G, K)).astype(np.float32))
-    wp = torch.zeros(int(lib.cdrl_gemm_x3_packed_bytes(N, K)), dtype=torch.uint8, device=DEV)
-    _lib.check(lib.cdrl_gemm_x3_pack(P(w), K, N, N, 1, P(wp), S()))
-    nb = int(lib.cdrl_pwconv_wide_partial_rows(G, Mg, N, K))
-    outs = []
-    for rep in range(2):
-        c = torch.full((M, ldc), 7.0, device=DEV)
-        part = torch.zeros((G, nb, 2, N), dtype=torch.float64, device=DEV)
-        _lib.check(lib.cdrl_pwconv_wide(P(a), lda, a_coff, P(stats), P(wp), P(bias), P(c), ldc, c_coff, G, Mg, N, K, P(part) if stats_epi else None, S()))
-        outs.append((c, part))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    c, part = outs[0]
-    av = a[:, a_coff:a_coff + K].double().view(G, Mg, K)
-    if pro:
-        av = (stats[2].view(G, 1, K).double() * av + stats[3].view(G, 1, K).double()).float().double()     # fmaf, one float32 rounding
-    ref = (av.view(M, K) @ w.double() + bias.double()).cpu().numpy()
-    got = c[:, c_coff:c_coff + N]
-    assert rel_err(got.cpu().numpy(), ref) < 1e-5
-    assert bool((c[:, :c_coff] == 7.0).all()) and bool((c[:, c_coff + N:] == 7.0).all())
-    if stats_epi:
-        sums = part.sum(dim=1)
-        g64 = got.double().view(G, Mg, N)
-        assert torch.allclose(sums[:, 0], g64.sum(1), rtol=1e-9, atol=1e-6) and torch.allclose(sums[:, 1], (g64 * g64).sum(1), rtol=1e-9, atol=1e-6)
-
-
 @pytest.mark.parametrize('M,K,N', [(12288, 464, 768), (12288, 768, 464), (1000, 232, 232), (130, 464, 768), (4099, 60, 92), (257, 16, 8)])
 def test_gemm_x3_split(lib, M, K, N):
     """General split-precision GEMM (head conv shapes, forward and backward-data orientation, ragged edges): float32 accuracy
