@@ -548,13 +548,14 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     const bool lds_shape = K >= 96 && N >= 96 && (lds_mode == 2 || (K <= 128 && N <= 128));
     if (bf16_operands && lds_mode != 0 && lds_shape && gemm_tn_lds_supported(A, D, N, K, dpro))
         return gemm_tn_lds(A, D, Cout, M, N, K, part, accumulate, st, G, pro_stats, dpro, at);
-    // float32 tensors through the same staging, opt-in (CDRL_TN_LDS_F32): 1 = float32 LDS columns + v_mfma_f32_32x32x2_f32, 2 = three
-    // bf16 planes per operand + six plane products on the bf16 pipe.  Measured in round 3 at K = N = 116,
-    // M = 196608 (B = 1024), isolated: direct 87.6 us, mode 1 104.1 us, mode 2 73.7 us (62.4 us with 512 workgroups); K = N = 232,
-    // M = 49152: 81.4 / 96.5 / 70.2 (59.6) us -- and the update-step: 15.78 (direct) | 16.58 (1) | 15.83 (2) ms at B = 256, 48.77 |
-    // 49.33 | 48.35 ms at B = 1024.  The filter gradients run on the side stream NEXT to the critical chain; there a kernel takes
-    // 2-4x its isolated time whichever form it has, and the step does not see a 30 % faster one.  The direct form stays the default.
-    static const int lds_f32 = cdrl_getenv("CDRL_TN_LDS_F32") ? atoi(cdrl_getenv("CDRL_TN_LDS_F32")) : 0;        // 1: float32 MFMA, 2: three bf16 planes
+    // float32 tensors through the same staging: three bf16 planes per operand + six plane products on the bf16 pipe (exact split, float32-
+    // accurate).  Round 3 measured it at K = N = 116, M = 196608 (B = 1024), isolated: direct 87.6 us, float32-MFMA LDS form 104.1 us,
+    // this form 73.7 us; K = N = 232, M = 49152: 81.4 / 96.5 / 70.2 us -- and NO gain in the update-step (15.78 direct | 16.58 | 15.83 ms):
+    // then the stage-0 / stage-1 filter gradients ran next to it on the side stream.  Since the fused conv backward took those over, what is
+    // left here are the 232-channel convs of stage 2, the head conv and the shortcut convs, and the faster kernel shortens the contention
+    // with the critical stream: round 5, same box, 14.27 (direct) | 14.31 (float32-MFMA LDS form) | 14.01 ms (this form).  Default since
+    // round 5; CDRL_TN_LDS_F32=0 -> direct form, 1 -> float32 LDS columns + v_mfma_f32_32x32x2_f32.
+    static const int lds_f32 = cdrl_getenv("CDRL_TN_LDS_F32") ? atoi(cdrl_getenv("CDRL_TN_LDS_F32")) : 2;
     if (!bf16_operands && lds_f32 && K >= 96 && N >= 96 && gemm_tn_lds_supported(A, D, N, K, dpro))
         return gemm_tn_lds(A, D, Cout, M, N, K, part, accumulate, st, G, pro_stats, dpro, 0, lds_f32 == 2 ? 2 : 1);
     const TndPlan p = tnd_plan(M, N, K, G, dpro != nullptr);
