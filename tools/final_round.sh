@@ -15,6 +15,15 @@ mkdir -p $out/pmc && cp gpurun_out/pmc_$r/*.txt $out/pmc/
 bash tools/pmc_mfma.sh $r > $out/pmc_mfma.log 2>&1
 cp gpurun_out/pmc_mfma_$r/mfma.json $out/pmc_mfma.json
 cp gpurun_out/pmc_mfma_$r/*.txt $out/pmc/
+# SQ issue / stall counters per kernel and the idle-time itemisation of the critical stream (item 5)
+bash tools/pmc_sq.sh $r > $out/pmc_sq.log 2>&1
+cp gpurun_out/pmc_sq_$r/sq.json $out/pmc_sq.json
+mkdir -p $out/pmc_sq && cp gpurun_out/pmc_sq_$r/step_*.txt $out/pmc_sq/
+python tools/timeline_idle.py gpurun_out/tl_$r/timeline.tsv > $out/timeline_idle.txt 2>&1
+# F5 three-camera width (90x360): HBM traffic + per-stream timeline + bench line
+bash tools/c3_traffic.sh w360$r --width 360 > $out/w360_traffic.log 2>&1
+mkdir -p $out/w360 && cp gpurun_out/c3t_w360$r/step_FETCH_SIZE.txt gpurun_out/c3t_w360$r/step_WRITE_SIZE.txt gpurun_out/c3t_w360$r/timeline_step.txt $out/w360/
+timeout 600 python bench.py --no-cpu-baseline --no-kernel-rooflines --width 360 --steps 30 2>/dev/null | tail -1 > $out/w360/bench.json
 cfg=$out/final_configs.txt
 echo "secondary configurations (python bench.py --no-cpu-baseline ...): ms_per_step / update-steps/s / roofline" > $cfg
 run() { echo "== $*" >> $cfg; timeout 600 python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline'])" >> $cfg 2>&1; }
