@@ -10,8 +10,6 @@
 //   * A is loaded as float32 (16-byte lanes), split on its way into LDS (three bf16 planes, 128 rows x 32 k per stage), double
 //     buffered: the loads of stage i+1 are issued before the MFMAs of stage i;
 //   * 128 x 128 output tile per workgroup, 2 x 2 waves of 64 x 64 (four 32x32 accumulators each).
-#include <stdlib.h>
-
 #include "colreduce.h"
 
 namespace cdrl {
@@ -187,126 +185,6 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// Round 5: the same product with a tile shape that DIVIDES THE CHIP.  The 128 x 128 kernel above puts the 464 -> 768 head conv of the
-// benchmark (M = 12288) on 96 x 6 = 576 workgroups for 512 resident slots: a second round of 64 tiles runs alone after the first 512
-// (93.7 us isolated for 21 us of matrix-pipe time, profiles/r04_iso_gx3_diag.txt).  Here a workgroup owns 96 rows x (32 WV) columns:
-// WV waves, each ONE column tile x three row tiles (18 MFMAs per K = 16 step against 3 fragment loads from L2 and 9 from LDS).
-//   forward   N = 768: WV = 6 -> 128 x 4 = 512 workgroups of 6 waves = 3 waves on every SIMD, one round;
-//   backward  N = 464: WV = 5 -> 128 x 3 = 384 workgroups (480 columns: 3 % padding instead of 10 %).
-// Same packed B, same LDS planes, same two-stage register prefetch of A; float32 only (NS = 3).
-template <int WV>
-__global__ void __launch_bounds__(64 * WV) gemm_x3w_kernel(GemmX3Args a) {
-    constexpr int BM = 96, BK = 32, LDA = BK + 8;
-    constexpr int NT = 64 * WV;
-    constexpr int NCH = (BM * 8 + NT - 1) / NT;                 // 16-byte chunks of an A stage per thread (768 chunks)
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BM * LDA];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = lane & 31, lk = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * (32 * WV) + wave * 32;
-    const int K = a.K, N = a.N;
-    const int nstage = (K + BK - 1) / BK;
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    const uint32_t OOR = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a.A.p, 0, (int)((int64_t)a.M * a.A.ld * 4), 0x00020000);
-    auto load_stage = [&](int s, u32x4_t (&ra)[NCH]) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + NT * i, r = c >> 3, k = s * BK + 4 * (c & 7);
-            const int64_t m = m0 + r;
-            const bool ok = c < BM * 8 && m < a.M && k < K;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (uint32_t)((m * a.A.ld + a.A.coff + k) * 4) : OOR, 0, 0);
-        }
-    };
-    auto store_stage = [&](int buf, const u32x4_t (&ra)[NCH]) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + NT * i, r = c >> 3, ck = 4 * (c & 7);
-            if (c >= BM * 8) continue;
-            bf16x4 h[3];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __bf16 h1, h2, h3;
-                gx3_split(__uint_as_float(ra[i][e]), h1, h2, h3);
-                h[0][e] = h1;
-                h[1][e] = h2;
-                h[2][e] = h3;
-            }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(&As[buf][p][r * LDA + ck]) = h[p];
-        }
-    };
-    f32x16 acc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    const int64_t plane = (int64_t)a.KS * 2 * a.NP * 8;
-    const bool ncol = n0 + lrow < a.NP;                         // (NP is a multiple of 128 >= N: the packed planes cover every column tile)
-    auto load_b = [&](int ks, bf16x8 (&bf)[3]) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            bf[p] = *reinterpret_cast<const bf16x8*>(a.Bp + p * plane + (((int64_t)ks * 2 + lk) * a.NP + (ncol ? n0 + lrow : 0)) * 8);
-    };
-    auto mma = [&](int buf, int kk, const bf16x8 (&bf)[3]) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int ao = (i * 32 + lrow) * LDA + 16 * kk + 8 * lk;
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[buf][0][ao]);
-            const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&As[buf][1][ao]);
-            const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&As[buf][2][ao]);
-            f32x16 c = acc[i];           // smallest terms first (as in the 128 x 128 kernel)
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bf[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf[2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bf[1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bf[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf[1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf[0], c, 0, 0, 0);
-            acc[i] = c;
-        }
-    };
-    bf16x8 b0[3], b1[3];
-    u32x4_t raA[NCH], raB[NCH];
-    load_stage(0, raA);
-    load_b(0, b0);
-    if (nstage > 1) load_stage(1, raB);
-    store_stage(0, raA);
-    if (nstage > 2) load_stage(2, raA);
-    __syncthreads();
-    auto iter = [&](int s, u32x4_t (&ruse)[NCH]) {
-        const int buf = s & 1, ks = 2 * s;
-        if (ks + 1 < a.KS) load_b(ks + 1, b1);
-        mma(buf, 0, b0);
-        if (ks + 1 < a.KS) {
-            if (ks + 2 < a.KS) load_b(ks + 2, b0);
-            mma(buf, 1, b1);
-        }
-        if (s + 1 < nstage) store_stage(buf ^ 1, ruse);
-        if (s + 3 < nstage) load_stage(s + 3, ruse);
-        __syncthreads();
-    };
-    for (int s = 0; s < nstage; s += 2) {
-        iter(s, raB);
-        if (s + 1 < nstage) iter(s + 1, raA);
-    }
-    const int n = n0 + lrow;
-    if (n >= N) return;
-    const float bv = a.bias ? a.bias[n] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (m < a.M) {
-                float* c = a.C.p + m * a.C.ld + a.C.coff + n;
-                float v = acc[i][r] + bv;
-                if (a.accumulate) v += *c;
-                *c = v;
-            }
-        }
-}
-
 // B(k, n) = w[k * sbk + n * sbn] -> [3][KS][2][NP][8] bf16
 __global__ void gemm_x3_pack_kernel(const GemmX3Pack* __restrict__ tab) {
     const GemmX3Pack d = tab[blockIdx.y];
@@ -371,17 +249,6 @@ int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int
     if (at && !bf16_operands) {
         set_error("gemm_x3: bf16 activation storage needs the bf16-operand variant");
         return -1;
-    }
-    // float32, wide products with enough rows: the chip-dividing tile (96 x 192 / 96 x 160) where its workgroup count fits one round
-    // better than the 128 x 128 tiling (CDRL_GX3_WIDE=0 -> always 128 x 128)
-    static const bool wide = !(cdrl_getenv("CDRL_GX3_WIDE") && atoi(cdrl_getenv("CDRL_GX3_WIDE")) == 0);
-    if (wide && !at && !bf16_operands && N >= 320 && K >= 64 && M >= 96 * 64) {
-        const int t6 = cdiv(N, 192), t5 = cdiv(N, 160);
-        const int wv = (t5 * 160 - N) < (t6 * 192 - N) ? 5 : 6;         // less column padding wins (768 -> 6, 464 -> 5)
-        if (wv == 6) hipLaunchKernelGGL(gemm_x3w_kernel<6>, dim3(cdiv(M, 96), t6), dim3(384), 0, st, a);
-        else hipLaunchKernelGGL(gemm_x3w_kernel<5>, dim3(cdiv(M, 96), t5), dim3(320), 0, st, a);
-        CDRL_LAUNCH_CHECK();
-        return 0;
     }
     if (at) hipLaunchKernelGGL((gemm_x3_kernel<1, true>), dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
     else if (bf16_operands) hipLaunchKernelGGL(gemm_x3_kernel<1>, dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
