@@ -54,6 +54,23 @@ int env_overrides(char* buf, int cap);      // "NAME=VALUE ..." of every CDRL_* 
 
 #define CDRL_LAUNCH_CHECK() CDRL_HIP(hipGetLastError())
 
+// "Set the dynamic-LDS attribute of this kernel once" guards: once PER DEVICE (a second engine on another device of the same process, or
+// the optional second enqueue thread racing the first launch, must not launch without it -- ADVICE r4): one flag per device and guard
+// site, set after the attribute call returned; the call is idempotent, so two threads doing it at once is harmless.
+struct LdsAttrOnce {
+    volatile unsigned char done[64] = {};
+    bool need() const {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return !done[d & 63];
+    }
+    void mark() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        done[d & 63] = 1;
+    }
+};
+
 #define CDRL_TRY(expr)            \
     do {                          \
         int _r = (expr);          \

@@ -579,10 +579,14 @@ __global__ void __launch_bounds__(DWF_T_BWD) dwf_bwd_kernel(const T* __restrict_
 //  second instantiation that needs > 64 KB would never get its attribute set)
 template <auto Kern>
 static int allow_lds(size_t bytes) {
-    static size_t allowed = 64 * 1024;
-    if (bytes > allowed) {
+    static size_t allowed[64];          // per device (zero-initialised: 64 KB are always allowed)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& a = allowed[dev & 63];
+    if (a < 64 * 1024) a = 64 * 1024;
+    if (bytes > a) {
         CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        allowed = bytes;
+        a = bytes;
     }
     return 0;
 }

@@ -300,11 +300,11 @@ static int launch_nn_persist(bool bt, bool vec, hipStream_t st, View A, const fl
     if (grid > ntiles) grid = ntiles;
 #define CDRL_PERSIST(BTv, VECv)                                                                                         \
     do {                                                                                                                \
-        static bool attr_done = false;                                                                                  \
-        if (!attr_done) {                                                                                               \
+        static LdsAttrOnce attr_done;                                                                                   \
+        if (attr_done.need()) {                                                                                               \
             CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nn_persist_kernel<NT, BTv, VECv>),           \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                       \
-            attr_done = true;                                                                                           \
+            attr_done.mark();                                                                                             \
         }                                                                                                               \
         hipLaunchKernelGGL((gemm_nn_persist_kernel<NT, BTv, VECv>), dim3(grid), dim3(256), lds, st, A, Bp, sbk, sbn, bias, \
                            C, M, N, K, acc, ntiles);                                                                    \

@@ -1033,10 +1033,10 @@ static int pwb_launch(const PwbArgs& a, hipStream_t st) {
     constexpr int BM = (KP == 128 || NP == 128) ? 32 : 64;
     constexpr size_t lds = (size_t)(3 * BM * (NP + 8) + 3 * (NP + KP) * (BM + 8)) * 2 + (size_t)7 * NP * sizeof(float);
     auto kern = pwb_kernel<KP, NP, SHUF, ANORM, ACC>;
-    static bool attr = false;
-    if (!attr) {
+    static LdsAttrOnce attr;
+    if (attr.need()) {
         CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg), dim3(512), lds, st, a);
     CDRL_LAUNCH_CHECK();
@@ -1048,10 +1048,10 @@ static int pwb16_launch(const PwbArgs& a, hipStream_t st) {
     constexpr int BM = P == 128 ? 32 : 64;
     constexpr size_t lds = (size_t)(BM * (P + 8) + 2 * P * (BM + 8)) * 2 + (size_t)7 * P * sizeof(float) + (size_t)(P / 16) * 2 * 128 * 8 * 2;
     auto kern = pwb16_kernel<P, P, SHUF, ANORM, ACC>;
-    static bool attr = false;
-    if (!attr && lds >= 64 * 1024) {
+    static LdsAttrOnce attr;
+    if (attr.need() && lds >= 64 * 1024) {
         CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL(kern, dim3(a.G * a.nbpg), dim3(512), lds, st, a);
     CDRL_LAUNCH_CHECK();

@@ -101,6 +101,10 @@ __global__ void __launch_bounds__(256, 2) pw_x3_kernel(PwX3Args a) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x2 x = f32x2{__uint_as_float(ra[i][2 * h]), __uint_as_float(ra[i][2 * h + 1])};
+                // columns beyond K inside the last 4-wide chunk (K = 58: 58, 59) are whatever the neighbouring channels of a wider
+                // tensor hold: a non-finite value there would survive the zero weights (0 * NaN); zeroed here
+                if (k4 + 2 * h >= K) x[0] = 0.0f;
+                if (k4 + 2 * h + 1 >= K) x[1] = 0.0f;
                 if (PRO) {
                     // (columns beyond K carry scale 0 / shift 0 in pc)
                     const f32x2 sc = f32x2{pc[0][k4 + 2 * h], pc[0][k4 + 2 * h + 1]}, sh = f32x2{pc[1][k4 + 2 * h], pc[1][k4 + 2 * h + 1]};

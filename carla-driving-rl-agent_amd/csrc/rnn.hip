@@ -113,11 +113,11 @@ int gru_step_fwd(const float* xp, const float* hprev, const float* R, const floa
     }
     GruFwdArgs a{xp, hprev, R, b1, z, r, hh, hp, hnew, out, B, u};
     const size_t lds = (size_t)(GT * (u + 4) + 4 * 3 * GT * 17) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static LdsAttrOnce attr;
+    if (attr.need()) {
         CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(cdiv(B, GT), u / GT), dim3(256), lds, st, a);
     CDRL_LAUNCH_CHECK();
@@ -222,11 +222,11 @@ int gru_step_bwd(View dh, const float* z, const float* r, const float* hh, const
     }
     GruBwdArgs a{dh, z, r, hh, hp, hprev, RT, dxp, dhp, dhprev, B, u};
     const size_t lds = (size_t)(GT * (3 * u + 4) + 4 * GT * 17) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static LdsAttrOnce attr;
+    if (attr.need()) {
         CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
-        attr = true;
+        attr.mark();
     }
     // first time step: no dh_prev consumer -> only the gate derivatives (one column of workgroups)
     hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(cdiv(B, GT), dhprev ? u / GT : 1), dim3(256), lds, st, a);

@@ -272,6 +272,7 @@ def _pinned_weight_check(views, w64, g64, m0, v0, t, lr, what, tol=TOL, floor_fr
     gmax = max(float(np.abs(_np(g)).max()) for g in g64.values())
     nsure = ntot = 0
     worst_sure = 0.0
+    worst_all = dict(rel_tensor_scale=0.0, in_units_of_lr=0.0, tensor=None)
     for name, g in g64.items():
         if is_degenerate_bias(name):
             continue
@@ -289,13 +290,22 @@ def _pinned_weight_check(views, w64, g64, m0, v0, t, lr, what, tol=TOL, floor_fr
         bound = 1.25 * dev + 2e-7 * wscale + 1e-9
         bad = np.abs(w_eng - w_ref) > bound
         assert not bad.any(), (what, name, float(np.abs(w_eng - w_ref).max()), float(bound[bad].max()), int(bad.sum()))
+        # the worst deviation over ALL elements, stable update or not -- relative to the tensor's scale (north_star's
+        # "updated weights within 1e-4" read literally) and in units of the learning rate (an element whose gradient lies inside the
+        # tolerance interval around 0 may legitimately move by up to 2 lr: Adam's first step is lr * sign(g))
+        diff_all = float(np.abs(w_eng - w_ref).max())
+        if diff_all / wscale > worst_all['rel_tensor_scale']:
+            worst_all = dict(rel_tensor_scale=diff_all / wscale, in_units_of_lr=diff_all / lr, tensor=name)
         sure = dev < 1e-6 * wscale
         nsure += int(sure.sum())
         ntot += sure.size
         if sure.any():
             worst_sure = max(worst_sure, float((np.abs(w_eng - w_ref)[sure]).max() / wscale))
     REPORT.append(dict(what=f'{what} (decision-pinned)', elements=ntot, elements_with_stable_update=nsure,
-                       worst_rel_err_on_stable_elements=worst_sure))
+                       worst_rel_err_on_stable_elements=worst_sure, worst_deviation_over_all_elements=worst_all,
+                       note='elements without a stable update have |g| within the gradient tolerance of 0, where one Adam step is '
+                            'lr * sign(g): they may differ by up to 2 lr (checked element-wise against the image of the tolerance interval)'))
+    assert worst_all['in_units_of_lr'] <= 2.0 + 1e-3, worst_all
     assert worst_sure <= tol
 
 
