@@ -109,6 +109,15 @@ def dominant_kernel(B, T, H, W):
         by = 4.0 * 4.0 * B * T * 48 * 116
         out.update(algorithmic_bytes_per_launch=by, achieved_GBs=round(by / (avg_us * 1e-6) / 1e9, 1),
                    frac=round(by / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), note='critical-stream kernel (stage-1 shape)')
+    elif name.startswith('pwb_reduce_kernel'):
+        # fixed-order reduce of the fused conv backward's per-workgroup partial tiles: reads 256 tiles of KP x NP floats (64 KB each at
+        # KP = NP = 128: stage 1; 16 KB at 64 x 64: stage 0) + the column-sum rows, writes dW / db (and BN2's coefficients).  Averaged
+        # over the 23 launches of a pass: 16 at stage 1, 7 at stage 0
+        by = (16 * 256 * 128 * 128 * 4.0 + 7 * 256 * 64 * 64 * 4.0) / 23
+        out.update(algorithmic_bytes_per_launch=by, achieved_GBs=round(by / (avg_us * 1e-6) / 1e9, 1),
+                   frac=round(by / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                   note='largest total over BOTH streams (46 launches per update-step: 24 on the critical stream, 22 on the side stream next '
+                        'to it); the partial tiles are L2 / Infinity-Cache resident writes of the kernel in front')
     if name.startswith('tn_direct_tr_kernel<4'):
         if name.startswith('tn_direct_tr_kernel<4, false'):
             # pw1 filter gradients (A = the unit's input, D = dz of BN1 recomputed in the operand prologue) of the stage-1 units
@@ -230,9 +239,33 @@ def kernel_rooflines(B, T, nsets=8):
     dw = torch.empty(Cc, Cc, device=dev)
     ws = torch.empty(int(lib.cdrl_gemm_tn_workspace_elems(M, Cc, Cc)), device=dev)
     t = timeit(lambda k: lib.cdrl_gemm_tn(P(a[k]), Cc, 0, P(y[k]), Cc, 0, P(dw), M, Cc, Cc, P(ws), 0, S()))
-    out.append(dict(kernel='tn_direct_kernel<4> + tn_reduce (filter gradient)', shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1),
+    out.append(dict(kernel='tn_lds_kernel<3> + tn_reduce (filter gradient, float32 tensors on the bf16 pipe by three-way split; off the path of '
+                           'stages 0 / 1 since the fused conv backward)', shape=f'M={M} K=N={Cc}', us=round(t * 1e6, 1),
                     algorithmic_bytes=by, achieved_GBs=round(by / t / 1e9, 1), frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
                     cache_state=cold))
+    # stage 2 (K = N = 232, 3x4 pixels: M = B*T*12 rows) -- 6 % of the bytes, 19 % of the step: the forward conv with
+    # the BatchNorm statistics epilogue and the filter gradient as the step runs them.  23 MB per launch: these launches are cache-resident
+    # at any number of rotating sets the Infinity Cache can be beaten with only from B = 1024 on (labelled)
+    C2, M2 = 232, G * B * 12
+    a2 = [torch.randn(M2, C2, device=dev) for _ in range(nsets)]
+    y2 = [torch.empty(M2, C2, device=dev) for _ in range(nsets)]
+    w2 = torch.randn(C2, C2, device=dev)
+    b2 = torch.randn(C2, device=dev)
+    nb2 = int(lib.cdrl_pwconv_fused_partial_rows(G, M2 // G, C2, C2))
+    part2 = torch.zeros(G * nb2 * 2 * C2, dtype=torch.float64, device=dev)
+    warm = f'{nsets} rotating buffer sets of {2 * M2 * C2 * 4 / 1e6:.0f} MB = {nsets * 2 * M2 * C2 * 4 / 1e6:.0f} MB: inside the 256 MB Infinity Cache'
+    t = timeit(lambda k: lib.cdrl_pwconv_fused(P(a2[k]), C2, 0, None, P(w2), C2, 1, P(b2), P(y2[k]), C2, 0, 0, G, M2 // G, C2, C2, 1, None,
+                                               None, P(part2), S()))
+    by2 = 4.0 * M2 * 2 * C2
+    out.append(dict(kernel='pw_nn_kernel<128,4,0,1> (stage-2 forward conv, K = N = 232, W in registers, float32 MFMA, statistics epilogue)',
+                    shape=f'M={M2} K=N={C2}', us=round(t * 1e6, 1), algorithmic_bytes=by2, achieved_GBs=round(by2 / t / 1e9, 1),
+                    frac=round(by2 / t / 1e9 / HBM_PEAK_GBS, 4), cache_state=warm))
+    dw2 = torch.empty(C2, C2, device=dev)
+    ws2 = torch.empty(int(lib.cdrl_gemm_tn_workspace_elems(M2, C2, C2)), device=dev)
+    t = timeit(lambda k: lib.cdrl_gemm_tn(P(a2[k]), C2, 0, P(y2[k]), C2, 0, P(dw2), M2, C2, C2, P(ws2), 0, S()))
+    out.append(dict(kernel='tn_lds_kernel<3> + tn_reduce (stage-2 filter gradient, K = N = 232)', shape=f'M={M2} K=N={C2}', us=round(t * 1e6, 1),
+                    algorithmic_bytes=by2, achieved_GBs=round(by2 / t / 1e9, 1), frac=round(by2 / t / 1e9 / HBM_PEAK_GBS, 4), cache_state=warm))
+    del a2, y2
     # round 4: the whole backward of a unit conv in one pass (backward-data + filter / bias gradient + the BatchNorm-backward sums of
     # the BatchNorm in front): reads dz (gathered through the channel shuffle), y, a and writes da
     dz = [torch.randn(M, 2 * Cc, device=dev) for _ in range(nsets)]

@@ -876,7 +876,24 @@ __global__ void __launch_bounds__(128 * PWB_RS) pwb_reduce_kernel(PwbReduceArgs 
             const float* pq = a.qpart + ((int64_t)g * a.nbpg * a.KP + k) * a.NP + n;
             const double* pd = a.dbpart + (int64_t)g * a.nbpg * a.NP + n;
             int b = b0;
-            for (; b + 16 <= b1; b += 16) {         // 32 loads in flight per thread (a slot's 32 partials are two rounds)
+            // the column sums of dy are needed for every k only when the BatchNorm sums of the conv input are derived here (ANORM); the
+            // plain form writes db from k == 0 alone -- 32 of its 64 loads per thread were for values nobody reads
+            const bool need_d = a.a_stats != nullptr || k == 0;
+            for (; b + 32 <= b1; b += 32) {         // a slot's 32 partials in ONE round of loads (two rounds of 16 before round 5)
+                float v[32];
+                double u[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    v[i] = pq[(int64_t)(b + i) * a.KP * a.NP];
+                    u[i] = need_d ? pd[(int64_t)(b + i) * a.NP] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    q += (double)v[i];
+                    d += u[i];
+                }
+            }
+            for (; b + 16 <= b1; b += 16) {
                 float v[16];
                 double u[16];
 #pragma unroll
