@@ -54,7 +54,7 @@ struct PwbArgs {
     double* fin_tot;
     int fin_nb;
     int at;                 // host dispatch: 1 = bf16 activation storage (pwb16_kernel)
-    int dbg;                // timing diagnostics (CDRL_DIAG=1 CDRL_DIAG_PWB=bits, wrong results): 1 no MFMA, 2 no LDS writes, 4 no stores, 8 no loads
+    int dbg;                // timing diagnostics (CDRL_DIAG=1 CDRL_DIAG_PWB=bits, wrong results): 1 no MFMA, 2 no LDS writes, 4 no stores, 8 no loads, 16 no partial-tile stores, 32 no W^T fragment loads
 };
 
 __device__ __forceinline__ void pwb_split3(float x, __bf16& h1, __bf16& h2, __bf16& h3) {
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int s = 0; s < KS_DA; ++s)
-                    breg[p][s] = *reinterpret_cast<const bf16x8*>(a.Wp + (((int64_t)(p * KS_DA + s) * 2 + lk) * 128 + n) * 8);
+                    if (!(a.dbg & 32)) breg[p][s] = *reinterpret_cast<const bf16x8*>(a.Wp + (((int64_t)(p * KS_DA + s) * 2 + lk) * 128 + n) * 8);
         }
         // the seven per-column coefficients live in LDS (28 registers otherwise: this role also holds the W^T fragments);
         // padded columns carry 0 everywhere, so their dy is 0
@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
             __syncthreads();
         }
         float* qp = a.qpart + ((int64_t)g * a.nbpg + b) * KP * NP;
+        if (!(a.dbg & 16))
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int n = (qnt0 + j) * 32 + lrow;

@@ -15,6 +15,7 @@ S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 def run(G, Mg, K, N, shuffle, anorm, nsets=4, iters=24):
     M = G * Mg
+    torch.manual_seed(G * 1000003 + Mg + K * 7 + N + shuffle * 2 + anorm)
     ctot, coff = (2 * N, N) if shuffle else (N, 0)
     sets = []
     for _ in range(nsets):
@@ -48,6 +49,15 @@ def run(G, Mg, K, N, shuffle, anorm, nsets=4, iters=24):
                                           P(ast) if anorm else None, P(w), G, Mg, N, K, P(dg), P(dbt), P(coef), P(s['da']), K, 0, 0,
                                           P(dW), P(dB), P(ws), S()))
 
+    if os.environ.get('PWB_HASH'):      # bit pattern of every output of the fused form (compare two builds / switches)
+        import hashlib
+        new(0)
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for t in (sets[0]['da'], dW, dB, adg, adb, acf):
+            h.update(t.cpu().numpy().tobytes())
+        print(f'G={G} Mg={Mg} K={K} N={N} shuffle={shuffle} anorm={anorm}: outputs sha256 {h.hexdigest()[:16]}')
+        return
     out = {}
     for name, fn in ((('fused', new),) if os.environ.get('PWB_NEW_ONLY') else (('fused', new), ('old composite (reduce + finalize + bwd-data + filter gradient)', old))):
         for k in range(nsets):
@@ -63,8 +73,19 @@ def run(G, Mg, K, N, shuffle, anorm, nsets=4, iters=24):
     print(f'G={G} Mg={Mg} K={K} N={N} shuffle={shuffle} anorm={anorm}: ' + ', '.join(f'{k}: {v:.1f} us' for k, v in out.items()))
 
 
+if __name__ == '__main__' and os.environ.get('PWB_FIXED'):        # fixed cost of a launch against its per-tile cost: 0 / 1 / 2 / 4 / 6 tiles per workgroup
+    for mg in (32, 2048, 4096, 8192, 12288):
+        run(4, mg, 116, 116, 0, 0)
+    for mg in (64, 4096, 8192, 16384, 42240):
+        run(4, mg, 58, 58, 0, 0)
+    sys.exit(0)
 if __name__ == '__main__':
     run(4, 12288, 116, 116, 1, 1)
     run(4, 12288, 116, 116, 0, 0)
     run(4, 42240, 58, 58, 1, 1)
     run(4, 42240, 58, 58, 0, 0)
+    if os.environ.get('PWB_HASH'):
+        run(4, 12288 - 37, 116, 116, 1, 1)      # ragged last tiles
+        run(3, 42240 - 5, 58, 58, 1, 1)
+        run(4, 42240, 24, 58, 0, 0)
+        run(4, 12288, 58, 116, 0, 0)            # 64 -> 128
