@@ -830,7 +830,7 @@ struct PoolBnReduceF {
         if (VEC == 4) am = *reinterpret_cast<const uint32_t*>(ps.argmax + row * C + c0);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const int k = VEC == 4 ? (int)((am >> (8 * i)) & 0xffu) : (int)ps.argmax[row * C + c0 + i];
+            const int k = (VEC == 4 ? (int)((am >> (8 * i)) & 0xffu) : (int)ps.argmax[row * C + c0 + i]) & 0x7f;      // (bit 7: ReLU6 flag of maxpool_bn_fwd)
             const int ky = k / 3, kx = k - 3 * ky;
             const int iy = 2 * oy - ps.pt + ky, ix = 2 * ox - ps.pl + kx;
             const float v = ldf(reinterpret_cast<const T*>(y) + ((n * ps.H + iy) * ps.W + ix) * C + c0 + i);
@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
                             // apply side (stem_bwd_filter_fused) takes the mask from the raw conv output -- decide from that here too
                             // (rare: one gather for the element)
                             const int64_t row = gbase + rr + u * CY;
-                            const int k = (int)ps.argmax[row * C + c0 + i];
+                            const int k = (int)ps.argmax[row * C + c0 + i] & 0x7f;
                             const int ox = (int)(row % ps.Wo);
                             const int64_t q = row / ps.Wo;
                             const int oy = (int)(q % ps.Ho);
@@ -946,7 +946,7 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
             for (int u = 0; u < RU; ++u)
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
-                    const int k = (int)((am[u] >> (8 * i)) & 0xffu);
+                    const int k = (int)((am[u] >> (8 * i)) & 0x7fu);
                     const int ky = k / 3, kx = k - 3 * ky;
                     v[u][i] = ldf(y + ybase[u] + ((int64_t)ky * ps.W + kx) * C + i);
                 }

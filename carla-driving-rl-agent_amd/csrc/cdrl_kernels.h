@@ -172,6 +172,15 @@ int64_t stem_bwd_direct_ws_floats(int B, int T, int H, int W);
 int stem_bwd_direct(const float* x, const PoolSrc& ps, const float* y, const float* stats, float* dgamma, float* dbeta, float* coef,
                     float* dw, float* db, int B, int T, int H, int W, int Cout, float* ws, hipStream_t st);
 bool stem_bwd_fused_supported(int Cout);
+// Coefficient-free form of the same gradient (conv.hip, round 5): Gram of the image patches in the forward, one gather pass over the
+// pooled gradient beside the BatchNorm reduction, a 28 x Cout combine once the coefficients exist.  part: stem_xt_part_floats(.., nc)
+// floats with nc = 28 (gram) / Cout (raw); gram [T][28][28], A [T][28][Cout] doubles.
+bool stem_bwd_raw_supported(int Cout);
+int64_t stem_xt_part_floats(int B, int T, int H, int W, int nc);
+int stem_gram(const float* x, int B, int T, int H, int W, float* part, double* gram, hipStream_t st);
+int stem_bwd_raw(const float* x, const PoolSrc& ps, int B, int T, int H, int W, int Cout, float* part, double* A, hipStream_t st);
+int stem_bwd_combine(const double* A, const double* gram, const float* w, const float* bias, const float* stats, const float* coef,
+                     int T, int Cout, float* dw, float* db, hipStream_t st);
 int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, const float* stats, const float* coef, float* dw,
                           float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st, int at = 0);
 int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,

@@ -229,11 +229,11 @@ __device__ __forceinline__ VecF<VEC> pool_gather(const PoolSrc& ps, int64_t row,
                 const uint32_t am = *reinterpret_cast<const uint32_t*>(ps.argmax + o);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i)
-                    if (((am >> (8 * i)) & 0xffu) == (uint32_t)(ky * 3 + kx)) acc.v[i] += d.v[i];
+                    if (((am >> (8 * i)) & 0x7fu) == (uint32_t)(ky * 3 + kx)) acc.v[i] += d.v[i];      // (bit 7: ReLU6 flag of maxpool_bn_fwd)
             } else {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i)
-                    if (ps.argmax[o + i] == (uint8_t)(ky * 3 + kx)) acc.v[i] += d.v[i];
+                    if ((ps.argmax[o + i] & 0x7f) == (uint8_t)(ky * 3 + kx)) acc.v[i] += d.v[i];
             }
         }
     }

@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restr
                     float d = 0.0f;
 #pragma unroll
                     for (int w4 = 0; w4 < 4; ++w4)
-                        if (((ga[j][w4] >> (8 * i)) & 0xffu) == wk[w4]) d += __uint_as_float(gd[j][w4][i]);
+                        if (((ga[j][w4] >> (8 * i)) & 0x7fu) == wk[w4]) d += __uint_as_float(gd[j][w4][i]);
                     const float v = __uint_as_float(gy[j][i]);
                     const float mean = CF[gs][0][c0 + i], inv = CF[gs][1][c0 + i], sc = CF[gs][2][c0 + i], sh = CF[gs][3][c0 + i];
                     const float k1 = CF[gs][4][c0 + i], k2 = CF[gs][5][c0 + i], k3 = CF[gs][6][c0 + i];
@@ -521,6 +521,244 @@ int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, con
     CDRL_LAUNCH_CHECK();
     CDRL_TRY(reduce_partials_f32(pf, nblk, (int64_t)27 * Cout, (int64_t)28 * Cout, dw, 0, st));
     return reduce_partials_f32(pf + 27 * Cout, nblk, Cout, (int64_t)28 * Cout, db, 0, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// COEFFICIENT-FREE form of the stem filter gradient (round 5, float32 engine).
+//
+// The fused form above needs the BatchNorm-backward coefficients (k1, k2, k3) of the stem BatchNorm, which exist only after the
+// LAST reduction of a backward pass (sums over the pooled gradient) -- so its 170 us pass over y, the pooled gradient and the
+// images sat, fully exposed, in the tail of every pass (0.36 ms per update-step, tools/r05_stem_diag.sh).  With
+//     dy = k1 (dzm - k2 - xhat k3),  dzm = ReLU6 mask * pool-gathered gradient,  xhat = (y - mean) invstd,  y = P W + b
+// (P = im2col patches [rows][27], per time slice g because the BatchNorm is per time slice) the product splits into three parts
+// none of which needs the coefficients:
+//     dW[k][c] = sum_g k1 ( A_g[k][c] - k2 SP_g[k] - k3 X_g[k][c] ),   db[c] = the same with the ones column k = 27
+//     A_g = [P | 1]^T dzm                  <- ONE gather pass over the pooled gradient and the images, started as soon as the pooled
+//                                             gradient is final, beside the BatchNorm reduction (stem_bwd_raw)
+//     SP_g[k] = sum_r P[r][k],  Gram_g = [P | 1]^T [P | 1]      <- depend on the IMAGES only: taken in the forward pass (stem_gram)
+//     X_g = [P | 1]^T xhat = invstd ( Gram_g[:, :27] W + SP_g b - mean SP_g )        <- no pass over y at all
+// and a 28 x 24 combine kernel in double once the coefficients exist (stem_bwd_combine).  The ReLU6 mask comes with the argmax code
+// (bit 7 set by maxpool_bn_fwd where the winning activation is clamped), so the gather needs neither y nor the pooled output.
+// Partials: one float tile [28][NC] per workgroup, workgroups never straddle a time slice, fixed-order reduction in double.
+// MODE 0: B operand = gathered dzm (NC = Cout);  MODE 1: B operand = the patch tile itself (NC = 28).
+template <int MODE, int NCH>
+__global__ void __launch_bounds__(256) stem_xt_kernel(const float* __restrict__ x, float* __restrict__ part, int B, int T, int H, int W,
+                                                      int Ho, int Wo, int Cout, int rows_per_group, int rows_per, int nbpg, PoolSrc ps) {
+    __shared__ float P[4][32][33];
+    __shared__ float D[MODE == 0 ? 4 : 1][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lcol = lane & 31, lk = lane >> 5;
+    const int g = blockIdx.x / nbpg, bg = blockIdx.x % nbpg;
+    const int r0 = g * rows_per_group + bg * rows_per;
+    const int r1 = min(r0 + rows_per, (g + 1) * rows_per_group);
+    f32x16_c acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int i = lane; i < 32 * 33; i += 64) {       // zero the padding columns once
+        (&P[wave][0][0])[i] = 0.0f;
+        if (MODE == 0) (&D[wave][0][0])[i] = 0.0f;
+    }
+    __amdgpu_buffer_rsrc_t rsDP, rsAM;
+    if (MODE == 0) {
+        const int64_t pel = (int64_t)B * T * ps.Ho * ps.Wo * Cout;
+        rsDP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.dp), 0, (int)(pel * sizeof(float)), 0x00020000);
+        rsAM = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ps.argmax), 0, (int)pel, 0x00020000);
+    }
+    for (int base = r0; base < r1; base += 128) {
+        const int wrow0 = base + wave * 32;
+        stem_wave_sync();
+        const int r = lane & 31, half = lane >> 5;
+        const int row = wrow0 + r;
+        const bool ok = row < r1;
+        int ox = 0, oy = 0, f = 0;
+        const float* xp = x;
+        if (ok) {
+            ox = row % Wo;
+            const int q = row / Wo;
+            oy = q % Ho;
+            f = q / Ho;
+            const int t = f / B, b = f - t * B;
+            xp = x + ((((int64_t)b * T + t) * H + 2 * oy) * W + 2 * ox) * 3;
+        }
+        // patch tile as in stem_bwd_mfma_kernel: 32 rows x 28 (27 taps + ones column), 14 columns per half-wave lane
+        float pv[14];
+#pragma unroll
+        for (int jj = 0; jj < 14; ++jj) {
+            const int j1 = jj == 13 ? 12 : 14 + jj;
+            const int o0 = (jj / 9) * W * 3 + (jj % 9);
+            const int o1 = (j1 / 9) * W * 3 + (j1 % 9);
+            pv[jj] = xp[half ? o1 : o0];
+        }
+        if (MODE == 0) {
+            // the (at most 2 x 2) pool windows that reach this pre-pool pixel, all loads unconditional through buffer descriptors
+            const uint32_t OOR = 0x80000000u;
+            const int kyA = (oy + ps.pt) & 1, kxA = (ox + ps.pl) & 1;
+            const int pyA = (oy + ps.pt - kyA) >> 1, pxA = (ox + ps.pl - kxA) >> 1;
+            const bool vyA = ok && pyA < ps.Ho, vyB = ok && kyA == 0 && pyA >= 1 && (pyA - 1) < ps.Ho;
+            const bool vxA = pxA < ps.Wo, vxB = kxA == 0 && pxA >= 1 && (pxA - 1) < ps.Wo;
+            const int pbase = ((f * ps.Ho + pyA) * ps.Wo + pxA) * Cout;
+            const int dyB = -ps.Wo * Cout, dxB = -Cout;
+            uint32_t wo[4], wk[4];
+            wo[0] = (vyA && vxA) ? (uint32_t)pbase : OOR;
+            wo[1] = (vyA && vxB) ? (uint32_t)(pbase + dxB) : OOR;
+            wo[2] = (vyB && vxA) ? (uint32_t)(pbase + dyB) : OOR;
+            wo[3] = (vyB && vxB) ? (uint32_t)(pbase + dyB + dxB) : OOR;
+            wk[0] = kyA * 3 + kxA;
+            wk[1] = kyA * 3 + kxA + 2;
+            wk[2] = (kyA + 2) * 3 + kxA;
+            wk[3] = (kyA + 2) * 3 + kxA + 2;
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t gd[NCH][4];
+            uint32_t ga[NCH][4];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c0 = (half * NCH + j) * 4;
+                const bool on = c0 < Cout;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    const uint32_t eo = (on && wo[w4] != OOR) ? wo[w4] + c0 : OOR;
+                    gd[j][w4] = __builtin_amdgcn_raw_buffer_load_b128(rsDP, eo == OOR ? OOR : eo * 4u, 0, 0);
+                    ga[j][w4] = __builtin_amdgcn_raw_buffer_load_b32(rsAM, eo, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c0 = (half * NCH + j) * 4;
+                if (c0 >= Cout) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float d = 0.0f;
+                    // a code with bit 7 (clamped activation: closed ReLU6) never equals a window code: masked for free
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4)
+                        if (((ga[j][w4] >> (8 * i)) & 0xffu) == wk[w4]) d += __uint_as_float(gd[j][w4][i]);
+                    D[wave][r][c0 + i] = d;      // (rows beyond r1: every window offset is out of range -> 0)
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 14; ++jj) {
+            float val = pv[jj];
+            if (jj == 13 && half) val = 1.0f;
+            if (!ok) val = 0.0f;
+            P[wave][r][half * 14 + jj] = val;
+        }
+        stem_wave_sync();
+#pragma unroll
+        for (int mm = 0; mm < 32; mm += 2) {
+            const float a = P[wave][mm + lk][lcol];
+            const float bq = MODE == 0 ? D[wave][mm + lk][lcol] : a;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][lcol] = acc[r];
+    __syncthreads();
+    const int NC = MODE == 0 ? Cout : 28;
+    float* out = part + (int64_t)blockIdx.x * 28 * NC;
+    for (int idx = tid; idx < 28 * NC; idx += 256) {
+        const int k = idx / NC, n = idx - k * NC;
+        out[idx] = (P[0][k][n] + P[1][k][n]) + (P[2][k][n] + P[3][k][n]);
+    }
+}
+
+// out[g][i] = sum_p part[g][p][i] in double, fixed order: 8 partial lanes x 32 elements per workgroup, lanes folded through LDS
+__global__ void __launch_bounds__(256) stem_part_reduce_kernel(const float* __restrict__ part, int nbpg, int n, double* __restrict__ out) {
+    __shared__ double sm[8][32];
+    const int g = blockIdx.y, e = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
+    double s = 0.0;
+    if (e < n)
+        for (int p = pl; p < nbpg; p += 8) s += (double)part[((int64_t)g * nbpg + p) * n + e];
+    sm[pl][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (pl == 0 && e < n) {
+        double t = sm[0][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += sm[q][threadIdx.x];
+        out[(int64_t)g * n + e] = t;
+    }
+}
+
+// dW [27][C], db [C] from the per-slice sums (all double): A [G][28][C], Gram [G][28][28] (column / row 27 = the ones column), the
+// conv parameters, the BatchNorm statistics block [4][G][C] (mean, invstd, ..) and the backward coefficients [3][G][C] (k1, k2, k3)
+__global__ void __launch_bounds__(256) stem_bwd_combine_kernel(const double* __restrict__ A, const double* __restrict__ gram,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               const float* __restrict__ stats, const float* __restrict__ coef, int G,
+                                                               int C, float* __restrict__ dw, float* __restrict__ db) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 28 * C) return;
+    const int k = idx / C, c = idx - k * C;
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const double* Gg = gram + (int64_t)g * 28 * 28;
+        double gw = 0.0;
+#pragma unroll 9
+        for (int j = 0; j < 27; ++j) gw += Gg[k * 28 + j] * (double)w[j * C + c];
+        const double sp = Gg[k * 28 + 27];
+        const double mean = (double)stats[(0 * G + g) * C + c], inv = (double)stats[(1 * G + g) * C + c];
+        const double k1 = (double)coef[(0 * G + g) * C + c], k2 = (double)coef[(1 * G + g) * C + c], k3 = (double)coef[(2 * G + g) * C + c];
+        const double xk = inv * (gw + sp * ((double)bias[c] - mean));
+        s += k1 * (A[((int64_t)g * 28 + k) * C + c] - k2 * sp - k3 * xk);
+    }
+    if (k < 27) dw[k * C + c] = (float)s;
+    else db[c] = (float)s;
+}
+
+static void stem_xt_geom(int B, int T, int H, int W, int& Ho, int& Wo, int& rows_per_group, int& rows_per, int& nbpg) {
+    Ho = (H - 3) / 2 + 1;
+    Wo = (W - 3) / 2 + 1;
+    rows_per_group = B * Ho * Wo;
+    const int want = std::max(1, stem_nblk() / std::max(T, 1));
+    rows_per = cdiv(cdiv(rows_per_group, want), 128) * 128;
+    nbpg = cdiv(rows_per_group, rows_per);
+}
+
+bool stem_bwd_raw_supported(int Cout) { return stem_bwd_fused_supported(Cout); }
+
+// float workspace of stem_gram / stem_bwd_raw: the per-workgroup tiles
+int64_t stem_xt_part_floats(int B, int T, int H, int W, int nc) {
+    int Ho, Wo, rpg, rp, nbpg;
+    stem_xt_geom(B, T, H, W, Ho, Wo, rpg, rp, nbpg);
+    return (int64_t)T * nbpg * 28 * nc;
+}
+
+int stem_gram(const float* x, int B, int T, int H, int W, float* part, double* gram, hipStream_t st) {
+    int Ho, Wo, rpg, rp, nbpg;
+    stem_xt_geom(B, T, H, W, Ho, Wo, rpg, rp, nbpg);
+    hipLaunchKernelGGL((stem_xt_kernel<1, 1>), dim3(T * nbpg), dim3(256), 0, st, x, part, B, T, H, W, Ho, Wo, 28, rpg, rp, nbpg, PoolSrc{});
+    CDRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stem_part_reduce_kernel, dim3(cdiv(28 * 28, 32), T), dim3(256), 0, st, part, nbpg, 28 * 28, gram);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+int stem_bwd_raw(const float* x, const PoolSrc& ps, int B, int T, int H, int W, int Cout, float* part, double* A, hipStream_t st) {
+    if (!stem_bwd_raw_supported(Cout)) {
+        set_error("stem_bwd_raw: Cout=%d not supported", Cout);
+        return -1;
+    }
+    int Ho, Wo, rpg, rp, nbpg;
+    stem_xt_geom(B, T, H, W, Ho, Wo, rpg, rp, nbpg);
+    if ((int64_t)B * T * ps.Ho * ps.Wo * Cout * 4 >= (1ll << 31)) {
+        set_error("stem_bwd_raw: pooled gradient of 2 GB or more is not supported");
+        return -1;
+    }
+    const bool n3 = ((Cout >> 2) + 1) / 2 <= 3;
+    if (n3) hipLaunchKernelGGL((stem_xt_kernel<0, 3>), dim3(T * nbpg), dim3(256), 0, st, x, part, B, T, H, W, Ho, Wo, Cout, rpg, rp, nbpg, ps);
+    else hipLaunchKernelGGL((stem_xt_kernel<0, 4>), dim3(T * nbpg), dim3(256), 0, st, x, part, B, T, H, W, Ho, Wo, Cout, rpg, rp, nbpg, ps);
+    CDRL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stem_part_reduce_kernel, dim3(cdiv(28 * Cout, 32), T), dim3(256), 0, st, part, nbpg, 28 * Cout, A);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+int stem_bwd_combine(const double* A, const double* gram, const float* w, const float* bias, const float* stats, const float* coef,
+                     int T, int Cout, float* dw, float* db, hipStream_t st) {
+    hipLaunchKernelGGL(stem_bwd_combine_kernel, dim3(cdiv(28 * Cout, 256)), dim3(256), 0, st, A, gram, w, bias, stats, coef, T, Cout, dw, db);
+    CDRL_LAUNCH_CHECK();
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -853,7 +1091,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const uint8_t* __restr
                     const int ox = nx >> 1;
                     if (ox >= Wo) continue;
                     const int64_t o = (((int64_t)n * Ho + oy) * Wo + ox) * C + c;
-                    if (argmax[o] == (uint8_t)(ky * 3 + kx)) acc += dp[o];
+                    if ((argmax[o] & 0x7f) == (uint8_t)(ky * 3 + kx)) acc += dp[o];
                 }
             }
             da[(int64_t)r * C + c] = acc;
@@ -930,6 +1168,11 @@ __global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const T* __restrict
                 }
             }
             vstore<VEC>(p + (int64_t)r * C + c0, best);
+            // bit 7 of the code: the winning activation is clamped (ReLU6 closed) -- the backward's mask, for kernels that do not
+            // read y (stem_xt_kernel); every decoder masks the bit away
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (!relu6_open(best.v[i])) bi[i] |= 0x80;
             if (VEC == 4) {
                 *reinterpret_cast<uint32_t*>(argmax + (int64_t)r * C + c0) =
                     (uint32_t)bi[0] | ((uint32_t)bi[1 % VEC] << 8) | ((uint32_t)bi[2 % VEC] << 16) | ((uint32_t)bi[3 % VEC] << 24);

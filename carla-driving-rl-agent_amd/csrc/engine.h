@@ -317,6 +317,11 @@ private:
     Scratch* build_scr_ = &scr_main_;
     std::vector<Op> aux_ops_;
     hipEvent_t ev_aux_fork_ = nullptr, ev_aux_done_ = nullptr;
+    // coefficient-free stem filter gradient (conv.hip stem_gram / stem_bwd_raw / stem_bwd_combine): its passes run on the aux stream
+    hipEvent_t ev_stem_fork_ = nullptr, ev_stem_done_ = nullptr;
+    bool stem_raw_ = false;
+    bool stem_raw_on() const { return stem_raw_ && !graphs_enabled_; }
+    hipStream_t stem_fork(hipStream_t st);
     void add_aux_fork(std::vector<Op>& ops);
     void add_aux_join(std::vector<Op>& ops);
     // Backward-pass side stream: the filter / bias gradients of the tower (gemm_tn, depthwise and stem

@@ -65,6 +65,8 @@ Learner::~Learner() {
         if (ev_sc_done_[i]) (void)hipEventDestroy(ev_sc_done_[i]);
     }
     if (ev_aux_fork_) (void)hipEventDestroy(ev_aux_fork_);
+    if (ev_stem_fork_) (void)hipEventDestroy(ev_stem_fork_);
+    if (ev_stem_done_) (void)hipEventDestroy(ev_stem_done_);
     if (ev_aux_done_) (void)hipEventDestroy(ev_aux_done_);
     if (side_) (void)hipStreamDestroy(side_);
     if (aux_) (void)hipStreamDestroy(aux_);
@@ -215,6 +217,14 @@ int Learner::defer_side(hipStream_t st, std::function<int(hipStream_t)> fn) {
     }
     deferred_.push_back(Deferred{slot_, std::move(fn)});
     return 0;
+}
+
+// aux stream behind an event recorded on `st` (the stem's Gram / gather passes); `st` itself without helper streams
+hipStream_t Learner::stem_fork(hipStream_t st) {
+    if (!side_enabled_) return st;
+    if (hipEventRecord(ev_stem_fork_, st) != hipSuccess) return st;
+    if (hipStreamWaitEvent(aux_, ev_stem_fork_, 0) != hipSuccess) return st;
+    return aux_;
 }
 
 int Learner::next_q(hipStream_t st) {
@@ -1085,7 +1095,25 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         const bool stem_fstats = stem_fwd_stats_supported(Cs) && !(cdrl_getenv("CDRL_FUSED_STEM") && atoi(cdrl_getenv("CDRL_FUSED_STEM")) == 0);
         const int nb_stem = stem_fstats ? stem_fwd_stats_nb(B, H, W) : 0;
         if (at && !stem_fstats) build_fail("bf16 activation storage needs the fused stem forward (stem channels %d, CDRL_FUSED_STEM)", Cs);
+        // Coefficient-free stem filter gradient (conv.hip, round 5; float32 engine, CDRL_STEM_RAW=0 -> the fused form in the tail):
+        // Gram of the image patches in the forward and the gather pass over the pooled gradient beside the BatchNorm reduction, both on
+        // the aux stream (idle there); a 28 x Cs combine on the critical stream once the coefficients exist.
+        stem_raw_ = !at && stem_bwd_fused_supported(Cs) && stem_bwd_raw_supported(Cs) && stem_fstats &&
+                    !(cdrl_getenv("CDRL_FUSED_STEM") && atoi(cdrl_getenv("CDRL_FUSED_STEM")) == 0) &&
+                    !(cdrl_getenv("CDRL_STEM_RAW") && atoi(cdrl_getenv("CDRL_STEM_RAW")) == 0) &&
+                    !(cdrl_getenv("CDRL_STEM_DIRECT") && atoi(cdrl_getenv("CDRL_STEM_DIRECT")) == 1);
+        float* xt_part = nullptr;
+        double *stem_gram_d = nullptr, *stem_a_d = nullptr;
+        if (stem_raw_) {
+            xt_part = alloc((size_t)std::max(stem_xt_part_floats(B, T, H, W, 28), stem_xt_part_floats(B, T, H, W, Cs)));
+            stem_gram_d = alloc_d((size_t)T * 28 * 28);
+            stem_a_d = alloc_d((size_t)T * 28 * Cs);
+        }
         op.fwd = [=](hipStream_t st, int training) -> int {
+            if (training && stem_raw_on()) {
+                hipStream_t ax = stem_fork(st);         // (the images are in place on `st`)
+                CDRL_TRY(stem_gram(in_image_, B, T, H, W, xt_part, stem_gram_d, ax));
+            }
             // (bf16 storage: the statistics form is the one with a bf16 store; its partials are simply unused in inference)
             if (stem_fstats && (training || at)) return stem_fwd_stats(in_image_, w.p, b.p, y.p, scr_main_.part, B, T, H, W, Cs, st, at);
             return stem_fwd(in_image_, w.p, b.p, y.p, B, T, H, W, Cs, st);
@@ -1111,11 +1139,17 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         float* stem_ws = stem_direct ? alloc((size_t)stem_bwd_direct_ws_floats(B, T, H, W)) : nullptr;
         op.bwd = [=](hipStream_t st) -> int {
             if (stem_direct) return 0;
+            if (stem_raw_on()) {        // A (aux stream, forked by the BatchNorm op's backward) + Gram + coefficients -> dW, db
+                if (side_enabled_) CDRL_HIP(hipStreamWaitEvent(st, ev_stem_done_, 0));
+                return stem_bwd_combine(stem_a_d, stem_gram_d, w.p, b.p, stem_stats, stem_coef, T, Cs, w.g, b.g, st);
+            }
             if (stem_fused) {
                 CDRL_TRY(next_slot(st));
                 hipStream_t side = fork_side(st);
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
-                CDRL_TRY(stem_bwd_filter_fused(in_image_, ps, y.p, stem_stats, stem_coef, w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side, at));
+                static const bool diag_skip = cdrl_getenv("CDRL_DIAG_SKIP_STEMF") && atoi(cdrl_getenv("CDRL_DIAG_SKIP_STEMF")) == 1;    // timing diagnostics only (no stem filter gradient)
+                if (!diag_skip)
+                    CDRL_TRY(stem_bwd_filter_fused(in_image_, ps, y.p, stem_stats, stem_coef, w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side, at));
                 return done_side(side);
             }
             hipStream_t side = fork_side(st);
@@ -1153,6 +1187,11 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 View none{nullptr, 0, 0};
                 if (stem_direct)
                     return stem_bwd_direct(in_image_, ps, y.p, stats, gamma.g, beta.g, coef, w.g, b.g, B, T, H, W, C, stem_ws, st);
+                if (stem_raw_on()) {    // the pooled gradient is final: gather pass of the stem filter gradient beside the reduction
+                    hipStream_t ax = stem_fork(st);
+                    CDRL_TRY(stem_bwd_raw(in_image_, ps, B, T, c.H, c.W, C, xt_part, stem_a_d, ax));
+                    if (ax != st) CDRL_HIP(hipEventRecord(ev_stem_done_, ax));
+                }
                 if (stem_fused) {       // sums in scatter form over the pooled gradient; the apply happens inside the stem filter-gradient GEMM
                     ps.pa = pool.p;                 // mask and xhat from the pooled activated output, no gather (bf16 storage: xhat from the ROUNDED pooled value)
                     CDRL_TRY(pool_bn_bwd_reduce(ps, y.p, G, B, C, stats, scr_main_.part, st, at));
@@ -1722,6 +1761,8 @@ int Learner::bind(const Buffers& b) {
         CDRL_HIP(hipStreamCreateWithPriority(&aux_, hipStreamNonBlocking, prio_lo));
         CDRL_HIP(hipEventCreateWithFlags(&ev_aux_fork_, hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_aux_done_, hipEventDisableTiming));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_stem_fork_, hipEventDisableTiming));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_stem_done_, hipEventDisableTiming));
         const char* tenv = cdrl_getenv("CDRL_AUX_THREAD");
         // opt-in (CDRL_AUX_THREAD=1): measured 20.76 vs 20.83 ms/update-step at B=256 -- the host is 8 ms per step ahead of
         // the GPU in steady state, so the second enqueue thread only pays off for small images (host-bound below ~45x60)

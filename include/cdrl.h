@@ -433,6 +433,17 @@ int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, cons
 int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp,
                                const float* pooled, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta, float* coef,
                                float* dw, float* db, double* workspace, void* stream);
+
+/* The same backward in its COEFFICIENT-FREE form (what the float32 engine runs since round 5; conv.hip): the filter gradient is assembled
+ * from A = [P | 1]^T (masked, pool-gathered gradient) -- one gather pass that needs neither y nor the BatchNorm-backward coefficients --,
+ * the Gram matrix [P | 1]^T [P | 1] of the image patches per time slice (images only: the engine takes it in the forward pass) and the conv
+ * parameters w (3,3,3,Cout), b: P^T xhat = invstd (Gram W + SP b - mean SP).  Needs the ReLU6 flag (bit 7) in the argmax codes, which
+ * cdrl_maxpool_bn_fwd writes.  Replaces, with cdrl_stem_block_bwd, tape.gradient through Conv2D(stem) -> BatchNormalization -> ReLU6 ->
+ * MaxPooling2D (core/architectures.py:159-161, core/carla_agent.py:364-365).  float32 tensors only. */
+int64_t cdrl_stem_block_bwd_gram_workspace_doubles(int B, int T, int H, int W, int Cout);
+int cdrl_stem_block_bwd_gram(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, const float* pooled,
+                             const float* w, const float* b, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta,
+                             float* coef, float* dw, float* db, double* workspace, void* stream);
 /* Rollout-time image augmentation of one observation stack (CARLAgent.augment, core/carla_agent.py:545-577; ops of
  * rl/augmentations/augmentations.py and simclr.color_jitter): color jitter (brightness -> contrast -> saturation -> hue ->
  * clip) -> random-kernel blur -> salt & pepper -> gaussian noise -> per-image min-max normalisation -> cutout -> coarse

@@ -486,6 +486,18 @@ def test_stem_block_bwd(lib, B, T, H, W):
     assert rel_err(dbt2.cpu().numpy(), p['b.beta'].grad.numpy()) < 2e-5
     assert rel_err(dw2.cpu().numpy(), wt.grad.numpy()) < 3e-5
     assert torch.equal(dbt, dbt2)                                       # sum dz: same decisions, same addends
+    # the coefficient-free form (Gram of the patches + one gather pass + combine: what the float32 engine runs since round 5)
+    assert int((am >= 128).sum()) > 0 and int((am.to(torch.int32) & 127).max()) <= 8        # ReLU6 flag in bit 7 of the codes
+    dg3, dbt3, coef3 = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(3 * T * Cc, device=DEV)
+    dw3, db3 = torch.zeros((3, 3, 3, Cc), device=DEV), torch.zeros(Cc, device=DEV)
+    ws3 = torch.zeros(int(lib.cdrl_stem_block_bwd_gram_workspace_doubles(B, T, H, W, Cc)), dtype=torch.float64, device=DEV)
+    _lib.check(lib.cdrl_stem_block_bwd_gram(P(X), P(y), P(stats), P(am), P(DP), P(pool), P(Wd), P(Bd), B, T, H, W, Cc, P(dg3), P(dbt3), P(coef3),
+                                            P(dw3), P(db3), P(ws3), S()))
+    assert torch.equal(dg3, dg2) and torch.equal(coef3, coef2)
+    assert rel_err(dw3.cpu().numpy(), wt.grad.numpy()) < 3e-5
+    assert np.abs(db3.cpu().numpy()).max() < 1e-4 * np.abs(dw3.cpu().numpy()).max()
+    print(f'stem filter gradient vs float64 autograd: fused form {rel_err(dw2.cpu().numpy(), wt.grad.numpy()):.2e}, '
+          f'coefficient-free form {rel_err(dw3.cpu().numpy(), wt.grad.numpy()):.2e}')
 
 
 @pytest.mark.parametrize('M,Cc', [(256, 512), (256, 320), (37, 352), (1024, 16), (5, 3)])

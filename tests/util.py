@@ -145,7 +145,7 @@ def engine_decisions(eng, ocfg):
     hs, ws = (H - 3) // 2 + 1, (W - 3) // 2 + 1
     items = [bn_regions('img.stem.bn', hs, ws)]
     hp, wp = -(-hs // 2), -(-ws // 2)
-    code = eng.named_buffer('img.stem.pool.argmax', torch.uint8).view(T * B, hp, wp, ocfg.stem_channels).long()
+    code = eng.named_buffer('img.stem.pool.argmax', torch.uint8).view(T * B, hp, wp, ocfg.stem_channels).long() & 0x7f      # (bit 7: ReLU6 flag)
     pl = max((wp - 1) * 2 + 3 - ws, 0) // 2
     wpad = ws + max((wp - 1) * 2 + 3 - ws, 0)
     oy = torch.arange(hp, device=code.device).view(1, hp, 1, 1)
