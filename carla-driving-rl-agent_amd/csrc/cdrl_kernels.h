@@ -176,6 +176,7 @@ bool stem_bwd_fused_supported(int Cout);
 // pooled gradient beside the BatchNorm reduction, a 28 x Cout combine once the coefficients exist.  part: stem_xt_part_floats(.., nc)
 // floats with nc = 28 (gram) / Cout (raw); gram [T][28][28], A [T][28][Cout] doubles.
 bool stem_bwd_raw_supported(int Cout);
+bool stem_xt_fits(int B, int T, int H, int W, int Cout);
 int64_t stem_xt_part_floats(int B, int T, int H, int W, int nc);
 int stem_gram(const float* x, int B, int T, int H, int W, float* part, double* gram, hipStream_t st);
 int stem_bwd_raw(const float* x, const PoolSrc& ps, int B, int T, int H, int W, int Cout, float* part, double* A, hipStream_t st);

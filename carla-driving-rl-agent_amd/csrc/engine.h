@@ -322,6 +322,8 @@ private:
     bool stem_raw_ = false;
     bool stem_raw_on() const { return stem_raw_ && !graphs_enabled_; }
     hipStream_t stem_fork(hipStream_t st);
+    float* stem_xt_part_ = nullptr;     // per-workgroup tiles of stem_gram / stem_bwd_raw (same stream, one after the other)
+    double* stem_gram_d_ = nullptr;
     void add_aux_fork(std::vector<Op>& ops);
     void add_aux_join(std::vector<Op>& ops);
     // Backward-pass side stream: the filter / bias gradients of the tower (gemm_tn, depthwise and stem

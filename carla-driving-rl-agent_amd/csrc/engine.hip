@@ -1095,12 +1095,15 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         const bool stem_fstats = stem_fwd_stats_supported(Cs) && !(cdrl_getenv("CDRL_FUSED_STEM") && atoi(cdrl_getenv("CDRL_FUSED_STEM")) == 0);
         const int nb_stem = stem_fstats ? stem_fwd_stats_nb(B, H, W) : 0;
         if (at && !stem_fstats) build_fail("bf16 activation storage needs the fused stem forward (stem channels %d, CDRL_FUSED_STEM)", Cs);
-        // Coefficient-free stem filter gradient (conv.hip, round 5; float32 engine, CDRL_STEM_RAW=0 -> the fused form in the tail):
-        // Gram of the image patches in the forward and the gather pass over the pooled gradient beside the BatchNorm reduction, both on
-        // the aux stream (idle there); a 28 x Cs combine on the critical stream once the coefficients exist.
-        stem_raw_ = !at && stem_bwd_fused_supported(Cs) && stem_bwd_raw_supported(Cs) && stem_fstats &&
+        // Coefficient-free stem filter gradient (conv.hip, round 5; float32 engine; OPT-IN, CDRL_STEM_RAW=1): Gram of the image patches
+        // when the backward starts and the gather pass over the pooled gradient beside the BatchNorm reduction, both on the aux stream; a
+        // 28 x Cs combine on the critical stream once the coefficients exist.  Takes the stem filter gradient (0.36 ms per update-step of
+        // exposed tail) off the end of the pass and is MORE accurate than the fused form (no rounded y in it), but the two passes are
+        // 170 + 91 us of matrix-pipe-bound float32 MFMA work against 174 us, and beside the other kernels of the tail the gather pass
+        // stretches to 317 us and the Gram slows the GRU steps it runs next to: 14.4 vs 14.1 ms per update-step.
+        stem_raw_ = !at && stem_bwd_fused_supported(Cs) && stem_bwd_raw_supported(Cs) && stem_fstats && stem_xt_fits(B, T, H, W, Cs) &&
                     !(cdrl_getenv("CDRL_FUSED_STEM") && atoi(cdrl_getenv("CDRL_FUSED_STEM")) == 0) &&
-                    !(cdrl_getenv("CDRL_STEM_RAW") && atoi(cdrl_getenv("CDRL_STEM_RAW")) == 0) &&
+                    (cdrl_getenv("CDRL_STEM_RAW") && atoi(cdrl_getenv("CDRL_STEM_RAW")) == 1) &&
                     !(cdrl_getenv("CDRL_STEM_DIRECT") && atoi(cdrl_getenv("CDRL_STEM_DIRECT")) == 1);
         float* xt_part = nullptr;
         double *stem_gram_d = nullptr, *stem_a_d = nullptr;
@@ -1109,11 +1112,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             stem_gram_d = alloc_d((size_t)T * 28 * 28);
             stem_a_d = alloc_d((size_t)T * 28 * Cs);
         }
+        stem_xt_part_ = xt_part;
+        stem_gram_d_ = stem_gram_d;
         op.fwd = [=](hipStream_t st, int training) -> int {
-            if (training && stem_raw_on()) {
-                hipStream_t ax = stem_fork(st);         // (the images are in place on `st`)
-                CDRL_TRY(stem_gram(in_image_, B, T, H, W, xt_part, stem_gram_d, ax));
-            }
             // (bf16 storage: the statistics form is the one with a bf16 store; its partials are simply unused in inference)
             if (stem_fstats && (training || at)) return stem_fwd_stats(in_image_, w.p, b.p, y.p, scr_main_.part, B, T, H, W, Cs, st, at);
             return stem_fwd(in_image_, w.p, b.p, y.p, B, T, H, W, Cs, st);
@@ -1494,6 +1495,19 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         add_gru(aux_ops_, std::string("gru_") + fnames[i], fout[i], c.feat, c.rnn_small, cat.v(c.rnn_image + i * c.rnn_small),
                 cat.gv(c.rnn_image + i * c.rnn_small), true);
     build_scr_ = &scr_main_;
+    if (stem_raw_) {
+        // Gram of the image patches (the coefficient-free stem filter gradient needs it in the LAST kernel of the backward): enqueued
+        // behind the small-modality backward on the aux stream when the backward starts -- the head / GRU region of the critical stream
+        // is a chain of small kernels, the chip is idle next to it (in the forward pass the same launch cost the stem forward 24 us)
+        Op gop;
+        gop.fwd = [](hipStream_t, int) -> int { return 0; };
+        gop.bwd = [=](hipStream_t st) -> int {
+            if (!stem_raw_on()) return 0;
+            hipStream_t ax = stem_fork(st);
+            return stem_gram(in_image_, c.B, c.T, c.H, c.W, stem_xt_part_, stem_gram_d_, ax);
+        };
+        ops.push_back(gop);
+    }
     add_aux_join(ops);
     Tens ncat = tens(B, catC);
     add_bn(ops, M_TRUNK, "dyn.bn", cat.v(), 1, B, catC, false, ACT_NONE, ncat.v(), 0, ncat.gv(), 0, cat.g);

@@ -410,7 +410,8 @@ int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle
                       double* workspace, void* stream);
 /* Fused stem block (core/architectures.py:160-161): BatchNorm-apply + ReLU6 + MaxPooling2D(3,2,'same') on the
  * raw conv output (stats from cdrl_bn_train_fwd), and the BatchNorm backward that gathers its incoming
- * gradient from the pooled gradient `dp` through the saved argmax. */
+ * gradient from the pooled gradient `dp` through the saved argmax.  argmax codes: ky * 3 + kx of the winning window position in bits 0-3;
+ * bit 7 is set where the winning activation is clamped (ReLU6 closed: no gradient flows) -- the mask of cdrl_stem_block_bwd_gram. */
 int cdrl_maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax,
                         int N, int H, int W, int C, void* stream);
 int cdrl_bn_train_bwd_pooled(const uint8_t* argmax, const float* dp, int H, int W, const float* y, int G, int Mg, int C,
@@ -434,7 +435,7 @@ int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stat
                                const float* pooled, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta, float* coef,
                                float* dw, float* db, double* workspace, void* stream);
 
-/* The same backward in its COEFFICIENT-FREE form (what the float32 engine runs since round 5; conv.hip): the filter gradient is assembled
+/* The same backward in its COEFFICIENT-FREE form (round 5, conv.hip; the float32 engine runs it with CDRL_STEM_RAW=1): the filter gradient is assembled
  * from A = [P | 1]^T (masked, pool-gathered gradient) -- one gather pass that needs neither y nor the BatchNorm-backward coefficients --,
  * the Gram matrix [P | 1]^T [P | 1] of the image patches per time slice (images only: the engine takes it in the forward pass) and the conv
  * parameters w (3,3,3,Cout), b: P^T xhat = invstd (Gram W + SP b - mean SP).  Needs the ReLU6 flag (bit 7) in the argmax codes, which

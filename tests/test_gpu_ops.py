@@ -486,7 +486,7 @@ def test_stem_block_bwd(lib, B, T, H, W):
     assert rel_err(dbt2.cpu().numpy(), p['b.beta'].grad.numpy()) < 2e-5
     assert rel_err(dw2.cpu().numpy(), wt.grad.numpy()) < 3e-5
     assert torch.equal(dbt, dbt2)                                       # sum dz: same decisions, same addends
-    # the coefficient-free form (Gram of the patches + one gather pass + combine: what the float32 engine runs since round 5)
+    # the coefficient-free form (Gram of the patches + one gather pass + combine: opt-in in the float32 engine, CDRL_STEM_RAW=1)
     assert int((am >= 128).sum()) > 0 and int((am.to(torch.int32) & 127).max()) <= 8        # ReLU6 flag in bit 7 of the codes
     dg3, dbt3, coef3 = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(3 * T * Cc, device=DEV)
     dw3, db3 = torch.zeros((3, 3, 3, Cc), device=DEV), torch.zeros(Cc, device=DEV)
