@@ -618,8 +618,12 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     // float32 engine and bf16 activation storage (not the operand-only mode), both channel counts padded alike (gemm_pw_bwd.hip)
     const View dz_probe = fuse.bb_dz.p ? fuse.bb_dz : make_view(reinterpret_cast<float*>(uintptr_t(16)), Cout);
     const bool anorm = fuse.pro_stats != nullptr;
-    // (24 input channels -- the first unit -- pad to 64: 158 vs 104 us for the two-kernel form; kept there)
-    const bool fbwd = fused_bwd_ && fuse.bb && fuse.bwd_pw && (!bfc || at) && G <= 8 && Cin >= 32 && pw_bwd_fused_supported(dz_probe, in, din, Cout, Cin, at) &&
+    // 24 input channels -- the first unit, the last conv of the backward -- pad to 64: 158 us against 104 us for the backward-data kernel of
+    // the two-kernel form, which is why rounds 4 kept it there; but that form's filter gradient (163 us on the side stream) then bounds the
+    // tail of the pass and slows the BatchNorm reduction beside it (117 us instead of 29): fused 14.00 vs 14.06 ms per update-step, and one
+    // pass over (dz, y) = 0.3 GB per pass less.  CDRL_FBWD_MIN_CIN=32 -> the two-kernel form for that conv.
+    static const int fbwd_min_cin = cdrl_getenv("CDRL_FBWD_MIN_CIN") ? atoi(cdrl_getenv("CDRL_FBWD_MIN_CIN")) : 24;
+    const bool fbwd = fused_bwd_ && fuse.bb && fuse.bwd_pw && (!bfc || at) && G <= 8 && Cin >= fbwd_min_cin && pw_bwd_fused_supported(dz_probe, in, din, Cout, Cin, at) &&
                       (!anorm || (fuse.bwd_ey == in.p && fuse.bwd_epi_stats == fuse.pro_stats && fuse.a_bn && in.ld == Cin && in.coff == 0)) &&
                       (anorm || !fuse.bwd_ey);
     const void* wpx = fbwd ? pw_x3_packed(w.p, Cout, Cin, 1, Cout) : nullptr;      // W^T planes: B(k = cout, n = cin)

@@ -76,7 +76,12 @@ def test_fused_conv_backward_agrees_with_the_two_kernel_backward_at_full_size(tm
     w = _worst(a1, a0, skip_zero_gradients=True)
     worst = sorted(w.items(), key=lambda kv: -kv[1])[:6]
     print('[fused conv backward vs two-kernel backward] worst tensors:', worst)
-    assert worst[0][1] < 5e-5, worst
+    # Since round 5 the LAST conv of the backward (24 -> 58 channels on the pooled stem output) is fused too: the gradient it
+    # accumulates into the pooled stem output then differs between the two runs at the 1e-6 level, and the stem BatchNorm's dbeta / dgamma
+    # -- sums of that gradient over 16 M elements of both signs, the end of the chain -- see it amplified: measured 8.7e-5 / 1.1e-5 of
+    # their scale between the two float32 paths (each is within 7e-5 of the float64 oracle in smoke()); they get north_star's 1e-4.
+    bad = {k: v for k, v in w.items() if v >= (1e-4 if k.startswith('trunk/img.stem.bn.') else 5e-5)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])
     gmax = max(v.abs().max().item() for k, v in a0.items() if k.startswith('trunk/'))
     for k in a1:        # the zero gradients stay negligible next to the real ones
         if k.startswith('trunk/') and _zero_gradient(k.split('/', 1)[-1]):
