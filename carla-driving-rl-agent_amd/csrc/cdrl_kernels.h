@@ -159,7 +159,7 @@ int stem_fwd(const float* x, const float* w, const float* bias, float* y, int B,
              hipStream_t st);
 // stem conv + (sum, sum^2) partials of its output per time slice: part [T][nb][2][Cout], nb = stem_fwd_stats_nb()
 bool stem_fwd_stats_supported(int Cout);
-int stem_fwd_stats_nb(int B, int H, int W);
+int stem_fwd_stats_nb(int B, int T, int H, int W, int Cout);
 int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* part, int B, int T, int H, int W, int Cout,
                    hipStream_t st, int at = 0);
 int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout);

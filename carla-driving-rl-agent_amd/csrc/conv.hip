@@ -175,9 +175,177 @@ __global__ void __launch_bounds__(256) stem_fwd_stats_kernel(const float* __rest
     }
 }
 
+// Band-staged form of the same kernel (round 5; float32 and bf16 storage): a workgroup walks (frame, band of R output rows) units of one
+// time slice; the band's 2 R + 1 image rows are contiguous and go to LDS with 16-byte lanes, the next band waits in registers while the
+// current one is convolved (the form above has every thread fetch its pixels' 27-float windows from global memory, 8 bytes per lane and
+// load, six channel lanes asking for the same bytes: 160 us for 50 us of traffic).  Per output element the SAME fmaf chain (bias, then taps
+// 0..26), so y is bit-identical; the statistics are per-thread doubles folded in a fixed order -- another order than above, i.e. the double
+// sums differ in their last bits and the float statistics derived from them do not (checked: tools/iso_stem_fwd.py).
+#ifndef STEM_FWD_NP
+#define STEM_FWD_NP 2        // pixels per thread and iteration (4: 256 VGPRs, one wave per SIMD)
+#endif
+struct StemFwdGeom {
+    int R, NB, nbpg, xs_floats, px;     // band rows, bands per frame, workgroups per time slice, LDS floats of a band, 16-byte chunks per thread
+    size_t lds;
+    bool ok;
+};
+
+template <int NP, int PX, class AT>
+__global__ void __launch_bounds__(256) stem_fwd_band_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            AT* __restrict__ y, double* __restrict__ part, int B, int T, int H, int W, int Ho,
+                                                            int Wo, int Cout, StemFwdGeom gm) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    float* xs = fsm;
+    float* ws = fsm + gm.xs_floats;             // [27][Cout] + [Cout]
+    const int tid = threadIdx.x;
+    const int CX = Cout / 4, CY = 256 / CX;     // channel lanes x pixel lanes (252 threads busy at 24 channels)
+    const int tx = tid % CX, ty = tid / CX;
+    const bool active = ty < CY;
+    for (int i = tid; i < 27 * Cout; i += 256) ws[i] = w[i];
+    for (int i = tid; i < Cout; i += 256) ws[27 * Cout + i] = bias[i];
+    const int g = blockIdx.x / gm.nbpg, bg = blockIdx.x % gm.nbpg;
+    const int R = gm.R, NB = gm.NB, units = B * NB, W3 = W * 3;
+    const int co = tx * 4;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)((int64_t)B * T * H * W3 * 4), 0x00020000);
+    const uint32_t OOR = 0x80000000u;
+    u32x4_t px[PX];
+    auto prefetch = [&](int u) {
+        const int b = u / NB, k = u - b * NB;
+        const int oy0 = k * R, Rb = min(R, Ho - oy0);
+        const uint32_t b0 = (uint32_t)(((((int64_t)b * T + g) * H + 2 * oy0) * W3) * 4);
+        const int nx = (2 * Rb + 1) * W3;
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            const int i = (q * 256 + tid) * 4;
+            px[q] = __builtin_amdgcn_raw_buffer_load_b128(rsX, i < nx ? b0 + (uint32_t)i * 4u : OOR, 0, 0);
+        }
+    };
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (bg < units) prefetch(bg);
+    __syncthreads();                            // weights / bias in place
+    const float4 bq = *reinterpret_cast<const float4*>(&ws[27 * Cout + co]);
+    for (int u = bg; u < units; u += gm.nbpg) {
+        const int b = u / NB, k = u - b * NB;
+        const int oy0 = k * R, Rb = min(R, Ho - oy0), npix = Rb * Wo;
+        __syncthreads();                        // the previous band's reads are done
+        {
+            const int nx = (2 * Rb + 1) * W3;
+#pragma unroll
+            for (int q = 0; q < PX; ++q) {
+                const int i = (q * 256 + tid) * 4;
+                if (i < nx) *reinterpret_cast<u32x4_t*>(xs + i) = px[q];
+            }
+        }
+        __syncthreads();
+        if (u + gm.nbpg < units) prefetch(u + gm.nbpg);
+        if (!active) continue;
+        const int64_t row0 = ((int64_t)(g * B + b) * Ho + oy0) * Wo;       // first output row of the band in y
+        for (int p0 = ty; p0 < npix; p0 += CY * NP) {
+            float xv[NP][27];
+#pragma unroll
+            for (int uu = 0; uu < NP; ++uu) {
+                const int p = min(p0 + uu * CY, npix - 1);
+                const int oyl = p / Wo, ox = p - oyl * Wo;
+                const float* xp = xs + (2 * oyl * W + 2 * ox) * 3;          // 8-byte aligned
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* xr = xp + ky * W3;
+                    if ((W3 & 1) == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float2 t = *reinterpret_cast<const float2*>(xr + 2 * j);
+                            xv[uu][ky * 9 + 2 * j] = t.x;
+                            xv[uu][ky * 9 + 2 * j + 1] = t.y;
+                        }
+                        xv[uu][ky * 9 + 8] = xr[8];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) xv[uu][ky * 9 + j] = xr[j];
+                    }
+                }
+            }
+            float4 acc[NP];
+#pragma unroll
+            for (int uu = 0; uu < NP; ++uu) acc[uu] = bq;
+#pragma unroll
+            for (int kk = 0; kk < 27; ++kk) {
+                const float4 wv = *reinterpret_cast<const float4*>(&ws[kk * Cout + co]);
+#pragma unroll
+                for (int uu = 0; uu < NP; ++uu) {
+                    acc[uu].x = fmaf(xv[uu][kk], wv.x, acc[uu].x);
+                    acc[uu].y = fmaf(xv[uu][kk], wv.y, acc[uu].y);
+                    acc[uu].z = fmaf(xv[uu][kk], wv.z, acc[uu].z);
+                    acc[uu].w = fmaf(xv[uu][kk], wv.w, acc[uu].w);
+                }
+            }
+#pragma unroll
+            for (int uu = 0; uu < NP; ++uu) {
+                const int p = p0 + uu * CY;
+                if (p >= npix) continue;
+                VecF<4> o4;
+                o4.v[0] = acc[uu].x; o4.v[1] = acc[uu].y; o4.v[2] = acc[uu].z; o4.v[3] = acc[uu].w;
+                vstore<4>(y + (row0 + p) * Cout + co, o4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double a = sizeof(AT) == 2 ? (double)(float)(bf16_t)o4.v[i] : (double)o4.v[i];
+                    s[i] += a;
+                    q2[i] += a * a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double* sm = reinterpret_cast<double*>(fsm);                    // [2][4][CY][CX]; the band and the weights are dead
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sm[((0 * 4 + i) * CY + ty) * CX + tx] = s[i];
+            sm[((1 * 4 + i) * CY + ty) * CX + tx] = q2[i];
+        }
+    }
+    __syncthreads();
+    if (active)
+        for (int j = ty; j < 8; j += CY) {
+            double a = 0.0;
+            for (int yy = 0; yy < CY; ++yy) a += sm[(j * CY + yy) * CX + tx];
+            const int qq = j >> 2, i = j & 3;
+            part[(((int64_t)g * gm.nbpg + bg) * 2 + qq) * Cout + co + i] = a;
+        }
+}
+
+static StemFwdGeom stem_fwd_geom(int B, int T, int H, int W, int Cout) {
+    const int Ho = (H - 3) / 2 + 1;
+    StemFwdGeom g{};
+    static const bool on = !(cdrl_getenv("CDRL_STEM_FWD_BAND") && atoi(cdrl_getenv("CDRL_STEM_FWD_BAND")) == 0);
+    if (!on || Cout % 4 || Cout > 64 || Cout < 4) return g;
+    const int CX = Cout / 4, CY = 256 / CX;
+    const size_t red = (size_t)8 * CY * CX * sizeof(double);
+    const int cand[] = {8, 6, 4, 3, 2, 1};
+    static const int rmax = cdrl_getenv("CDRL_STEM_FWD_R") ? atoi(cdrl_getenv("CDRL_STEM_FWD_R")) : 8;
+    for (int R : cand) {
+        const int nx = (2 * R + 1) * W * 3;
+        const int px = cdiv(nx, 1024);
+        if (px > 6 || (R > rmax && R != 1)) continue;
+        g.R = R;
+        g.NB = cdiv(Ho, R);
+        g.xs_floats = (nx + 3) / 4 * 4 + 4;
+        g.px = px <= 2 ? 2 : px <= 4 ? 4 : 6;
+        g.lds = std::max((size_t)(g.xs_floats + 28 * Cout) * sizeof(float), red);
+        g.ok = true;
+        break;
+    }
+    if (!g.ok) return g;
+    static const int wgs_env = cdrl_getenv("CDRL_STEM_FWD_WGS") ? atoi(cdrl_getenv("CDRL_STEM_FWD_WGS")) : 512;     // two workgroups per CU are resident (196-216 VGPRs)
+    g.nbpg = std::max(1, std::min(wgs_env / std::max(T, 1), B * g.NB));
+    return g;
+}
+
 bool stem_fwd_stats_supported(int Cout) { return (Cout % 4) == 0 && Cout <= 64; }
 
-int stem_fwd_stats_nb(int B, int H, int W) {
+int stem_fwd_stats_nb(int B, int T, int H, int W, int Cout) {
+    const StemFwdGeom bg = stem_fwd_geom(B, T, H, W, Cout);
+    if (bg.ok) return bg.nbpg;
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int Mg = B * Ho * Wo;
     const int rb = cdiv(Mg, NB_STATS);
@@ -191,6 +359,33 @@ int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, 
         return -1;
     }
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    const StemFwdGeom bg = stem_fwd_geom(B, T, H, W, Cout);
+    if (bg.ok && (int64_t)B * T * H * W * 3 * 4 < (1ll << 31)) {
+#define CDRL_STEM_FWD_BAND_LAUNCH(NPN, PXN)                                                                                                 \
+    do {                                                                                                                                    \
+        if (at) hipLaunchKernelGGL((stem_fwd_band_kernel<NPN, PXN, bf16_t>), dim3(T * bg.nbpg), dim3(256), bg.lds, st, x, w, bias,          \
+                                   reinterpret_cast<bf16_t*>(y), part, B, T, H, W, Ho, Wo, Cout, bg);                                       \
+        else hipLaunchKernelGGL((stem_fwd_band_kernel<NPN, PXN, float>), dim3(T * bg.nbpg), dim3(256), bg.lds, st, x, w, bias, y, part, B,  \
+                                T, H, W, Ho, Wo, Cout, bg);                                                                                 \
+    } while (0)
+        static const int npx = cdrl_getenv("CDRL_STEM_FWD_NP") ? atoi(cdrl_getenv("CDRL_STEM_FWD_NP")) : STEM_FWD_NP;
+        if (npx >= 4) {
+            if (bg.px == 2) CDRL_STEM_FWD_BAND_LAUNCH(4, 2);
+            else if (bg.px == 4) CDRL_STEM_FWD_BAND_LAUNCH(4, 4);
+            else CDRL_STEM_FWD_BAND_LAUNCH(4, 6);
+        } else if (npx == 3) {
+            if (bg.px == 2) CDRL_STEM_FWD_BAND_LAUNCH(3, 2);
+            else if (bg.px == 4) CDRL_STEM_FWD_BAND_LAUNCH(3, 4);
+            else CDRL_STEM_FWD_BAND_LAUNCH(3, 6);
+        } else {
+            if (bg.px == 2) CDRL_STEM_FWD_BAND_LAUNCH(2, 2);
+            else if (bg.px == 4) CDRL_STEM_FWD_BAND_LAUNCH(2, 4);
+            else CDRL_STEM_FWD_BAND_LAUNCH(2, 6);
+        }
+#undef CDRL_STEM_FWD_BAND_LAUNCH
+        CDRL_LAUNCH_CHECK();
+        return 0;
+    }
     const int Mg = B * Ho * Wo;
     const int rb = cdiv(Mg, NB_STATS);
     const int nb = cdiv(Mg, rb);

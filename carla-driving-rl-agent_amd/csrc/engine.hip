@@ -1097,7 +1097,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         const int H = c.H, W = c.W, Cs = c.stem;
         // forward: BN statistics in the conv's epilogue (training only; inference uses the moving statistics)
         const bool stem_fstats = stem_fwd_stats_supported(Cs) && !(cdrl_getenv("CDRL_FUSED_STEM") && atoi(cdrl_getenv("CDRL_FUSED_STEM")) == 0);
-        const int nb_stem = stem_fstats ? stem_fwd_stats_nb(B, H, W) : 0;
+        const int nb_stem = stem_fstats ? stem_fwd_stats_nb(B, T, H, W, Cs) : 0;
         if (at && !stem_fstats) build_fail("bf16 activation storage needs the fused stem forward (stem channels %d, CDRL_FUSED_STEM)", Cs);
         // Coefficient-free stem filter gradient (conv.hip, round 5; float32 engine; OPT-IN, CDRL_STEM_RAW=1): Gram of the image patches
         // when the backward starts and the gather pass over the pooled gradient beside the BatchNorm reduction, both on the aux stream; a

@@ -138,3 +138,14 @@ def test_coefficient_free_stem_filter_gradient_agrees_with_the_fused_form_at_ful
     print(f'[coefficient-free stem filter gradient vs fused form] max |diff| / max |dW| = {err:.2e}')
     assert 0.0 < err < 5e-5, err            # (0: the switch did not take effect)
     assert a1['trunk/img.stem.conv.b'].abs().max().item() < 1e-5 * w0.abs().max().item()
+
+
+def test_band_staged_stem_forward_is_bit_identical_to_the_window_form_at_full_size(tmp_path):
+    """Round 5: the stem conv + statistics kernel with the image band staged in LDS (stem_fwd_band_kernel, the default) vs the form whose
+    threads fetch their pixels' windows from global memory (CDRL_STEM_FWD_BAND=0): the same fmaf chain per output element, and per-thread
+    double statistics folded in another order -- the float statistics, hence every decision, the loss and every gradient, are bit-identical."""
+    a1 = _run(str(tmp_path / 'band.pt'))
+    a0 = _run(str(tmp_path / 'window.pt'), CDRL_STEM_FWD_BAND=0)
+    assert a1['loss'].item() == a0['loss'].item()
+    for k in a1:
+        assert torch.equal(a1[k], a0[k]), k
