@@ -1150,7 +1150,10 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             }
             if (stem_fused) {
                 CDRL_TRY(next_slot(st));
-                hipStream_t side = fork_side(st);
+                // the last kernel of the backward: nothing is left on the critical stream to run beside it, so the hand-over to the side
+                // stream and back only costs its two event bubbles (CDRL_STEM_BWD_MAIN=0 -> side stream as in rounds 1-4)
+                static const bool on_main = !(cdrl_getenv("CDRL_STEM_BWD_MAIN") && atoi(cdrl_getenv("CDRL_STEM_BWD_MAIN")) == 0);
+                hipStream_t side = on_main ? st : fork_side(st);
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
                 static const bool diag_skip = cdrl_getenv("CDRL_DIAG_SKIP_STEMF") && atoi(cdrl_getenv("CDRL_DIAG_SKIP_STEMF")) == 1;    // timing diagnostics only (no stem filter gradient)
                 if (!diag_skip)
