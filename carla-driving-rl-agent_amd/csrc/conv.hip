@@ -472,9 +472,12 @@ __device__ __forceinline__ void stem_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef STEM_BWD_WGS
+#define STEM_BWD_WGS 3      // waves per SIMD the register allocation aims at (153 + 16 registers sat one above the three-wave step: 180 -> 173 us)
+#endif
 // AT: element type of the pooled gradient and of the raw conv output y in the FUSED form (bf16 activation storage)
 template <bool FUSED, int NCH, class AT = float>
-__global__ void __launch_bounds__(256) stem_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ void __launch_bounds__(256, STEM_BWD_WGS) stem_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ part, int B, int T, int H, int W, int Ho,
                                                             int Wo, int Cout, int rows, int rows_per, StemBnBwd bb) {
     __shared__ float P[4][32][33];
