@@ -123,6 +123,8 @@ PROTOTYPES = {
     'cdrl_linear_heads_fwd': (_i, [_fp, _i, _fp, _fp, _fp, _fp, _i, _i, _fp]),
     'cdrl_linear_heads_bwd': (_i, [_fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp]),
     'cdrl_stem_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),
+    'cdrl_stem_fwd_stats_rows': (_i, [_i] * 5),
+    'cdrl_stem_fwd_stats': (_i, [_fp] * 5 + [_i] * 5 + [_fp]),
     'cdrl_stem_bwd_workspace_doubles': (_i64, [_i, _i, _i, _i, _i]),
     'cdrl_stem_bwd_filter': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp]),
     'cdrl_dwconv_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp]),

@@ -584,6 +584,13 @@ int cdrl_stem_fwd(const float* x, const float* w, const float* bias, float* y, i
     return stem_fwd(x, w, bias, y, B, T, H, W, Cout, S(stream));
 }
 
+int cdrl_stem_fwd_stats_rows(int B, int T, int H, int W, int Cout) { return stem_fwd_stats_nb(B, T, H, W, Cout); }
+
+int cdrl_stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* part, int B, int T, int H, int W, int Cout,
+                        void* stream) {
+    return stem_fwd_stats(x, w, bias, y, part, B, T, H, W, Cout, S(stream), g_op_at);
+}
+
 int64_t cdrl_stem_bwd_workspace_doubles(int B, int T, int H, int W, int Cout) {
     return stem_bwd_part_elems(B, T, H, W, Cout);
 }

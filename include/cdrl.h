@@ -309,6 +309,14 @@ int cdrl_gemm_tn(const float* A, int lda, int a_coff, const float* D, int ldd, i
 /* Conv2D(24, 3, strides=2) stem (core/architectures.py:159) */
 int cdrl_stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
                   void* stream);
+/* The same conv with the statistics of the BatchNorm behind it in the epilogue (what the engine runs in training; conv.hip
+ * stem_fwd_band_kernel: the image band staged in LDS, or the window form with CDRL_STEM_FWD_BAND=0): y bit-identical to cdrl_stem_fwd,
+ * part [T][rows][2][Cout] doubles = per-workgroup (sum y, sum y^2) per time slice, rows = cdrl_stem_fwd_stats_rows(), the layout
+ * cdrl_bn_train_fwd's finalize consumes.  Cout % 4 == 0, <= 64; y 16-byte aligned.  Replaces Conv2D(stem) + the moments of its
+ * BatchNormalization (core/architectures.py:159-160). */
+int cdrl_stem_fwd_stats_rows(int B, int T, int H, int W, int Cout);
+int cdrl_stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* part, int B, int T, int H, int W, int Cout,
+                        void* stream);
 int64_t cdrl_stem_bwd_workspace_doubles(int B, int T, int H, int W, int Cout);
 int cdrl_stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,
                          double* workspace, void* stream);

@@ -204,6 +204,31 @@ def test_stem(lib, B, T, H, W):
     assert rel_err(db.cpu().numpy(), bt.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('B,T,H,W,Cc', [(3, 4, 90, 120, 24), (2, 2, 31, 33, 24), (5, 1, 21, 28, 24), (2, 3, 41, 58, 24), (1, 4, 90, 360, 24),
+                                        (2, 2, 17, 19, 32), (3, 1, 9, 7, 8)])
+def test_stem_fwd_with_statistics(lib, B, T, H, W, Cc):
+    """Stem conv + (sum, sum of squares) of its output per time slice in one kernel (round 5: image band staged in LDS): the conv output is
+    BIT-identical to the plain conv kernel (same fmaf chain per element), the statistics agree with float64 sums of that output to 1e-12."""
+    rng = np.random.default_rng(B * H + W + Cc)
+    x = rng.uniform(0.0, 1.0, (B, T, H, W, 3)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, Cc)) * 0.4).astype(np.float32)
+    b = rng.standard_normal(Cc).astype(np.float32)
+    Ho, Wo = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+    X, Wd, Bd = dev(x), dev(w), dev(b)
+    y0 = torch.zeros((T * B, Ho, Wo, Cc), device=DEV)
+    _lib.check(lib.cdrl_stem_fwd(P(X), P(Wd), P(Bd), P(y0), B, T, H, W, Cc, S()))
+    rows = int(lib.cdrl_stem_fwd_stats_rows(B, T, H, W, Cc))
+    y1 = torch.full((T * B, Ho, Wo, Cc), 7.0, device=DEV)
+    part = torch.full((T, rows, 2, Cc), float('nan'), dtype=torch.float64, device=DEV)
+    _lib.check(lib.cdrl_stem_fwd_stats(P(X), P(Wd), P(Bd), P(y1), P(part), B, T, H, W, Cc, S()))
+    assert torch.equal(y1, y0)
+    yd = y0.double().view(T, B * Ho * Wo, Cc)
+    s, q = part[:, :, 0].sum(1), part[:, :, 1].sum(1)
+    assert not bool(torch.isnan(part).any())
+    assert float(((s - yd.sum(1)).abs() / yd.abs().sum(1)).max()) < 1e-12
+    assert float(((q - (yd * yd).sum(1)).abs() / (yd * yd).sum(1)).max()) < 1e-12
+
+
 @pytest.mark.parametrize('N,H,W,Cc,stride', [(3, 22, 30, 58, 2), (2, 11, 15, 58, 1), (2, 6, 8, 116, 1), (3, 11, 15, 116, 2),
                                              (2, 3, 4, 232, 1), (2, 6, 23, 232, 2), (2, 5, 6, 24, 2)])
 def test_dwconv(lib, N, H, W, Cc, stride):
