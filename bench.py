@@ -301,6 +301,22 @@ def kernel_rooflines(B, T, nsets=8):
     out.append(dict(kernel='dwf_fwd_kernel<1,4,true> + bn_finalize (BN+ReLU6 -> dw3x3 -> BN statistics)', shape=f'{N}x{Hh}x{Ww}x{Cc}',
                     us=round(t * 1e6, 1), algorithmic_bytes=byd, achieved_GBs=round(byd / t / 1e9, 1),
                     frac=round(byd / t / 1e9 / HBM_PEAK_GBS, 4), cache_state=cold))
+    # round 5: the stem conv + BatchNorm statistics of the benchmark shape (stem_fwd_band_kernel: image band staged in LDS); one buffer set
+    # is 399 MB (images 133 MB read, conv output 265 MB written) > the 256 MB Infinity Cache, so a single set is cold already
+    Hs, Ws, Cs = 90, 120, 24
+    Ho, Wo = (Hs - 3) // 2 + 1, (Ws - 3) // 2 + 1
+    xs = torch.rand(B, T, Hs, Ws, 3, device=dev)
+    ws_ = torch.randn(3, 3, 3, Cs, device=dev) * 0.3
+    bs_ = torch.randn(Cs, device=dev)
+    ys = torch.empty(B * T, Ho, Wo, Cs, device=dev)
+    rows = int(lib.cdrl_stem_fwd_stats_rows(B, T, Hs, Ws, Cs))
+    parts = torch.zeros(T * rows * 2 * Cs, dtype=torch.float64, device=dev)
+    t = timeit(lambda k: lib.cdrl_stem_fwd_stats(P(xs), P(ws_), P(bs_), P(ys), P(parts), B, T, Hs, Ws, Cs, S()), iters=16)
+    bys = 4.0 * (xs.numel() + ys.numel())
+    out.append(dict(kernel='stem_fwd_band_kernel<2,6> (3x3/s2 stem conv, 3 -> 24 channels, + BatchNorm statistics; image band staged in LDS)',
+                    shape=f'{B}x{T}x{Hs}x{Ws}x3 -> {B * T}x{Ho}x{Wo}x{Cs}', us=round(t * 1e6, 1), algorithmic_bytes=bys,
+                    achieved_GBs=round(bys / t / 1e9, 1), frac=round(bys / t / 1e9 / HBM_PEAK_GBS, 4),
+                    cache_state='cold: one buffer set (399 MB) exceeds the 256 MB Infinity Cache'))
     return out
 
 
