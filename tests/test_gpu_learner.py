@@ -148,6 +148,20 @@ def _dump_report(tag):
         json.dump(REPORT, f, indent=1)
 
 
+def _dump_margin(case):
+    """One line per pinned case into gpurun_out/parity_margin.json (-> profiles/r06_parity_margin.json): worst / median error and the
+    worst tensor per parameter group and pass, so that the margin below north_star's 1e-4 is visible per draw of the decisions."""
+    import json, os
+    path = 'gpurun_out/parity_margin.json'
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    rows = [r for r in REPORT if 'engine_worst_err' in r and 'decision-pinned' in r.get('what', '')]
+    table[case] = dict(worst=max([r['engine_worst_err'] for r in rows], default=None),
+                       groups=[dict(what=r['what'].split(' (')[0], group=r['group'], worst=r['engine_worst_err'], tensor=r['tensor'],
+                                    median=r['engine_median_err'], bound=r['bound']) for r in rows])
+    with open(path, 'w') as f:
+        json.dump(table, f, indent=1)
+
+
 @pytest.mark.parametrize('B,H,W,A,faithful', [(32, 48, 64, 2, True), (24, 41, 58, 3, False), (16, 90, 120, 2, True)])
 def test_policy_then_value_step(B, H, W, A, faithful):
     oracle, eng = make_pair(B, H, W, seed=3, A=A, with64=True)
@@ -309,9 +323,23 @@ def _pinned_weight_check(views, w64, g64, m0, v0, t, lr, what, tol=TOL, floor_fr
     assert worst_sure <= tol
 
 
-@pytest.mark.parametrize('B,H,W,A,faithful,heads', [(64, 48, 64, 2, True, 'init'), (64, 41, 58, 3, False, 'init'), (64, 90, 120, 2, True, 'init'),
-                                                    (64, 48, 64, 2, True, 'trained'), (256, 90, 120, 2, True, 'init')])
-def test_pinned_decisions_gradients_and_weights(B, H, W, A, faithful, heads):
+# (B, H, W, A, faithful, heads, seed, extra dims).  Round 6: three seeds at north_star's minibatch (smoke()'s 48x64 size) so that the 1e-4
+# gate does not rest on one draw of the ReLU6 / max-pool decisions, and the reference-faithful input shapes -- configs[0]'s own spaces and
+# minibatch (FakeCARLAEnvironment: 90x360 three-camera image, A = 3, vehicle 5, navigation 10; reference core/carla_agent.py:26-52) with
+# the odd map widths 179 / 45 / 23, and config 5's 135x180 resolution (reference main.py:79-90).
+_PINNED_CASES = [(64, 48, 64, 2, True, 'init', 3, None), (64, 41, 58, 3, False, 'init', 3, None), (64, 90, 120, 2, True, 'init', 3, None),
+                 (64, 48, 64, 2, True, 'trained', 3, None), (256, 90, 120, 2, True, 'init', 3, None),
+                 (256, 48, 64, 2, True, 'init', 5, None), (256, 48, 64, 2, True, 'init', 6, None), (256, 48, 64, 2, True, 'init', 7, None),
+                 (32, 90, 360, 3, True, 'init', 3, dict(vehicle=5, navigation=10)), (16, 135, 180, 2, True, 'init', 3, None)]
+
+
+def _pinned_id(c):
+    B, H, W, A, faithful, heads, seed, dims = c
+    return f'{B}-{H}-{W}-{A}-{faithful}-{heads}' + (f'-seed{seed}' if seed != 3 else '') + ('-fake_env_spaces' if dims else '')
+
+
+@pytest.mark.parametrize('B,H,W,A,faithful,heads,seed,dims', _PINNED_CASES, ids=[_pinned_id(c) for c in _PINNED_CASES])
+def test_pinned_decisions_gradients_and_weights(B, H, W, A, faithful, heads, seed, dims):
     """A11 at north_star's bar: gradients and updated weights within 1e-4 of the oracle, measured on a WELL-DEFINED
     quantity.  ReLU6 regions and max-pool argmax are discrete decisions on float32 pre-activations; two implementations
     that differ by one rounding flip an element and move a tower gradient by percents (the float32 oracle itself sits
@@ -327,13 +355,17 @@ def test_pinned_decisions_gradients_and_weights(B, H, W, A, faithful, heads):
     # moving variances of mean 36, trained gammas) instead of a random initialisation -- tests/golden/ref_trained_heads.npz.
     # B = 256, 90x120: north_star's own size -- every group INCLUDING the feature nets at 1e-4 (the float64 oracle on the host
     # takes about a minute per pass there).
-    oracle, eng = make_pair(B, H, W, seed=3, A=A, with64=True, heads=trained_heads() if heads == 'trained' else None)
+    dims = dims or {}
+    oracle, eng = make_pair(B, H, W, seed=seed, A=A, with64=True, heads=trained_heads() if heads == 'trained' else None, **dims)
     o64 = oracle.o64
-    pol, val = make_batches(B, H, W, seed=3, A=A, faithful=faithful)
+    pol, val = make_batches(B, H, W, seed=seed, A=A, faithful=faithful, **dims)
     dpol, dval = to_dev(pol), to_dev(val)
     del REPORT[:]
     hp = oracle.hp
-    bounds = _pinned_tol(B)
+    # minibatches below 64 (configs[0]'s own 32, config 5's 16 here): the tower / GRUs / tail / heads stay at 1e-4; the three tiny
+    # feature nets normalise over B rows per time slice and their float32 conditioning alone costs more than 1e-4 there (the float32
+    # oracle shows the same) -- their bound is stated next to the measured figure in the report
+    bounds = _pinned_tol(B) if B >= 64 else dict(tower=TOL, tail=TOL, featnet=4 * TOL)
 
     with32 = H * W < 90 * 120          # the float32 replay is informational (engine vs float32 oracle on the same decisions)
 
@@ -390,7 +422,9 @@ def test_pinned_decisions_gradients_and_weights(B, H, W, A, faithful, heads):
         gvc = {n: OM.clip_by_norm(g, hp['clip_norm_value']) for n, g in gv64.items()}
         _pinned_weight_check(eng.param_views('value'), o64.value, gvc, None, None, 1, hp['value_lr'], 'updated value weights', bounds=bounds)
     finally:
-        _dump_report(f'pinned_B{B}_{H}x{W}' + ('_trained_heads' if heads == 'trained' else ''))
+        _dump_report(f'pinned_B{B}_{H}x{W}' + ('_trained_heads' if heads == 'trained' else '') + (f'_seed{seed}' if seed != 3 else '') +
+                     (f'_A{A}' if dims else ''))
+        _dump_margin(f'B{B}_{H}x{W}_A{A}_{heads}_seed{seed}')
 
 
 @pytest.mark.parametrize('A', [2, 3])
