@@ -260,6 +260,18 @@ def kernel_rooflines(B, T, nsets=8):
     out.append(dict(kernel='pw_nn_kernel<128,4,0,1> (stage-2 forward conv, K = N = 232, W in registers, float32 MFMA, statistics epilogue)',
                     shape=f'M={M2} K=N={C2}', us=round(t * 1e6, 1), algorithmic_bytes=by2, achieved_GBs=round(by2 / t / 1e9, 1),
                     frac=round(by2 / t / 1e9 / HBM_PEAK_GBS, 4), cache_state=warm))
+    # round 6: the form the step runs for these convs now -- one 32-row tile and one block of 128 columns per workgroup, three bf16 planes
+    # per operand (pw_x3_wide_kernel), with and without the BatchNorm-apply prologue
+    wpx2 = torch.zeros(int(lib.cdrl_pwconv_x3_packed_bytes_n(C2, C2)), dtype=torch.uint8, device=dev)
+    lib.cdrl_pwconv_x3_pack(P(w2), C2, C2, C2, 1, P(wpx2), S())
+    nbx2 = int(lib.cdrl_pwconv_x3_partial_rows(G, M2 // G, C2, C2))
+    partx2 = torch.zeros(G * nbx2 * 2 * C2, dtype=torch.float64, device=dev)
+    stx2 = torch.rand(4 * G * C2, device=dev) + 0.5
+    for pro, label in ((None, 'statistics epilogue'), (stx2, 'BN-apply prologue, statistics epilogue')):
+        t = timeit(lambda k: lib.cdrl_pwconv_x3(P(a2[k]), C2, 0, P(pro), P(wpx2), P(b2), P(y2[k]), C2, 0, G, M2 // G, C2, C2, P(partx2), S()))
+        out.append(dict(kernel=f'pw_x3_wide_kernel<{label}> (stage-2 forward conv, K = N = 232, one tile per workgroup, three-way bf16 split)',
+                        shape=f'M={M2} K=N={C2}', us=round(t * 1e6, 1), algorithmic_bytes=by2, achieved_GBs=round(by2 / t / 1e9, 1),
+                        frac=round(by2 / t / 1e9 / HBM_PEAK_GBS, 4), cache_state=warm))
     dw2 = torch.empty(C2, C2, device=dev)
     ws2 = torch.empty(int(lib.cdrl_gemm_tn_workspace_elems(M2, C2, C2)), device=dev)
     t = timeit(lambda k: lib.cdrl_gemm_tn(P(a2[k]), C2, 0, P(y2[k]), C2, 0, P(dw2), M2, C2, C2, P(ws2), 0, S()))

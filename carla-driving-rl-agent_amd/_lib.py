@@ -81,6 +81,7 @@ PROTOTYPES = {
     'cdrl_learner_policy_backward': (_i, [_L, C.POINTER(PolicyBatch), _f, _fp]),
     'cdrl_learner_policy_forward_backward_resample': (_i, [_L, C.POINTER(PolicyBatch), C.c_uint64, C.c_uint64, _f, _fp]),
     'cdrl_pwconv_x3_packed_bytes': (_i64, [_i]),
+    'cdrl_pwconv_x3_packed_bytes_n': (_i64, [_i, _i]),
     'cdrl_pwconv_x3_partial_rows': (_i, [_i, _i, _i, _i]),
     'cdrl_pwconv_x3_pack': (_i, [_fp, _i, _i, _i, _i, _fp, _fp]),
     'cdrl_pwconv_x3': (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp]),
@@ -136,8 +137,6 @@ PROTOTYPES = {
     'cdrl_stem_block_bwd_workspace_doubles': (_i64, [_i] * 5),
     'cdrl_stem_block_bwd': (_i, [_fp] * 5 + [_i] * 5 + [_fp] * 7),
     'cdrl_stem_block_bwd_pooled': (_i, [_fp] * 6 + [_i] * 5 + [_fp] * 7),
-    'cdrl_stem_block_bwd_gram_workspace_doubles': (_i64, [_i] * 5),
-    'cdrl_stem_block_bwd_gram': (_i, [_fp] * 8 + [_i] * 5 + [_fp] * 7),
     'cdrl_pwconv_fused_partial_rows': (_i, [_i, _i, _i, _i]),
     'cdrl_pwconv_fused': (_i, [_fp, _i, _i, _fp, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp]),
     'cdrl_pwconv_pack_elems': (_i64, [_i, _i]),

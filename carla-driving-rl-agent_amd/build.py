@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libcdrl_hip.so')
 OBJ = os.path.join(HERE, 'build')
-SOURCES = ['common', 'bn', 'gemm', 'gemm_tn_direct', 'gemm_tn_lds', 'gemm_pw', 'gemm_pw_bf16', 'gemm_pw_x3', 'gemm_pw_bwd', 'gemm_x3', 'conv', 'stem_bwd', 'dwfused', 'rnn', 'heads', 'loss', 'optim', 'gae', 'sample', 'augment', 'engine', 'capi']
+SOURCES = ['common', 'bn', 'gemm', 'gemm_tn_direct', 'gemm_tn_lds', 'gemm_pw', 'gemm_pw_bf16', 'gemm_pw_x3', 'gemm_pw_bwd', 'gemm_x3', 'conv', 'dwfused', 'rnn', 'heads', 'loss', 'optim', 'gae', 'sample', 'augment', 'engine', 'capi']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
 
 

@@ -88,7 +88,7 @@ __device__ __forceinline__ void strided_sum2(const double* __restrict__ p0, cons
 // slots on one CU before it starts; in the backward pass the side stream keeps the CUs busy and the finalize kernels of the
 // critical stream then queue behind it (outliers of 74 us for a 5.6 us kernel).  CDRL_FIN_PY = 128 | 64 | 32.
 static int fin_py() {
-    static const int v = cdrl_getenv("CDRL_FIN_PY") ? atoi(cdrl_getenv("CDRL_FIN_PY")) : 64;
+    static const int v = 64;
     return v >= 128 ? 128 : (v >= 64 ? 64 : 32);
 }
 
@@ -502,7 +502,7 @@ template <class T>
 static int bn_apply_t(View y, int G, int Mg, int C, const float* stats, int act, View dst, int shuffle_ctot,
                       hipStream_t st, const View* pass_src, const View* pass_dst) {
     {
-        static const bool fast = !(cdrl_getenv("CDRL_APPLY_FAST") && atoi(cdrl_getenv("CDRL_APPLY_FAST")) == 0);
+        static const bool fast = true;
         const VColGeom g = vcol_geom(Mg, C, 2048);
         View ps{nullptr, 0, 0}, pd{nullptr, 0, 0};
         if (pass_src && pass_dst) {
@@ -769,7 +769,7 @@ static void launch_bbr_shuf(const VColGeom& g, int G, hipStream_t st, View da, i
 int bn_bwd_reduce(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, int act,
                   double* part, hipStream_t st, const PoolSrc* pool, const View* pass_gsrc, const View* pass_gdst, int bcast_rows, int at) {
     {
-        static const bool fast = !(cdrl_getenv("CDRL_BBR_FAST") && atoi(cdrl_getenv("CDRL_BBR_FAST")) == 0);
+        static const bool fast = true;
         const VColGeom g = vcol_geom(Mg, C, NB_STATS);
         View pgs{nullptr, 0, 0}, pgd{nullptr, 0, 0};
         if (pass_gsrc && pass_gdst) {
@@ -993,13 +993,13 @@ __global__ void __launch_bounds__(256) pool_bn_bwd_reduce_v4_kernel(PoolSrc ps, 
 int pool_bn_bwd_reduce(const PoolSrc& ps, const float* y, int G, int frames_per_group, int C, const float* stats, double* part,
                        hipStream_t st, int at) {
     {
-        static const bool fast = !(cdrl_getenv("CDRL_POOLRED_FAST") && atoi(cdrl_getenv("CDRL_POOLRED_FAST")) == 0);
+        static const bool fast = true;
         const int Mg = frames_per_group * ps.Ho * ps.Wo;
         const VColGeom g = vcol_geom(Mg, C, NB_STATS);
         if (fast && g.vec == 4 && g.nloop == 1) {
             dim3 grid(g.nb, G), block(g.cx, g.cy);
             const size_t smb = (size_t)g.cy * 4 * g.cx * sizeof(double);
-            static const bool pooled_env = !(cdrl_getenv("CDRL_POOLRED_POOLED") && atoi(cdrl_getenv("CDRL_POOLRED_POOLED")) == 0);
+            static const bool pooled_env = true;
             if (at && ps.pa && pooled_env) hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<bf16_t, true>), grid, block, smb, st, ps, reinterpret_cast<const bf16_t*>(y), stats, G * C, C, Mg, g.rb, part);
             else if (at) hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<bf16_t, false>), grid, block, smb, st, ps, reinterpret_cast<const bf16_t*>(y), stats, G * C, C, Mg, g.rb, part);
             else if (ps.pa && pooled_env) hipLaunchKernelGGL((pool_bn_bwd_reduce_v4_kernel<float, true>), grid, block, smb, st, ps, y, stats, G * C, C, Mg, g.rb, part);
@@ -1209,7 +1209,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(View da, int cto
 int bn_bwd_apply(View da, int shuffle_ctot, View y, int G, int Mg, int C, const float* stats, const float* coef,
                  int act, float* dy, double* part2, hipStream_t st, const PoolSrc* pool, int bcast_rows, int at) {
     {
-        static const bool fast = !(cdrl_getenv("CDRL_BBA_FAST") && atoi(cdrl_getenv("CDRL_BBA_FAST")) == 0);
+        static const bool fast = true;
         const VColGeom g = vcol_geom(Mg, C, NB_STATS);
         const bool ydense = y.ld == C && y.coff == 0 && view_aligned(y, g.vec);
         if (fast && !pool && g.nloop == 1 && g.vec >= 2 && ydense && (reinterpret_cast<uintptr_t>(dy) % (4 * g.vec)) == 0) {

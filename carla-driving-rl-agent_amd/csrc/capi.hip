@@ -420,6 +420,7 @@ int cdrl_gae_returns(const float* rewards, const float* values_be, int N, double
 }
 
 int64_t cdrl_pwconv_x3_packed_bytes(int K) { return pw_x3_packed_bytes(K); }
+int64_t cdrl_pwconv_x3_packed_bytes_n(int K, int N) { return pw_x3_packed_bytes_n(K, N); }
 int cdrl_pwconv_x3_partial_rows(int G, int Mg, int N, int K) { return pw_x3_partial_rows(G, Mg, N, K); }
 
 int cdrl_pwconv_x3_pack(const float* W, int K, int N, int sbk, int sbn, void* packed, void* stream) {
@@ -635,9 +636,7 @@ int cdrl_augment_images(const float* in, float* out, int T, int H, int W, const 
 int64_t cdrl_stem_block_bwd_workspace_doubles(int B, int T, int H, int W, int Cout) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
-    const int64_t two_pass = (int64_t)T * vcol_geom(B * Hp * Wp, Cout).nb * 2 * Cout + stem_bwd_part_elems(B, T, H, W, Cout);
-    const int64_t one_pass = (stem_bwd_direct_ws_floats(B, T, H, W) + 1) / 2;
-    return two_pass > one_pass ? two_pass : one_pass;
+    return (int64_t)T * vcol_geom(B * Hp * Wp, Cout).nb * 2 * Cout + stem_bwd_part_elems(B, T, H, W, Cout);
 }
 
 int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, int B, int T,
@@ -654,47 +653,12 @@ int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stat
     hipStream_t st = S(stream);
     PoolSrc ps = make_pool_src(argmax, dp, Ho, Wo);
     ps.pa = pooled;
-    static const bool one_pass = cdrl_getenv("CDRL_STEM_DIRECT") && atoi(cdrl_getenv("CDRL_STEM_DIRECT")) == 1;
-    if (one_pass && stem_bwd_direct_supported(Cout))        // one pass: BN sums + filter sums together (stem_bwd.hip), opt-in
-        return stem_bwd_direct(x, ps, y, stats, dgamma, dbeta, coef, dw, db, B, T, H, W, Cout, reinterpret_cast<float*>(workspace), st);
     const int nb = vcol_geom(B * Hp * Wp, Cout).nb;
     double* part = workspace;
     double* fpart = workspace + (int64_t)T * nb * 2 * Cout;
     CDRL_TRY(pool_bn_bwd_reduce(ps, y, T, B, Cout, stats, part, st, g_op_at));
     CDRL_TRY(bn_bwd_finalize(part, nb, T, B * Ho * Wo, Cout, stats, dgamma, dbeta, coef, st));
     return stem_bwd_filter_fused(x, ps, y, stats, coef, dw, db, B, T, H, W, Cout, fpart, st, g_op_at);
-}
-
-int64_t cdrl_stem_block_bwd_gram_workspace_doubles(int B, int T, int H, int W, int Cout) {
-    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
-    const int64_t xt = std::max(stem_xt_part_floats(B, T, H, W, 28), stem_xt_part_floats(B, T, H, W, Cout));
-    return (int64_t)T * vcol_geom(B * Hp * Wp, Cout).nb * 2 * Cout + (int64_t)T * 28 * 28 + (int64_t)T * 28 * Cout + (xt + 1) / 2 + 96;
-}
-
-int cdrl_stem_block_bwd_gram(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, const float* pooled,
-                             const float* w, const float* b, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta,
-                             float* coef, float* dw, float* db, double* workspace, void* stream) {
-    if (!stem_bwd_raw_supported(Cout) || g_op_at) {
-        set_error("cdrl_stem_block_bwd_gram: float32 tensors, Cout %% 4 == 0, Cout <= 32");
-        return -1;
-    }
-    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
-    hipStream_t st = S(stream);
-    PoolSrc ps = make_pool_src(argmax, dp, Ho, Wo);
-    const int nb = vcol_geom(B * Hp * Wp, Cout).nb;
-    auto up32 = [](int64_t n) { return (n + 31) / 32 * 32; };        // 256-byte blocks
-    double* part = workspace;
-    double* gram = part + up32((int64_t)T * nb * 2 * Cout);
-    double* A = gram + up32((int64_t)T * 28 * 28);
-    float* xt = reinterpret_cast<float*>(A + up32((int64_t)T * 28 * Cout));
-    CDRL_TRY(stem_gram(x, B, T, H, W, xt, gram, st));                        // (the engine: forward pass, aux stream)
-    CDRL_TRY(stem_bwd_raw(x, ps, B, T, H, W, Cout, xt, A, st));              // (the engine: aux stream, beside the reduction below)
-    ps.pa = pooled;
-    CDRL_TRY(pool_bn_bwd_reduce(ps, y, T, B, Cout, stats, part, st, 0));
-    CDRL_TRY(bn_bwd_finalize(part, nb, T, B * Ho * Wo, Cout, stats, dgamma, dbeta, coef, st));
-    return stem_bwd_combine(A, gram, w, b, stats, coef, T, Cout, dw, db, st);
 }
 
 int cdrl_pwconv_fused_partial_rows(int G, int Mg, int N, int K) { return pw_nn_plan(G, Mg, N, K).nbpg; }

@@ -165,23 +165,7 @@ int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, 
 int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout);
 // stem filter gradient with the stem BatchNorm's backward apply + max-pool gather fused into the operand load (dy is
 // never materialised); y: raw stem conv output, stats/coef: the stem BN's [4|3][T][Cout] blocks
-// (stem_bwd.hip) ONE pass from the pooled gradient: BN sums + the three filter sums as MFMA products with operands
-// generated into the fragment registers, then a finalize kernel -> dgamma, dbeta, coef, dw, db.  ws: stem_bwd_direct_ws_floats()
-bool stem_bwd_direct_supported(int Cout);
-int64_t stem_bwd_direct_ws_floats(int B, int T, int H, int W);
-int stem_bwd_direct(const float* x, const PoolSrc& ps, const float* y, const float* stats, float* dgamma, float* dbeta, float* coef,
-                    float* dw, float* db, int B, int T, int H, int W, int Cout, float* ws, hipStream_t st);
 bool stem_bwd_fused_supported(int Cout);
-// Coefficient-free form of the same gradient (conv.hip, round 5): Gram of the image patches in the forward, one gather pass over the
-// pooled gradient beside the BatchNorm reduction, a 28 x Cout combine once the coefficients exist.  part: stem_xt_part_floats(.., nc)
-// floats with nc = 28 (gram) / Cout (raw); gram [T][28][28], A [T][28][Cout] doubles.
-bool stem_bwd_raw_supported(int Cout);
-bool stem_xt_fits(int B, int T, int H, int W, int Cout);
-int64_t stem_xt_part_floats(int B, int T, int H, int W, int nc);
-int stem_gram(const float* x, int B, int T, int H, int W, float* part, double* gram, hipStream_t st);
-int stem_bwd_raw(const float* x, const PoolSrc& ps, int B, int T, int H, int W, int Cout, float* part, double* A, hipStream_t st);
-int stem_bwd_combine(const double* A, const double* gram, const float* w, const float* bias, const float* stats, const float* coef,
-                     int T, int Cout, float* dw, float* db, hipStream_t st);
 int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, const float* stats, const float* coef, float* dw,
                           float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st, int at = 0);
 int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,
@@ -258,7 +242,8 @@ struct PwX3Pack {
 };
 bool pw_x3_supported(View A, int N, int K);
 int pw_x3_partial_rows(int G, int Mg, int N, int K);
-int64_t pw_x3_packed_bytes(int K);
+int64_t pw_x3_packed_bytes(int K);                 // N <= 128 (one column block)
+int64_t pw_x3_packed_bytes_n(int K, int N);        // any N <= 256: column blocks of 128
 PwX3Pack pw_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, int sbn);
 int pw_x3_pack_many(const PwX3Pack* tab_dev, int n, hipStream_t st);
 // nbpg > 0: workgroups (= partial rows) per group chosen by the caller (the engine keeps pw_nn_plan's count)

@@ -322,7 +322,7 @@ static StemFwdGeom stem_fwd_geom(int B, int T, int H, int W, int Cout) {
     const int CX = Cout / 4, CY = 256 / CX;
     const size_t red = (size_t)8 * CY * CX * sizeof(double);
     const int cand[] = {8, 6, 4, 3, 2, 1};
-    static const int rmax = cdrl_getenv("CDRL_STEM_FWD_R") ? atoi(cdrl_getenv("CDRL_STEM_FWD_R")) : 8;
+    static const int rmax = 8;
     for (int R : cand) {
         const int nx = (2 * R + 1) * W * 3;
         const int px = cdiv(nx, 1024);
@@ -336,7 +336,7 @@ static StemFwdGeom stem_fwd_geom(int B, int T, int H, int W, int Cout) {
         break;
     }
     if (!g.ok) return g;
-    static const int wgs_env = cdrl_getenv("CDRL_STEM_FWD_WGS") ? atoi(cdrl_getenv("CDRL_STEM_FWD_WGS")) : 512;     // two workgroups per CU are resident (196-216 VGPRs)
+    static const int wgs_env = 512;     // two workgroups per CU are resident (196-216 VGPRs)
     g.nbpg = std::max(1, std::min(wgs_env / std::max(T, 1), B * g.NB));
     return g;
 }
@@ -368,7 +368,7 @@ int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, 
         else hipLaunchKernelGGL((stem_fwd_band_kernel<NPN, PXN, float>), dim3(T * bg.nbpg), dim3(256), bg.lds, st, x, w, bias, y, part, B,  \
                                 T, H, W, Ho, Wo, Cout, bg);                                                                                 \
     } while (0)
-        static const int npx = cdrl_getenv("CDRL_STEM_FWD_NP") ? atoi(cdrl_getenv("CDRL_STEM_FWD_NP")) : STEM_FWD_NP;
+        static const int npx = STEM_FWD_NP;
         if (npx >= 4) {
             if (bg.px == 2) CDRL_STEM_FWD_BAND_LAUNCH(4, 2);
             else if (bg.px == 4) CDRL_STEM_FWD_BAND_LAUNCH(4, 4);
@@ -393,7 +393,7 @@ int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, 
     size_t lds = (size_t)(27 * Cout + Cout) * sizeof(float);
     const size_t red = (size_t)8 * cy * cx * sizeof(double);
     if (lds < red) lds = red;
-    static const int np = cdrl_getenv("CDRL_STEM_NP") ? atoi(cdrl_getenv("CDRL_STEM_NP")) : 4;
+    static const int np = 4;
     if (at) hipLaunchKernelGGL((stem_fwd_stats_kernel<4, bf16_t>), dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, reinterpret_cast<bf16_t*>(y), part, B, T, H, W, Ho, Wo, Cout, rb);
     else if (np >= 4) hipLaunchKernelGGL((stem_fwd_stats_kernel<4, float>), dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
     else if (np >= 2) hipLaunchKernelGGL((stem_fwd_stats_kernel<2, float>), dim3(nb, T), dim3(cx, cy), lds, st, x, w, bias, y, part, B, T, H, W, Ho, Wo, Cout, rb);
@@ -451,7 +451,7 @@ struct StemBwdF {
 typedef float f32x16_c __attribute__((ext_vector_type(16)));
 #define STEM_NBLK_MAX 2048                          // capacity of the partial buffer
 static int stem_nblk() {
-    static const int n = cdrl_getenv("CDRL_STEM_NBLK") ? atoi(cdrl_getenv("CDRL_STEM_NBLK")) : 1024;
+    static const int n = 1024;
     return n < 64 ? 64 : (n > STEM_NBLK_MAX ? STEM_NBLK_MAX : n);
 }
 
@@ -719,396 +719,6 @@ int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, con
     CDRL_LAUNCH_CHECK();
     CDRL_TRY(reduce_partials_f32(pf, nblk, (int64_t)27 * Cout, (int64_t)28 * Cout, dw, 0, st));
     return reduce_partials_f32(pf + 27 * Cout, nblk, Cout, (int64_t)28 * Cout, db, 0, st);
-}
-
-// ------------------------------------------------------------------------------------------
-// COEFFICIENT-FREE form of the stem filter gradient (round 5, float32 engine).
-//
-// OPT-IN in the engine (CDRL_STEM_RAW=1): correct, more accurate than the fused form (1.9e-7 .. 5e-7 against 4.3e-7 .. 5.3e-7 of float64
-// autograd: no rounded y in it), and it does take the filter gradient off the end of the pass -- but its two passes are 170 + 91 us of
-// float32-MFMA-bound work (16 v_mfma_f32_32x32x2_f32 of 64 cycles per 32 pixels) against 174 us, and beside the other kernels of the
-// tail the gather pass stretches to 317 us: 14.4 vs 14.1 ms per update-step.  DESIGN.md section 3 has the measurements.
-//
-// The fused form above needs the BatchNorm-backward coefficients (k1, k2, k3) of the stem BatchNorm, which exist only after the
-// LAST reduction of a backward pass (sums over the pooled gradient) -- so its 170 us pass over y, the pooled gradient and the
-// images sits, fully exposed, in the tail of every pass (0.36 ms per update-step, tools/r05_stem_diag.sh).  With
-//     dy = k1 (dzm - k2 - xhat k3),  dzm = ReLU6 mask * pool-gathered gradient,  xhat = (y - mean) invstd,  y = P W + b
-// (P = im2col patches [rows][27], per time slice g because the BatchNorm is per time slice) the product splits into three parts
-// none of which needs the coefficients:
-//     dW[k][c] = sum_g k1 ( A_g[k][c] - k2 SP_g[k] - k3 X_g[k][c] ),   db[c] = the same with the ones column k = 27
-//     A_g = [P | 1]^T dzm                  <- ONE gather pass over the pooled gradient and the images, started as soon as the pooled
-//                                             gradient is final, beside the BatchNorm reduction (stem_bwd_raw)
-//     SP_g[k] = sum_r P[r][k],  Gram_g = [P | 1]^T [P | 1]      <- depend on the IMAGES only: taken in the forward pass (stem_gram)
-//     X_g = [P | 1]^T xhat = invstd ( Gram_g[:, :27] W + SP_g b - mean SP_g )        <- no pass over y at all
-// and a 28 x 24 combine kernel in double once the coefficients exist (stem_bwd_combine).  The ReLU6 mask comes with the argmax code
-// (bit 7 set by maxpool_bn_fwd where the winning activation is clamped), so the gather needs neither y nor the pooled output.
-// Partials: one float tile [28][NC] per workgroup, workgroups never straddle a time slice, fixed-order reduction in double.
-// MODE 0: B operand = gathered dzm (NC = Cout);  MODE 1: B operand = the patch tile itself (NC = 28).
-// Band-staged form: a workgroup walks (frame, band of R conv-output rows) units of ONE time slice.  The unit's image rows (2 R + 1 of them),
-// pooled-gradient rows and argmax rows are CONTIGUOUS in memory and go to LDS with 16-byte lanes (the first version gathered patch
-// taps and pool windows straight from global memory, 4 bytes per lane and load: 225 us, latency-bound); patches and pool windows are then
-// read from LDS.  The MFMA A operand needs no patch tile at all: P[pixel][tap] = xs[pixel offset + tap offset] with the pixel offset of
-// row k taken from lane k by v_readlane.  Wave w takes 32-pixel tiles w, w + 4, .. of the band; accumulators live across units.
-#define STEM_XT_PX 6                // 16-byte chunks per thread of an image band (<= 24 KB), of a pooled-gradient band (<= 16 KB);
-#define STEM_XT_PD 4                // the argmax band is one chunk per thread (<= 4 KB)
-struct StemXtGeom {
-    int R, NB, nbpg, dp_rows;       // band rows, bands per frame, workgroups per time slice, pooled rows staged per band (max)
-    int xs_floats;                  // LDS floats of the image band (padded)
-    size_t lds;
-    bool ok;                        // a band fits the prefetch registers (images up to 682 pixels wide)
-    int dbg;                        // timing diagnostics (CDRL_DIAG=1 CDRL_DIAG_STEMXT=bits, wrong results): 1 no MFMA loop, 2 no gather tile, 4 no staging
-};
-
-template <int MODE, int NCH>
-__global__ void __launch_bounds__(256) stem_xt_kernel(const float* __restrict__ x, float* __restrict__ part, int B, int T, int H, int W,
-                                                      int Ho, int Wo, int Cout, StemXtGeom gm, PoolSrc ps) {
-    extern __shared__ __attribute__((aligned(16))) float stem_sm[];
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    float* xs = stem_sm;
-    float* dps = xs + gm.xs_floats;
-    const int dp_floats = MODE == 0 ? gm.dp_rows * ps.Wo * Cout : 0;
-    uint32_t* ams = reinterpret_cast<uint32_t*>(dps + dp_floats);                      // argmax codes, 4 per word
-    float(*D)[32][33] = reinterpret_cast<float(*)[32][33]>(ams + (MODE == 0 ? dp_floats / 4 + 4 : 0));
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lcol = lane & 31, lk = lane >> 5;
-    const int g = blockIdx.x / gm.nbpg, bg = blockIdx.x % gm.nbpg;
-    const int R = gm.R, NB = gm.NB, units = B * NB;
-    const int W3 = W * 3;
-    // two accumulators, alternating over the K steps: a dependent chain of v_mfma on ONE accumulator runs at ~1.7x its issue time
-    // (tools/ubench_mfma_valu.hip); summed before the cross-wave fold
-    f32x16_c acc, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = acc1[i] = 0.0f;
-    if (MODE == 0)
-        for (int i = lane; i < 32 * 33; i += 64) (&D[wave][0][0])[i] = 0.0f;       // padding columns once
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)((int64_t)B * T * H * W3 * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rsDP, rsAM;
-    if (MODE == 0) {
-        const int64_t pel = (int64_t)B * T * ps.Ho * ps.Wo * Cout;
-        rsDP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.dp), 0, (int)(pel * 4), 0x00020000);
-        rsAM = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ps.argmax), 0, (int)pel, 0x00020000);
-    }
-    // tap offset of this lane's patch column inside the image band: tap = (ky * 3 + kx) * 3 + ci -> ky * W3 + (tap % 9)
-    const int tapoff = lcol < 27 ? (lcol / 9) * W3 + (lcol % 9) : 0;
-    // The band of the NEXT unit is requested into registers before the current one is multiplied (a unit's compute phase is ~2 us, a
-    // round trip under load 3-5 us: without the prefetch the kernel was latency-bound at 181 us) and moves to LDS after it.
-    constexpr int PX = STEM_XT_PX, PD = STEM_XT_PD;
-    u32x4_t px[PX], pd[MODE == 0 ? PD : 1], pa;
-    const uint32_t OOR = 0x80000000u;
-    auto prefetch = [&](int u) {
-        const int b = u / NB, k = u - b * NB;
-        const int f = g * B + b;
-        const int oy0 = k * R, Rb = min(R, Ho - oy0);
-        const uint32_t b0 = (uint32_t)(((((int64_t)b * T + g) * H + 2 * oy0) * W3) * 4);
-        const int nx = (2 * Rb + 1) * W3;
-#pragma unroll
-        for (int q = 0; q < PX; ++q) {                      // (the last chunk may read past the band: inside the tensor or 0)
-            const int i = (q * 256 + tid) * 4;
-            px[q] = __builtin_amdgcn_raw_buffer_load_b128(rsX, i < nx ? b0 + (uint32_t)i * 4u : OOR, 0, 0);
-        }
-        if (MODE == 0) {
-            const int py_lo = max(0, ((oy0 + ps.pt) >> 1) - 1), py_hi = min(ps.Ho - 1, (oy0 + Rb - 1 + ps.pt) >> 1);
-            const int nd = (py_hi - py_lo + 1) * ps.Wo * Cout;                      // floats (= argmax bytes); a multiple of 4
-            const uint32_t e0 = (uint32_t)((f * ps.Ho + py_lo) * ps.Wo * Cout);
-#pragma unroll
-            for (int q = 0; q < PD; ++q) {
-                const int i = (q * 256 + tid) * 4;
-                pd[q] = __builtin_amdgcn_raw_buffer_load_b128(rsDP, i < nd ? (e0 + (uint32_t)i) * 4u : OOR, 0, 0);
-            }
-            const int i = tid * 16;
-            pa = __builtin_amdgcn_raw_buffer_load_b128(rsAM, i < nd ? e0 + (uint32_t)i : OOR, 0, 0);
-        }
-    };
-    if (bg < units) prefetch(bg);
-    for (int u = bg; u < units; u += gm.nbpg) {
-        const int b = u / NB, k = u - b * NB;
-        const int oy0 = k * R, Rb = min(R, Ho - oy0), npix = Rb * Wo;
-        const int py_lo = MODE == 0 ? max(0, ((oy0 + ps.pt) >> 1) - 1) : 0;
-        __syncthreads();                                    // the previous unit's LDS reads are done
-        {
-            const int nx = (2 * Rb + 1) * W3;
-#pragma unroll
-            for (int q = 0; q < PX; ++q) {
-                const int i = (q * 256 + tid) * 4;
-                if (i < nx) *reinterpret_cast<u32x4_t*>(xs + i) = px[q];
-            }
-            if (MODE == 0) {
-                const int py_hi = min(ps.Ho - 1, (oy0 + Rb - 1 + ps.pt) >> 1);
-                const int nd = (py_hi - py_lo + 1) * ps.Wo * Cout;
-#pragma unroll
-                for (int q = 0; q < PD; ++q) {
-                    const int i = (q * 256 + tid) * 4;
-                    if (i < nd) *reinterpret_cast<u32x4_t*>(dps + i) = pd[q];
-                }
-                if (tid * 16 < nd) *reinterpret_cast<u32x4_t*>(ams + tid * 4) = pa;
-            }
-        }
-        __syncthreads();
-        if (u + gm.nbpg < units && !(gm.dbg & 4)) prefetch(u + gm.nbpg);
-        // The pixels of a band are taken in four PARITY CLASSES (row parity cy of oy + pt, column parity cx of ox + pl): a pixel of class
-        // (1, 1) is reached by one pool window, (0, 1) / (1, 0) by two, (0, 0) by four -- with one class per 32-pixel tile the gather
-        // below skips the windows a class does not have on a scalar branch (2.25 instead of 4 windows per pixel on average).  The sum
-        // over pixels does not care about their order.
-        const int fy0 = (oy0 + ps.pt) & 1;                  // parity of the band's first row
-        const int fx1 = (1 - ps.pl) & 1;                    // first column of column parity 1; parity 0 starts at ps.pl & 1
-        int ctiles[4], cny[4], cnx[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int cy = c >> 1, cx = c & 1;
-            const int ry0 = (cy - fy0) & 1, rx0 = cx ? fx1 : (ps.pl & 1);
-            cny[c] = (Rb - ry0 + 1) >> 1;
-            cnx[c] = (Wo - rx0 + 1) >> 1;
-            ctiles[c] = MODE == 0 ? (cny[c] * cnx[c] + 31) >> 5 : 0;
-        }
-        const int ntiles = MODE == 0 ? ctiles[0] + ctiles[1] + ctiles[2] + ctiles[3] : (npix + 31) >> 5;
-        for (int tile = wave; tile < ntiles; tile += 4) {
-            stem_wave_sync();                               // (the previous tile's D reads)
-            const int r = lane & 31, half = lane >> 5;
-            int cls = 0, q = tile * 32 + r;
-            bool ok;
-            int oyl = 0, ox = 0;
-            if (MODE == 0) {
-                int tb = tile;
-                if (tb >= ctiles[0]) { tb -= ctiles[0]; cls = 1; if (tb >= ctiles[1]) { tb -= ctiles[1]; cls = 2; if (tb >= ctiles[2]) { tb -= ctiles[2]; cls = 3; } } }
-                cls = __builtin_amdgcn_readfirstlane(cls);
-                const int ny = cls == 0 ? cny[0] : cls == 1 ? cny[1] : cls == 2 ? cny[2] : cny[3];
-                const int nx = cls == 0 ? cnx[0] : cls == 1 ? cnx[1] : cls == 2 ? cnx[2] : cnx[3];
-                q = tb * 32 + r;
-                ok = q < ny * nx;
-                const int i = ok ? q / nx : 0, j = ok ? q - i * nx : 0;
-                const int cy = cls >> 1, cx = cls & 1;
-                oyl = ((cy - fy0) & 1) + 2 * i;
-                ox = (cx ? fx1 : (ps.pl & 1)) + 2 * j;
-            } else {
-                ok = q < npix;
-                oyl = ok ? q / Wo : 0;
-                ox = ok ? q - oyl * Wo : 0;
-            }
-            const int po = ok ? (2 * oyl * W + 2 * ox) * 3 : -1;        // pixel offset inside the band, -1: no pixel
-            if (MODE == 0 && !(gm.dbg & 2)) {
-                const int oy = oy0 + oyl;
-                const int kyA = (oy + ps.pt) & 1, kxA = (ox + ps.pl) & 1;
-                const int pyA = (oy + ps.pt - kyA) >> 1, pxA = (ox + ps.pl - kxA) >> 1;
-                const bool vyA = ok && pyA < ps.Ho, vyB = ok && kyA == 0 && pyA >= 1 && (pyA - 1) < ps.Ho;
-                const bool vxA = pxA < ps.Wo, vxB = kxA == 0 && pxA >= 1 && (pxA - 1) < ps.Wo;
-                const int ebase = ((pyA - py_lo) * ps.Wo + pxA) * Cout;
-                const int dyB = -ps.Wo * Cout, dxB = -Cout;
-                int wo[4];
-                uint32_t wk[4];         // window codes; 0xff (no window) never equals a stored code
-                wo[0] = (vyA && vxA) ? ebase : -1;
-                wo[1] = (vyA && vxB) ? ebase + dxB : -1;
-                wo[2] = (vyB && vxA) ? ebase + dyB : -1;
-                wo[3] = (vyB && vxB) ? ebase + dyB + dxB : -1;
-                wk[0] = kyA * 3 + kxA;
-                wk[1] = kyA * 3 + kxA + 2;
-                wk[2] = (kyA + 2) * 3 + kxA;
-                wk[3] = (kyA + 2) * 3 + kxA + 2;
-#pragma unroll
-                for (int w4 = 0; w4 < 4; ++w4)
-                    if (wo[w4] < 0) {
-                        wo[w4] = 0;
-                        wk[w4] = 0xffu;
-                    }
-                // windows this tile's class does not have (wave-uniform): (., B) needs column parity 0, (B, .) row parity 0
-                const bool en[4] = {true, (cls & 1) == 0, (cls >> 1) == 0, cls == 0};
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    const int c0 = (half * NCH + j) * 4;
-                    if (c0 >= Cout) continue;
-                    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4) {
-                        if (!en[w4]) continue;
-                        const float4 gd = *reinterpret_cast<const float4*>(dps + wo[w4] + c0);
-                        const uint32_t ga = ams[(wo[w4] + c0) >> 2];
-                        // a code with bit 7 (clamped activation: closed ReLU6) never equals a window code: masked for free
-                        if ((ga & 0xffu) == wk[w4]) d[0] += gd.x;
-                        if (((ga >> 8) & 0xffu) == wk[w4]) d[1] += gd.y;
-                        if (((ga >> 16) & 0xffu) == wk[w4]) d[2] += gd.z;
-                        if ((ga >> 24) == wk[w4]) d[3] += gd.w;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) D[wave][r][c0 + i] = d[i];
-                }
-                stem_wave_sync();
-            }
-            if (!(gm.dbg & 1))
-#pragma unroll
-            for (int mm = 0; mm < 32; mm += 2) {
-                const int p0 = __builtin_amdgcn_readlane(po, mm), p1 = __builtin_amdgcn_readlane(po, mm + 1);
-                const int pk = lk ? p1 : p0;
-                float a = xs[max(pk, 0) + tapoff];
-                if (lcol == 27) a = 1.0f;
-                if (pk < 0 || lcol > 27) a = 0.0f;
-                const float bq = MODE == 0 ? D[wave][mm + lk][lcol] : a;
-                if (mm & 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc1, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
-    __syncthreads();
-    // sum the 4 wave accumulators through LDS (the staging area is dead)
-    float(*Pq)[32][33] = reinterpret_cast<float(*)[32][33]>(stem_sm);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Pq[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][lcol] = acc[r];
-    __syncthreads();
-    const int NC = MODE == 0 ? Cout : 28;
-    float* out = part + (int64_t)blockIdx.x * 28 * NC;
-    for (int idx = tid; idx < 28 * NC; idx += 256) {
-        const int k = idx / NC, n = idx - k * NC;
-        out[idx] = (Pq[0][k][n] + Pq[1][k][n]) + (Pq[2][k][n] + Pq[3][k][n]);
-    }
-}
-
-// out[g][i] = sum_p part[g][p][i] in double, fixed order: 8 partial lanes x 32 elements per workgroup, lanes folded through LDS
-__global__ void __launch_bounds__(256) stem_part_reduce_kernel(const float* __restrict__ part, int nbpg, int n, double* __restrict__ out) {
-    __shared__ double sm[8][32];
-    const int g = blockIdx.y, e = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
-    double s = 0.0;
-    if (e < n)
-        for (int p = pl; p < nbpg; p += 8) s += (double)part[((int64_t)g * nbpg + p) * n + e];
-    sm[pl][threadIdx.x & 31] = s;
-    __syncthreads();
-    if (pl == 0 && e < n) {
-        double t = sm[0][threadIdx.x];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) t += sm[q][threadIdx.x];
-        out[(int64_t)g * n + e] = t;
-    }
-}
-
-// dW [27][C], db [C] from the per-slice sums (all double): A [G][28][C], Gram [G][28][28] (column / row 27 = the ones column), the
-// conv parameters, the BatchNorm statistics block [4][G][C] (mean, invstd, ..) and the backward coefficients [3][G][C] (k1, k2, k3)
-__global__ void __launch_bounds__(256) stem_bwd_combine_kernel(const double* __restrict__ A, const double* __restrict__ gram,
-                                                               const float* __restrict__ w, const float* __restrict__ bias,
-                                                               const float* __restrict__ stats, const float* __restrict__ coef, int G,
-                                                               int C, float* __restrict__ dw, float* __restrict__ db) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 28 * C) return;
-    const int k = idx / C, c = idx - k * C;
-    double s = 0.0;
-    for (int g = 0; g < G; ++g) {
-        const double* Gg = gram + (int64_t)g * 28 * 28;
-        double gw = 0.0;
-#pragma unroll 9
-        for (int j = 0; j < 27; ++j) gw += Gg[k * 28 + j] * (double)w[j * C + c];
-        const double sp = Gg[k * 28 + 27];
-        const double mean = (double)stats[(0 * G + g) * C + c], inv = (double)stats[(1 * G + g) * C + c];
-        const double k1 = (double)coef[(0 * G + g) * C + c], k2 = (double)coef[(1 * G + g) * C + c], k3 = (double)coef[(2 * G + g) * C + c];
-        const double xk = inv * (gw + sp * ((double)bias[c] - mean));
-        s += k1 * (A[((int64_t)g * 28 + k) * C + c] - k2 * sp - k3 * xk);
-    }
-    if (k < 27) dw[k * C + c] = (float)s;
-    else db[c] = (float)s;
-}
-
-// mode 0: gather pass (needs the pooled geometry), 1: Gram
-static StemXtGeom stem_xt_geom(int B, int T, int H, int W, int Cout, int mode) {
-    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2), pt = same_pad_before(Ho, 2);
-    static const int budget = cdrl_getenv("CDRL_STEM_XT_LDS") ? atoi(cdrl_getenv("CDRL_STEM_XT_LDS")) : 53 * 1024;     // three workgroups per CU
-    StemXtGeom g{};
-    const int cand[] = {8, 6, 4, 3, 2, 1};
-    for (int R : cand) {
-        if (R > Ho && R != 1) continue;
-        const int NB = cdiv(Ho, R);
-        int dp_rows = 0;
-        for (int k = 0; k < NB; ++k) {
-            const int oy0 = k * R, Rb = std::min(R, Ho - oy0);
-            const int lo = std::max(0, ((oy0 + pt) >> 1) - 1), hi = std::min(Hp - 1, (oy0 + Rb - 1 + pt) >> 1);
-            dp_rows = std::max(dp_rows, hi - lo + 1);
-        }
-        const int xs_floats = ((2 * R + 1) * W * 3 + 3) / 4 * 4 + 4;
-        const size_t dpf = mode == 0 ? (size_t)dp_rows * Wp * Cout : 0;
-        size_t lds = (size_t)xs_floats * 4 + dpf * 4 + (mode == 0 ? dpf + 16 : 0) + (mode == 0 ? sizeof(float) * 4 * 32 * 33 : 0);
-        lds = std::max(lds, sizeof(float) * 4 * 32 * 33);           // the final cross-wave sum reuses the staging area
-        g.R = R;
-        g.NB = NB;
-        g.dp_rows = dp_rows;
-        g.xs_floats = xs_floats;
-        g.lds = lds;
-        const bool fits_regs = (size_t)(2 * R + 1) * W * 3 <= (size_t)STEM_XT_PX * 1024 && dpf <= (size_t)STEM_XT_PD * 1024;
-        g.ok = fits_regs;
-        if (lds <= (size_t)budget && fits_regs) break;
-    }
-    const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / std::max<size_t>(g.lds, 1))));
-    static const int wgs_env = cdrl_getenv("CDRL_STEM_XT_WGS") ? atoi(cdrl_getenv("CDRL_STEM_XT_WGS")) : 0;
-    const int total = wgs_env > 0 ? wgs_env : 256 * per_cu;
-    g.nbpg = std::max(1, std::min(total / std::max(T, 1), B * g.NB));
-    static const int dbg = cdrl_getenv("CDRL_DIAG_STEMXT") ? atoi(cdrl_getenv("CDRL_DIAG_STEMXT")) : 0;
-    g.dbg = dbg;
-    return g;
-}
-
-bool stem_bwd_raw_supported(int Cout) { return stem_bwd_fused_supported(Cout); }
-
-// both passes find a band that fits LDS and the prefetch registers (images up to ~680 pixels wide with 24 stem channels)
-bool stem_xt_fits(int B, int T, int H, int W, int Cout) {
-    const StemXtGeom g0 = stem_xt_geom(B, T, H, W, Cout, 0), g1 = stem_xt_geom(B, T, H, W, Cout, 1);
-    return g0.ok && g1.ok && g0.lds <= 160 * 1024 && g1.lds <= 160 * 1024;
-}
-
-// float workspace of stem_gram / stem_bwd_raw: the per-workgroup tiles
-int64_t stem_xt_part_floats(int B, int T, int H, int W, int nc) {
-    const StemXtGeom g = stem_xt_geom(B, T, H, W, nc == 28 ? 24 : nc, nc == 28 ? 1 : 0);
-    return (int64_t)T * g.nbpg * 28 * nc;
-}
-
-template <int MODE, int NCH>
-static int stem_xt_launch(const float* x, float* part, int B, int T, int H, int W, int Cout, const StemXtGeom& g, const PoolSrc& ps, hipStream_t st) {
-    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    if ((int64_t)B * T * H * W * 3 * 4 >= (1ll << 31)) {
-        set_error("stem_xt: image batch of 2 GB or more is not supported");
-        return -1;
-    }
-    if (g.lds > 160 * 1024 || !g.ok) {
-        set_error("stem_xt: a one-row band of %d x %d images does not fit LDS / the prefetch registers", H, W);
-        return -1;
-    }
-    auto kern = stem_xt_kernel<MODE, NCH>;
-    static LdsAttrOnce attr;
-    if (attr.need() && g.lds >= 48 * 1024) {
-        CDRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr.mark();
-    }
-    hipLaunchKernelGGL(kern, dim3(T * g.nbpg), dim3(256), g.lds, st, x, part, B, T, H, W, Ho, Wo, Cout, g, ps);
-    CDRL_LAUNCH_CHECK();
-    return 0;
-}
-
-int stem_gram(const float* x, int B, int T, int H, int W, float* part, double* gram, hipStream_t st) {
-    const StemXtGeom g = stem_xt_geom(B, T, H, W, 24, 1);
-    CDRL_TRY((stem_xt_launch<1, 1>(x, part, B, T, H, W, 28, g, PoolSrc{}, st)));
-    hipLaunchKernelGGL(stem_part_reduce_kernel, dim3(cdiv(28 * 28, 32), T), dim3(256), 0, st, part, g.nbpg, 28 * 28, gram);
-    CDRL_LAUNCH_CHECK();
-    return 0;
-}
-
-int stem_bwd_raw(const float* x, const PoolSrc& ps, int B, int T, int H, int W, int Cout, float* part, double* A, hipStream_t st) {
-    if (!stem_bwd_raw_supported(Cout)) {
-        set_error("stem_bwd_raw: Cout=%d not supported", Cout);
-        return -1;
-    }
-    if ((int64_t)B * T * ps.Ho * ps.Wo * Cout * 4 >= (1ll << 31)) {
-        set_error("stem_bwd_raw: pooled gradient of 2 GB or more is not supported");
-        return -1;
-    }
-    const StemXtGeom g = stem_xt_geom(B, T, H, W, Cout, 0);
-    const bool n3 = ((Cout >> 2) + 1) / 2 <= 3;
-    if (n3) CDRL_TRY((stem_xt_launch<0, 3>(x, part, B, T, H, W, Cout, g, ps, st)));
-    else CDRL_TRY((stem_xt_launch<0, 4>(x, part, B, T, H, W, Cout, g, ps, st)));
-    hipLaunchKernelGGL(stem_part_reduce_kernel, dim3(cdiv(28 * Cout, 32), T), dim3(256), 0, st, part, g.nbpg, 28 * Cout, A);
-    CDRL_LAUNCH_CHECK();
-    return 0;
-}
-
-int stem_bwd_combine(const double* A, const double* gram, const float* w, const float* bias, const float* stats, const float* coef,
-                     int T, int Cout, float* dw, float* db, hipStream_t st) {
-    hipLaunchKernelGGL(stem_bwd_combine_kernel, dim3(cdiv(28 * Cout, 256)), dim3(256), 0, st, A, gram, w, bias, stats, coef, T, Cout, dw, db);
-    CDRL_LAUNCH_CHECK();
-    return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1518,8 +1128,8 @@ __global__ void __launch_bounds__(256) maxpool_bn_fwd_kernel(const T* __restrict
                 }
             }
             vstore<VEC>(p + (int64_t)r * C + c0, best);
-            // bit 7 of the code: the winning activation is clamped (ReLU6 closed) -- the backward's mask, for kernels that do not
-            // read y (stem_xt_kernel); every decoder masks the bit away
+            // bit 7 of the code: the winning activation is clamped (ReLU6 closed) -- a backward mask for kernels that do not read y
+            // (round 5's coefficient-free stem gradient used it); every decoder masks the bit away
 #pragma unroll
             for (int i = 0; i < VEC; ++i)
                 if (!relu6_open(best.v[i])) bi[i] |= 0x80;

@@ -58,16 +58,16 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     // (a separate budget for the stride-2 blocks, CDRL_DWF_LDS_KB_S2: 38 | 52 | 76 | 110 KB -> 15.76 | 15.74 | 15.82 | 16.07 ms / update-step
     //  at float32 B = 256 and 40.6 | - | 41.9 ms at bf16-storage B = 1024: their backward kernel alone is faster with the larger tile
     //  (105 vs 119 us), the step is not)
-    static const size_t lds_budget_s1 = cdrl_getenv("CDRL_DWF_LDS_KB") ? (size_t)atoi(cdrl_getenv("CDRL_DWF_LDS_KB")) * 1024 : DWF_LDS_BUDGET;
-    static const size_t lds_budget_s2 = cdrl_getenv("CDRL_DWF_LDS_KB_S2") ? (size_t)atoi(cdrl_getenv("CDRL_DWF_LDS_KB_S2")) * 1024 : lds_budget_s1;
+    static const size_t lds_budget_s1 = DWF_LDS_BUDGET;
+    static const size_t lds_budget_s2 = lds_budget_s1;
     size_t lds_budget = stride == 2 ? lds_budget_s2 : lds_budget_s1;
     // wide frames (three-camera 90x360, 135x180): at 38 KB their channel chunks drop below ~24 channels -- a dozen channel lanes
     // per workgroup and 5-6 chunks per frame (40.9 vs 38.3 ms / update-step at 90x360 with 76 KB) -- so the budget grows in steps
     // until a chunk holds at least CDRL_DWF_MINCHUNK channels (or the whole frame)
     // (22: the 11x15x58 units of the 90x120 configuration sit exactly there and were measured best at 38 KB; the stride-2 blocks of that
     //  configuration, 8 channels per chunk, likewise: see above)
-    static const int min_chunk = cdrl_getenv("CDRL_DWF_MINCHUNK") ? atoi(cdrl_getenv("CDRL_DWF_MINCHUNK")) : 22;
-    static const int min_chunk_s2 = cdrl_getenv("CDRL_DWF_MINCHUNK_S2") ? atoi(cdrl_getenv("CDRL_DWF_MINCHUNK_S2")) : 8;   // (22x30x24 at 38 KB: 8)
+    static const int min_chunk = 22;
+    static const int min_chunk_s2 = 8;   // (22x30x24 at 38 KB: 8)
     for (const size_t kb : {52, 76}) {
         const int mc = (int)(lds_budget / per_c) / g.vec * g.vec;
         if (mc >= C || mc >= (stride == 2 ? min_chunk_s2 : min_chunk)) break;
@@ -88,8 +88,8 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     // wide workgroups: the tile loads are a latency chain of (pixels / cy) rounds that every thread sits through before
     // the first barrier, so the pixel lanes are made as many as the frame has output pixels (<= 1024 threads forward)
     const int Po_ = Ho * Wo;
-    static const int t_fwd = cdrl_getenv("CDRL_DWF_TF") ? atoi(cdrl_getenv("CDRL_DWF_TF")) : DWF_T_FWD_DEFAULT;
-    static const int t_bwd = cdrl_getenv("CDRL_DWF_TB") ? atoi(cdrl_getenv("CDRL_DWF_TB")) : DWF_T_BWD_DEFAULT;
+    static const int t_fwd = DWF_T_FWD_DEFAULT;
+    static const int t_bwd = DWF_T_BWD_DEFAULT;
     g.cx = g.cchunk / g.vec;
     g.cy = t_fwd / g.cx;
     if (g.cy > Po_) g.cy = Po_;
@@ -101,7 +101,7 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     // large batches (configuration 3): once every CU has two rounds of 4 workgroups anyway, more frames per workgroup only shrink
     // the partial rows (10 + 2 doubles per channel and workgroup: 38 MB per launch at B = 1024 with one frame each) and the
     // finalize kernels that read them
-    static const int min_blocks = cdrl_getenv("CDRL_DWF_MINBLOCKS") ? atoi(cdrl_getenv("CDRL_DWF_MINBLOCKS")) : 2048;
+    static const int min_blocks = 2048;
     while (fpb < 8 && B % (fpb * 2) == 0 && (int64_t)G * (B / (fpb * 2)) * g.nch >= min_blocks) fpb *= 2;
     g.fpb = fpb;
     g.nb = B / fpb;
@@ -127,7 +127,7 @@ DwfGeom dwf_geom(int B, int G, int H, int W, int C, int stride) {
     g.nb_bwd = g.nb;
     g.strip.ok = false;
     static const bool strips = !(cdrl_getenv("CDRL_DWS") && atoi(cdrl_getenv("CDRL_DWS")) == 0);
-    static const int want_env = cdrl_getenv("CDRL_DWS_WGS") ? atoi(cdrl_getenv("CDRL_DWS_WGS")) : 0;
+    static const int want_env = 0;
     const int want_wgs = want_env ? want_env : (H * W <= 16 ? 512 : 256);
     if (strips && (stride == 1 || stride == 2) && (int64_t)G * B * H * W * C * 8 < (int64_t)1 << 31) {
         // (the channel-chunk count of the plan does not depend on fpb: plan with 1 first)
@@ -1157,8 +1157,8 @@ static DwsGeom dws_geom(int B, int G, int fpb, int H, int W, int C) {
     DwsGeom d;
     d.ok = false;
     if (C % 2 != 0) return d;
-    static const int lds_kb = cdrl_getenv("CDRL_DWS_LDS_KB") ? atoi(cdrl_getenv("CDRL_DWS_LDS_KB")) : 56;
-    static const int max_thr = cdrl_getenv("CDRL_DWS_THREADS") ? atoi(cdrl_getenv("CDRL_DWS_THREADS")) : 384;
+    static const int lds_kb = 56;
+    static const int max_thr = 384;
     const size_t budget = (size_t)lds_kb * 1024;
     // strips of 8 pixels when every thread then has ONE strip per tile batch (the activated strips live in registers across the
     // barrier: 16 VGPRs per strip of 8), strips of 4 with up to 3 per thread otherwise
@@ -1208,8 +1208,8 @@ static DwsGeom dws2_geom(int B, int G, int fpb, int H, int W, int C) {
     DwsGeom d;
     d.ok = false;
     if (C % 2 != 0) return d;
-    static const int lds_kb = cdrl_getenv("CDRL_DWS_LDS_KB") ? atoi(cdrl_getenv("CDRL_DWS_LDS_KB")) : 60;
-    static const int max_thr = cdrl_getenv("CDRL_DWS2_THREADS") ? atoi(cdrl_getenv("CDRL_DWS2_THREADS")) : 384;
+    static const int lds_kb = 60;
+    static const int max_thr = 384;
     const int Ho = same_out(H, 2), Wo = same_out(W, 2);
     const int S = cdiv(W, 8), NS1 = H * S;
     const int Wdp = std::max(4 * S + 2, Wo + 2), Hdp = Ho + 2;

@@ -258,6 +258,7 @@ private:
     int fused_bb_ = 1;
     bool fused_bwd_ = true;             // backward-data + filter gradient of the unit convs as one kernel (gemm_pw_bwd.hip)
     int pw_fwd_nbpg(int G, int Mg, int N, int K) const;    // statistics partial rows per group written by a unit conv's forward
+    bool pw_fwd_x3_wide(int N, int K) const;               // that forward runs on pw_x3_wide_kernel (float32 engine, 128 < K or N <= 256)
     void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
                    View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);
     void add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,
@@ -317,13 +318,6 @@ private:
     Scratch* build_scr_ = &scr_main_;
     std::vector<Op> aux_ops_;
     hipEvent_t ev_aux_fork_ = nullptr, ev_aux_done_ = nullptr;
-    // coefficient-free stem filter gradient (conv.hip stem_gram / stem_bwd_raw / stem_bwd_combine): its passes run on the aux stream
-    hipEvent_t ev_stem_fork_ = nullptr, ev_stem_done_ = nullptr;
-    bool stem_raw_ = false;
-    bool stem_raw_on() const { return stem_raw_ && !graphs_enabled_; }
-    hipStream_t stem_fork(hipStream_t st);
-    float* stem_xt_part_ = nullptr;     // per-workgroup tiles of stem_gram / stem_bwd_raw (same stream, one after the other)
-    double* stem_gram_d_ = nullptr;
     void add_aux_fork(std::vector<Op>& ops);
     void add_aux_join(std::vector<Op>& ops);
     // Backward-pass side stream: the filter / bias gradients of the tower (gemm_tn, depthwise and stem

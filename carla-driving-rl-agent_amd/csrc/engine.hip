@@ -65,8 +65,6 @@ Learner::~Learner() {
         if (ev_sc_done_[i]) (void)hipEventDestroy(ev_sc_done_[i]);
     }
     if (ev_aux_fork_) (void)hipEventDestroy(ev_aux_fork_);
-    if (ev_stem_fork_) (void)hipEventDestroy(ev_stem_fork_);
-    if (ev_stem_done_) (void)hipEventDestroy(ev_stem_done_);
     if (ev_aux_done_) (void)hipEventDestroy(ev_aux_done_);
     if (side_) (void)hipStreamDestroy(side_);
     if (aux_) (void)hipStreamDestroy(aux_);
@@ -209,7 +207,7 @@ void Learner::flush_deferred() {
 }
 
 int Learner::defer_side(hipStream_t st, std::function<int(hipStream_t)> fn) {
-    static const bool on = !(cdrl_getenv("CDRL_DEFER_SIDE") && atoi(cdrl_getenv("CDRL_DEFER_SIDE")) == 0);
+    static const bool on = true;
     if (!side_enabled_ || !on || (g_diag_noev & 2)) {
         hipStream_t side = fork_side(st);
         CDRL_TRY(fn(side));
@@ -217,14 +215,6 @@ int Learner::defer_side(hipStream_t st, std::function<int(hipStream_t)> fn) {
     }
     deferred_.push_back(Deferred{slot_, std::move(fn)});
     return 0;
-}
-
-// aux stream behind an event recorded on `st` (the stem's Gram / gather passes); `st` itself without helper streams
-hipStream_t Learner::stem_fork(hipStream_t st) {
-    if (!side_enabled_) return st;
-    if (hipEventRecord(ev_stem_fork_, st) != hipSuccess) return st;
-    if (hipStreamWaitEvent(aux_, ev_stem_fork_, 0) != hipSuccess) return st;
-    return aux_;
 }
 
 int Learner::next_q(hipStream_t st) {
@@ -445,13 +435,22 @@ float* Learner::pw_packed(const float* w, int K, int N, int sbk, int sbn, bool b
 }
 
 const void* Learner::pw_x3_packed(const float* w, int K, int N, int sbk, int sbn) {
-    void* wp = alloc((size_t)pw_x3_packed_bytes(K) / sizeof(float));
+    void* wp = alloc((size_t)pw_x3_packed_bytes_n(K, N) / sizeof(float));
     h_pack3_.push_back(pw_x3_pack_entry(w, wp, K, N, sbk, sbn));
     return wp;
 }
 
 int Learner::pw_fwd_nbpg(int G, int Mg, int N, int K) const {
+    // float32 engine, K or N above 128 (stage 2): the forward runs on the one-tile-per-workgroup split-precision kernel
+    // (gemm_pw_x3.hip pw_x3_wide_kernel), which writes one statistics row per 32-row tile
+    if (pw_fwd_x3_wide(N, K)) return pw_x3_partial_rows(G, Mg, N, K);
     return pw_nn_plan(G, Mg, N, K).nbpg;
+}
+
+bool Learner::pw_fwd_x3_wide(int N, int K) const {
+    static const bool x3_env = !(cdrl_getenv("CDRL_PW_X3") && atoi(cdrl_getenv("CDRL_PW_X3")) == 0);
+    static const bool wide_env = !(cdrl_getenv("CDRL_PW_X3_WIDE") && atoi(cdrl_getenv("CDRL_PW_X3_WIDE")) == 0);
+    return cfg_.compute == 0 && x3_env && wide_env && (K > 128 || N > 128) && K <= 256 && N <= 256 && K % 4 == 0;
 }
 
 const void* Learner::gemm_x3_packed(const float* w, int K, int N, int sbk, int sbn) {
@@ -519,7 +518,7 @@ Learner::BnRec Learner::add_bn(std::vector<Op>& ops, int model, const std::strin
     if (inf_batched) note_bn_inference(gamma.p, beta.p, mm.p, mv.p, stats, G, C);
     // single-group BatchNorm over a few hundred rows (dense BNs of the trunk tail and the control branches): one launch per
     // direction instead of three
-    static const bool small_env = !(cdrl_getenv("CDRL_BN_SMALL") && atoi(cdrl_getenv("CDRL_BN_SMALL")) == 0);
+    static const bool small_env = true;
     const bool small = small_env && G == 1 && Mg <= 2048 && !bessel && act == ACT_NONE && !out_shuffle && !dout_shuffle && dx &&
                        !stats_nb && !defer_apply && !pass.fsrc.p && !pass.gsrc.p && !pass.gap_out;
     const bool gap = pass.gap_out != nullptr;
@@ -570,8 +569,8 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     PRef w = param(M_TRUNK, prefix + ".w", {1, 1, Cin, Cout}, true);
     PRef b = param(M_TRUNK, prefix + ".b", {Cout}, true);
     const int G = cfg_.T, Mg = rows / G;
-    static const bool pack_env = !(cdrl_getenv("CDRL_PW_PACK") && atoi(cdrl_getenv("CDRL_PW_PACK")) == 0);
-    static const bool wt_env = !(cdrl_getenv("CDRL_PW_WT") && atoi(cdrl_getenv("CDRL_PW_WT")) == 0);
+    static const bool pack_env = true;
+    static const bool wt_env = true;
     const float* wt = (wt_env && !pack_env && fuse.bwd_pw) ? pw_transposed(prefix, w.p, Cin, Cout) : nullptr;
     const float* wb = wt ? wt : w.p;                    // backward-data operand B(k = cout, n = cin)
     const int wb_sk = wt ? Cin : 1, wb_sn = wt ? 1 : Cout;
@@ -582,7 +581,10 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     const int at = at_;
     // forward on the bf16 matrix pipe (exact three-way operand split, gemm_pw_x3.hip) where the shape allows it
     static const bool x3_env = !(cdrl_getenv("CDRL_PW_X3") && atoi(cdrl_getenv("CDRL_PW_X3")) == 0);
-    const void* w3f = (!bfc && x3_env && fuse.fwd_pw && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
+    const bool x3_shape = (Cin <= 128 && Cout <= 128) || pw_fwd_x3_wide(Cout, Cin);
+    const void* w3f = (!bfc && x3_env && fuse.fwd_pw && x3_shape && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
+    if (fuse.fwd_pw && pw_fwd_x3_wide(Cout, Cin) && !w3f && !dry_)
+        build_fail("%s: the wide split-precision forward needs 16-byte aligned input rows (ld %d, offset %d)", prefix.c_str(), in.ld, in.coff);
     const int nb_fwd = pw_fwd_nbpg(G, Mg, Cout, Cin);
     // plain (unfused) wide convs -- the 464 -> 768 head conv, the 232-wide shortcut conv -- on the bf16 matrix pipe too (gemm_x3.hip)
     const bool wide = Cin >= 128 || Cout > 128;
@@ -622,7 +624,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     // the two-kernel form, which is why rounds 4 kept it there; but that form's filter gradient (163 us on the side stream) then bounds the
     // tail of the pass and slows the BatchNorm reduction beside it (117 us instead of 29): fused 14.00 vs 14.06 ms per update-step, and one
     // pass over (dz, y) = 0.3 GB per pass less.  CDRL_FBWD_MIN_CIN=32 -> the two-kernel form for that conv.
-    static const int fbwd_min_cin = cdrl_getenv("CDRL_FBWD_MIN_CIN") ? atoi(cdrl_getenv("CDRL_FBWD_MIN_CIN")) : 24;
+    static const int fbwd_min_cin = 24;
     const bool fbwd = fused_bwd_ && fuse.bb && fuse.bwd_pw && (!bfc || at) && G <= 8 && Cin >= fbwd_min_cin && pw_bwd_fused_supported(dz_probe, in, din, Cout, Cin, at) &&
                       (!anorm || (fuse.bwd_ey == in.p && fuse.bwd_epi_stats == fuse.pro_stats && fuse.a_bn && in.ld == Cin && in.coff == 0)) &&
                       (anorm || !fuse.bwd_ey);
@@ -729,7 +731,7 @@ void Learner::add_dw(std::vector<Op>& ops, const std::string& prefix, View in, i
     PRef b = param(M_TRUNK, prefix + ".b", {C}, true);
     const int Ho = same_out_h(H, stride), Wo = same_out_h(W, stride);
     note_scratch(0, 0, (size_t)N * Ho * Wo * C, 0, (size_t)dw_bwd_part_elems(N, H, W, C, stride));
-    static const bool fuse_env = !(cdrl_getenv("CDRL_FUSE_BNRED") && atoi(cdrl_getenv("CDRL_FUSE_BNRED")) == 0);
+    static const bool fuse_env = true;
     const bool fuse = fuse_env && pre_bn && pre_bn->y && din_acc == 0 && pre_bn->C == C && pre_bn->Mg * pre_bn->G == N * H * W;
     BnRec pre;
     if (fuse) {
@@ -1099,25 +1101,6 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         const bool stem_fstats = stem_fwd_stats_supported(Cs) && !(cdrl_getenv("CDRL_FUSED_STEM") && atoi(cdrl_getenv("CDRL_FUSED_STEM")) == 0);
         const int nb_stem = stem_fstats ? stem_fwd_stats_nb(B, T, H, W, Cs) : 0;
         if (at && !stem_fstats) build_fail("bf16 activation storage needs the fused stem forward (stem channels %d, CDRL_FUSED_STEM)", Cs);
-        // Coefficient-free stem filter gradient (conv.hip, round 5; float32 engine; OPT-IN, CDRL_STEM_RAW=1): Gram of the image patches
-        // when the backward starts and the gather pass over the pooled gradient beside the BatchNorm reduction, both on the aux stream; a
-        // 28 x Cs combine on the critical stream once the coefficients exist.  Takes the stem filter gradient (0.36 ms per update-step of
-        // exposed tail) off the end of the pass and is MORE accurate than the fused form (no rounded y in it), but the two passes are
-        // 170 + 91 us of matrix-pipe-bound float32 MFMA work against 174 us, and beside the other kernels of the tail the gather pass
-        // stretches to 317 us and the Gram slows the GRU steps it runs next to: 14.4 vs 14.1 ms per update-step.
-        stem_raw_ = !at && stem_bwd_fused_supported(Cs) && stem_bwd_raw_supported(Cs) && stem_fstats && stem_xt_fits(B, T, H, W, Cs) &&
-                    !(cdrl_getenv("CDRL_FUSED_STEM") && atoi(cdrl_getenv("CDRL_FUSED_STEM")) == 0) &&
-                    (cdrl_getenv("CDRL_STEM_RAW") && atoi(cdrl_getenv("CDRL_STEM_RAW")) == 1) &&
-                    !(cdrl_getenv("CDRL_STEM_DIRECT") && atoi(cdrl_getenv("CDRL_STEM_DIRECT")) == 1);
-        float* xt_part = nullptr;
-        double *stem_gram_d = nullptr, *stem_a_d = nullptr;
-        if (stem_raw_) {
-            xt_part = alloc((size_t)std::max(stem_xt_part_floats(B, T, H, W, 28), stem_xt_part_floats(B, T, H, W, Cs)));
-            stem_gram_d = alloc_d((size_t)T * 28 * 28);
-            stem_a_d = alloc_d((size_t)T * 28 * Cs);
-        }
-        stem_xt_part_ = xt_part;
-        stem_gram_d_ = stem_gram_d;
         op.fwd = [=](hipStream_t st, int training) -> int {
             // (bf16 storage: the statistics form is the one with a bf16 store; its partials are simply unused in inference)
             if (stem_fstats && (training || at)) return stem_fwd_stats(in_image_, w.p, b.p, y.p, scr_main_.part, B, T, H, W, Cs, st, at);
@@ -1136,23 +1119,12 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         note_named("img.stem.pool.argmax", argmax, (size_t)N * Hp0 * Wp0 * Cs);
         note_named("img.stem.pool.out", pool.p, (size_t)N * Hp0 * Wp0 * Cs * esz());
         note_named("img.stem.pool.out.g", pool.g, (size_t)N * Hp0 * Wp0 * Cs * esz());
-        // one-pass form (stem_bwd.hip): BN sums and filter sums together, everything in the BN op's backward.  Opt-in
-        // (CDRL_STEM_DIRECT=1): measured 747 us (three accumulator tiles, 64 KB LDS -> two workgroups per CU) against
-        // 206 + 453 us for the two-pass form whose second pass overlaps on the side stream: 22.3 vs 22.0 ms/update-step.
-        const bool stem_direct = !at && stem_fused && stem_bwd_direct_supported(Cs) &&
-                                 (cdrl_getenv("CDRL_STEM_DIRECT") && atoi(cdrl_getenv("CDRL_STEM_DIRECT")) == 1);
-        float* stem_ws = stem_direct ? alloc((size_t)stem_bwd_direct_ws_floats(B, T, H, W)) : nullptr;
         op.bwd = [=](hipStream_t st) -> int {
-            if (stem_direct) return 0;
-            if (stem_raw_on()) {        // A (aux stream, forked by the BatchNorm op's backward) + Gram + coefficients -> dW, db
-                if (side_enabled_) CDRL_HIP(hipStreamWaitEvent(st, ev_stem_done_, 0));
-                return stem_bwd_combine(stem_a_d, stem_gram_d, w.p, b.p, stem_stats, stem_coef, T, Cs, w.g, b.g, st);
-            }
             if (stem_fused) {
                 CDRL_TRY(next_slot(st));
                 // the last kernel of the backward: nothing is left on the critical stream to run beside it, so the hand-over to the side
                 // stream and back only costs its two event bubbles (CDRL_STEM_BWD_MAIN=0 -> side stream as in rounds 1-4)
-                static const bool on_main = !(cdrl_getenv("CDRL_STEM_BWD_MAIN") && atoi(cdrl_getenv("CDRL_STEM_BWD_MAIN")) == 0);
+                static const bool on_main = true;
                 hipStream_t side = on_main ? st : fork_side(st);
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
                 static const bool diag_skip = cdrl_getenv("CDRL_DIAG_SKIP_STEMF") && atoi(cdrl_getenv("CDRL_DIAG_SKIP_STEMF")) == 1;    // timing diagnostics only (no stem filter gradient)
@@ -1193,13 +1165,6 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             bn.bwd = [=](hipStream_t st) -> int {
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
                 View none{nullptr, 0, 0};
-                if (stem_direct)
-                    return stem_bwd_direct(in_image_, ps, y.p, stats, gamma.g, beta.g, coef, w.g, b.g, B, T, H, W, C, stem_ws, st);
-                if (stem_raw_on()) {    // the pooled gradient is final: gather pass of the stem filter gradient beside the reduction
-                    hipStream_t ax = stem_fork(st);
-                    CDRL_TRY(stem_bwd_raw(in_image_, ps, B, T, c.H, c.W, C, xt_part, stem_a_d, ax));
-                    if (ax != st) CDRL_HIP(hipEventRecord(ev_stem_done_, ax));
-                }
                 if (stem_fused) {       // sums in scatter form over the pooled gradient; the apply happens inside the stem filter-gradient GEMM
                     ps.pa = pool.p;                 // mask and xhat from the pooled activated output, no gather (bf16 storage: xhat from the ROUNDED pooled value)
                     CDRL_TRY(pool_bn_bwd_reduce(ps, y.p, G, B, C, stats, scr_main_.part, st, at));
@@ -1233,7 +1198,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 note_named(pre + ".out.g", out.g, (size_t)rows_out * C * esz());
                 // stride-2 units: the shortcut branch (dw3x3/s2 -> BN -> 1x1 -> BN+ReLU6) only depends on the unit input; in the
                 // FORWARD pass (where the side stream is idle) it runs on the side stream next to the main branch
-                static const bool sc_overlap_env = !(cdrl_getenv("CDRL_SC_OVERLAP") && atoi(cdrl_getenv("CDRL_SC_OVERLAP")) == 0);
+                static const bool sc_overlap_env = true;
                 const bool sc_overlap = sc_overlap_env && stride == 2;
                 const int sc_ev = s;
                 if (sc_overlap) {
@@ -1417,7 +1382,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         Tens yh = tens_a(rows, c.last, false);
         add_pw(ops, "img.head.conv", X.v(), rows, curC, c.last, yh.p, X.gv(), 0, bnrec(T, B * P, c.last));
         feat_ = tens(N, c.last);
-        static const bool gap_fused = !(cdrl_getenv("CDRL_FUSED_GAP") && atoi(cdrl_getenv("CDRL_FUSED_GAP")) == 0);
+        static const bool gap_fused = true;
         if (gap_fused) {
             // BatchNorm + ReLU6 + GlobalAveragePooling2D as one op: the 12288 x 768 activated tensor and its gradient are never
             // written -- the forward pools on the fly, the backward reads the pooled gradient broadcast over the frame's pixels
@@ -1502,19 +1467,6 @@ void Learner::build_trunk(std::vector<Op>& ops) {
         add_gru(aux_ops_, std::string("gru_") + fnames[i], fout[i], c.feat, c.rnn_small, cat.v(c.rnn_image + i * c.rnn_small),
                 cat.gv(c.rnn_image + i * c.rnn_small), true);
     build_scr_ = &scr_main_;
-    if (stem_raw_) {
-        // Gram of the image patches (the coefficient-free stem filter gradient needs it in the LAST kernel of the backward): enqueued
-        // behind the small-modality backward on the aux stream when the backward starts -- the head / GRU region of the critical stream
-        // is a chain of small kernels, the chip is idle next to it (in the forward pass the same launch cost the stem forward 24 us)
-        Op gop;
-        gop.fwd = [](hipStream_t, int) -> int { return 0; };
-        gop.bwd = [=](hipStream_t st) -> int {
-            if (!stem_raw_on()) return 0;
-            hipStream_t ax = stem_fork(st);
-            return stem_gram(in_image_, c.B, c.T, c.H, c.W, stem_xt_part_, stem_gram_d_, ax);
-        };
-        ops.push_back(gop);
-    }
     add_aux_join(ops);
     Tens ncat = tens(B, catC);
     add_bn(ops, M_TRUNK, "dyn.bn", cat.v(), 1, B, catC, false, ACT_NONE, ncat.v(), 0, ncat.gv(), 0, cat.g);
@@ -1534,7 +1486,7 @@ void Learner::build_head(std::vector<Op>& ops, int model, const std::string& pre
     int L = 0;
     for (int i = 0; i < nheads; ++i) L += head_dims[i];
     lin = tens(B, L);
-    static const bool fused_heads = !(cdrl_getenv("CDRL_FUSED_HEADS") && atoi(cdrl_getenv("CDRL_FUSED_HEADS")) == 0);
+    static const bool fused_heads = true;
     if (fused_heads && nheads <= HEADS_MAX && L <= HEADS_MAX_OUT) {
         // all linear heads of the branch in one launch per direction (heads.hip); same parameter names / order as add_dense
         HeadSet hs{};
@@ -1755,14 +1707,12 @@ int Learner::bind(const Buffers& b) {
         const char* genv = cdrl_getenv("CDRL_GRAPH");
         graphs_enabled_ = genv && atoi(genv) != 0;
         // All three streams at the default priority.  Giving the main stream (the dependent chain) the highest and the side /
-        // aux streams the lowest priority (CDRL_STREAM_PRIO=1) changes nothing for the update-step (15.98 vs 16.01 ms) but costs
+        // aux streams the lowest priority (measured in round 2) changes nothing for the update-step (15.98 vs 16.01 ms) but costs
         // rollout inference 4.4 ms per call: whenever the high-priority queue sits on a barrier that waits for a kernel of a
         // low-priority queue (the small-modality nets on the aux stream: at 1..128 environments the main stream reaches the join
         // first), the command processor comes back to the low-priority queue only after milliseconds -- predict() 5.5 ms instead
         // of 1.1 ms at E = 1 (tools/bench_rollout_rows.py).
-        int prio_lo = 0, prio_hi = 0;
-        const char* penv = cdrl_getenv("CDRL_STREAM_PRIO");
-        if (penv && atoi(penv) == 1) CDRL_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        const int prio_lo = 0, prio_hi = 0;
         CDRL_HIP(hipStreamCreateWithPriority(&main_, hipStreamNonBlocking, prio_hi));
         CDRL_HIP(hipEventCreateWithFlags(&ev_in_, hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_out_, hipEventDisableTiming));
@@ -1782,8 +1732,6 @@ int Learner::bind(const Buffers& b) {
         CDRL_HIP(hipStreamCreateWithPriority(&aux_, hipStreamNonBlocking, prio_lo));
         CDRL_HIP(hipEventCreateWithFlags(&ev_aux_fork_, hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_aux_done_, hipEventDisableTiming));
-        CDRL_HIP(hipEventCreateWithFlags(&ev_stem_fork_, hipEventDisableTiming));
-        CDRL_HIP(hipEventCreateWithFlags(&ev_stem_done_, hipEventDisableTiming));
         const char* tenv = cdrl_getenv("CDRL_AUX_THREAD");
         // opt-in (CDRL_AUX_THREAD=1): measured 20.76 vs 20.83 ms/update-step at B=256 -- the host is 8 ms per step ahead of
         // the GPU in steady state, so the second enqueue thread only pays off for small images (host-bound below ~45x60)

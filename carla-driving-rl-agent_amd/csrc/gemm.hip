@@ -542,8 +542,7 @@ int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C
         }
     }
     if (g_nn_bm64_threshold < 0) {
-        const char* e = cdrl_getenv("CDRL_NN_BM64_BLOCKS");      // tuning knob: use 64-row tiles below this many 128-row blocks
-        g_nn_bm64_threshold = e ? atoi(e) : (1 << 30);   // measured: 64-row tiles win at every learner shape
+        g_nn_bm64_threshold = 1 << 30;   // use 64-row tiles below this many 128-row blocks; measured: 64-row tiles win at every learner shape
     }
     int nt = cdiv(N, 32);
     if (nt > 4) nt = 4;
@@ -554,8 +553,8 @@ int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C
     const bool bt = sbn != 1;
     const bool vec = (K % 2 == 0) && (A.ld % 2 == 0) && (A.coff % 2 == 0) && ((reinterpret_cast<uintptr_t>(A.p) & 7) == 0);
     {   // row-stacked tiles for the wide late layers
-        static const int rt = cdrl_getenv("CDRL_NN_RT") ? atoi(cdrl_getenv("CDRL_NN_RT")) : 3;
-        static const int rt_minn = cdrl_getenv("CDRL_NN_RT_MINN") ? atoi(cdrl_getenv("CDRL_NN_RT_MINN")) : 129;
+        static const int rt = 3;
+        static const int rt_minn = 129;
         const bool a16 = (K % 4 == 0) && (A.ld % 4 == 0) && (A.coff % 4 == 0) && ((reinterpret_cast<uintptr_t>(A.p) & 15) == 0);
         const bool b16 = ((reinterpret_cast<uintptr_t>(Bp) & 15) == 0) &&
                          (bt ? (sbk == 1 && sbn % 4 == 0) : (sbn == 1 && sbk % 4 == 0 && N % 4 == 0));
@@ -572,8 +571,7 @@ int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C
         // measured at B=256 (768 tiles of 64 rows over 512 resident workgroups): 40.8 us vs 26.7 us for the
         // non-persistent 64-row kernel at M=49152, K=N=116 -- too few tiles per workgroup to amortise the
         // weight panel, and 1.5 tiles/workgroup is badly balanced.  Off by default; worth re-testing at B>=1024.
-        const char* e = cdrl_getenv("CDRL_NN_PERSIST");
-        persist = e ? atoi(e) : 0;
+        persist = 0;
     }
     if (persist && gy == 1 && K <= 128 && (nt == 2 || nt == 4) && M >= 4096) {
         if (nt == 2) CDRL_TRY(launch_nn_persist<2>(bt, vec, st, A, Bp, sbk, sbn, bias, C, M, N, K, accumulate));
@@ -729,7 +727,7 @@ __global__ void __launch_bounds__(256) tn_reduce_few_kernel(const float* __restr
 
 int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride, float* out, int accumulate,
                         hipStream_t st) {
-    static const bool v4 = !(cdrl_getenv("CDRL_TNRED_V4") && atoi(cdrl_getenv("CDRL_TNRED_V4")) == 0);
+    static const bool v4 = true;
     if (v4 && n % 4 == 0 && stride % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0 && nparts < 16 && n >= 4096) {
         hipLaunchKernelGGL(tn_reduce_few_kernel, dim3((unsigned)cdiv64(n, 1024)), dim3(256), 0, st, part, nparts, n, stride, out, accumulate);
         CDRL_LAUNCH_CHECK();

@@ -196,7 +196,7 @@ static inline int pw_bf16_nt(int N) { return N <= 32 ? 1 : (N <= 64 ? 2 : 4); }
 bool pw_bf16_supported(int lda, int a_coff, int N, int K) { return K >= 4 && K <= 128 && N >= 1 && N <= 128 && lda % 4 == 0 && a_coff % 4 == 0 && K % 4 == 0; }
 
 static int pw_bf16_occ() {
-    static const int v = cdrl_getenv("CDRL_PWB_OCC") ? atoi(cdrl_getenv("CDRL_PWB_OCC")) : 2;
+    static const int v = 2;
     return v < 1 ? 1 : (v > 8 ? 8 : v);
 }
 

@@ -181,15 +181,133 @@ __global__ void __launch_bounds__(256, 2) pw_x3_kernel(PwX3Args a) {
     }
 }
 
-static inline int x3_kp(int K) { return K <= 32 ? 32 : (K <= 64 ? 64 : 128); }
+
+// K, N up to 256 (the 232-channel convs of stage 2; M = 12288 rows at B = 256): the product is tiny and the persistent form -- one
+// workgroup per CU that walks three tiles with all of W in its registers (gemm_pw.hip <128, 4>: 116 float32-MFMA steps of 64 cycles per
+// tile and column tile, one wave per SIMD, 26-36 us per launch for 23 MB) -- is a serial chain of load / MFMA / store phases.  Here a
+// workgroup takes ONE 32-row tile and one block of 128 columns: W^(column block) as three bf16 planes in registers (16 K steps x 3 planes
+// x 4 VGPRs = 192), the A tile split into three planes in LDS (50 KB), 96 bf16 MFMAs of 32 cycles per wave, two workgroups per CU so
+// that one loads / stores while the other multiplies.  Grid = (groups x tiles, column blocks); statistics: one partial row per tile.
+template <bool PRO, bool EPI>
+__global__ void __launch_bounds__(256, 2) pw_x3_wide_kernel(PwX3Args a) {
+    constexpr int KP = 256, BM = 32, KS = KP / 16, LDA = KP + 8, CPR = KP / 4, NCH = BM * CPR / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * LDA];
+    __shared__ float pc[2][KP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int g = blockIdx.x / a.nbpg, t = blockIdx.x % a.nbpg;        // nbpg = tiles per group
+    const int K = a.K, N = a.N;
+    const int64_t mbeg = (int64_t)g * a.Mg, mend = mbeg + a.Mg;
+    const int64_t m0 = mbeg + (int64_t)t * BM;
+    const int nl = wave * 32 + lrow, n = blockIdx.y * 128 + nl;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const uint32_t OOR = 0x80000000u;
+    const int64_t Mtot = (int64_t)a.G * a.Mg;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a.A.p, 0, (int)(Mtot * a.A.ld * 4), 0x00020000);
+    // the A tile first (HBM / Infinity Cache), the weight fragments (L2) behind it: both in flight before anything is consumed
+    u32x4_t ra[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + 256 * i, r = c / CPR, k4 = 4 * (c % CPR);
+        const bool ok = (m0 + r < mend) && (k4 < K);
+        const uint32_t off = (uint32_t)(((m0 + r) * a.A.ld + a.A.coff + k4) * 4);
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : OOR, 0, 0);
+    }
+    if (PRO) {
+        const int GK = a.G * K;
+        for (int k = tid; k < KP; k += 256) {
+            pc[0][k] = k < K ? a.pro_stats[2 * GK + g * K + k] : 0.0f;
+            pc[1][k] = k < K ? a.pro_stats[3 * GK + g * K + k] : 0.0f;
+        }
+    }
+    const __bf16* wp = a.Wp + (int64_t)blockIdx.y * 3 * KS * 2 * 128 * 8;
+    bf16x8 breg[3][KS];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            breg[p][s] = *reinterpret_cast<const bf16x8*>(wp + (((int64_t)(p * KS + s) * 2 + lk) * 128 + nl) * 8);
+    const float bv = (a.bias && n < N) ? a.bias[n] : 0.0f;
+    if (PRO) __syncthreads();
+    {
+        auto widen = [](uint32_t w) -> f32x2 { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; };
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, r = c / CPR, k4 = 4 * (c % CPR);
+            uint32_t hw[3][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x2 x = f32x2{__uint_as_float(ra[i][2 * h]), __uint_as_float(ra[i][2 * h + 1])};
+                if (k4 + 2 * h >= K) x[0] = 0.0f;          // (columns beyond K inside the last chunk: see pw_x3_kernel)
+                if (k4 + 2 * h + 1 >= K) x[1] = 0.0f;
+                if (PRO) {
+                    const f32x2 sc = f32x2{pc[0][k4 + 2 * h], pc[0][k4 + 2 * h + 1]}, sh = f32x2{pc[1][k4 + 2 * h], pc[1][k4 + 2 * h + 1]};
+                    x = __builtin_elementwise_fma(sc, x, sh);
+                }
+                hw[0][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+                const f32x2 r1 = x - widen(hw[0][h]);
+                hw[1][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+                hw[2][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1 - widen(hw[1][h]), bf16x2));
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2_t*>(&As[p][r * LDA + k4]) = u32x2_t{hw[p][0], hw[p][1]};
+        }
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int ao = lrow * LDA + 8 * lk;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[0][ao + 16 * s]);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&As[1][ao + 16 * s]);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&As[2][ao + 16 * s]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, breg[0][s], acc, 0, 0, 0);       // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[2][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[1][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[0][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[1][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[0][s], acc, 0, 0, 0);
+    }
+    if (n >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m < mend) {
+            const float v = acc[r] + bv;
+            if (EPI) {
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
+            }
+            a.C.p[m * a.C.ld + a.C.coff + n] = v;
+        }
+    }
+    if (EPI && a.part) {
+        const double f1 = s1 + __shfl_down(s1, 32), f2 = s2 + __shfl_down(s2, 32);
+        if (lk == 0) {
+            double* p = a.part + ((int64_t)g * a.nbpg + t) * 2 * N;
+            p[n] = f1;
+            p[N + n] = f2;
+        }
+    }
+}
+
+static inline int x3_kp(int K) { return K <= 32 ? 32 : (K <= 64 ? 64 : (K <= 128 ? 128 : 256)); }
+static inline bool x3_wide(int N, int K) { return K > 128 || N > 128; }
 static inline int x3_nt(int N) { return N <= 32 ? 1 : (N <= 64 ? 2 : 4); }
 
 // B(k, n) = w[k * sbk + n * sbn] -> three bf16 planes of MFMA B fragments [3][KP/16][2][128][8]
 __global__ void pw_x3_pack_many_kernel(const PwX3Pack* __restrict__ tab) {
     const PwX3Pack d = tab[blockIdx.y];
-    const int ks = d.kp / 16, total = ks * 2 * 128;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int n = i % 128, lk = (i / 128) % 2, s = i / 256;
+    const int ks = d.kp / 16, total = ks * 2 * 128, nblk = (d.N + 127) / 128;       // column blocks of 128: [block][3][KP/16][2][128][8]
+    for (int ii = blockIdx.x * 256 + threadIdx.x; ii < total * nblk; ii += gridDim.x * 256) {
+        const int blk = ii / total, i = ii % total;
+        const int nl = i % 128, n = blk * 128 + nl, lk = (i / 128) % 2, s = i / 256;
         bf16x8 v[3];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -202,11 +320,13 @@ __global__ void pw_x3_pack_many_kernel(const PwX3Pack* __restrict__ tab) {
             v[2][e] = h3;
         }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(d.wp + ((int64_t)p * total + i) * 8) = v[p];
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(d.wp + (((int64_t)blk * 3 + p) * total + i) * 8) = v[p];
     }
 }
 
-int64_t pw_x3_packed_bytes(int K) { return (int64_t)3 * (x3_kp(K) / 16) * 2 * 128 * 8 * 2; }
+int64_t pw_x3_packed_bytes(int K) { return (int64_t)3 * (x3_kp(K) / 16) * 2 * 128 * 8 * 2; }      // one column block (N <= 128)
+// (the wide form always runs with KP = 256: its kernel is instantiated for that padding only)
+int64_t pw_x3_packed_bytes_n(int K, int N) { return x3_wide(N, K) ? pw_x3_packed_bytes(256) * ((N + 127) / 128) : pw_x3_packed_bytes(K); }
 
 PwX3Pack pw_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, int sbn) {
     PwX3Pack e;
@@ -216,7 +336,7 @@ PwX3Pack pw_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, int s
     e.N = N;
     e.sbk = sbk;
     e.sbn = sbn;
-    e.kp = x3_kp(K);
+    e.kp = x3_wide(N, K) ? 256 : x3_kp(K);
     return e;
 }
 
@@ -228,16 +348,17 @@ int pw_x3_pack_many(const PwX3Pack* tab_dev, int n, hipStream_t st) {
 }
 
 bool pw_x3_supported(View A, int N, int K) {
-    return K >= 4 && K <= 128 && N >= 1 && N <= 128 && K % 4 == 0 && A.ld % 4 == 0 && A.coff % 4 == 0 &&
+    return K >= 4 && K <= 256 && N >= 1 && N <= 256 && K % 4 == 0 && A.ld % 4 == 0 && A.coff % 4 == 0 &&
            (reinterpret_cast<uintptr_t>(A.p) & 15) == 0;
 }
 
 static int x3_occ() {
-    static const int v = cdrl_getenv("CDRL_X3_OCC") ? atoi(cdrl_getenv("CDRL_X3_OCC")) : 2;
+    static const int v = 2;
     return v < 1 ? 1 : (v > 8 ? 8 : v);
 }
 
 int pw_x3_partial_rows(int G, int Mg, int N, int K) {
+    if (x3_wide(N, K)) return cdiv(Mg, 32);         // one partial row per 32-row tile
     const int bm = 32 * (4 / x3_nt(N)), tiles = cdiv(Mg, bm);
     int nb = 256 * x3_occ() / G;
     if (nb < 1) nb = 1;
@@ -266,6 +387,19 @@ int pw_x3(View A, const float* pro_stats, const void* Wp, const float* bias, Vie
     PwX3Args a{A, pro_stats, reinterpret_cast<const __bf16*>(Wp), bias, C, part, N, K, G, Mg, nbpg > 0 ? nbpg : pw_x3_partial_rows(G, Mg, N, K)};
     const int kp = x3_kp(K), nt = x3_nt(N);
     const bool pro = pro_stats != nullptr, epi = part != nullptr;
+    if (x3_wide(N, K)) {
+        if (a.nbpg != cdiv(Mg, 32)) {
+            set_error("pw_x3: the wide form writes one partial row per 32-row tile (%d), not %d", cdiv(Mg, 32), a.nbpg);
+            return -1;
+        }
+        const dim3 grid(G * a.nbpg, cdiv(N, 128)), block(256);
+        if (pro && epi) hipLaunchKernelGGL((pw_x3_wide_kernel<true, true>), grid, block, 0, st, a);
+        else if (pro) hipLaunchKernelGGL((pw_x3_wide_kernel<true, false>), grid, block, 0, st, a);
+        else if (epi) hipLaunchKernelGGL((pw_x3_wide_kernel<false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_x3_wide_kernel<false, false>), grid, block, 0, st, a);
+        CDRL_LAUNCH_CHECK();
+        return 0;
+    }
 #define CDRL_X3(KPV, NTV) pw_x3_launch<KPV, NTV>(a, pro, epi, st)
     if (kp == 32) { if (nt == 1) CDRL_X3(32, 1); else if (nt == 2) CDRL_X3(32, 2); else CDRL_X3(32, 4); }
     else if (kp == 64) { if (nt == 1) CDRL_X3(64, 1); else if (nt == 2) CDRL_X3(64, 2); else CDRL_X3(64, 4); }

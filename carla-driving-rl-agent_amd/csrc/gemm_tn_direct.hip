@@ -441,7 +441,7 @@ static TndPlan tnd_plan(int M, int N, int K, int G, bool dpro = false) {
     p.gy = cdiv(K, 128);
     p.gz = cdiv(N, 128);
     int KT = K >= 128 ? 4 : cdiv(K, 32), NT = N >= 128 ? 4 : cdiv(N, 32);   // tiles of the (first) 128-block
-    static const bool tr_on = !(cdrl_getenv("CDRL_TN_TR") && atoi(cdrl_getenv("CDRL_TN_TR")) == 0);
+    static const bool tr_on = true;
     p.TR = (dpro && tr_on) ? 1 : 0;
     if (p.TR) {                                  // same mapping with the roles of k and n exchanged
         const int t = KT;
@@ -456,12 +456,12 @@ static TndPlan tnd_plan(int M, int N, int K, int G, bool dpro = false) {
     p.RS = left / p.NSPL;
     const int Mg = M / G;
     // enough workgroups to fill the chip a few times over, but >= 128 rows each so that the partial buffer stays small
-    static const int tn_target = cdrl_getenv("CDRL_TN_TARGET") ? atoi(cdrl_getenv("CDRL_TN_TARGET")) : 1024;     // 2048 doubles the split-M partial traffic (8.8 GB/update-step) for no measurable gain
+    static const int tn_target = 1024;     // 2048 doubles the split-M partial traffic (8.8 GB/update-step) for no measurable gain
     int target = tn_target / (p.gy * p.gz * G * p.RS);
     if (target < 1) target = 1;
-    static const int tn_minrows = cdrl_getenv("CDRL_TN_MINROWS") ? atoi(cdrl_getenv("CDRL_TN_MINROWS")) : 128;
+    static const int tn_minrows = 128;
     // in-workgroup row halves (8 waves): the same rows per wave, twice the rows per partial
-    static const int tn_rs2 = cdrl_getenv("CDRL_TN_RS2") ? atoi(cdrl_getenv("CDRL_TN_RS2")) : 2;
+    static const int tn_rs2 = 2;
     p.RS2 = (tn_rs2 == 2 && Mg >= 2 * tn_minrows) ? 2 : 1;
     int ns = Mg / (tn_minrows * p.RS2);
     if (ns > target) ns = target;
@@ -506,8 +506,8 @@ static void launch_tnd(bool apro, bool dpro, dim3 grid, hipStream_t st, const Tn
         launch_tnd_u<NJW, 8, 1>(apro, dpro, grid, st, a);
         return;
     }
-    static const int u = cdrl_getenv("CDRL_TN_U") ? atoi(cdrl_getenv("CDRL_TN_U")) : 4;
-    static const int ud = cdrl_getenv("CDRL_TN_UD") ? atoi(cdrl_getenv("CDRL_TN_UD")) : 8;      // D prologue (transposed mapping: 200 VGPRs at U = 8; 19.6 -> 19.2 ms/update-step over U = 4)
+    static const int u = 4;
+    static const int ud = 8;      // D prologue (transposed mapping: 200 VGPRs at U = 8; 19.6 -> 19.2 ms/update-step over U = 4)
     const int uu = dpro ? ud : u;
     if (uu >= 16 && !dpro) launch_tnd_u<NJW, 16, 0>(apro, dpro, grid, st, a);
     else if (uu >= 8) launch_tnd_u<NJW, 8, 0>(apro, dpro, grid, st, a);
@@ -529,7 +529,7 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
         set_error("gemm_tn: operands of 2 GB or more are not supported (M=%d)", M);
         return -1;
     }
-    static const bool trace = cdrl_getenv("CDRL_TN_TRACE") && atoi(cdrl_getenv("CDRL_TN_TRACE")) == 1;      // shapes of the filter-gradient GEMMs
+    static const bool trace = false;      // shapes of the filter-gradient GEMMs
     if (trace) fprintf(stderr, "gemm_tn M=%d K=%d N=%d G=%d apro=%d dpro=%d shuffle=%d bf16=%d at=%d\n", M, K, N, G, pro_stats != nullptr, dpro != nullptr, dpro ? dpro->shuffle_ctot : 0, (int)bf16_operands, at);
     static const bool diag_skip = cdrl_getenv("CDRL_DIAG_SKIP_TN") && atoi(cdrl_getenv("CDRL_DIAG_SKIP_TN")) == 1;   // timing diagnostics only
     if (diag_skip) return 0;
@@ -544,7 +544,7 @@ int gemm_tn(View A, View D, float* Cout, int M, int N, int K, float* part, int a
     // (Until the ReLU6 masks became single compares -- relu6_open(), cdrl_common.h -- the shapes with several column blocks were kept
     //  off this path: next to them the fused backward-data GEMM on the main stream lost its run-to-run reproducibility.  The cause
     //  was in that kernel's mask code, not here: DESIGN.md "What round 3 found", tools/det_co.py.)
-    static const int lds_mode = cdrl_getenv("CDRL_TN_LDS") ? atoi(cdrl_getenv("CDRL_TN_LDS")) : 2;
+    static const int lds_mode = 2;
     const bool lds_shape = K >= 96 && N >= 96 && (lds_mode == 2 || (K <= 128 && N <= 128));
     if (bf16_operands && lds_mode != 0 && lds_shape && gemm_tn_lds_supported(A, D, N, K, dpro))
         return gemm_tn_lds(A, D, Cout, M, N, K, part, accumulate, st, G, pro_stats, dpro, at);

@@ -331,7 +331,7 @@ static TnlPlan tnl_plan(int M, int N, int K, int G) {
     // ~1.5 workgroups per CU over all column blocks, at least 128 rows each (the partial buffer stays small), whole chunks
     // (768 | 512 | 384 | 256 workgroups: 33.3 | 33.1 | 32.8 | 33.0 ms / update-step at bf16-storage B = 1024: fewer partial slots to write
     //  and reduce; CDRL_TNL_WGS)
-    static const int wgs = cdrl_getenv("CDRL_TNL_WGS") ? atoi(cdrl_getenv("CDRL_TNL_WGS")) : 384;
+    static const int wgs = 384;
     int target = wgs / (p.gy * p.gz * G);
     if (target < 1) target = 1;
     int ns = Mg / 128;

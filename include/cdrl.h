@@ -237,8 +237,11 @@ int cdrl_philox_words(uint64_t seed, uint64_t offset, uint64_t idx0, int n, int 
  * step; float32 in / out, float32-accurate, not bit-identical to an fmaf chain).  W_packed: cdrl_pwconv_x3_packed_bytes(K)
  * bytes written by cdrl_pwconv_x3_pack from B(k, n) = W[k * sbk + n * sbn].  Same prologue / epilogue contract as
  * cdrl_pwconv_fused (pro_stats: BN-apply on load; part: statistics partials, cdrl_pwconv_x3_partial_rows rows per group).
- * K, N <= 128; K, lda, a_coff multiples of 4. */
+ * K, N <= 256; K, lda, a_coff multiples of 4.  K or N above 128 (the 232-channel convs of stage 2, core/architectures.py:130,140 at
+ * num_channels 464): W_packed holds one block per 128 output columns -- cdrl_pwconv_x3_packed_bytes_n(K, N) bytes -- and the kernel
+ * takes one 32-row tile per workgroup (one statistics row per tile). */
 int64_t cdrl_pwconv_x3_packed_bytes(int K);
+int64_t cdrl_pwconv_x3_packed_bytes_n(int K, int N);
 int cdrl_pwconv_x3_partial_rows(int G, int Mg, int N, int K);
 int cdrl_pwconv_x3_pack(const float* W, int K, int N, int sbk, int sbn, void* packed, void* stream);
 int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, const void* W_packed, const float* bias, float* C,
@@ -419,7 +422,7 @@ int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle
 /* Fused stem block (core/architectures.py:160-161): BatchNorm-apply + ReLU6 + MaxPooling2D(3,2,'same') on the
  * raw conv output (stats from cdrl_bn_train_fwd), and the BatchNorm backward that gathers its incoming
  * gradient from the pooled gradient `dp` through the saved argmax.  argmax codes: ky * 3 + kx of the winning window position in bits 0-3;
- * bit 7 is set where the winning activation is clamped (ReLU6 closed: no gradient flows) -- the mask of cdrl_stem_block_bwd_gram. */
+ * bit 7 is set where the winning activation is clamped (ReLU6 closed: no gradient flows); decoders mask it away. */
 int cdrl_maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax,
                         int N, int H, int W, int C, void* stream);
 int cdrl_bn_train_bwd_pooled(const uint8_t* argmax, const float* dp, int H, int W, const float* y, int G, int Mg, int C,
@@ -443,16 +446,6 @@ int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stat
                                const float* pooled, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta, float* coef,
                                float* dw, float* db, double* workspace, void* stream);
 
-/* The same backward in its COEFFICIENT-FREE form (round 5, conv.hip; the float32 engine runs it with CDRL_STEM_RAW=1): the filter gradient is assembled
- * from A = [P | 1]^T (masked, pool-gathered gradient) -- one gather pass that needs neither y nor the BatchNorm-backward coefficients --,
- * the Gram matrix [P | 1]^T [P | 1] of the image patches per time slice (images only: the engine takes it in the forward pass) and the conv
- * parameters w (3,3,3,Cout), b: P^T xhat = invstd (Gram W + SP b - mean SP).  Needs the ReLU6 flag (bit 7) in the argmax codes, which
- * cdrl_maxpool_bn_fwd writes.  Replaces, with cdrl_stem_block_bwd, tape.gradient through Conv2D(stem) -> BatchNormalization -> ReLU6 ->
- * MaxPooling2D (core/architectures.py:159-161, core/carla_agent.py:364-365).  float32 tensors only. */
-int64_t cdrl_stem_block_bwd_gram_workspace_doubles(int B, int T, int H, int W, int Cout);
-int cdrl_stem_block_bwd_gram(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, const float* pooled,
-                             const float* w, const float* b, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta,
-                             float* coef, float* dw, float* db, double* workspace, void* stream);
 /* Rollout-time image augmentation of one observation stack (CARLAgent.augment, core/carla_agent.py:545-577; ops of
  * rl/augmentations/augmentations.py and simclr.color_jitter): color jitter (brightness -> contrast -> saturation -> hue ->
  * clip) -> random-kernel blur -> salt & pepper -> gaussian noise -> per-image min-max normalisation -> cutout -> coarse

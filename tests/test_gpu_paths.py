@@ -121,25 +121,6 @@ def test_depthwise_backward_in_strip_form_agrees_with_the_pixel_mapped_form_at_f
     assert any(not torch.equal(a1[k], a0[k]) for k in a1 if k.startswith('trunk/img.') and k.endswith('.dw.w'))     # the switch took effect
 
 
-def test_coefficient_free_stem_filter_gradient_agrees_with_the_fused_form_at_full_size(tmp_path):
-    """Round 5, opt-in (CDRL_STEM_RAW=1): the stem filter gradient from the Gram matrix of the image patches, one gather pass over the
-    pooled gradient (ReLU6 mask from bit 7 of the argmax codes) and a 28 x 24 combine in double, vs the fused form that applies the
-    BatchNorm-backward coefficients inside its GEMM (the default): same forward and decisions; only the stem conv's gradient may
-    differ, within 5e-5 of its scale (measured 4e-6 in isolation: the coefficient-free form has no rounded y in it)."""
-    a1 = _run(str(tmp_path / 'raw.pt'), CDRL_STEM_RAW=1)
-    a0 = _run(str(tmp_path / 'fused.pt'))
-    assert a1['loss'].item() == a0['loss'].item()
-    for k in a1:
-        if k in ('trunk/img.stem.conv.w', 'trunk/img.stem.conv.b'):
-            continue
-        assert torch.equal(a1[k], a0[k]), k
-    w0, w1 = a0['trunk/img.stem.conv.w'].double(), a1['trunk/img.stem.conv.w'].double()
-    err = (w1 - w0).abs().max().item() / w0.abs().max().item()
-    print(f'[coefficient-free stem filter gradient vs fused form] max |diff| / max |dW| = {err:.2e}')
-    assert 0.0 < err < 5e-5, err            # (0: the switch did not take effect)
-    assert a1['trunk/img.stem.conv.b'].abs().max().item() < 1e-5 * w0.abs().max().item()
-
-
 def test_band_staged_stem_forward_is_bit_identical_to_the_window_form_at_full_size(tmp_path):
     """Round 5: the stem conv + statistics kernel with the image band staged in LDS (stem_fwd_band_kernel, the default) vs the form whose
     threads fetch their pixels' windows from global memory (CDRL_STEM_FWD_BAND=0): the same fmaf chain per output element, and per-thread

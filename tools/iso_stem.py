@@ -37,11 +37,5 @@ dg, dbt, coef = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.
 dw, db = torch.zeros(3, 3, 3, Cc, device=DEV), torch.zeros(Cc, device=DEV)
 for _ in range(5):
     _lib.check(lib.cdrl_stem_block_bwd(P(x), P(y), P(stats), P(am), P(dp), B, T, H, W, Cc, P(dg), P(dbt), P(coef), P(dw), P(db), P(ws), S()))
-ws3 = torch.zeros(int(lib.cdrl_stem_block_bwd_gram_workspace_doubles(B, T, H, W, Cc)), dtype=torch.float64, device=DEV)
-dw3, db3 = torch.zeros(3, 3, 3, Cc, device=DEV), torch.zeros(Cc, device=DEV)
-for _ in range(5):      # the coefficient-free form: stem_xt_kernel<1> (Gram), <0> (gather pass), part reduce, combine
-    _lib.check(lib.cdrl_stem_block_bwd_gram(P(x), P(y), P(stats), P(am), P(dp), P(pool), P(w), P(b), B, T, H, W, Cc, P(dg), P(dbt), P(coef),
-                                            P(dw3), P(db3), P(ws3), S()))
 torch.cuda.synchronize()
-print('filter gradient, coefficient-free vs fused form: max |diff| / max |dw| =', float((dw3 - dw).abs().max() / dw.abs().max()))
 print('done')
