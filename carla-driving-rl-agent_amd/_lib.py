@@ -85,6 +85,8 @@ PROTOTYPES = {
     'cdrl_pwconv_x3_partial_rows': (_i, [_i, _i, _i, _i]),
     'cdrl_pwconv_x3_pack': (_i, [_fp, _i, _i, _i, _i, _fp, _fp]),
     'cdrl_pwconv_x3': (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp]),
+    'cdrl_pwconv_x3_wide_bwd_rows': (_i, [_i]),
+    'cdrl_pwconv_x3_wide_bwd': (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     'cdrl_pwconv_bwd_fused_workspace': (_i64, [_i, _i, _i, _i, _i]),
     'cdrl_pwconv_bwd_fused': (_i, [_fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p, _fp, _i,
                                    _i, _i, _fp, _fp, _fp, C.c_void_p, _i, _i, _i, _i, C.c_void_p]),

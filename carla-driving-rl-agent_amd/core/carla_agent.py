@@ -199,9 +199,15 @@ class CARLAgent(PPOAgent):
         # every rank runs learn() to its end: checkpoints, summaries and traces are written by rank 0 alone
         return not self.data_parallel or self.rank == 0
 
-    def rank_barrier(self):
-        if self.data_parallel:
-            dist.barrier()
+    def rank_barrier(self, failed: bool = False):
+        if not self.data_parallel:
+            return
+        # the meeting point doubles as a status exchange: MAX over the ranks' failure flags, so that a writer whose save() raised
+        # takes every rank down with an error instead of leaving them in a barrier until the process-group timeout
+        flag = torch.tensor([1.0 if failed else 0.0], device=self.device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) > 0.0 and not failed:
+            raise RuntimeError('data-parallel learn(): the writer rank failed to save the checkpoint (see its traceback)')
 
     def load(self):
         super().load()

@@ -445,6 +445,20 @@ int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, 
                  part, S(stream));
 }
 
+int cdrl_pwconv_x3_wide_bwd_rows(int Mg) { return pw_x3_wide_bwd_rows(Mg); }
+
+int cdrl_pwconv_x3_wide_bwd(const float* dz, int ld_dz, int dz_coff, int dz_shuffle, int act, const float* y, const float* stats,
+                            const float* coef, const void* W_packed, float* da, int ldda, int da_coff, int accumulate, int G, int Mg,
+                            int Cin, int Cout, double* part2, const float* ey, const float* epi_stats, double* part, void* stream) {
+    if (!dz || !y || !stats || !coef || !W_packed || !da) {
+        cdrl::set_error("cdrl_pwconv_x3_wide_bwd: null argument");
+        return -1;
+    }
+    PwBnBwd bb{y, stats, coef, dz_shuffle, act ? ACT_RELU6 : ACT_NONE, part2};
+    return pw_x3_wide_bwd(make_view(const_cast<float*>(dz), ld_dz, dz_coff), bb, W_packed, make_view(da, ldda, da_coff), accumulate, G, Mg,
+                          Cin, Cout, ey, epi_stats, part, S(stream));
+}
+
 int64_t cdrl_pwconv_bwd_fused_workspace(int G, int Mg, int N, int K, int which) {
     return which == 0 ? pw_bwd_fused_qpart_elems(G, Mg, N, K, g_op_at) : pw_bwd_fused_dbpart_elems(G, Mg, N, K, g_op_at);
 }
@@ -699,7 +713,7 @@ int cdrl_pwconv_fused_packed(const float* a, int lda, int a_coff, const float* p
 static int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 
 int64_t cdrl_pwconv_bn_bwd_workspace_bytes(int G, int Mg, int N, int K) {
-    const int64_t nbr = vcol_geom(Mg, N).nb, nbp = pw_nn_plan(G, Mg, K, N).nbpg;
+    const int64_t nbr = vcol_geom(Mg, N).nb, nbp = std::max(pw_nn_plan(G, Mg, K, N).nbpg, pw_x3_wide_bwd_rows(Mg));
     return al256((int64_t)G * nbr * 2 * N * 8) + al256((int64_t)G * nbp * N * 8) + al256(gemm_tn_part_elems(G * Mg, N, K, G) * 4);
 }
 
@@ -715,7 +729,7 @@ static int pwconv_bn_bwd_impl(const float* dout, int dout_ld, int dout_coff, int
     double* part = reinterpret_cast<double*>(ws);
     ws += al256((int64_t)G * nbr * 2 * N * 8);
     double* part2 = reinterpret_cast<double*>(ws);
-    ws += al256((int64_t)G * nbp * N * 8);
+    ws += al256((int64_t)G * std::max(nbp, pw_x3_wide_bwd_rows(Mg)) * N * 8);
     float* tn = reinterpret_cast<float*>(ws);
     View vd = make_view(const_cast<float*>(dout), dout_ld, dout_coff), vy = make_view(const_cast<float*>(y), N);
     View vx = make_view(const_cast<float*>(x), x_ld, x_coff);
@@ -723,9 +737,30 @@ static int pwconv_bn_bwd_impl(const float* dout, int dout_ld, int dout_coff, int
     CDRL_TRY(bn_bwd_finalize(part, nbr, G, Mg, N, stats, dgamma, dbeta, coef, st));
     PwBnBwd bb{y, stats, coef, shuffle_ctot, act, part2};
     // dx[m,k] = sum_n dy[m,n] W[k,n]: GEMM with "K" = N (reduction over the conv outputs) and "N" = K
-    CDRL_TRY(pw_nn(vd, nullptr, w, 1, N, nullptr, make_view(dx, dx_ld, dx_coff), accumulate, G, Mg, K, N, 0, nullptr, nullptr, nullptr,
-                   st, &bb, wt_packed, packed_bf16 != 0, g_op_at));
-    CDRL_TRY(reduce_partials(part2, G * nbp, N, N, db, 0, st));
+    const View vdx = make_view(dx, dx_ld, dx_coff);
+    if (!g_op_at && !packed_bf16 && pw_x3_wide_bwd_supported(vd, vdx, K, N, shuffle_ctot)) {
+        // 232-channel shapes, float32: the one-tile-per-workgroup split-precision kernel the engine runs (gemm_pw_x3.hip); the packed
+        // operand is built here through a temporary device buffer (test / tooling entry point)
+        void* wp = nullptr;
+        PwX3Pack* d = nullptr;
+        if (hipMalloc(&wp, (size_t)pw_x3_packed_bytes_n(N, K)) != hipSuccess) return -2;
+        if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(PwX3Pack)) != hipSuccess) {
+            (void)hipFree(wp);
+            return -2;
+        }
+        PwX3Pack e = pw_x3_pack_entry(w, wp, N, K, 1, N);
+        int rc = hipMemcpy(d, &e, sizeof(e), hipMemcpyHostToDevice) == hipSuccess ? pw_x3_pack_many(d, 1, st) : -2;
+        if (rc == 0) rc = pw_x3_wide_bwd(vd, bb, wp, vdx, accumulate, G, Mg, K, N, nullptr, nullptr, nullptr, st);
+        if (rc == 0) rc = reduce_partials(part2, G * pw_x3_wide_bwd_rows(Mg), N, N, db, 0, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(d);
+        (void)hipFree(wp);
+        if (rc != 0) return rc;
+    } else {
+        CDRL_TRY(pw_nn(vd, nullptr, w, 1, N, nullptr, vdx, accumulate, G, Mg, K, N, 0, nullptr, nullptr, nullptr,
+                       st, &bb, wt_packed, packed_bf16 != 0, g_op_at));
+        CDRL_TRY(reduce_partials(part2, G * nbp, N, N, db, 0, st));
+    }
     TnBnBwd tb{y, stats, coef, shuffle_ctot, act};
     return gemm_tn(vx, vd, dw, G * Mg, N, K, tn, 0, st, G, x_pro_stats, &tb, wt_packed && packed_bf16 != 0, g_op_at);
 }

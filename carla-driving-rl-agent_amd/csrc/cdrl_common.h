@@ -97,11 +97,7 @@ struct ColGeom {
 // single-group filter-gradient reductions (depthwise / stem): enough workgroups to fill 256 CUs.
 // (128 since round 5 -- 256 before: the step is indifferent to it alone, 14.33 vs 14.32 ms, 64 costs +0.48 ms; with 128 rows the finalize
 //  folded into the consumer's prologue (CDRL_FIN_ON_LOAD) reads half as much per workgroup: 14.15 vs 14.31 ms same box)
-inline int nb_stats_rt() {
-    static const int v = cdrl_getenv("CDRL_NB_STATS") ? atoi(cdrl_getenv("CDRL_NB_STATS")) : 128;
-    return v;
-}
-#define NB_STATS (::cdrl::nb_stats_rt())
+constexpr int NB_STATS = 128;
 constexpr int NB_FILTER = 1024;
 
 inline ColGeom col_geom(int rows_per_group, int C, int max_blocks_per_group = NB_STATS) {

@@ -247,6 +247,12 @@ int64_t pw_x3_packed_bytes_n(int K, int N);        // any N <= 256: column block
 PwX3Pack pw_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, int sbn);
 int pw_x3_pack_many(const PwX3Pack* tab_dev, int n, hipStream_t st);
 // nbpg > 0: workgroups (= partial rows) per group chosen by the caller (the engine keeps pw_nn_plan's count)
+// backward-data of the wide convs (128 < K or N <= 256) with the BatchNorm-backward prologue, one 32-row tile per workgroup: C[M][N] (+)=
+// dy W^T, Wp = pw_x3_pack_entry(W, wp, K, N, 1, K) (B(k = conv output channel, n = conv input channel)); one part2 / part row per tile
+bool pw_x3_wide_bwd_supported(View dz, View C, int N, int K, int shuffle_ctot);
+int pw_x3_wide_bwd_rows(int Mg);
+int pw_x3_wide_bwd(View dz, const PwBnBwd& bb, const void* Wp, View C, int accumulate, int G, int Mg, int N, int K, const float* ey,
+                   const float* epi_stats, double* part, hipStream_t st);
 int pw_x3(View A, const float* pro_stats, const void* Wp, const float* bias, View C, int G, int Mg, int N, int K, double* part,
           hipStream_t st, int nbpg = 0);
 

@@ -319,6 +319,9 @@ static StemFwdGeom stem_fwd_geom(int B, int T, int H, int W, int Cout) {
     StemFwdGeom g{};
     static const bool on = !(cdrl_getenv("CDRL_STEM_FWD_BAND") && atoi(cdrl_getenv("CDRL_STEM_FWD_BAND")) == 0);
     if (!on || Cout % 4 || Cout > 64 || Cout < 4) return g;
+    // the band kernel addresses the images through a 32-bit buffer descriptor: planner (stem_fwd_stats_nb) and launcher must agree
+    // on the form, so the size test lives here
+    if ((int64_t)B * T * H * W * 3 * 4 >= (1ll << 31)) return g;
     const int CX = Cout / 4, CY = 256 / CX;
     const size_t red = (size_t)8 * CY * CX * sizeof(double);
     const int cand[] = {8, 6, 4, 3, 2, 1};
@@ -360,7 +363,7 @@ int stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, 
     }
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const StemFwdGeom bg = stem_fwd_geom(B, T, H, W, Cout);
-    if (bg.ok && (int64_t)B * T * H * W * 3 * 4 < (1ll << 31)) {
+    if (bg.ok) {
 #define CDRL_STEM_FWD_BAND_LAUNCH(NPN, PXN)                                                                                                 \
     do {                                                                                                                                    \
         if (at) hipLaunchKernelGGL((stem_fwd_band_kernel<NPN, PXN, bf16_t>), dim3(T * bg.nbpg), dim3(256), bg.lds, st, x, w, bias,          \

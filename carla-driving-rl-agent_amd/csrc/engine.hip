@@ -447,6 +447,17 @@ int Learner::pw_fwd_nbpg(int G, int Mg, int N, int K) const {
     return pw_nn_plan(G, Mg, N, K).nbpg;
 }
 
+// backward-data of the same convs (N = conv input channels, K = conv output channels): pw_x3_wide_bwd_kernel, one part2 / part row per tile
+bool Learner::pw_bwd_x3_wide(int N, int K) const {
+    static const bool on = !(cdrl_getenv("CDRL_PW_X3_WIDE_BWD") && atoi(cdrl_getenv("CDRL_PW_X3_WIDE_BWD")) == 0);
+    return on && pw_fwd_x3_wide(N, K);
+}
+
+int Learner::pw_bwd_nbpg(int G, int Mg, int N, int K) const {
+    if (pw_bwd_x3_wide(N, K)) return pw_x3_wide_bwd_rows(Mg);
+    return pw_nn_plan(G, Mg, N, K).nbpg;
+}
+
 bool Learner::pw_fwd_x3_wide(int N, int K) const {
     static const bool x3_env = !(cdrl_getenv("CDRL_PW_X3") && atoi(cdrl_getenv("CDRL_PW_X3")) == 0);
     static const bool wide_env = !(cdrl_getenv("CDRL_PW_X3_WIDE") && atoi(cdrl_getenv("CDRL_PW_X3_WIDE")) == 0);
@@ -602,7 +613,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     const int tn_groups = (fuse.pro_stats || fuse.bb) ? G : 1;
     note_scratch(0, 0, (size_t)rows * Cout, (size_t)gemm_tn_part_elems(rows, Cout, Cin, tn_groups));
     if (fuse.epi_stats) note_scratch((size_t)G * nb_fwd * 2 * Cout, 0, 0, 0);
-    if (fuse.bwd_ey) note_scratch((size_t)G * pw_nn_plan(G, Mg, Cin, Cout).nbpg * 2 * Cin, 0, 0, 0);
+    if (fuse.bwd_ey) note_scratch((size_t)G * pw_bwd_nbpg(G, Mg, Cin, Cout) * 2 * Cin, 0, 0, 0);
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
         if (w3f)
@@ -614,7 +625,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         if (g3f) return gemm_x3(in, g3f, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st, bfc, at);
         return gemm_nn(in, w.p, Cout, 1, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
     };
-    const int nbp_bwd = fuse.bb ? pw_nn_plan(G, Mg, Cin, Cout).nbpg : 0;
+    const int nbp_bwd = fuse.bb ? pw_bwd_nbpg(G, Mg, Cin, Cout) : 0;
     if (fuse.bb) note_scratch(0, (size_t)G * nbp_bwd * Cout, 0, 0);
     // One kernel for backward-data + filter gradient + bias gradient (+ the backward sums of the BatchNorm in front of the conv):
     // float32 engine and bf16 activation storage (not the operand-only mode), both channel counts padded alike (gemm_pw_bwd.hip)
@@ -628,7 +639,13 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     const bool fbwd = fused_bwd_ && fuse.bb && fuse.bwd_pw && (!bfc || at) && G <= 8 && Cin >= fbwd_min_cin && pw_bwd_fused_supported(dz_probe, in, din, Cout, Cin, at) &&
                       (!anorm || (fuse.bwd_ey == in.p && fuse.bwd_epi_stats == fuse.pro_stats && fuse.a_bn && in.ld == Cin && in.coff == 0)) &&
                       (anorm || !fuse.bwd_ey);
-    const void* wpx = fbwd ? pw_x3_packed(w.p, Cout, Cin, 1, Cout) : nullptr;      // W^T planes: B(k = cout, n = cin)
+    // 232-channel convs (stage 2), float32: backward-data with the BatchNorm-backward prologue on the one-tile-per-workgroup
+    // split-precision kernel (round 6; the filter gradient stays on the side stream)
+    const bool wbw = !bfc && !at && fuse.bb && fuse.bwd_pw && !fbwd && pw_bwd_x3_wide(Cin, Cout);
+    if (wbw && !pw_x3_wide_bwd_supported(dz_probe, din, Cin, Cout, fuse.bb_shuffle))
+        build_fail("%s: the wide split-precision backward needs even / 16-byte aligned gradient rows (ld %d, offset %d, shuffle %d)", prefix.c_str(),
+                   dz_probe.ld, dz_probe.coff, fuse.bb_shuffle);
+    const void* wpx = (fbwd || wbw) ? pw_x3_packed(w.p, Cout, Cin, 1, Cout) : nullptr;      // W^T planes: B(k = cout, n = cin)
     if (fbwd) {
         max_qpart_ = std::max(max_qpart_, (size_t)pw_bwd_fused_qpart_elems(G, Mg, Cout, Cin, at));
         max_dbpart_ = std::max(max_dbpart_, (size_t)pw_bwd_fused_dbpart_elems(G, Mg, Cout, Cin, at));
@@ -700,8 +717,12 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             CDRL_TRY(gemm_tn(in, dz, w.g, rows, Cout, Cin, tns_[slot_], 0, side, G, fuse.pro_stats, &tb, bfc, at));
             CDRL_TRY(done_side(side));
             PwBnBwd pb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act, part2s_[slot_]};
-            CDRL_TRY(pw_nn(dz, nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
-                           fuse.bwd_epi_stats, scr_main_.part, st, &pb, wpb, bfc, at));
+            if (wbw)
+                CDRL_TRY(pw_x3_wide_bwd(dz, pb, wpx, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey, fuse.bwd_epi_stats,
+                                        fuse.bwd_ey ? scr_main_.part : nullptr, st));
+            else
+                CDRL_TRY(pw_nn(dz, nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
+                               fuse.bwd_epi_stats, scr_main_.part, st, &pb, wpb, bfc, at));
             // bias gradient = column sums of the (virtual) dy, reduced from the GEMM's partials: rides on the next fork
             double* p2 = part2s_[slot_];
             return defer_side(st, [=](hipStream_t sd) -> int { return reduce_partials(p2, G * nbp_bwd, Cout, Cout, b.g, 0, sd); });
@@ -1275,7 +1296,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     add_pw(ops, pre + ".pw1", X.v(main_off), rows_in, main_in, mid, y1.p, X.gv(main_off), stride == 2 ? 1 : 0,
                            bnrec(T, Mg_in, mid), f1);
                     const int nb1 = pw_fwd_nbpg(T, Mg_in, mid, main_in);
-                    const int nbb = pw_nn_plan(T, Mg_out, mid, main_out).nbpg;        // pw2 backward-data epilogue rows
+                    const int nbb = pw_bwd_nbpg(T, Mg_out, mid, main_out);        // pw2 backward-data epilogue rows
                     float* coef2 = nullptr;
                     std::shared_ptr<bool> bn2_done = std::make_shared<bool>(false);
                     float* stats2 = add_dw_block(ops, pre, "bn1", "dw", "bn2", y1.p, curH, curW, mid, stride, y2.p, a2.v(), a2.gv(),

@@ -223,13 +223,17 @@ __global__ void __launch_bounds__(256, 2) pw_x3_wide_kernel(PwX3Args a) {
             pc[1][k] = k < K ? a.pro_stats[3 * GK + g * K + k] : 0.0f;
         }
     }
-    const __bf16* wp = a.Wp + (int64_t)blockIdx.y * 3 * KS * 2 * 128 * 8;
-    bf16x8 breg[3][KS];
+    // A workgroup uses every weight fragment ONCE (one tile), so holding all 3 x 16 of them (192 VGPRs) buys nothing but the early issue
+    // of their loads -- and spilled next to the prologue.  A ring of PF K-steps (3 planes each) is requested ahead instead.
+    const __bf16* wp = a.Wp + (int64_t)blockIdx.y * 3 * KS * 2 * 128 * 8 + ((int64_t)lk * 128 + nl) * 8;
+    constexpr int PF = 6;
+    bf16x8 ring[PF][3];
+    auto wload = [&](int s, bf16x8* dst) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)(p * KS + s) * 2 * 128 * 8);
+    };
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-            breg[p][s] = *reinterpret_cast<const bf16x8*>(wp + (((int64_t)(p * KS + s) * 2 + lk) * 128 + nl) * 8);
+    for (int s = 0; s < PF; ++s) wload(s, ring[s]);
     const float bv = (a.bias && n < N) ? a.bias[n] : 0.0f;
     if (PRO) __syncthreads();
     {
@@ -266,12 +270,14 @@ __global__ void __launch_bounds__(256, 2) pw_x3_wide_kernel(PwX3Args a) {
         const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[0][ao + 16 * s]);
         const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&As[1][ao + 16 * s]);
         const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&As[2][ao + 16 * s]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, breg[0][s], acc, 0, 0, 0);       // smallest terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[2][s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[1][s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[0][s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[1][s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[0][s], acc, 0, 0, 0);
+        const bf16x8 b1 = ring[s % PF][0], b2 = ring[s % PF][1], b3 = ring[s % PF][2];
+        if (s + PF < KS) wload(s + PF, ring[s % PF]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);       // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
     }
     if (n >= N) return;
     double s1 = 0.0, s2 = 0.0;
@@ -294,6 +300,211 @@ __global__ void __launch_bounds__(256, 2) pw_x3_wide_kernel(PwX3Args a) {
             p[n] = f1;
             p[N + n] = f2;
         }
+    }
+}
+
+
+// Backward-data of the same convs, one tile per workgroup (round 6): C[M, N] (+)= dy[M, K] W^T with the BatchNorm backward of the BatchNorm
+// behind the conv applied on load -- dy = k1 (mask dz - k2 - xhat(y) k3), dz optionally gathered through the channel shuffle (destination
+// columns c, c + 2 and c + 1, c + 3 are adjacent pairs of the source), column sums of dy (the conv's bias gradient) as one partial row per
+// tile -- and optionally the backward sums (sum c, sum c xhat(ey)) of the BatchNorm the OUTPUT feeds (EPI) or accumulation onto the old
+// output (ACC).  Same contract as pw_nn_kernel<128, 4, PRO_BNBWD, EPI, 0, ACC> (gemm_pw.hip), which ran these shapes as three serial tiles
+// per CU on the float32 matrix pipe (32-53 us per launch at M = 12288).  The weight fragments are requested behind the prologue (its raw
+// tiles and the 192 fragment VGPRs do not fit together at two workgroups per CU); the co-resident workgroup covers that latency.
+struct PwX3BwdArgs {
+    View A;                     // dz
+    int a_shuffle, a_act;
+    const float* a_y;           // raw input of the BatchNorm behind the conv [M][K] dense
+    const float* pro_stats;     // [4][G][K]
+    const float* pro_coef;      // [3][G][K]
+    double* part2;              // [G][nbpg][K] or null
+    const __bf16* Wp;           // pw_x3 packing of B(k, n), column blocks of 128
+    View C;
+    const float* ey;            // EPI: [M][N] dense
+    const float* epi_stats;     // EPI: [4][G][N]
+    double* part;               // EPI: [G][nbpg][2][N]
+    int N, K, G, Mg, nbpg;
+};
+
+template <bool SHUF, bool EPI, bool ACC>
+__global__ void __launch_bounds__(256, 2) pw_x3_wide_bwd_kernel(PwX3BwdArgs a) {
+    constexpr int KP = 256, BM = 32, KS = KP / 16, LDA = KP + 8, CPR = KP / 4, NCH = BM * CPR / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * LDA];
+    __shared__ float qc[7][KP];         // mean, invstd, scale, shift, k1, k2, k3 of the dy columns (0 beyond K)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int g = blockIdx.x / a.nbpg, t = blockIdx.x % a.nbpg;
+    const int K = a.K, N = a.N;
+    const int64_t mbeg = (int64_t)g * a.Mg, mend = mbeg + a.Mg;
+    const int64_t m0 = mbeg + (int64_t)t * BM;
+    const int nl = wave * 32 + lrow, n = blockIdx.y * 128 + nl;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t OOR = 0x80000000u;
+    const int64_t Mtot = (int64_t)a.G * a.Mg;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a.A.p, 0, (int)(Mtot * a.A.ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.a_y), 0, (int)(Mtot * K * 4), 0x00020000);
+    // a thread's chunks: rows r0 + 4 i, ALWAYS the same four columns k4 .. k4 + 3 (256 % CPR == 0)
+    const int k4 = 4 * (tid % CPR), r0 = tid / CPR;
+    const bool kon = k4 < K;                    // (K % 4 == 0: a chunk is valid or not as a whole)
+    uint32_t voD0, voD1;                        // byte offsets inside a row: SHUF -> sources of columns (0, 2) and (1, 3); dense -> one 16-byte chunk
+    if (SHUF) {
+        voD0 = kon ? (uint32_t)shuffle_dst(a.A.coff + k4, a.a_shuffle) * 4u : OOR;
+        voD1 = kon ? (uint32_t)shuffle_dst(a.A.coff + k4 + 1, a.a_shuffle) * 4u : OOR;
+    } else {
+        voD0 = kon ? (uint32_t)(a.A.coff + k4) * 4u : OOR;
+        voD1 = OOR;
+    }
+    const uint32_t voY = kon ? (uint32_t)k4 * 4u : OOR;
+    const uint32_t rowA = (uint32_t)a.A.ld * 4u, rowY = (uint32_t)K * 4u;
+    u32x4_t rz[NCH], ry[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int64_t m = m0 + r0 + 4 * i;
+        const uint32_t msk = m < mend ? 0u : OOR;
+        const uint32_t mu = (uint32_t)m;
+        if (SHUF) {
+            const u32x2_t p0 = __builtin_amdgcn_raw_buffer_load_b64(rsA, (voD0 + mu * rowA) | msk | (voD0 & OOR), 0, 0);
+            const u32x2_t p1 = __builtin_amdgcn_raw_buffer_load_b64(rsA, (voD1 + mu * rowA) | msk | (voD1 & OOR), 0, 0);
+            rz[i] = u32x4_t{p0[0], p1[0], p0[1], p1[1]};
+        } else {
+            rz[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (voD0 + mu * rowA) | msk | (voD0 & OOR), 0, 0);
+        }
+        ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsY, (voY + mu * rowY) | msk | (voY & OOR), 0, 0);
+    }
+    {
+        const int GK = a.G * K;
+        for (int i = tid; i < 7 * KP; i += 256) {
+            const int q = i / KP, k = i % KP;
+            qc[q][k] = k < K ? (q < 4 ? a.pro_stats[q * GK + g * K + k] : a.pro_coef[(q - 4) * GK + g * K + k]) : 0.0f;
+        }
+    }
+    __syncthreads();
+    double cs[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+        auto widen = [](uint32_t w) -> f32x2 { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; };
+        const bool relu6 = a.a_act == ACT_RELU6;
+        f32x2 cmean[2], cinv[2], csc[2], csh[2], ck1[2], ck2[2], ck3[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            cmean[h] = f32x2{qc[0][k4 + 2 * h], qc[0][k4 + 2 * h + 1]};
+            cinv[h] = f32x2{qc[1][k4 + 2 * h], qc[1][k4 + 2 * h + 1]};
+            csc[h] = f32x2{qc[2][k4 + 2 * h], qc[2][k4 + 2 * h + 1]};
+            csh[h] = f32x2{qc[3][k4 + 2 * h], qc[3][k4 + 2 * h + 1]};
+            ck1[h] = f32x2{qc[4][k4 + 2 * h], qc[4][k4 + 2 * h + 1]};
+            ck2[h] = f32x2{qc[5][k4 + 2 * h], qc[5][k4 + 2 * h + 1]};
+            ck3[h] = f32x2{qc[6][k4 + 2 * h], qc[6][k4 + 2 * h + 1]};
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int r = r0 + 4 * i;
+            const bool rok = m0 + r < mend;
+            uint32_t hw[3][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x2 d = f32x2{__uint_as_float(rz[i][2 * h]), __uint_as_float(rz[i][2 * h + 1])};
+                const f32x2 yv = f32x2{__uint_as_float(ry[i][2 * h]), __uint_as_float(ry[i][2 * h + 1])};
+                if (relu6) {
+                    const f32x2 z = __builtin_elementwise_fma(csc[h], yv, csh[h]);      // = fmaf(scale, y, shift) of the forward
+                    if (!relu6_open(z[0])) d[0] = 0.0f;
+                    if (!relu6_open(z[1])) d[1] = 0.0f;
+                }
+                const f32x2 xh = (yv - cmean[h]) * cinv[h];
+                f32x2 v = ck1[h] * (d - ck2[h] - xh * ck3[h]);          // columns beyond K: every coefficient 0 -> 0
+                if (!rok) v = f32x2{0.0f, 0.0f};
+                cs[2 * h] += (double)v[0];
+                cs[2 * h + 1] += (double)v[1];
+                hw[0][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+                const f32x2 r1 = v - widen(hw[0][h]);
+                hw[1][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+                hw[2][h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1 - widen(hw[1][h]), bf16x2));
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2_t*>(&As[p][r * LDA + k4]) = u32x2_t{hw[p][0], hw[p][1]};
+        }
+    }
+    // weight fragments + the epilogue's operands: requested now, consumed behind the barrier
+    const __bf16* wp = a.Wp + (int64_t)blockIdx.y * 3 * KS * 2 * 128 * 8 + ((int64_t)lk * 128 + nl) * 8;
+    constexpr int PF = 6;                       // ring of K-steps requested ahead (see pw_x3_wide_kernel)
+    bf16x8 ring[PF][3];
+    auto wload = [&](int s, bf16x8* dst) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)(p * KS + s) * 2 * 128 * 8);
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) wload(s, ring[s]);
+    const bool non = n < N;
+    float ext[(EPI || ACC) ? 16 : 1];           // EPI: raw input of the BatchNorm the output feeds; ACC: old output values
+    if (EPI || ACC) {
+        const __amdgpu_buffer_rsrc_t rsE = EPI ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ey), 0, (int)(Mtot * N * 4), 0x00020000)
+                                               : __builtin_amdgcn_make_buffer_rsrc(a.C.p, 0, (int)(Mtot * a.C.ld * 4), 0x00020000);
+        const uint32_t rowE = EPI ? (uint32_t)N * 4u : (uint32_t)a.C.ld * 4u;
+        const uint32_t voE = non ? (uint32_t)((EPI ? 0 : a.C.coff) + n) * 4u : OOR;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            ext[(EPI || ACC) ? r : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsE, (voE + (uint32_t)m * rowE) | (m < mend ? 0u : OOR) | (voE & OOR), 0, 0));
+        }
+    }
+    float emean = 0.0f, einv = 0.0f;
+    if (EPI && non) {
+        emean = a.epi_stats[0 * a.G * N + g * N + n];
+        einv = a.epi_stats[1 * a.G * N + g * N + n];
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int ao = lrow * LDA + 8 * lk;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[0][ao + 16 * s]);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&As[1][ao + 16 * s]);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(&As[2][ao + 16 * s]);
+        const bf16x8 b1 = ring[s % PF][0], b2 = ring[s % PF][1], b3 = ring[s % PF][2];
+        if (s + PF < KS) wload(s + PF, ring[s % PF]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);       // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+    }
+    double s1 = 0.0, s2 = 0.0;
+    if (non) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m < mend) {
+                float v = acc[r];
+                if (EPI) {
+                    const float xh = (ext[EPI ? r : 0] - emean) * einv;
+                    s1 += (double)v;
+                    s2 += (double)v * (double)xh;
+                }
+                if (ACC) v += ext[ACC ? r : 0];
+                a.C.p[m * a.C.ld + a.C.coff + n] = v;
+            }
+        }
+    }
+    if (EPI && a.part) {
+        const double f1 = s1 + __shfl_down(s1, 32), f2 = s2 + __shfl_down(s2, 32);
+        if (lk == 0 && non) {
+            double* p = a.part + ((int64_t)g * a.nbpg + t) * 2 * N;
+            p[n] = f1;
+            p[N + n] = f2;
+        }
+    }
+    if (a.part2 && blockIdx.y == 0) {
+        // column sums of dy: the four row groups of a column chunk folded in fixed order (the LDS planes are dead: barrier first)
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(&As[0][0]);     // [4][KP]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[r0 * KP + k4 + e] = cs[e];
+        __syncthreads();
+        for (int k = tid; k < K; k += 256) a.part2[((int64_t)g * a.nbpg + t) * K + k] = (red[k] + red[KP + k]) + (red[2 * KP + k] + red[3 * KP + k]);
     }
 }
 
@@ -405,6 +616,65 @@ int pw_x3(View A, const float* pro_stats, const void* Wp, const float* bias, Vie
     else if (kp == 64) { if (nt == 1) CDRL_X3(64, 1); else if (nt == 2) CDRL_X3(64, 2); else CDRL_X3(64, 4); }
     else { if (nt == 1) CDRL_X3(128, 1); else if (nt == 2) CDRL_X3(128, 2); else CDRL_X3(128, 4); }
 #undef CDRL_X3
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
+
+bool pw_x3_wide_bwd_supported(View dz, View C, int N, int K, int shuffle_ctot) {
+    // N = conv input channels (columns of the output), K = conv output channels (columns of dz / y)
+    if (!(K > 128 || N > 128) || K > 256 || N > 256 || (K & 3)) return false;
+    if ((reinterpret_cast<uintptr_t>(dz.p) & 15) || (dz.ld & 1)) return false;
+    if (shuffle_ctot) return (dz.coff & 1) == 0 && ((shuffle_ctot >> 1) & 1) == 0;
+    return (dz.ld & 3) == 0 && (dz.coff & 3) == 0;
+}
+
+int pw_x3_wide_bwd_rows(int Mg) { return cdiv(Mg, 32); }
+
+int pw_x3_wide_bwd(View dz, const PwBnBwd& bb, const void* Wp, View C, int accumulate, int G, int Mg, int N, int K, const float* ey,
+                   const float* epi_stats, double* part, hipStream_t st) {
+    if (!pw_x3_wide_bwd_supported(dz, C, N, K, bb.shuffle_ctot) || !Wp || !bb.y || !bb.stats || !bb.coef) {
+        set_error("pw_x3_wide_bwd: unsupported shape / alignment K=%d N=%d ld=%d coff=%d", K, N, dz.ld, dz.coff);
+        return -1;
+    }
+    if ((ey != nullptr) && accumulate) {
+        set_error("pw_x3_wide_bwd: the BatchNorm-sum epilogue and accumulation are not instantiated together");
+        return -1;
+    }
+    const int64_t Mtot = (int64_t)G * Mg;
+    if (Mtot * dz.ld * 4 >= (int64_t)1 << 31 || Mtot * K * 4 >= (int64_t)1 << 31 || Mtot * C.ld * 4 >= (int64_t)1 << 31) {
+        set_error("pw_x3_wide_bwd: operand of 2 GB or more");
+        return -1;
+    }
+    PwX3BwdArgs a;
+    a.A = dz;
+    a.a_shuffle = bb.shuffle_ctot;
+    a.a_act = bb.act;
+    a.a_y = bb.y;
+    a.pro_stats = bb.stats;
+    a.pro_coef = bb.coef;
+    a.part2 = bb.part2;
+    a.Wp = reinterpret_cast<const __bf16*>(Wp);
+    a.C = C;
+    a.ey = ey;
+    a.epi_stats = epi_stats;
+    a.part = part;
+    a.N = N;
+    a.K = K;
+    a.G = G;
+    a.Mg = Mg;
+    a.nbpg = cdiv(Mg, 32);
+    const dim3 grid(G * a.nbpg, cdiv(N, 128)), block(256);
+    const bool shuf = bb.shuffle_ctot != 0, epi = ey != nullptr, acc = accumulate != 0;
+#define CDRL_X3B(SH)                                                                                          \
+    do {                                                                                                      \
+        if (epi) hipLaunchKernelGGL((pw_x3_wide_bwd_kernel<SH, true, false>), grid, block, 0, st, a);         \
+        else if (acc) hipLaunchKernelGGL((pw_x3_wide_bwd_kernel<SH, false, true>), grid, block, 0, st, a);    \
+        else hipLaunchKernelGGL((pw_x3_wide_bwd_kernel<SH, false, false>), grid, block, 0, st, a);            \
+    } while (0)
+    if (shuf) CDRL_X3B(true);
+    else CDRL_X3B(false);
+#undef CDRL_X3B
     CDRL_LAUNCH_CHECK();
     return 0;
 }

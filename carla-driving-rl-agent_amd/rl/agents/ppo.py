@@ -213,9 +213,17 @@ class PPOAgent(Agent):
                     self.statistics.stats = {}
                 self.on_episode_end()
                 if episode % save_period == 0:
+                    # the writer's failure (disk full, permissions) must not leave the other ranks waiting in a bare barrier until the
+                    # process-group timeout: the meeting point carries a status flag and every rank raises
+                    failure = None
                     if self.is_writer():
-                        self.save()
-                    self.rank_barrier()
+                        try:
+                            self.save()
+                        except Exception as exc:       # noqa: BLE001 -- re-raised below, on every rank
+                            failure = exc
+                    self.rank_barrier(failed=failure is not None)
+                    if failure is not None:
+                        raise failure
         finally:
             if close:
                 for env in shard:
@@ -225,8 +233,9 @@ class PPOAgent(Agent):
         """Hook for data-parallel agents: the rank that writes checkpoints, summaries and traces."""
         return True
 
-    def rank_barrier(self):
-        """Hook for data-parallel agents: all ranks meet here after the writer has written."""
+    def rank_barrier(self, failed: bool = False):
+        """Hook for data-parallel agents: all ranks meet here after the writer has written; `failed` = this rank's write raised --
+        the hook must make EVERY rank raise then."""
 
     def observe(self, observations: list, preprocess_fn) -> dict:
         """Per-environment observations -> one dict of (E, ...) device tensors: keys get the reference's `state_` prefix, the
@@ -309,6 +318,7 @@ class PPOAgent(Agent):
             self.trajectory_stored(e, rollout)
             if keep_open or e < E - 1:
                 self.memory.drop_bootstrap()
+        rollout.blocks = None               # the trajectories were copied into the memory: release the timesteps-long staging blocks
 
     def trajectory_stored(self, env_index: int, rollout: 'Rollout'):
         """Hook: environment `env_index`'s trajectory of this rollout now sits at the end of the memory."""
@@ -386,7 +396,9 @@ class Rollout:
     def trajectory(self, e: int):
         """-> (states, actions, rewards, values, log_probs) of environment e: its first `length[e]` steps."""
         n = self.length[e]
-        take = lambda k: self.blocks[k][:n, e].contiguous()
+        # a COPY of the environment's rows: for one environment `[:n, 0].contiguous()` would be a view that keeps the whole
+        # timesteps-long block alive inside the memory after an early episode end (ADVICE r5)
+        take = lambda k: self.blocks[k][:n, e].clone(memory_format=torch.contiguous_format)
         states = {k: take(k) for k in self.blocks if not k.startswith('/')}
         return states, take('/action'), self.rewards[e][:n], take('/value'), take('/log_prob')
 

@@ -297,9 +297,16 @@ def save_checkpoint(prefix: str, tensors: Dict[str, np.ndarray], full_names: Dic
     # a torn file, and an index never points at shards that are not there yet
     for suffix, blob in (('.data-00000-of-00002', shard0), ('.data-00001-of-00002', bytes(shard1)), ('.index', bytes(index))):
         tmp = f'{prefix}{suffix}.tmp{os.getpid()}'
-        with open(tmp, 'wb') as f:
-            f.write(blob)
-        os.replace(tmp, prefix + suffix)
+        try:
+            with open(tmp, 'wb') as f:
+                f.write(blob)
+            os.replace(tmp, prefix + suffix)
+        except BaseException:
+            try:                            # no temporary file left behind by a failed write (disk full, permissions)
+                os.unlink(tmp)
+            except OSError:
+                pass
+            raise
 
 
 def keras_full_names(model: str, stage_n=(4, 8, 4)) -> Dict[str, str]:

@@ -246,6 +246,18 @@ int cdrl_pwconv_x3_partial_rows(int G, int Mg, int N, int K);
 int cdrl_pwconv_x3_pack(const float* W, int K, int N, int sbk, int sbn, void* packed, void* stream);
 int cdrl_pwconv_x3(const float* A, int lda, int a_coff, const float* pro_stats, const void* W_packed, const float* bias, float* C,
                    int ldc, int c_coff, int G, int Mg, int N, int K, double* part, void* stream);
+/* Backward-data of those wide convs (128 < Cin or Cout <= 256, Cout % 4 == 0) with the BatchNorm backward of the BatchNorm behind the conv
+ * applied on load (core/architectures.py:130-141 under tape.gradient): da[G*Mg][ldda] (+ da_coff; += when accumulate) = dy W^T with
+ * dy = k1 (mask dz - k2 - xhat(y) k3); dz [G*Mg][ld_dz] (+ dz_coff, gathered through the channel shuffle of dz_shuffle channels when
+ * non-zero, ReLU6-masked from the BatchNorm output when act), y [G*Mg][Cout] raw conv output, stats [4][G][Cout] / coef [3][G][Cout].
+ * W_packed: cdrl_pwconv_x3_pack(W, Cout, Cin, 1, Cout, ...) with cdrl_pwconv_x3_packed_bytes_n(Cout, Cin) bytes.  part2 (or NULL):
+ * [G][rows][Cout] column sums of dy (the conv's bias gradient partials), rows = cdrl_pwconv_x3_wide_bwd_rows(Mg) (one per 32-row tile).
+ * ey / epi_stats / part (all or none; not with accumulate): (sum da, sum da xhat(ey)) of the BatchNorm whose raw input is ey [G*Mg][Cin],
+ * part [G][rows][2][Cin].  float32 tensors only. */
+int cdrl_pwconv_x3_wide_bwd_rows(int Mg);
+int cdrl_pwconv_x3_wide_bwd(const float* dz, int ld_dz, int dz_coff, int dz_shuffle, int act, const float* y, const float* stats,
+                            const float* coef, const void* W_packed, float* da, int ldda, int da_coff, int accumulate, int G, int Mg,
+                            int Cin, int Cout, double* part2, const float* ey, const float* epi_stats, double* part, void* stream);
 
 
 /* Backward of the unit's 1x1 convolution + BatchNorm (core/architectures.py:130-141 under tape.gradient, core/carla_agent.py:

@@ -9,6 +9,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -258,3 +259,55 @@ def test_minibatch_count_is_agreed_collectively_with_unequal_shards(tmp_path):
         full_idx = [i for i, r in enumerate(case[0]) if r == 4][:case[2]]
         rag_idx = [i for i, r in enumerate(case[0]) if r != 4] if case[3] else []
         assert a[2] == full_idx + rag_idx, (case, a)
+
+
+# ---- a writer rank whose save() raises must take every rank down, not leave them in a barrier --------------------------
+def _writer_failure_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from carla_driving_rl_agent_amd.core import CARLAgent
+
+    class Stub:
+        data_parallel, device = True, 'cpu'
+        rank_barrier = CARLAgent.rank_barrier
+
+    stub, got = Stub(), []
+    stub.rank_barrier(failed=False)                     # healthy round: nobody raises
+    got.append('ok')
+    try:                                                # the writer (rank 0) failed: the other rank raises at the meeting point
+        stub.rank_barrier(failed=(rank == 0))
+        got.append('writer' if rank == 0 else 'missed')
+    except RuntimeError as exc:
+        got.append(f'raised: {exc}')
+    torch.save(got, os.path.join(out, f'wf{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_writer_failure_reaches_every_rank(tmp_path):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_writer_failure_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = torch.load(tmp_path / 'wf0.pt'), torch.load(tmp_path / 'wf1.pt')
+    assert g0 == ['ok', 'writer']                       # (the writer re-raises its own exception in learn())
+    assert g1[0] == 'ok' and g1[1].startswith('raised: data-parallel learn(): the writer rank failed')
+
+
+def test_checkpoint_writer_leaves_no_temporary_file_behind_on_failure(tmp_path, monkeypatch):
+    from carla_driving_rl_agent_amd import tf_checkpoint as TC
+    import numpy as np
+    real_replace = os.replace
+
+    def failing_replace(src, dst):
+        if dst.endswith('.index'):
+            raise OSError('disk full (injected)')
+        return real_replace(src, dst)
+
+    monkeypatch.setattr(os, 'replace', failing_replace)
+    prefix = str(tmp_path / 'net')
+    with pytest.raises(OSError):
+        TC.save_checkpoint(prefix, {'layer_with_weights-0/kernel': np.zeros((3, 2), np.float32)})
+    assert not [f for f in os.listdir(tmp_path) if '.tmp' in f]

@@ -126,7 +126,7 @@ def test_pwconv_fused(lib, G, Mg, K, N, pro, epi, bt):
 
 @pytest.mark.parametrize('G,Mg,K,N,relu,shuffle,xpro', [(4, 330, 58, 58, 1, 1, 0), (4, 96, 116, 116, 1, 1, 1), (2, 500, 24, 58, 1, 0, 0),
                                                         (4, 257, 58, 24, 0, 0, 1), (4, 1500, 116, 116, 1, 1, 1), (1, 64, 58, 116, 0, 0, 0),
-                                                        (4, 120, 232, 232, 1, 1, 1)])
+                                                        (4, 120, 232, 232, 1, 1, 1), (4, 3072, 232, 232, 1, 1, 1), (2, 777, 232, 232, 0, 0, 0)])
 def test_pwconv_bn_bwd(lib, G, Mg, K, N, relu, shuffle, xpro):
     """Backward of conv1x1 -> BN(train, per time slice) (+ReLU6) (+shuffled store) with the BN-backward apply fused
     into the operand loads of the backward-data and filter-gradient GEMMs: against torch autograd."""
@@ -735,6 +735,70 @@ def test_pwconv_x3_split(lib, G, Mg, K, N, pro):
         gc = got.contiguous()
         _lib.check(lib.cdrl_pwconv_x3(P(gc), N, 0, None, P(wp2), None, P(d), K, 0, G, Mg, K, N, None, S()))
         assert rel_err(d.cpu().numpy(), (gc.double() @ w.double().t()).cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('G,Mg,Cin,Cout,shuffle,act,epi,acc', [(4, 3072, 232, 232, 1, 1, 1, 0), (4, 3072, 232, 232, 0, 0, 0, 0), (4, 1000, 232, 232, 0, 0, 0, 1),
+                                                               (2, 333, 232, 140, 1, 1, 0, 1), (3, 97, 116, 232, 0, 1, 1, 0), (1, 64, 232, 232, 1, 0, 0, 0)])
+def test_pwconv_x3_wide_bwd(lib, G, Mg, Cin, Cout, shuffle, act, epi, acc):
+    """Round 6: backward-data of the 232-channel convs (stage 2) on the one-tile-per-workgroup split-precision kernel, with the
+    BatchNorm-backward prologue (shuffle gather, ReLU6 mask), the column sums of dy, the BatchNorm-sum epilogue and the accumulate
+    variant -- against a float64 evaluation of the same formulas (reference: tape.gradient through Conv2D(k=1) -> BatchNormalization,
+    core/architectures.py:130-141)."""
+    rng = np.random.default_rng(G * Mg + Cin + Cout + 7 * shuffle + 3 * act + epi + 2 * acc)
+    M = G * Mg
+    ctot = 2 * Cout if shuffle else Cout + 8
+    coff = Cout if shuffle else 4
+    dz = rng.standard_normal((M, ctot)).astype(np.float32)
+    y = (rng.standard_normal((M, Cout)) * 1.5 + 1.0).astype(np.float32)
+    stats = np.stack([rng.uniform(0.5, 1.5, (G, Cout)), rng.uniform(0.5, 1.5, (G, Cout)), rng.uniform(0.5, 1.5, (G, Cout)),
+                      rng.uniform(-0.5, 2.0, (G, Cout))]).astype(np.float32)
+    coef = np.stack([rng.uniform(0.5, 1.5, (G, Cout)), rng.uniform(-0.1, 0.1, (G, Cout)), rng.uniform(-0.1, 0.1, (G, Cout))]).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout)) / np.sqrt(Cout)).astype(np.float32)
+    idx = [((coff + c) & 1) * (ctot // 2) + ((coff + c) >> 1) for c in range(Cout)] if shuffle else [coff + c for c in range(Cout)]
+    d64 = dz[:, idx].astype(np.float64).reshape(G, Mg, Cout)
+    y64 = y.astype(np.float64).reshape(G, Mg, Cout)
+    st = stats.astype(np.float64)[:, :, None, :]
+    cf = coef.astype(np.float64)[:, :, None, :]
+    if act:
+        z = (st[2] * y64 + st[3]).astype(np.float32)        # fmaf(scale, y, shift): one float32 rounding
+        d64 = d64 * ((z > 0) & (z < 6))
+    xh = (y64 - st[0]) * st[1]
+    dy = cf[0] * (d64 - cf[1] - xh * cf[2])
+    ref = (dy.reshape(M, Cout) @ w.astype(np.float64).T)
+    ldda, dco = Cin + 8, 4
+    da0 = rng.standard_normal((M, ldda)).astype(np.float32)
+    if acc:
+        ref_out = ref + da0[:, dco:dco + Cin]
+    else:
+        ref_out = ref
+    DZ, Y, ST, CF, Wd, DA = dev(dz), dev(y), dev(stats), dev(coef), dev(w), dev(da0)
+    wp = torch.zeros(int(lib.cdrl_pwconv_x3_packed_bytes_n(Cout, Cin)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cdrl_pwconv_x3_pack(P(Wd), Cout, Cin, 1, Cout, P(wp), S()))
+    rows = int(lib.cdrl_pwconv_x3_wide_bwd_rows(Mg))
+    part2 = torch.zeros((G, rows, Cout), dtype=torch.float64, device=DEV)
+    ey = est = part = None
+    if epi:
+        ey_np = rng.standard_normal((M, Cin)).astype(np.float32)
+        est_np = np.stack([rng.uniform(-0.5, 0.5, (G, Cin)), rng.uniform(0.5, 1.5, (G, Cin)), np.ones((G, Cin)), np.zeros((G, Cin))]).astype(np.float32)
+        ey, est = dev(ey_np), dev(est_np)
+        part = torch.zeros((G, rows, 2, Cin), dtype=torch.float64, device=DEV)
+    _lib.check(lib.cdrl_pwconv_x3_wide_bwd(P(DZ), ctot, coff, ctot if shuffle else 0, act, P(Y), P(ST), P(CF), P(wp), P(DA), ldda, dco, acc, G, Mg,
+                                           Cin, Cout, P(part2), P(ey), P(est), P(part), S()))
+    got = DA.cpu().numpy()
+    assert rel_err(got[:, dco:dco + Cin], ref_out) < 1e-5
+    assert np.array_equal(got[:, :dco], da0[:, :dco]) and np.array_equal(got[:, dco + Cin:], da0[:, dco + Cin:])        # padding untouched
+    assert rel_err(part2.sum(dim=1).cpu().numpy(), dy.sum(axis=1)) < 1e-6
+    if epi:
+        g3 = (got[:, dco:dco + Cin].astype(np.float64) - (da0[:, dco:dco + Cin] if acc else 0.0)).reshape(G, Mg, Cin)
+        xe = (ey_np.astype(np.float64).reshape(G, Mg, Cin) - est_np[0].astype(np.float64)[:, None, :]) * est_np[1].astype(np.float64)[:, None, :]
+        ps = part.sum(dim=1).cpu().numpy()
+        assert rel_err(ps[:, 0], g3.sum(axis=1)) < 1e-9 and rel_err(ps[:, 1], (g3 * xe).sum(axis=1)) < 1e-9
+    # bit-wise reproducible
+    DA2 = dev(da0)
+    part2b = torch.zeros_like(part2)
+    _lib.check(lib.cdrl_pwconv_x3_wide_bwd(P(DZ), ctot, coff, ctot if shuffle else 0, act, P(Y), P(ST), P(CF), P(wp), P(DA2), ldda, dco, acc, G, Mg,
+                                           Cin, Cout, P(part2b), P(ey), P(est), P(part), S()))
+    assert torch.equal(DA, DA2) and torch.equal(part2, part2b)
 
 
 @pytest.mark.parametrize('M,K,N', [(12288, 464, 768), (12288, 768, 464), (1000, 232, 232), (130, 464, 768), (4099, 60, 92), (257, 16, 8)])

@@ -79,8 +79,16 @@ def test_fused_conv_backward_agrees_with_the_two_kernel_backward_at_full_size(tm
     # Since round 5 the LAST conv of the backward (24 -> 58 channels on the pooled stem output) is fused too: the gradient it
     # accumulates into the pooled stem output then differs between the two runs at the 1e-6 level, and the stem BatchNorm's dbeta / dgamma
     # -- sums of that gradient over 16 M elements of both signs, the end of the chain -- see it amplified: measured 8.7e-5 / 1.1e-5 of
-    # their scale between the two float32 paths (each is within 7e-5 of the float64 oracle in smoke()); they get north_star's 1e-4.
-    bad = {k: v for k, v in w.items() if v >= (1e-4 if k.startswith('trunk/img.stem.bn.') else 5e-5)}
+    # their scale between the two float32 paths.  Each path is held to the float64 oracle at north_star's 1e-4 elsewhere (smoke(),
+    # test_pinned_decisions_*: measured <= 7e-5 for these two tensors); two such paths may sit up to twice that apart, so the gate
+    # BETWEEN them is 2e-4 (a 1e-4 gate with 8.7e-5 measured would flake across boxes) and the measured value is recorded.
+    stem_bn = {k: v for k, v in w.items() if k.startswith('trunk/img.stem.bn.')}
+    print('[fused conv backward vs two-kernel backward] stem BatchNorm gradients between the two float32 paths:', stem_bn)
+    import json, os
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/paths_fused_vs_two_kernel_backward.json', 'w') as f:
+        json.dump(dict(worst=worst, stem_bn=stem_bn, gates=dict(stem_bn=2e-4, others=5e-5)), f, indent=1)
+    bad = {k: v for k, v in w.items() if v >= (2e-4 if k.startswith('trunk/img.stem.bn.') else 5e-5)}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])
     gmax = max(v.abs().max().item() for k, v in a0.items() if k.startswith('trunk/'))
     for k in a1:        # the zero gradients stay negligible next to the real ones
