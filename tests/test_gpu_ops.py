@@ -792,7 +792,8 @@ def test_pwconv_x3_wide_bwd(lib, G, Mg, Cin, Cout, shuffle, act, epi, acc):
         g3 = (got[:, dco:dco + Cin].astype(np.float64) - (da0[:, dco:dco + Cin] if acc else 0.0)).reshape(G, Mg, Cin)
         xe = (ey_np.astype(np.float64).reshape(G, Mg, Cin) - est_np[0].astype(np.float64)[:, None, :]) * est_np[1].astype(np.float64)[:, None, :]
         ps = part.sum(dim=1).cpu().numpy()
-        assert rel_err(ps[:, 0], g3.sum(axis=1)) < 1e-9 and rel_err(ps[:, 1], (g3 * xe).sum(axis=1)) < 1e-9
+        # (xhat is evaluated in float32 by the kernel, as by pw_nn's epilogue: 3-4e-8 measured)
+        assert rel_err(ps[:, 0], g3.sum(axis=1)) < 1e-9 and rel_err(ps[:, 1], (g3 * xe).sum(axis=1)) < 1e-6
     # bit-wise reproducible
     DA2 = dev(da0)
     part2b = torch.zeros_like(part2)
