@@ -258,9 +258,9 @@ private:
     int fused_bb_ = 1;
     bool fused_bwd_ = true;             // backward-data + filter gradient of the unit convs as one kernel (gemm_pw_bwd.hip)
     int pw_fwd_nbpg(int G, int Mg, int N, int K) const;    // statistics partial rows per group written by a unit conv's forward
-    bool pw_bwd_x3_wide(int N, int K) const;               // backward-data on pw_x3_wide_bwd_kernel (N = conv inputs, K = conv outputs)
+    bool pw_bwd_x3_wide(int G, int Mg, int N, int K) const;               // backward-data on pw_x3_wide_bwd_kernel (N = conv inputs, K = conv outputs)
     int pw_bwd_nbpg(int G, int Mg, int N, int K) const;    // partial rows per group of a unit conv's backward-data (bias sums, BatchNorm sums)
-    bool pw_fwd_x3_wide(int N, int K) const;               // that forward runs on pw_x3_wide_kernel (float32 engine, 128 < K or N <= 256)
+    bool pw_fwd_x3_wide(int G, int Mg, int N, int K) const;               // that forward runs on pw_x3_wide_kernel (float32 engine, 128 < K or N <= 256)
     void add_dense(std::vector<Op>& ops, int model, const std::string& prefix, View in, int M, int K, int N, int act,
                    View out, View dout, View din, int din_acc, bool need_din, const char* bias_init);
     void add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, int In, int u, View out, View dout,

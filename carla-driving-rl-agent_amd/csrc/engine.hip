@@ -443,25 +443,30 @@ const void* Learner::pw_x3_packed(const float* w, int K, int N, int sbk, int sbn
 int Learner::pw_fwd_nbpg(int G, int Mg, int N, int K) const {
     // float32 engine, K or N above 128 (stage 2): the forward runs on the one-tile-per-workgroup split-precision kernel
     // (gemm_pw_x3.hip pw_x3_wide_kernel), which writes one statistics row per 32-row tile
-    if (pw_fwd_x3_wide(N, K)) return pw_x3_partial_rows(G, Mg, N, K);
+    if (pw_fwd_x3_wide(G, Mg, N, K)) return pw_x3_partial_rows(G, Mg, N, K);
     return pw_nn_plan(G, Mg, N, K).nbpg;
 }
 
 // backward-data of the same convs (N = conv input channels, K = conv output channels): pw_x3_wide_bwd_kernel, one part2 / part row per tile
-bool Learner::pw_bwd_x3_wide(int N, int K) const {
+// Small products only (M = 12288 rows at B = 256: the 3x4-pixel maps of stage 2): every workgroup streams its block of W^T once, so at
+// M = 49152 (the stride-2 unit's first conv, on the 6x8 maps) the fragment traffic (3072 x 196 KB) outweighs what the persistent kernel
+// loses to its serial tiles -- measured in the step: 140 us against 100 us there, 36 against 53 us (BatchNorm-sum epilogue) at M = 12288.
+bool Learner::pw_bwd_x3_wide(int G, int Mg, int N, int K) const {
     static const bool on = !(cdrl_getenv("CDRL_PW_X3_WIDE_BWD") && atoi(cdrl_getenv("CDRL_PW_X3_WIDE_BWD")) == 0);
-    return on && pw_fwd_x3_wide(N, K);
+    return on && pw_fwd_x3_wide(G, Mg, N, K) && (int64_t)G * Mg <= 16384;
 }
 
 int Learner::pw_bwd_nbpg(int G, int Mg, int N, int K) const {
-    if (pw_bwd_x3_wide(N, K)) return pw_x3_wide_bwd_rows(Mg);
+    if (pw_bwd_x3_wide(G, Mg, N, K)) return pw_x3_wide_bwd_rows(Mg);
     return pw_nn_plan(G, Mg, N, K).nbpg;
 }
 
-bool Learner::pw_fwd_x3_wide(int N, int K) const {
+bool Learner::pw_fwd_x3_wide(int G, int Mg, int N, int K) const {
     static const bool x3_env = !(cdrl_getenv("CDRL_PW_X3") && atoi(cdrl_getenv("CDRL_PW_X3")) == 0);
     static const bool wide_env = !(cdrl_getenv("CDRL_PW_X3_WIDE") && atoi(cdrl_getenv("CDRL_PW_X3_WIDE")) == 0);
-    return cfg_.compute == 0 && x3_env && wide_env && (K > 128 || N > 128) && K <= 256 && N <= 256 && K % 4 == 0;
+    // (measured at M = 12288 and 49152 rows: 16-20 against 26-36 us, ~60 against 80 us; beyond that every 32-row tile would still stream
+    //  its own copy of W -- 196 KB per tile and column block -- and the persistent kernel keeps the shape)
+    return cfg_.compute == 0 && x3_env && wide_env && (K > 128 || N > 128) && K <= 256 && N <= 256 && K % 4 == 0 && (int64_t)G * Mg <= 49152;
 }
 
 const void* Learner::gemm_x3_packed(const float* w, int K, int N, int sbk, int sbn) {
@@ -592,9 +597,9 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     const int at = at_;
     // forward on the bf16 matrix pipe (exact three-way operand split, gemm_pw_x3.hip) where the shape allows it
     static const bool x3_env = !(cdrl_getenv("CDRL_PW_X3") && atoi(cdrl_getenv("CDRL_PW_X3")) == 0);
-    const bool x3_shape = (Cin <= 128 && Cout <= 128) || pw_fwd_x3_wide(Cout, Cin);
+    const bool x3_shape = (Cin <= 128 && Cout <= 128) || pw_fwd_x3_wide(G, Mg, Cout, Cin);
     const void* w3f = (!bfc && x3_env && fuse.fwd_pw && x3_shape && pw_x3_supported(in, Cout, Cin)) ? pw_x3_packed(w.p, Cin, Cout, Cout, 1) : nullptr;
-    if (fuse.fwd_pw && pw_fwd_x3_wide(Cout, Cin) && !w3f && !dry_)
+    if (fuse.fwd_pw && pw_fwd_x3_wide(G, Mg, Cout, Cin) && !w3f && !dry_)
         build_fail("%s: the wide split-precision forward needs 16-byte aligned input rows (ld %d, offset %d)", prefix.c_str(), in.ld, in.coff);
     const int nb_fwd = pw_fwd_nbpg(G, Mg, Cout, Cin);
     // plain (unfused) wide convs -- the 464 -> 768 head conv, the 232-wide shortcut conv -- on the bf16 matrix pipe too (gemm_x3.hip)
@@ -641,7 +646,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
                       (anorm || !fuse.bwd_ey);
     // 232-channel convs (stage 2), float32: backward-data with the BatchNorm-backward prologue on the one-tile-per-workgroup
     // split-precision kernel (round 6; the filter gradient stays on the side stream)
-    const bool wbw = !bfc && !at && fuse.bb && fuse.bwd_pw && !fbwd && pw_bwd_x3_wide(Cin, Cout);
+    const bool wbw = !bfc && !at && fuse.bb && fuse.bwd_pw && !fbwd && pw_bwd_x3_wide(G, Mg, Cin, Cout);
     if (wbw && !pw_x3_wide_bwd_supported(dz_probe, din, Cin, Cout, fuse.bb_shuffle))
         build_fail("%s: the wide split-precision backward needs even / 16-byte aligned gradient rows (ld %d, offset %d, shuffle %d)", prefix.c_str(),
                    dz_probe.ld, dz_probe.coff, fuse.bb_shuffle);
