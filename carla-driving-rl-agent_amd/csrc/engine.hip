@@ -585,6 +585,8 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     PRef w = param(M_TRUNK, prefix + ".w", {1, 1, Cin, Cout}, true);
     PRef b = param(M_TRUNK, prefix + ".b", {Cout}, true);
     const int G = cfg_.T, Mg = rows / G;
+    Scratch* sc = build_scr_;           // statistics / BatchNorm-sum partials: the scratch of the stream this op's forward runs on (the shortcut
+                                        // branch of a stride-2 unit runs beside the main branch and has its own)
     static const bool pack_env = true;
     static const bool wt_env = true;
     const float* wt = (wt_env && !pack_env && fuse.bwd_pw) ? pw_transposed(prefix, w.p, Cin, Cout) : nullptr;
@@ -622,11 +624,11 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
         if (w3f)
-            return pw_x3(in, fuse.pro_stats, w3f, b.p, make_view(y, Cout), G, Mg, Cout, Cin, fuse.epi_stats ? scr_main_.part : nullptr, st,
+            return pw_x3(in, fuse.pro_stats, w3f, b.p, make_view(y, Cout), G, Mg, Cout, Cin, fuse.epi_stats ? sc->part : nullptr, st,
                          nb_fwd);
         if (fuse.fwd_pw)
             return pw_nn(in, fuse.pro_stats, w.p, Cout, 1, b.p, make_view(y, Cout), 0, G, Mg, Cout, Cin, fuse.epi_stats ? 1 : 0,
-                         nullptr, nullptr, scr_main_.part, st, nullptr, wpf, bfc, at);
+                         nullptr, nullptr, sc->part, st, nullptr, wpf, bfc, at);
         if (g3f) return gemm_x3(in, g3f, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st, bfc, at);
         return gemm_nn(in, w.p, Cout, 1, b.p, make_view(y, Cout), rows, Cout, Cin, 0, st);
     };
@@ -724,10 +726,10 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
             PwBnBwd pb{y, fuse.bb_stats, fuse.bb_coef, fuse.bb_shuffle, fuse.bb_act, part2s_[slot_]};
             if (wbw)
                 CDRL_TRY(pw_x3_wide_bwd(dz, pb, wpx, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey, fuse.bwd_epi_stats,
-                                        fuse.bwd_ey ? scr_main_.part : nullptr, st));
+                                        fuse.bwd_ey ? sc->part : nullptr, st));
             else
                 CDRL_TRY(pw_nn(dz, nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout, fuse.bwd_ey ? 2 : 0, fuse.bwd_ey,
-                               fuse.bwd_epi_stats, scr_main_.part, st, &pb, wpb, bfc, at));
+                               fuse.bwd_epi_stats, sc->part, st, &pb, wpb, bfc, at));
             // bias gradient = column sums of the (virtual) dy, reduced from the GEMM's partials: rides on the next fork
             double* p2 = part2s_[slot_];
             return defer_side(st, [=](hipStream_t sd) -> int { return reduce_partials(p2, G * nbp_bwd, Cout, Cout, b.g, 0, sd); });
@@ -742,7 +744,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
         if (din.p) {
             if (fuse.bwd_pw)
                 return pw_nn(make_view(dy, Cout), nullptr, wb, wb_sk, wb_sn, nullptr, din, din_acc, G, Mg, Cin, Cout,
-                             fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, scr_main_.part, st, nullptr, wpb, bfc, at);
+                             fuse.bwd_ey ? 2 : 0, fuse.bwd_ey, fuse.bwd_epi_stats, sc->part, st, nullptr, wpb, bfc, at);
             if (g3b) return gemm_x3(make_view(dy, Cout), g3b, nullptr, din, rows, Cin, Cout, din_acc, st, bfc, at);
             CDRL_TRY(gemm_nn(make_view(dy, Cout), w.p, 1, Cout, nullptr, din, rows, Cin, Cout, din_acc, st));
         }
@@ -1368,6 +1370,60 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     const size_t sc_begin = ops.size();
                     if (sc_overlap) build_scr_ = &scr_sc_;
                     Tens ys1 = tens_a(rows_out, sc_c, false), b1 = tens_a(rows_out, sc_c);
+                    // Round 6: the shortcut branch dw3x3/s2 -> BN -> 1x1 -> BN+ReLU6 (core/architectures.py:133-137) is the second half of a
+                    // main branch and runs on the same fused ops: BN-apply of sc_bn1 on the conv's operand load (its output is never
+                    // written), statistics of sc_bn2 in the conv's epilogue, and in the backward the BatchNorm-backward of sc_bn2 as the
+                    // conv's operand prologue, sc_bn1's backward sums out of the conv backward (fused conv backward: stages 0 / 1; the
+                    // BatchNorm-sum epilogue of the wide kernel: stage 2).  Before: 3 more launches per stride-2 unit on the critical
+                    // stream of every backward (apply of sc_bn2, reduce + finalize of sc_bn1) and two on the forward's side stream.
+                    static const bool sc_fused_env = !(cdrl_getenv("CDRL_FUSED_SC") && atoi(cdrl_getenv("CDRL_FUSED_SC")) == 0);
+                    const bool sc_fpw = sc_fused_env && fused_dw_ && fused_pw_ && (fused_pw_wide_ || sc_c <= 128) && (fused_bb_ & 2) &&
+                                        gemm_tn_dpro_supported(sc_c) && pw_nn_supported(ys1.v(), sc_c, sc_c);
+                    if (sc_fpw) {
+                        const int nbb_sc = pw_bwd_nbpg(T, Mg_out, sc_c, sc_c);      // conv backward-data epilogue rows (BatchNorm sums of sc_bn1)
+                        float* coef_s1 = nullptr;
+                        std::shared_ptr<bool> s1_done = std::make_shared<bool>(false);
+                        float* stats_s1 = add_dw_block(ops, pre, nullptr, "sc_dw", "sc_bn1", X.p, curH, curW, sc_c, 2, ys1.p, b1.v(), b1.gv(),
+                                                       X.gv(0), 0, false, nbb_sc, nullptr, nullptr, false, &coef_s1, s1_done, nullptr);
+                        Tens ys2 = tens_a(rows_out, sc_c, false);
+                        PwFuse fs;
+                        fs.fwd_pw = true;
+                        fs.pro_stats = stats_s1;
+                        fs.epi_stats = true;
+                        fs.bwd_pw = true;
+                        fs.bwd_ey = ys1.p;
+                        fs.bwd_epi_stats = stats_s1;
+                        {
+                            PRef g1 = param(M_TRUNK, pre + ".sc_bn1.gamma", {sc_c}, true), bt1 = param(M_TRUNK, pre + ".sc_bn1.beta", {sc_c}, true);
+                            fs.a_gamma = g1.p;
+                            fs.a_beta = bt1.p;
+                            fs.a_dgamma = g1.g;
+                            fs.a_dbeta = bt1.g;
+                            fs.a_coef = coef_s1;
+                            fs.a_bn = true;
+                        }
+                        const size_t scpw_at = ops.size();
+                        add_pw(ops, pre + ".sc_pw", ys1.v(), rows_out, sc_c, sc_c, ys2.p, b1.gv(), 0, bnrec(T, Mg_out, sc_c), fs);
+                        BnRec rs = add_bn(ops, M_TRUNK, pre + ".sc_bn2", ys2.v(), T, Mg_out, sc_c, true, ACT_RELU6, out.v(0), C, out.gv(0), C,
+                                          nullptr, pw_fwd_nbpg(T, Mg_out, sc_c, sc_c), true);
+                        fs.bb = true;
+                        fs.bb_stats = rs.stats;
+                        fs.bb_coef = rs.coef;
+                        fs.bb_dz = out.gv(0);
+                        fs.bb_shuffle = C;
+                        fs.bb_act = ACT_RELU6;
+                        fs.bb_claim_slot = true;
+                        fs.a_bn_done = s1_done;
+                        fs.bb_fin = true;
+                        fs.bb_fin_part = rs.part_ptr;
+                        fs.bb_fin_nb = rs.nb;
+                        fs.bb_dgamma = rs.dgamma;
+                        fs.bb_dbeta = rs.dbeta;
+                        fs.bb_fin_done = rs.fin_by_consumer;
+                        std::vector<Op> tmp;
+                        add_pw(tmp, pre + ".sc_pw", ys1.v(), rows_out, sc_c, sc_c, ys2.p, b1.gv(), 0, bnrec(T, Mg_out, sc_c), fs);
+                        ops[scpw_at] = tmp[0];
+                    } else {
                     if (fused_dw_) {
                         add_dw_block(ops, pre, nullptr, "sc_dw", "sc_bn1", X.p, curH, curW, sc_c, 2, ys1.p, b1.v(), b1.gv(),
                                      X.gv(0));
@@ -1380,6 +1436,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     add_pw(ops, pre + ".sc_pw", b1.v(), rows_out, sc_c, sc_c, ys2.p, b1.gv(), 0, bnrec(T, Mg_out, sc_c));
                     add_bn(ops, M_TRUNK, pre + ".sc_bn2", ys2.v(), T, Mg_out, sc_c, true, ACT_RELU6, out.v(0), C, out.gv(0),
                            C, nullptr);
+                    }
                     if (sc_overlap) {
                         build_scr_ = &scr_main_;
                         for (size_t i = sc_begin; i < ops.size(); ++i) {        // forward of the shortcut ops -> side stream
