@@ -243,6 +243,7 @@ struct PwX3Pack {
 bool pw_x3_supported(View A, int N, int K);
 int pw_x3_partial_rows(int G, int Mg, int N, int K);
 int64_t pw_x3_packed_bytes(int K);                 // N <= 128 (one column block)
+int pw_x3_ksteps(int K);                           // K = 16 steps per plane of that pack
 int64_t pw_x3_packed_bytes_n(int K, int N);        // any N <= 256: column blocks of 128
 PwX3Pack pw_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, int sbn);
 int pw_x3_pack_many(const PwX3Pack* tab_dev, int n, hipStream_t st);

@@ -41,6 +41,7 @@ struct PwbArgs {
     View a;                 // conv input [M][K]
     const float* a_stats;   // [4][G][K] (ANORM) or null
     const __bf16* Wp;       // W^T as three planes of MFMA B fragments: pw_x3 packing of B(k = n_out, n = k_in)
+    int wp_ks;              // K = 16 steps per plane of that pack (pw_x3_ksteps(n_out): 2 for n_out <= 32 -- fewer than NP / 16; the rest are zero)
     View da;
     float* qpart;           // [G][nbpg][KP][NP]
     double* dbpart;         // [G][nbpg][NP]
@@ -162,8 +163,15 @@ __global__ void __launch_bounds__(512, 1) pwb_kernel(PwbArgs a) {
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int s = 0; s < KS_DA; ++s)
-                    if (!(a.dbg & 32)) breg[p][s] = *reinterpret_cast<const bf16x8*>(a.Wp + (((int64_t)(p * KS_DA + s) * 2 + lk) * 128 + n) * 8);
+                for (int s = 0; s < KS_DA; ++s) {
+                    // (a pack of n_out <= 32 channels holds fewer K steps per plane than the padding NP / 16: round 6, the 24-channel
+                    //  shortcut conv -- reading past it multiplied garbage, NaN included, into the input gradient)
+                    bf16x8 z;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+                    breg[p][s] = z;
+                    if (!(a.dbg & 32) && s < a.wp_ks) breg[p][s] = *reinterpret_cast<const bf16x8*>(a.Wp + (((int64_t)(p * a.wp_ks + s) * 2 + lk) * 128 + n) * 8);
+                }
         }
         // the seven per-column coefficients live in LDS (28 registers otherwise: this role also holds the W^T fragments);
         // padded columns carry 0 everywhere, so their dy is 0
@@ -523,8 +531,13 @@ __global__ void __launch_bounds__(512, 4) pwb16_kernel(PwbArgs a) {
 
     if (role == 0) {
         const int dwr = wave % DA_WR, dwc = wave / DA_WR;
-        for (int i = tid; i < KS_DA * 2 * 128; i += 256)       // W^T fragments (plane 0 of the packed operand) -> LDS, once
-            *reinterpret_cast<bf16x8*>(&Wl[i * 8]) = *reinterpret_cast<const bf16x8*>(a.Wp + (int64_t)i * 8);
+        for (int i = tid; i < KS_DA * 2 * 128; i += 256) {     // W^T fragments (plane 0 of the packed operand) -> LDS, once
+            bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+            if (i < a.wp_ks * 2 * 128) z = *reinterpret_cast<const bf16x8*>(a.Wp + (int64_t)i * 8);      // (steps beyond the pack: zero)
+            *reinterpret_cast<bf16x8*>(&Wl[i * 8]) = z;
+        }
         const int GN = a.G * N;
         for (int i = tid; i < 7 * NP; i += 256) {
             const int q = i / NP, c = i % NP;
@@ -1117,6 +1130,7 @@ int pw_bwd_fused(const PwBwdFused& f, hipStream_t st) {
     a.a = f.a;
     a.a_stats = f.a_stats;
     a.Wp = reinterpret_cast<const __bf16*>(f.Wp);
+    a.wp_ks = pw_x3_ksteps(f.N);
     a.da = f.da;
     a.qpart = f.qpart;
     a.dbpart = f.dbpart;

@@ -536,6 +536,7 @@ __global__ void pw_x3_pack_many_kernel(const PwX3Pack* __restrict__ tab) {
 }
 
 int64_t pw_x3_packed_bytes(int K) { return (int64_t)3 * (x3_kp(K) / 16) * 2 * 128 * 8 * 2; }      // one column block (N <= 128)
+int pw_x3_ksteps(int K) { return x3_kp(K) / 16; }       // K = 16 steps per plane of a pack (K <= 128: 2 | 4 | 8)
 // (the wide form always runs with KP = 256: its kernel is instantiated for that padding only)
 int64_t pw_x3_packed_bytes_n(int K, int N) { return x3_wide(N, K) ? pw_x3_packed_bytes(256) * ((N + 127) / 128) : pw_x3_packed_bytes(K); }
 

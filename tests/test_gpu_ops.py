@@ -832,7 +832,8 @@ def test_gemm_x3_split(lib, M, K, N):
     (4, 330, 58, 58, 1, 1, 1, 0, 0), (4, 96, 116, 116, 1, 1, 1, 0, 0), (4, 4100, 116, 116, 1, 0, 0, 1, 0), (2, 77, 58, 58, 0, 0, 0, 1, 1),
     (4, 100, 116, 116, 1, 1, 1, 0, 1), (1, 64, 40, 60, 0, 0, 1, 0, 1), (2, 8300, 58, 58, 1, 1, 1, 0, 0), (4, 1500, 116, 116, 1, 1, 0, 0, 1),
     (4, 12288, 116, 116, 1, 1, 1, 0, 0), (4, 330, 58, 92, 1, 1, 1, 0, 0), (2, 4300, 58, 92, 1, 0, 0, 1, 1), (4, 77, 36, 100, 0, 1, 1, 0, 1),
-    (4, 2700, 24, 58, 1, 0, 0, 1, 0)])     # (last: the first unit's conv on the pooled stem output, accumulating -- fused since round 5)
+    (4, 2700, 24, 58, 1, 0, 0, 1, 0),      # (the first unit's conv on the pooled stem output, accumulating -- fused since round 5)
+    (4, 2700, 24, 24, 1, 1, 1, 0, 0), (2, 333, 32, 16, 0, 0, 1, 0, 1)])     # (round 6: the 24-channel shortcut conv; N <= 32: a weight pack of two K steps)
 def test_pwconv_bwd_fused(lib, G, Mg, K, N, relu, shuffle, anorm, acc, generic):
     """cdrl_pwconv_bwd_fused: BatchNorm-backward apply on load + backward-data + filter / bias gradient (+ the backward sums of
     the BatchNorm in FRONT of the conv, derived from the filter product) in one pass, against a float64 numpy evaluation of
@@ -936,7 +937,8 @@ def _bf(x):
 
 @pytest.mark.parametrize('G,Mg,K,N,relu,shuffle,anorm,acc', [
     (4, 330, 58, 58, 1, 1, 1, 0), (4, 96, 116, 116, 1, 1, 1, 0), (4, 4100, 116, 116, 1, 0, 0, 1), (2, 77, 58, 58, 0, 0, 0, 1),
-    (4, 100, 116, 116, 1, 1, 1, 0), (2, 8300, 58, 58, 1, 1, 1, 0), (4, 1500, 116, 116, 1, 1, 0, 0), (4, 12288, 116, 116, 1, 1, 1, 0)])
+    (4, 100, 116, 116, 1, 1, 1, 0), (2, 8300, 58, 58, 1, 1, 1, 0), (4, 1500, 116, 116, 1, 1, 0, 0), (4, 12288, 116, 116, 1, 1, 1, 0),
+    (4, 2700, 24, 24, 1, 1, 1, 0)])
 def test_pwconv_bwd_fused_bf16_storage(lib, G, Mg, K, N, relu, shuffle, anorm, acc):
     """The bf16-storage form of cdrl_pwconv_bwd_fused (configuration 3): bf16 tensors in HBM, float32 BatchNorm-backward prologue,
     ONE bf16 plane per MFMA operand.  Reference: float64 evaluation of the same contract -- dy, xhat / a and W rounded to bf16
