@@ -104,7 +104,6 @@ PROTOTYPES = {
     'cdrl_beta_sample_logp': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp]),
     'cdrl_beta_sample': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp, _fp, _fp]),
     'cdrl_gamma_implicit_grad': (_i, [_fp, _fp, _i, _fp, _fp]),
-    'cdrl_set_op_activation_type': (_i, [_i]),
     'cdrl_beta_sample_gammas': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp]),
     'cdrl_philox_words': (_i, [C.c_uint64, C.c_uint64, C.c_uint64, _i, _i, _fp, _fp]),
     'cdrl_learner_policy_apply': (_i, [_L, _fp]),
@@ -163,6 +162,46 @@ PROTOTYPES = {
 _lib = None
 
 
+# Op-level entry points whose ACTIVATION tensors may be bf16 (configuration 3's storage): the C ABI takes the element type as an explicit
+# `int act_type` argument (0 float32, 1 bf16) in front of the stream -- the library keeps no mode of its own (round 6; it had a
+# thread-local switch).  The prototypes above list the arguments WITHOUT it; it is spliced in here, and the binding object below offers
+# the tests a mode of its own (`lib.cdrl_set_op_activation_type(at)`, a Python attribute of the binding) that fills it in.
+ACT_TYPE_BEFORE_STREAM = ('cdrl_pwconv_bwd_fused', 'cdrl_gemm_tn', 'cdrl_gemm_x3', 'cdrl_stem_fwd_stats', 'cdrl_stem_block_bwd',
+                          'cdrl_stem_block_bwd_pooled', 'cdrl_pwconv_fused_packed', 'cdrl_pwconv_bn_bwd', 'cdrl_pwconv_bn_bwd_packed',
+                          'cdrl_dwconv_bn_fwd', 'cdrl_dwconv_bn_bwd', 'cdrl_bn_train_fwd', 'cdrl_bn_train_bwd', 'cdrl_maxpool_bn_fwd')
+ACT_TYPE_LAST = ('cdrl_pwconv_bwd_fused_workspace',)
+for _n in ACT_TYPE_BEFORE_STREAM:
+    _r, _a = PROTOTYPES[_n]
+    PROTOTYPES[_n] = (_r, list(_a[:-1]) + [_i, _a[-1]])
+for _n in ACT_TYPE_LAST:
+    _r, _a = PROTOTYPES[_n]
+    PROTOTYPES[_n] = (_r, list(_a) + [_i])
+
+
+class Binding:
+    """libcdrl_hip.so through ctypes.  Attribute access returns the C function; for the op-level entry points with an `act_type`
+    argument it returns a wrapper that fills the argument from `self.act_type` (0 unless a test sets it), so that callers spell the
+    float32 and the bf16-storage call alike.  `raw` is the ctypes library itself (every argument explicit)."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, 'raw', cdll)
+        object.__setattr__(self, 'act_type', 0)
+
+    def cdrl_set_op_activation_type(self, at: int) -> int:
+        if at not in (0, 1):
+            raise ValueError('activation type: 0 (float32) or 1 (bf16)')
+        object.__setattr__(self, 'act_type', int(at))
+        return 0
+
+    def __getattr__(self, name):
+        fn = getattr(self.raw, name)
+        if name in ACT_TYPE_BEFORE_STREAM:
+            return lambda *a: fn(*a[:-1], self.act_type, a[-1])
+        if name in ACT_TYPE_LAST:
+            return lambda *a: fn(*a, self.act_type)
+        return fn
+
+
 def load():
     """Loads libcdrl_hip.so; raises ImportError (never falls back) when it is absent."""
     global _lib
@@ -181,8 +220,8 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = Binding(lib)
+    return _lib
 
 
 def env_overrides():

@@ -21,19 +21,14 @@ static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); 
         return -1;                         \
     }
 
-// element type of the activation tensors handed to the OP-LEVEL entry points below (cdrl_set_op_activation_type): 0 float32, 1 bf16
-static thread_local int g_op_at = 0;
+// act_type of the op-level entry points below: element type of their ACTIVATION tensors -- 0 float32, 1 bf16 (configuration 3's storage)
+static inline bool bad_act_type(int at) {
+    if (at == 0 || at == 1) return false;
+    cdrl::set_error("act_type: 0 (float32) or 1 (bf16)");
+    return true;
+}
 
 extern "C" {
-
-int cdrl_set_op_activation_type(int at) {
-    if (at != 0 && at != 1) {
-        cdrl::set_error("cdrl_set_op_activation_type: 0 (float32) or 1 (bf16)");
-        return -1;
-    }
-    g_op_at = at;
-    return 0;
-}
 
 const char* cdrl_last_error(void) { return cdrl::last_error(); }
 int cdrl_version(void) { return CDRL_VERSION; }
@@ -459,15 +454,15 @@ int cdrl_pwconv_x3_wide_bwd(const float* dz, int ld_dz, int dz_coff, int dz_shuf
                           Cin, Cout, ey, epi_stats, part, S(stream));
 }
 
-int64_t cdrl_pwconv_bwd_fused_workspace(int G, int Mg, int N, int K, int which) {
-    return which == 0 ? pw_bwd_fused_qpart_elems(G, Mg, N, K, g_op_at) : pw_bwd_fused_dbpart_elems(G, Mg, N, K, g_op_at);
+int64_t cdrl_pwconv_bwd_fused_workspace(int G, int Mg, int N, int K, int which, int act_type) {
+    return which == 0 ? pw_bwd_fused_qpart_elems(G, Mg, N, K, act_type) : pw_bwd_fused_dbpart_elems(G, Mg, N, K, act_type);
 }
 
 int cdrl_pwconv_bwd_fused(const float* dz, int ld_dz, int dz_coff, int dz_shuffle, int act, const float* y, const float* stats,
                           const float* coef, const float* a, int lda, int a_coff, const float* a_stats, const float* a_gamma,
                           const float* a_beta, float* a_dgamma, float* a_dbeta, float* a_coef, const float* W, const void* W_packed,
                           float* da, int ldda, int da_coff, int accumulate, float* dW, float* db, float* qpart, double* dbpart, int G,
-                          int Mg, int N, int K, void* stream) {
+                          int Mg, int N, int K, int act_type, void* stream) {
     if (!dz || !y || !stats || !coef || !a || !W || !W_packed || !da || !dW || !db || !qpart || !dbpart) {
         cdrl::set_error("cdrl_pwconv_bwd_fused: null argument");
         return -1;
@@ -498,7 +493,7 @@ int cdrl_pwconv_bwd_fused(const float* dz, int ld_dz, int dz_coff, int dz_shuffl
     f.Mg = Mg;
     f.N = N;
     f.K = K;
-    f.at = g_op_at;
+    f.at = act_type;
     CDRL_TRY(pw_bwd_fused(f, S(stream)));
     return pw_bwd_fused_reduce(f, S(stream));
 }
@@ -517,13 +512,13 @@ int cdrl_gemm_x3_pack(const float* B, int K, int N, int sbk, int sbn, void* pack
 }
 
 int cdrl_gemm_x3(const float* A, int lda, int a_coff, const void* B_packed, const float* bias, float* C, int ldc, int c_coff, int M,
-                 int N, int K, int accumulate, void* stream) {
+                 int N, int K, int accumulate, int act_type, void* stream) {
     if (!A || !B_packed || !C) {
         cdrl::set_error("cdrl_gemm_x3: null argument");
         return -1;
     }
     return gemm_x3(make_view(const_cast<float*>(A), lda, a_coff), B_packed, bias, make_view(C, ldc, c_coff), M, N, K, accumulate,
-                   S(stream), g_op_at != 0, g_op_at);
+                   S(stream), act_type != 0, act_type);
 }
 
 int cdrl_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
@@ -589,9 +584,9 @@ int cdrl_gemm_nn(const float* A, int lda, int a_coff, const float* B, int sbk, i
 int64_t cdrl_gemm_tn_workspace_elems(int M, int N, int K) { return gemm_tn_part_elems(M, N, K); }
 
 int cdrl_gemm_tn(const float* A, int lda, int a_coff, const float* D, int ldd, int d_coff, float* out, int M, int N,
-                 int K, float* workspace, int accumulate, void* stream) {
+                 int K, float* workspace, int accumulate, int act_type, void* stream) {
     return gemm_tn(make_view(const_cast<float*>(A), lda, a_coff), make_view(const_cast<float*>(D), ldd, d_coff), out, M, N,
-                   K, workspace, accumulate, S(stream), 1, nullptr, nullptr, g_op_at != 0, g_op_at);
+                   K, workspace, accumulate, S(stream), 1, nullptr, nullptr, act_type != 0, act_type);
 }
 
 int cdrl_stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
@@ -602,8 +597,8 @@ int cdrl_stem_fwd(const float* x, const float* w, const float* bias, float* y, i
 int cdrl_stem_fwd_stats_rows(int B, int T, int H, int W, int Cout) { return stem_fwd_stats_nb(B, T, H, W, Cout); }
 
 int cdrl_stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* part, int B, int T, int H, int W, int Cout,
-                        void* stream) {
-    return stem_fwd_stats(x, w, bias, y, part, B, T, H, W, Cout, S(stream), g_op_at);
+                        int act_type, void* stream) {
+    return stem_fwd_stats(x, w, bias, y, part, B, T, H, W, Cout, S(stream), act_type);
 }
 
 int64_t cdrl_stem_bwd_workspace_doubles(int B, int T, int H, int W, int Cout) {
@@ -655,13 +650,13 @@ int64_t cdrl_stem_block_bwd_workspace_doubles(int B, int T, int H, int W, int Co
 
 int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, int B, int T,
                         int H, int W, int Cout, float* dgamma, float* dbeta, float* coef, float* dw, float* db,
-                        double* workspace, void* stream) {
-    return cdrl_stem_block_bwd_pooled(x, y, stats, argmax, dp, nullptr, B, T, H, W, Cout, dgamma, dbeta, coef, dw, db, workspace, stream);
+                        double* workspace, int act_type, void* stream) {
+    return cdrl_stem_block_bwd_pooled(x, y, stats, argmax, dp, nullptr, B, T, H, W, Cout, dgamma, dbeta, coef, dw, db, workspace, act_type, stream);
 }
 
 int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp,
                                const float* pooled, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta, float* coef,
-                               float* dw, float* db, double* workspace, void* stream) {
+                               float* dw, float* db, double* workspace, int act_type, void* stream) {
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
     const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
     hipStream_t st = S(stream);
@@ -670,9 +665,9 @@ int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stat
     const int nb = vcol_geom(B * Hp * Wp, Cout).nb;
     double* part = workspace;
     double* fpart = workspace + (int64_t)T * nb * 2 * Cout;
-    CDRL_TRY(pool_bn_bwd_reduce(ps, y, T, B, Cout, stats, part, st, g_op_at));
+    CDRL_TRY(pool_bn_bwd_reduce(ps, y, T, B, Cout, stats, part, st, act_type));
     CDRL_TRY(bn_bwd_finalize(part, nb, T, B * Ho * Wo, Cout, stats, dgamma, dbeta, coef, st));
-    return stem_bwd_filter_fused(x, ps, y, stats, coef, dw, db, B, T, H, W, Cout, fpart, st, g_op_at);
+    return stem_bwd_filter_fused(x, ps, y, stats, coef, dw, db, B, T, H, W, Cout, fpart, st, act_type);
 }
 
 int cdrl_pwconv_fused_partial_rows(int G, int Mg, int N, int K) { return pw_nn_plan(G, Mg, N, K).nbpg; }
@@ -701,13 +696,13 @@ int cdrl_pwconv_pack(const float* W, int K, int N, int sbk, int sbn, float* pack
 int cdrl_pwconv_fused_packed(const float* a, int lda, int a_coff, const float* pro_stats, const float* w, int sbk, int sbn,
                              const float* bias, float* c, int ldc, int c_coff, int accumulate, int G, int Mg, int N, int K,
                              int epilogue, const float* epi_y, const float* epi_stats, double* part, const float* w_packed,
-                             int packed_bf16, void* stream) {
+                             int packed_bf16, int act_type, void* stream) {
     if (!w_packed) {
         cdrl::set_error("cdrl_pwconv_fused_packed: null packed weights");
         return -1;
     }
     return pw_nn(make_view(const_cast<float*>(a), lda, a_coff), pro_stats, w, sbk, sbn, bias, make_view(c, ldc, c_coff),
-                 accumulate, G, Mg, N, K, epilogue, epi_y, epi_stats, part, S(stream), nullptr, w_packed, packed_bf16 != 0, g_op_at);
+                 accumulate, G, Mg, N, K, epilogue, epi_y, epi_stats, part, S(stream), nullptr, w_packed, packed_bf16 != 0, act_type);
 }
 
 static int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
@@ -721,7 +716,7 @@ static int pwconv_bn_bwd_impl(const float* dout, int dout_ld, int dout_coff, int
                               const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
                               int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
                               int dx_coff, int accumulate, float* dw, float* db, void* workspace, const float* wt_packed,
-                              int packed_bf16, void* stream) {
+                              int packed_bf16, int act_type, void* stream) {
     hipStream_t st = S(stream);
     const int act = relu6 ? ACT_RELU6 : ACT_NONE;
     const int nbr = vcol_geom(Mg, N).nb, nbp = pw_nn_plan(G, Mg, K, N).nbpg;
@@ -733,12 +728,12 @@ static int pwconv_bn_bwd_impl(const float* dout, int dout_ld, int dout_coff, int
     float* tn = reinterpret_cast<float*>(ws);
     View vd = make_view(const_cast<float*>(dout), dout_ld, dout_coff), vy = make_view(const_cast<float*>(y), N);
     View vx = make_view(const_cast<float*>(x), x_ld, x_coff);
-    CDRL_TRY(bn_bwd_reduce(vd, shuffle_ctot, vy, G, Mg, N, stats, act, part, st, nullptr, nullptr, nullptr, 0, g_op_at));
+    CDRL_TRY(bn_bwd_reduce(vd, shuffle_ctot, vy, G, Mg, N, stats, act, part, st, nullptr, nullptr, nullptr, 0, act_type));
     CDRL_TRY(bn_bwd_finalize(part, nbr, G, Mg, N, stats, dgamma, dbeta, coef, st));
     PwBnBwd bb{y, stats, coef, shuffle_ctot, act, part2};
     // dx[m,k] = sum_n dy[m,n] W[k,n]: GEMM with "K" = N (reduction over the conv outputs) and "N" = K
     const View vdx = make_view(dx, dx_ld, dx_coff);
-    if (!g_op_at && !packed_bf16 && pw_x3_wide_bwd_supported(vd, vdx, K, N, shuffle_ctot)) {
+    if (!act_type && !packed_bf16 && pw_x3_wide_bwd_supported(vd, vdx, K, N, shuffle_ctot)) {
         // 232-channel shapes, float32: the one-tile-per-workgroup split-precision kernel the engine runs (gemm_pw_x3.hip); the packed
         // operand is built here through a temporary device buffer (test / tooling entry point)
         void* wp = nullptr;
@@ -758,32 +753,32 @@ static int pwconv_bn_bwd_impl(const float* dout, int dout_ld, int dout_coff, int
         if (rc != 0) return rc;
     } else {
         CDRL_TRY(pw_nn(vd, nullptr, w, 1, N, nullptr, vdx, accumulate, G, Mg, K, N, 0, nullptr, nullptr, nullptr,
-                       st, &bb, wt_packed, packed_bf16 != 0, g_op_at));
+                       st, &bb, wt_packed, packed_bf16 != 0, act_type));
         CDRL_TRY(reduce_partials(part2, G * nbp, N, N, db, 0, st));
     }
     TnBnBwd tb{y, stats, coef, shuffle_ctot, act};
-    return gemm_tn(vx, vd, dw, G * Mg, N, K, tn, 0, st, G, x_pro_stats, &tb, wt_packed && packed_bf16 != 0, g_op_at);
+    return gemm_tn(vx, vd, dw, G * Mg, N, K, tn, 0, st, G, x_pro_stats, &tb, wt_packed && packed_bf16 != 0, act_type);
 }
 
 int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
                        const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
                        int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
-                       int dx_coff, int accumulate, float* dw, float* db, void* workspace, void* stream) {
+                       int dx_coff, int accumulate, float* dw, float* db, void* workspace, int act_type, void* stream) {
     return pwconv_bn_bwd_impl(dout, dout_ld, dout_coff, shuffle_ctot, relu6, y, stats, x, x_ld, x_coff, x_pro_stats, w, G, Mg, N, K,
-                              dgamma, dbeta, coef, dx, dx_ld, dx_coff, accumulate, dw, db, workspace, nullptr, 0, stream);
+                              dgamma, dbeta, coef, dx, dx_ld, dx_coff, accumulate, dw, db, workspace, nullptr, 0, act_type, stream);
 }
 
 int cdrl_pwconv_bn_bwd_packed(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
                               const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
                               int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
                               int dx_coff, int accumulate, float* dw, float* db, void* workspace, const float* wt_packed,
-                              int packed_bf16, void* stream) {
+                              int packed_bf16, int act_type, void* stream) {
     if (!wt_packed) {
         cdrl::set_error("cdrl_pwconv_bn_bwd_packed: null packed weights");
         return -1;
     }
     return pwconv_bn_bwd_impl(dout, dout_ld, dout_coff, shuffle_ctot, relu6, y, stats, x, x_ld, x_coff, x_pro_stats, w, G, Mg, N, K,
-                              dgamma, dbeta, coef, dx, dx_ld, dx_coff, accumulate, dw, db, workspace, wt_packed, packed_bf16, stream);
+                              dgamma, dbeta, coef, dx, dx_ld, dx_coff, accumulate, dw, db, workspace, wt_packed, packed_bf16, act_type, stream);
 }
 
 int64_t cdrl_dwconv_bn_workspace_doubles(int G, int B, int H, int W, int C, int stride) {
@@ -795,9 +790,9 @@ int64_t cdrl_dwconv_bn_workspace_doubles(int G, int B, int H, int W, int C, int 
 
 int cdrl_dwconv_bn_fwd(const float* x, const float* pre_stats, const float* w, const float* bias, float* y, int G, int B,
                        int H, int W, int C, int stride, const float* gamma, const float* beta, float* moving_mean,
-                       float* moving_var, int bessel, float* post_stats, double* workspace, void* stream) {
+                       float* moving_var, int bessel, float* post_stats, double* workspace, int act_type, void* stream) {
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
-    CDRL_TRY(dwf_fwd(x, pre_stats, w, bias, y, workspace, G, B, H, W, C, stride, S(stream), g_op_at));
+    CDRL_TRY(dwf_fwd(x, pre_stats, w, bias, y, workspace, G, B, H, W, C, stride, S(stream), act_type));
     return bn_finalize(workspace, dwf_geom(B, G, H, W, C, stride).nb, G, B * Ho * Wo, C, gamma, beta, moving_mean, moving_var,
                        bessel, 1, post_stats, S(stream));
 }
@@ -805,7 +800,7 @@ int cdrl_dwconv_bn_fwd(const float* x, const float* pre_stats, const float* w, c
 int cdrl_dwconv_bn_bwd(const float* x, const float* pre_stats, const float* dout, const float* y, const float* post_stats,
                        const float* w, int G, int B, int H, int W, int C, int stride, float* dx, float* dw, float* db,
                        float* dgamma_post, float* dbeta_post, float* coef_post, float* dgamma_pre, float* dbeta_pre,
-                       float* coef_pre, double* workspace, void* stream) {
+                       float* coef_pre, double* workspace, int act_type, void* stream) {
     const int Ho = same_out(H, stride), Wo = same_out(W, stride);
     const int Mo = B * Ho * Wo, Mi = B * H * W;
     const DwfGeom g = dwf_geom(B, G, H, W, C, stride);
@@ -814,15 +809,15 @@ int cdrl_dwconv_bn_bwd(const float* x, const float* pre_stats, const float* dout
     double* part_r = part_w + dwf_filter_part_elems(B, G, H, W, C, stride);
     hipStream_t st = S(stream);
     View vd = make_view(const_cast<float*>(dout), C), vy = make_view(const_cast<float*>(y), C);
-    CDRL_TRY(bn_bwd_reduce(vd, 0, vy, G, Mo, C, post_stats, ACT_NONE, part_r, st, nullptr, nullptr, nullptr, 0, g_op_at));
+    CDRL_TRY(bn_bwd_reduce(vd, 0, vy, G, Mo, C, post_stats, ACT_NONE, part_r, st, nullptr, nullptr, nullptr, 0, act_type));
     CDRL_TRY(bn_bwd_finalize(part_r, vcol_geom(Mo, C).nb, G, Mo, C, post_stats, dgamma_post, dbeta_post, coef_post, st));
-    CDRL_TRY(dwf_bwd(x, pre_stats, dout, y, post_stats, coef_post, w, make_view(dx, C), part_bn, part_w, G, B, H, W, C, stride, st, g_op_at));
+    CDRL_TRY(dwf_bwd(x, pre_stats, dout, y, post_stats, coef_post, w, make_view(dx, C), part_bn, part_w, G, B, H, W, C, stride, st, act_type));
     CDRL_TRY(reduce_partials(part_w, G * g.nb_bwd, 9 * C, (int64_t)10 * C, dw, 0, st));
     CDRL_TRY(reduce_partials(part_w + 9 * C, G * g.nb_bwd, C, (int64_t)10 * C, db, 0, st));
     if (pre_stats) {
         CDRL_TRY(bn_bwd_finalize(part_bn, g.nb_bwd, G, Mi, C, pre_stats, dgamma_pre, dbeta_pre, coef_pre, st));
         View vx = make_view(const_cast<float*>(x), C);
-        CDRL_TRY(bn_bwd_apply(make_view(dx, C), 0, vx, G, Mi, C, pre_stats, coef_pre, ACT_NONE, dx, part_r, st, nullptr, 0, g_op_at));
+        CDRL_TRY(bn_bwd_apply(make_view(dx, C), 0, vx, G, Mi, C, pre_stats, coef_pre, ACT_NONE, dx, part_r, st, nullptr, 0, act_type));
     }
     return 0;
 }
@@ -837,25 +832,25 @@ int cdrl_maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, i
 
 int cdrl_bn_train_fwd(const float* y, int G, int Mg, int C, const float* gamma, const float* beta, float* moving_mean,
                       float* moving_var, int bessel, int relu6, float* out, int out_ld, int out_coff, int shuffle_ctot,
-                      float* stats, double* workspace, void* stream) {
+                      float* stats, double* workspace, int act_type, void* stream) {
     View yv = make_view(const_cast<float*>(y), C);
     const int nb = vcol_geom(Mg, C).nb;
-    CDRL_TRY(colstats(yv, G, Mg, C, workspace, S(stream), g_op_at));
+    CDRL_TRY(colstats(yv, G, Mg, C, workspace, S(stream), act_type));
     CDRL_TRY(bn_finalize(workspace, nb, G, Mg, C, gamma, beta, moving_mean, moving_var, bessel, 1, stats, S(stream)));
     return bn_apply(yv, G, Mg, C, stats, relu6 ? ACT_RELU6 : ACT_NONE, make_view(out, out_ld, out_coff), shuffle_ctot,
-                    S(stream), nullptr, nullptr, g_op_at);
+                    S(stream), nullptr, nullptr, act_type);
 }
 
 int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, const float* y, int G, int Mg,
                       int C, const float* stats, int relu6, float* dgamma, float* dbeta, float* dy, float* coef,
-                      double* workspace, void* stream) {
+                      double* workspace, int act_type, void* stream) {
     View yv = make_view(const_cast<float*>(y), C);
     View dv = make_view(const_cast<float*>(dout), dout_ld, dout_coff);
     const int nb = vcol_geom(Mg, C).nb;
     const int act = relu6 ? ACT_RELU6 : ACT_NONE;
-    CDRL_TRY(bn_bwd_reduce(dv, shuffle_ctot, yv, G, Mg, C, stats, act, workspace, S(stream), nullptr, nullptr, nullptr, 0, g_op_at));
+    CDRL_TRY(bn_bwd_reduce(dv, shuffle_ctot, yv, G, Mg, C, stats, act, workspace, S(stream), nullptr, nullptr, nullptr, 0, act_type));
     CDRL_TRY(bn_bwd_finalize(workspace, nb, G, Mg, C, stats, dgamma, dbeta, coef, S(stream)));
-    return bn_bwd_apply(dv, shuffle_ctot, yv, G, Mg, C, stats, coef, act, dy, workspace, S(stream), nullptr, 0, g_op_at);
+    return bn_bwd_apply(dv, shuffle_ctot, yv, G, Mg, C, stats, coef, act, dy, workspace, S(stream), nullptr, 0, act_type);
 }
 
 int cdrl_bn_small_fwd(const float* y, int M, int C, const float* gamma, const float* beta, float* moving_mean,
@@ -908,8 +903,8 @@ int cdrl_linear_heads_bwd(const float* a, int nheads, const int* n, const float*
 }
 
 int cdrl_maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax,
-                        int N, int H, int W, int C, void* stream) {
-    return maxpool_bn_fwd(y, stats, G, frames_per_group, p, argmax, N, H, W, C, S(stream), g_op_at);
+                        int N, int H, int W, int C, int act_type, void* stream) {
+    return maxpool_bn_fwd(y, stats, G, frames_per_group, p, argmax, N, H, W, C, S(stream), act_type);
 }
 
 int cdrl_bn_train_bwd_pooled(const uint8_t* argmax, const float* dp, int H, int W, const float* y, int G, int Mg, int C,

@@ -216,13 +216,14 @@ int cdrl_beta_sample(const float* alpha, const float* beta, int rows, int A, int
  * log-density of the sample clipped to [eps, 1 - eps], no Jacobians. */
 int cdrl_beta_sample_logp(const float* alpha, const float* beta, int rows, int A, int ld, uint64_t seed, uint64_t offset,
                           float* u, float* log_prob, void* stream);
-/* bf16 ACTIVATION STORAGE at op level (configuration 3): after cdrl_set_op_activation_type(1) the activation tensors of the op-level
- * entry points that have a bf16-storage form -- cdrl_bn_train_fwd / _bwd (y, out, dout, dy), cdrl_dwconv_bn_fwd / _bwd (x, y, dout,
- * dx), cdrl_pwconv_fused_packed and cdrl_pwconv_bn_bwd_packed with packed_bf16 = 1 (a, c, epi_y; dout, y, x, dx), cdrl_gemm_tn (A, D),
- * cdrl_gemm_x3 (A, C), cdrl_maxpool_bn_fwd (y, p), cdrl_stem_block_bwd (y, dp) -- are bf16 (same pointer spelling, element strides
- * and offsets; round-to-nearest-even on store); statistics, coefficient blocks, partial sums, weights and weight gradients stay
- * float32 / double.  The switch is per calling thread and does not touch cdrl_learner_* (Config::compute selects its storage). */
-int cdrl_set_op_activation_type(int at);
+/* bf16 ACTIVATION STORAGE at op level (configuration 3): the op-level entry points that have a bf16-storage form -- cdrl_bn_train_fwd /
+ * _bwd (y, out, dout, dy), cdrl_dwconv_bn_fwd / _bwd (x, y, dout, dx), cdrl_pwconv_fused_packed and cdrl_pwconv_bn_bwd(_packed) with
+ * packed_bf16 = 1 (a, c, epi_y; dout, y, x, dx), cdrl_pwconv_bwd_fused (+ _workspace), cdrl_gemm_tn (A, D), cdrl_gemm_x3 (A, C),
+ * cdrl_maxpool_bn_fwd (y, p), cdrl_stem_fwd_stats (y), cdrl_stem_block_bwd(_pooled) (y, dp) -- take the element type of those ACTIVATION
+ * tensors as an explicit argument `int act_type` in front of the stream: 0 float32, 1 bf16 (same pointer spelling, element strides and
+ * offsets; round-to-nearest-even on store).  Statistics, coefficient blocks, partial sums, weights and weight gradients stay float32 /
+ * double.  The library keeps no mode of its own (rounds 3-5 had a thread-local switch, cdrl_set_op_activation_type); cdrl_learner_* is
+ * not concerned (Config::compute selects its storage). */
 int cdrl_gamma_implicit_grad(const double* a, const double* g, int n, double* out, void* stream);
 /* Test hook: the two Gamma draws (g1 ~ Gamma(alpha), g2 ~ Gamma(beta)) behind the sample u = g1 / (g1 + g2) of the same
  * (seed, offset) stream -> gammas[rows * A][2] doubles.  Lets a test check du/dalpha, du/dbeta sample by sample. */
@@ -269,14 +270,14 @@ int cdrl_pwconv_x3_wide_bwd(const float* dz, int ld_dz, int dz_coff, int dz_shuf
  * product, no pass over da).  W [K][N]; W_packed: cdrl_pwconv_x3_pack(W, N, K, 1, N, ...) (the transposed operand).
  * da [G*Mg][ldda] (+ da_coff; += when accumulate).  Workspaces: qpart cdrl_pwconv_bwd_fused_workspace(G, Mg, N, K, 0) floats,
  * dbpart (..., 1) doubles.  K, N <= 128 and padded alike (both <= 64 or both > 64), even; float32-accurate.
- * After cdrl_set_op_activation_type(1): dz, y, a, da are bf16 (bf16 activation storage: one bf16 plane per MFMA operand, i.e. dy,
+ * act_type = 1: dz, y, a, da are bf16 (bf16 activation storage: one bf16 plane per MFMA operand, i.e. dy,
  * xhat / a and W rounded to nearest even; leading dimensions / offsets even); workspaces sized under the same setting. */
-int64_t cdrl_pwconv_bwd_fused_workspace(int G, int Mg, int N, int K, int which);
+int64_t cdrl_pwconv_bwd_fused_workspace(int G, int Mg, int N, int K, int which, int act_type);
 int cdrl_pwconv_bwd_fused(const float* dz, int ld_dz, int dz_coff, int dz_shuffle, int act, const float* y, const float* stats,
                           const float* coef, const float* a, int lda, int a_coff, const float* a_stats, const float* a_gamma,
                           const float* a_beta, float* a_dgamma, float* a_dbeta, float* a_coef, const float* W, const void* W_packed,
                           float* da, int ldda, int da_coff, int accumulate, float* dW, float* db, float* qpart, double* dbpart, int G,
-                          int Mg, int N, int K, void* stream);
+                          int Mg, int N, int K, int act_type, void* stream);
 
 /* General float32 GEMM C (+)= A B + bias on the bf16 matrix pipe (three-way operand split; the 464 -> 768 head conv of
  * core/architectures.py:170 and its backward-data product).  B_packed: cdrl_gemm_x3_packed_bytes(N, K) bytes written by
@@ -284,7 +285,7 @@ int cdrl_pwconv_bwd_fused(const float* dz, int ld_dz, int dz_coff, int dz_shuffl
 int64_t cdrl_gemm_x3_packed_bytes(int N, int K);
 int cdrl_gemm_x3_pack(const float* B, int K, int N, int sbk, int sbn, void* packed, void* stream);
 int cdrl_gemm_x3(const float* A, int lda, int a_coff, const void* B_packed, const float* bias, float* C, int ldc, int c_coff, int M,
-                 int N, int K, int accumulate, void* stream);
+                 int N, int K, int accumulate, int act_type, void* stream);
 
 /* bf16 path (BASELINE.json configuration 3), first kernel: the unit's 1x1 convolution (core/architectures.py:130,140) with
  * bf16 activations in HBM, float32 master weights / bias, v_mfma_f32_32x32x16_bf16 with float32 accumulate.  A [G*Mg][lda]
@@ -320,7 +321,7 @@ int cdrl_gemm_nn(const float* A, int lda, int a_coff, const float* B, int sbk, i
                  int ldc, int c_coff, int M, int N, int K, int accumulate, void* stream);
 int64_t cdrl_gemm_tn_workspace_elems(int M, int N, int K);
 int cdrl_gemm_tn(const float* A, int lda, int a_coff, const float* D, int ldd, int d_coff, float* out, int M, int N,
-                 int K, float* workspace, int accumulate, void* stream);
+                 int K, float* workspace, int accumulate, int act_type, void* stream);
 /* Conv2D(24, 3, strides=2) stem (core/architectures.py:159) */
 int cdrl_stem_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int H, int W, int Cout,
                   void* stream);
@@ -331,7 +332,7 @@ int cdrl_stem_fwd(const float* x, const float* w, const float* bias, float* y, i
  * BatchNormalization (core/architectures.py:159-160). */
 int cdrl_stem_fwd_stats_rows(int B, int T, int H, int W, int Cout);
 int cdrl_stem_fwd_stats(const float* x, const float* w, const float* bias, float* y, double* part, int B, int T, int H, int W, int Cout,
-                        void* stream);
+                        int act_type, void* stream);
 int64_t cdrl_stem_bwd_workspace_doubles(int B, int T, int H, int W, int Cout);
 int cdrl_stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,
                          double* workspace, void* stream);
@@ -365,7 +366,7 @@ int cdrl_pwconv_pack(const float* W, int K, int N, int sbk, int sbn, float* pack
 int cdrl_pwconv_fused_packed(const float* a, int lda, int a_coff, const float* pro_stats, const float* w, int sbk, int sbn,
                              const float* bias, float* c, int ldc, int c_coff, int accumulate, int G, int Mg, int N, int K,
                              int epilogue, const float* epi_y, const float* epi_stats, double* part, const float* w_packed,
-                             int packed_bf16, void* stream);
+                             int packed_bf16, int act_type, void* stream);
 /* Backward of [Conv2D(k=1) -> BatchNormalization(training, per time slice) (+ReLU6) (+channel_shuffle on the store)]
  * (core/architectures.py:130-131,140-145) without materialising the gradient w.r.t. the conv output: the BN-backward
  * "apply" runs as the operand prologue of the two GEMMs.  dout: gradient w.r.t. the BN output (view ld/coff, read through
@@ -377,7 +378,7 @@ int64_t cdrl_pwconv_bn_bwd_workspace_bytes(int G, int Mg, int N, int K);
 int cdrl_pwconv_bn_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, int relu6, const float* y,
                        const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
                        int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
-                       int dx_coff, int accumulate, float* dw, float* db, void* workspace, void* stream);
+                       int dx_coff, int accumulate, float* dw, float* db, void* workspace, int act_type, void* stream);
 /* ... with the backward-data operand W^T pre-packed: cdrl_pwconv_pack(W, N, K, 1, N, wt_packed, bf16) packs
  * B(k = n_out, n = k_in) = W[k_in * N + n_out]; packed_bf16 = 1 runs the backward-data GEMM AND the filter-gradient GEMM in the
  * bf16-operand mode (dz rounded to bf16 after the BatchNorm-backward prologue, x after its BatchNorm-apply prologue); db,
@@ -386,7 +387,7 @@ int cdrl_pwconv_bn_bwd_packed(const float* dout, int dout_ld, int dout_coff, int
                               const float* stats, const float* x, int x_ld, int x_coff, const float* x_pro_stats, const float* w,
                               int G, int Mg, int N, int K, float* dgamma, float* dbeta, float* coef, float* dx, int dx_ld,
                               int dx_coff, int accumulate, float* dw, float* db, void* workspace, const float* wt_packed,
-                              int packed_bf16, void* stream);
+                              int packed_bf16, int act_type, void* stream);
 /* Fused depthwise block of the ShuffleNet unit: [BatchNormalization + ReLU6 of the previous 1x1 conv, applied on
  * load] -> DepthwiseConv2D(3, stride, 'same') -> statistics of the BatchNormalization that follows
  * (core/architectures.py:130-139; per-time-slice BN :44-57).  Whole frames are staged in LDS; the normalised
@@ -397,7 +398,7 @@ int cdrl_pwconv_bn_bwd_packed(const float* dout, int dout_ld, int dout_coff, int
 int64_t cdrl_dwconv_bn_workspace_doubles(int G, int B, int H, int W, int C, int stride);
 int cdrl_dwconv_bn_fwd(const float* x, const float* pre_stats, const float* w, const float* bias, float* y, int G, int B,
                        int H, int W, int C, int stride, const float* gamma, const float* beta, float* moving_mean,
-                       float* moving_var, int bessel, float* post_stats, double* workspace, void* stream);
+                       float* moving_var, int bessel, float* post_stats, double* workspace, int act_type, void* stream);
 /* Backward of the same block.  dout: gradient w.r.t. the OUTPUT of the following BatchNormalization (no activation);
  * y: raw depthwise output.  Produces dw (3,3,C,1), db, the following BN's dgamma/dbeta (+ coef_post, 3*G*C scratch)
  * and dx = gradient w.r.t. x; with pre_stats != NULL the previous BN(+ReLU6) is back-propagated too
@@ -405,7 +406,7 @@ int cdrl_dwconv_bn_fwd(const float* x, const float* pre_stats, const float* w, c
 int cdrl_dwconv_bn_bwd(const float* x, const float* pre_stats, const float* dout, const float* y, const float* post_stats,
                        const float* w, int G, int B, int H, int W, int C, int stride, float* dx, float* dw, float* db,
                        float* dgamma_post, float* dbeta_post, float* coef_post, float* dgamma_pre, float* dbeta_pre,
-                       float* coef_pre, double* workspace, void* stream);
+                       float* coef_pre, double* workspace, int act_type, void* stream);
 /* MaxPooling2D(3, 2, 'same') (core/architectures.py:161) */
 int cdrl_maxpool_fwd(const float* a, float* p, uint8_t* argmax, int N, int H, int W, int C, void* stream);
 int cdrl_maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, int H, int W, int C, void* stream);
@@ -413,7 +414,7 @@ int cdrl_maxpool_bwd(const uint8_t* argmax, const float* dp, float* da, int N, i
  * the store (core/architectures.py:44-57,109-118).  stats: 4*G*C floats, workspace: G*256*2*C doubles. */
 int cdrl_bn_train_fwd(const float* y, int G, int Mg, int C, const float* gamma, const float* beta, float* moving_mean,
                       float* moving_var, int bessel, int relu6, float* out, int out_ld, int out_coff, int shuffle_ctot,
-                      float* stats, double* workspace, void* stream);
+                      float* stats, double* workspace, int act_type, void* stream);
 /* Single-group BatchNorm over a few hundred rows (the dense BatchNorms of the trunk tail and of control_branch,
  * core/networks.py:59-66, :53-54) as ONE launch per direction: statistics + moving-average update + apply (forward),
  * sums + coefficients + apply (backward).  y / out / dout / dx dense [M][C]; stats 4*C, coef 3*C floats. */
@@ -430,13 +431,13 @@ int cdrl_linear_heads_bwd(const float* a, int nheads, const int* n, const float*
                           float* const* dw, float* const* db, int B, int K, void* stream);
 int cdrl_bn_train_bwd(const float* dout, int dout_ld, int dout_coff, int shuffle_ctot, const float* y, int G, int Mg,
                       int C, const float* stats, int relu6, float* dgamma, float* dbeta, float* dy, float* coef,
-                      double* workspace, void* stream);
+                      double* workspace, int act_type, void* stream);
 /* Fused stem block (core/architectures.py:160-161): BatchNorm-apply + ReLU6 + MaxPooling2D(3,2,'same') on the
  * raw conv output (stats from cdrl_bn_train_fwd), and the BatchNorm backward that gathers its incoming
  * gradient from the pooled gradient `dp` through the saved argmax.  argmax codes: ky * 3 + kx of the winning window position in bits 0-3;
  * bit 7 is set where the winning activation is clamped (ReLU6 closed: no gradient flows); decoders mask it away. */
 int cdrl_maxpool_bn_fwd(const float* y, const float* stats, int G, int frames_per_group, float* p, uint8_t* argmax,
-                        int N, int H, int W, int C, void* stream);
+                        int N, int H, int W, int C, int act_type, void* stream);
 int cdrl_bn_train_bwd_pooled(const uint8_t* argmax, const float* dp, int H, int W, const float* y, int G, int Mg, int C,
                              const float* stats, float* dgamma, float* dbeta, float* dy, float* coef, double* workspace,
                              void* stream);
@@ -449,14 +450,14 @@ int cdrl_bn_train_bwd_pooled(const uint8_t* argmax, const float* dp, int H, int 
 int64_t cdrl_stem_block_bwd_workspace_doubles(int B, int T, int H, int W, int Cout);
 int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp, int B, int T,
                         int H, int W, int Cout, float* dgamma, float* dbeta, float* coef, float* dw, float* db,
-                        double* workspace, void* stream);
+                        double* workspace, int act_type, void* stream);
 /* Same, with the pooled ACTIVATED output `pooled` of cdrl_maxpool_bn_fwd (null = the form above; element type as y / dp): the
  * BatchNorm sums then take the ReLU6 decision and xhat from it instead of gathering the pre-pool value through the argmax (a dense
  * read of a tensor a quarter the size; what the engine does).  Channels with |gamma * invstd| < 0.05 keep the gather.  With bf16
  * storage xhat comes from the ROUNDED pooled value: bf16-level agreement with the gather form, not bit-wise. */
 int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp,
                                const float* pooled, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta, float* coef,
-                               float* dw, float* db, double* workspace, void* stream);
+                               float* dw, float* db, double* workspace, int act_type, void* stream);
 
 /* Rollout-time image augmentation of one observation stack (CARLAgent.augment, core/carla_agent.py:545-577; ops of
  * rl/augmentations/augmentations.py and simclr.color_jitter): color jitter (brightness -> contrast -> saturation -> hue ->
