@@ -1663,11 +1663,6 @@ void Learner::build(bool dry) {
     h_bninf_.clear();
     bninf_max_c_ = 0;
     build_trunk(trunk_ops_);
-    d_bninf_ = reinterpret_cast<BnInfEntry*>(alloc((h_bninf_.size() + 1) * sizeof(BnInfEntry) / sizeof(float) + 4));
-    d_pack_ = reinterpret_cast<PwPack*>(alloc((h_pack_.size() + 1) * sizeof(PwPack) / sizeof(float) + 4));
-    d_pack3_ = reinterpret_cast<PwX3Pack*>(alloc((h_pack3_.size() + 1) * sizeof(PwX3Pack) / sizeof(float) + 4));
-    d_gpack_ = reinterpret_cast<GemmX3Pack*>(alloc((h_gpack_.size() + 1) * sizeof(GemmX3Pack) / sizeof(float) + 4));
-    d_pwt_ = reinterpret_cast<PwTranspose*>(alloc((h_pwt_.size() + 1) * sizeof(PwTranspose) / sizeof(float) + 4));
     const int A = cfg_.A;
     const int pdims[4] = {A, A, 1, 1};
     const char* const pnames[4] = {"alpha", "beta", "similarity", "speed"};
@@ -1676,6 +1671,13 @@ void Learner::build(bool dry) {
     const char* const vnames[4] = {"base", "exp", "speed", "similarity"};
     build_head(value_ops_, M_VALUE, "v", lin_v_, 4, vdims, vnames);
     build_head(old_policy_ops_, M_OLD_POLICY, "pi", lin_old_, 4, pdims, pnames);
+    // device copies of the per-pass tables (packed weights, inference statistics, transposes): sized AFTER the heads are built -- since
+    // round 6 the control branches register packed operands too (gemm_x3_rows)
+    d_bninf_ = reinterpret_cast<BnInfEntry*>(alloc((h_bninf_.size() + 1) * sizeof(BnInfEntry) / sizeof(float) + 4));
+    d_pack_ = reinterpret_cast<PwPack*>(alloc((h_pack_.size() + 1) * sizeof(PwPack) / sizeof(float) + 4));
+    d_pack3_ = reinterpret_cast<PwX3Pack*>(alloc((h_pack3_.size() + 1) * sizeof(PwX3Pack) / sizeof(float) + 4));
+    d_gpack_ = reinterpret_cast<GemmX3Pack*>(alloc((h_gpack_.size() + 1) * sizeof(GemmX3Pack) / sizeof(float) + 4));
+    d_pwt_ = reinterpret_cast<PwTranspose*>(alloc((h_pwt_.size() + 1) * sizeof(PwTranspose) / sizeof(float) + 4));
     metrics_p_ = alloc(16);
     metrics_v_ = alloc(16);
     aux_p_ = alloc((size_t)cfg_.B * 4 * A);
