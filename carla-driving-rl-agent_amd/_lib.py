@@ -93,7 +93,6 @@ PROTOTYPES = {
     'cdrl_gemm_x3_packed_bytes': (_i64, [_i, _i]),
     'cdrl_gemm_x3_pack': (_i, [_fp, _i, _i, _i, _i, _fp, _fp]),
     'cdrl_gemm_x3': (_i, [_fp, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
-    'cdrl_gemm_x3_rows': (_i, [_fp, _i, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     'cdrl_f32_to_bf16': (_i, [_fp, _fp, _i64, _fp]),
     'cdrl_bf16_to_f32': (_i, [_fp, _fp, _i64, _fp]),
     'cdrl_pwconv_bf16_partial_rows': (_i, [_i, _i, _i, _i]),

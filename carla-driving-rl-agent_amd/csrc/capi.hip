@@ -521,15 +521,6 @@ int cdrl_gemm_x3(const float* A, int lda, int a_coff, const void* B_packed, cons
                    S(stream), act_type != 0, act_type);
 }
 
-int cdrl_gemm_x3_rows(const float* A, int lda, int a_coff, const void* B_packed, const float* bias, float* C, int ldc, int c_coff, int M,
-                      int N, int K, int accumulate, void* stream) {
-    if (!A || !B_packed || !C) {
-        cdrl::set_error("cdrl_gemm_x3_rows: null argument");
-        return -1;
-    }
-    return gemm_x3_rows(make_view(const_cast<float*>(A), lda, a_coff), B_packed, bias, make_view(C, ldc, c_coff), M, N, K, accumulate, S(stream));
-}
-
 int cdrl_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
     if (!x || !y) return -1;
     return f32_to_bf16(x, y, n, S(stream));

@@ -314,9 +314,6 @@ int gemm_x3_pack_many(const GemmX3Pack* tab_dev, int n, hipStream_t st);
 // bf16_operands: one product per step on the first plane only (operands rounded to bf16: configuration 3's compute mode)
 int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st,
             bool bf16_operands = false, int at = 0);
-// small-M form (M <= 4096: the dense layers behind the tower): one wave per 32 x 32 output tile over the whole K, no LDS, no split-K
-bool gemm_x3_rows_supported(View A, int M, int K);
-int gemm_x3_rows(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st);
 
 // ---------------------------------------------------------------- bf16 pointwise conv (gemm_pw_bf16.hip)
 // bf16 activations (A, C), float32 master weights / bias / BatchNorm blocks, bf16 MFMA with float32 accumulate; optional

@@ -895,19 +895,10 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
     Scratch* sc = build_scr_;
     const size_t dskn = (size_t)std::max(gemm_nn_splitk_elems(M, N, K), gemm_nn_splitk_elems(M, K, N));
     float* dsk = dskn ? alloc(dskn) : nullptr;          // split-K scratch (batch-sized M, K >= 256)
-    // Round 6: the dense products behind the tower on the small-M split-precision kernel (gemm_x3.hip gemm_x3_rows_kernel: one wave per
-    // 32 x 32 tile over the whole K, one launch instead of split-K GEMM + slab reduce); CDRL_X3_ROWS=0 -> the tiled float32-MFMA GEMM
-    static const bool rows_env = !(cdrl_getenv("CDRL_X3_ROWS") && atoi(cdrl_getenv("CDRL_X3_ROWS")) == 0);
-    const View dz_probe = act != ACT_NONE ? make_view(reinterpret_cast<float*>(uintptr_t(16)), N) : dout;
-    const bool xf = rows_env && gemm_x3_rows_supported(in, M, K), xb = rows_env && need_din && gemm_x3_rows_supported(dz_probe, M, N);
-    const void* wxf = xf ? gemm_x3_packed(w.p, K, N, N, 1) : nullptr;          // B(k, n) = W[k][n]
-    const void* wxb = xb ? gemm_x3_packed(w.p, N, K, 1, N) : nullptr;          // backward-data: B(k = n_out, n = k_in) = W[n][k]
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
-        const View zo = act == ACT_NONE ? out : make_view(z, N);
-        if (xf) CDRL_TRY(gemm_x3_rows(in, wxf, b.p, zo, M, N, K, 0, st));
-        else CDRL_TRY(gemm_nn(in, w.p, N, 1, b.p, zo, M, N, K, 0, st, dsk));
-        if (act == ACT_NONE) return 0;
+        if (act == ACT_NONE) return gemm_nn(in, w.p, N, 1, b.p, out, M, N, K, 0, st, dsk);
+        CDRL_TRY(gemm_nn(in, w.p, N, 1, b.p, make_view(z, N), M, N, K, 0, st, dsk));
         return act_fwd(z, out.p, (int64_t)M * N, act, st);
     };
     op.bwd = [=](hipStream_t st) -> int {
@@ -917,10 +908,7 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
             dzv = make_view(dz, N);
         }
         // critical path first, then the weight / bias gradients on the side stream (main-stream layers only)
-        if (need_din) {
-            if (xb) CDRL_TRY(gemm_x3_rows(dzv, wxb, nullptr, din, M, K, N, din_acc, st));
-            else CDRL_TRY(gemm_nn(dzv, w.p, 1, N, nullptr, din, M, K, N, din_acc, st, dsk));
-        }
+        if (need_din) CDRL_TRY(gemm_nn(dzv, w.p, 1, N, nullptr, din, M, K, N, din_acc, st, dsk));
         if (sc == &scr_main_) {
             CDRL_TRY(next_slot(st));
             hipStream_t side = fork_side(st);
@@ -966,15 +954,9 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
     size_t skn = 0;
     for (int64_t e : {gemm_nn_splitk_elems(T * B, U3, In), gemm_nn_splitk_elems(T * B, In, U3)}) skn = std::max(skn, (size_t)e);
     float* sk = skn ? alloc(skn) : nullptr;
-    static const bool rows_env = !(cdrl_getenv("CDRL_X3_ROWS") && atoi(cdrl_getenv("CDRL_X3_ROWS")) == 0);
-    const bool xf = rows_env && gemm_x3_rows_supported(xv, T * B, In);
-    const bool xb = rows_env && need_dx && gemm_x3_rows_supported(make_view(reinterpret_cast<float*>(uintptr_t(16)), U3), T * B, U3);
-    const void* wxf = xf ? gemm_x3_packed(Kp.p, In, U3, U3, 1) : nullptr;      // input projection: B(k, n) = kernel[k][n]
-    const void* wxb = xb ? gemm_x3_packed(Kp.p, U3, In, 1, U3) : nullptr;      // its backward-data product
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
-        if (xf) CDRL_TRY(gemm_x3_rows(xv, wxf, bp.p, make_view(XP, U3), T * B, U3, In, 0, st));
-        else CDRL_TRY(gemm_nn(xv, Kp.p, U3, 1, bp.p, make_view(XP, U3), T * B, U3, In, 0, st, sk));
+        CDRL_TRY(gemm_nn(xv, Kp.p, U3, 1, bp.p, make_view(XP, U3), T * B, U3, In, 0, st, sk));
         for (int t = 0; t < T; ++t)         // one fused kernel per step: h R + b1, gates, saved tensors, (last step) the concat slot
             CDRL_TRY(gru_step_fwd(XP + (size_t)t * B * U3, Hs + (size_t)t * B * u, Rp.p, bp.p + U3, Z + (size_t)t * B * u,
                                   R + (size_t)t * B * u, HH + (size_t)t * B * u, HP + (size_t)t * B * U3,
@@ -992,10 +974,7 @@ void Learner::add_gru(std::vector<Op>& ops, const std::string& name, Tens& x, in
             nxt = nxt == dHa ? dHb : dHa;
         }
         // critical path first: the gradient w.r.t. the GRU input
-        if (need_dx) {
-            if (xb) CDRL_TRY(gemm_x3_rows(make_view(dXP, U3), wxb, nullptr, xg, T * B, In, U3, 0, st));
-            else CDRL_TRY(gemm_nn(make_view(dXP, U3), Kp.p, 1, U3, nullptr, xg, T * B, In, U3, 0, st, sk));
-        }
+        if (need_dx) CDRL_TRY(gemm_nn(make_view(dXP, U3), Kp.p, 1, U3, nullptr, xg, T * B, In, U3, 0, st, sk));
         // weight / bias gradients: off the critical path -> side stream with a rotating scratch slot (main-stream GRU only;
         // the small-modality GRUs already run on the aux stream with their own scratch)
         hipStream_t ws = st;

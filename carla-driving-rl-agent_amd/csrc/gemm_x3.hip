@@ -185,95 +185,6 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
     }
 }
 
-
-// SMALL-M form (round 6): the dense products behind the tower -- GRU input projections (M = T B = 1024), the trunk's Dense and the
-// control branches (M = B = 256), K, N = 320 .. 768.  The tiled float32-MFMA GEMM needed split-K plus a slab reduce for them (two
-// launches, 15-35 us: ~40 of the ~80 launches of the latency-bound stretch between the tower's forward and backward).  Here ONE wave owns
-// a 32 x 32 output tile over the whole K: no LDS, no barrier -- the lane's A fragment (8 consecutive k of its row: two 16-byte loads) is
-// split into three bf16 planes in registers, the B fragments come from the packed planes (gemm_x3_pack), both through a ring of PF K-steps
-// requested ahead; six bf16 MFMAs per K = 16 step.  Grid = (row tiles, blocks of 4 column tiles): 32 .. 192 workgroups, each wave a chain
-// of K / 16 steps of ~250 cycles.  Bias, accumulate.
-template <bool ACC>
-__global__ void __launch_bounds__(256) gemm_x3_rows_kernel(GemmX3Args a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lrow = lane & 31, lk = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * 32;
-    const int nt0 = blockIdx.y * 128 + wave * 32;
-    if (nt0 >= a.N) return;                              // (the whole wave: its column tile does not exist)
-    const int n = nt0 + lrow;
-    const int K = a.K;
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    const uint32_t OOR = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(a.A.p, 0, (int)((int64_t)a.M * a.A.ld * 4), 0x00020000);
-    const bool rok = m0 + lrow < a.M;
-    const uint32_t voA = rok ? (uint32_t)(((m0 + lrow) * a.A.ld + a.A.coff + 8 * lk) * 4) : OOR;
-    const int64_t plane = (int64_t)a.KS * 2 * a.NP * 8;
-    const __bf16* bp = a.Bp + ((int64_t)lk * a.NP + n) * 8;
-    constexpr int PF = 4;
-    u32x4_t ra[PF][2];
-    bf16x8 rb[PF][3];
-    auto load = [&](int ks, u32x4_t* da, bf16x8* db) {
-        const int k = 16 * ks + 8 * lk;                 // K % 4 == 0: a 4-float chunk is inside K or beyond it as a whole
-        da[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (rok && k < K) ? voA + (uint32_t)(64 * ks) : OOR, 0, 0);
-        da[1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (rok && k + 4 < K) ? voA + (uint32_t)(64 * ks + 16) : OOR, 0, 0);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) db[p] = *reinterpret_cast<const bf16x8*>(bp + p * plane + (int64_t)ks * 2 * a.NP * 8);
-    };
-    auto widen = [](uint32_t w) -> f32x2 { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < PF; ++s)
-        if (s < a.KS) load(s, ra[s], rb[s]);
-    for (int ks0 = 0; ks0 < a.KS; ks0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int ks = ks0 + u;
-            if (ks >= a.KS) break;
-            uint32_t h[3][4];                           // three planes x four packed pairs = the lane's 8 k values
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const f32x2 x = f32x2{__uint_as_float(ra[u][c][2 * e]), __uint_as_float(ra[u][c][2 * e + 1])};
-                    const uint32_t h1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
-                    const f32x2 r1 = x - widen(h1);
-                    const uint32_t h2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
-                    const uint32_t h3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1 - widen(h2), bf16x2));
-                    h[0][2 * c + e] = h1;
-                    h[1][2 * c + e] = h2;
-                    h[2][2 * c + e] = h3;
-                }
-            const bf16x8 a1 = __builtin_bit_cast(bf16x8, u32x4_t{h[0][0], h[0][1], h[0][2], h[0][3]});
-            const bf16x8 a2 = __builtin_bit_cast(bf16x8, u32x4_t{h[1][0], h[1][1], h[1][2], h[1][3]});
-            const bf16x8 a3 = __builtin_bit_cast(bf16x8, u32x4_t{h[2][0], h[2][1], h[2][2], h[2][3]});
-            const bf16x8 b1 = rb[u][0], b2 = rb[u][1], b3 = rb[u][2];
-            if (ks + PF < a.KS) load(ks + PF, ra[u], rb[u]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);       // smallest terms first
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
-        }
-    }
-    if (n >= a.N) return;
-    const float bv = a.bias ? a.bias[n] : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m < a.M) {
-            float* c = a.C.p + m * a.C.ld + a.C.coff + n;
-            float v = acc[r] + bv;
-            if (ACC) v += *c;
-            *c = v;
-        }
-    }
-}
-
 // B(k, n) = w[k * sbk + n * sbn] -> [3][KS][2][NP][8] bf16
 __global__ void gemm_x3_pack_kernel(const GemmX3Pack* __restrict__ tab) {
     const GemmX3Pack d = tab[blockIdx.y];
@@ -342,24 +253,6 @@ int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int
     if (at) hipLaunchKernelGGL((gemm_x3_kernel<1, true>), dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
     else if (bf16_operands) hipLaunchKernelGGL(gemm_x3_kernel<1>, dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm_x3_kernel<3>, dim3(cdiv(M, 128), cdiv(N, 128)), dim3(256), 0, st, a);
-    CDRL_LAUNCH_CHECK();
-    return 0;
-}
-
-
-// small-M products (see gemm_x3_rows_kernel); same packed operand as gemm_x3
-bool gemm_x3_rows_supported(View A, int M, int K) { return M <= 4096 && gemm_x3_supported(A, K); }
-
-int gemm_x3_rows(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st) {
-    if (M <= 0 || N <= 0) return 0;
-    if (!gemm_x3_rows_supported(A, M, K) || !Bp) {
-        set_error("gemm_x3_rows: unsupported shape / alignment M=%d K=%d ld=%d coff=%d", M, K, A.ld, A.coff);
-        return -1;
-    }
-    GemmX3Args a{A, reinterpret_cast<const __bf16*>(Bp), bias, C, accumulate, M, N, K, cdiv(K, 16), cdiv(N, 128) * 128};
-    const dim3 grid(cdiv(M, 32), cdiv(N, 128)), block(256);
-    if (accumulate) hipLaunchKernelGGL(gemm_x3_rows_kernel<true>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(gemm_x3_rows_kernel<false>, grid, block, 0, st, a);
     CDRL_LAUNCH_CHECK();
     return 0;
 }

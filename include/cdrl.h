@@ -286,11 +286,6 @@ int64_t cdrl_gemm_x3_packed_bytes(int N, int K);
 int cdrl_gemm_x3_pack(const float* B, int K, int N, int sbk, int sbn, void* packed, void* stream);
 int cdrl_gemm_x3(const float* A, int lda, int a_coff, const void* B_packed, const float* bias, float* C, int ldc, int c_coff, int M,
                  int N, int K, int accumulate, int act_type, void* stream);
-/* The same product for SMALL M (<= 4096 rows): the Dense layers behind the tower -- GRU input projections (core/networks.py:47-50), the
- * trunk's Dense(512) (:30) and the control branches (:63-64) -- and their backward-data products.  One wave per 32 x 32 output tile over
- * the whole K, no LDS, no split-K (one launch where the tiled GEMM needed two); same packed operand, float32 tensors only. */
-int cdrl_gemm_x3_rows(const float* A, int lda, int a_coff, const void* B_packed, const float* bias, float* C, int ldc, int c_coff, int M,
-                      int N, int K, int accumulate, void* stream);
 
 /* bf16 path (BASELINE.json configuration 3), first kernel: the unit's 1x1 convolution (core/architectures.py:130,140) with
  * bf16 activations in HBM, float32 master weights / bias, v_mfma_f32_32x32x16_bf16 with float32 accumulate.  A [G*Mg][lda]

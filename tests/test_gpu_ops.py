@@ -737,37 +737,6 @@ def test_pwconv_x3_split(lib, G, Mg, K, N, pro):
         assert rel_err(d.cpu().numpy(), (gc.double() @ w.double().t()).cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('M,K,N,acc', [(256, 352, 512, 0), (256, 512, 320, 0), (256, 320, 320, 1), (1024, 768, 768, 0), (1024, 16, 96, 0), (1024, 96, 16, 1),
-                                       (250, 20, 36, 0), (33, 768, 512, 1)])
-def test_gemm_x3_rows(lib, M, K, N, acc):
-    """Round 6: the small-M split-precision GEMM (one wave per 32 x 32 tile over the whole K) of the dense layers behind the tower, forward
-    and backward-data orientation, ragged M / K / N, bias, accumulate into a strided view -- against float64."""
-    rng = np.random.default_rng(M + K + N)
-    lda, a_coff = K + 8, 4
-    a = dev(rng.standard_normal((M, lda)).astype(np.float32))
-    b = dev((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32))
-    bias = dev(rng.standard_normal(N).astype(np.float32))
-    bp = torch.zeros(int(lib.cdrl_gemm_x3_packed_bytes(N, K)), dtype=torch.uint8, device=DEV)
-    _lib.check(lib.cdrl_gemm_x3_pack(P(b), K, N, N, 1, P(bp), S()))
-    c0 = rng.standard_normal((M, N + 5)).astype(np.float32)
-    c = dev(c0)
-    _lib.check(lib.cdrl_gemm_x3_rows(P(a), lda, a_coff, P(bp), P(bias), P(c), N + 5, 2, M, N, K, acc, S()))
-    ref = a[:, a_coff:a_coff + K].double() @ b.double() + bias.double()
-    if acc:
-        ref = ref + torch.as_tensor(c0[:, 2:2 + N]).double().to(DEV)
-    got = c.cpu().numpy()
-    assert rel_err(got[:, 2:2 + N], ref.cpu().numpy()) < 1e-5
-    assert np.array_equal(got[:, :2], c0[:, :2]) and np.array_equal(got[:, 2 + N:], c0[:, 2 + N:])
-    # transposed operand: B(k, n) = b[n][k] (the backward-data product of a Dense layer)
-    bp2 = torch.zeros(int(lib.cdrl_gemm_x3_packed_bytes(K, N)), dtype=torch.uint8, device=DEV)
-    if N % 4 == 0:
-        _lib.check(lib.cdrl_gemm_x3_pack(P(b), N, K, 1, N, P(bp2), S()))
-        g = dev(rng.standard_normal((M, N)).astype(np.float32))
-        d = torch.zeros((M, K), device=DEV)
-        _lib.check(lib.cdrl_gemm_x3_rows(P(g), N, 0, P(bp2), None, P(d), K, 0, M, K, N, 0, S()))
-        assert rel_err(d.cpu().numpy(), (g.double() @ b.double().t()).cpu().numpy()) < 1e-5
-
-
 @pytest.mark.parametrize('G,Mg,Cin,Cout,shuffle,act,epi,acc', [(4, 3072, 232, 232, 1, 1, 1, 0), (4, 3072, 232, 232, 0, 0, 0, 0), (4, 1000, 232, 232, 0, 0, 0, 1),
                                                                (2, 333, 232, 140, 1, 1, 0, 1), (3, 97, 116, 232, 0, 1, 1, 0), (1, 64, 232, 232, 1, 0, 0, 0)])
 def test_pwconv_x3_wide_bwd(lib, G, Mg, Cin, Cout, shuffle, act, epi, acc):
