@@ -1650,8 +1650,8 @@ void Learner::build(bool dry) {
     const char* const vnames[4] = {"base", "exp", "speed", "similarity"};
     build_head(value_ops_, M_VALUE, "v", lin_v_, 4, vdims, vnames);
     build_head(old_policy_ops_, M_OLD_POLICY, "pi", lin_old_, 4, pdims, pnames);
-    // device copies of the per-pass tables (packed weights, inference statistics, transposes): sized AFTER the heads are built -- since
-    // round 6 the control branches register packed operands too (gemm_x3_rows)
+    // device copies of the per-pass tables (packed weights, inference statistics, transposes): sized AFTER the heads are built, so that an
+    // op of a control branch may register entries too (round 6: a small-M GEMM that did so overflowed the table sized behind the trunk)
     d_bninf_ = reinterpret_cast<BnInfEntry*>(alloc((h_bninf_.size() + 1) * sizeof(BnInfEntry) / sizeof(float) + 4));
     d_pack_ = reinterpret_cast<PwPack*>(alloc((h_pack_.size() + 1) * sizeof(PwPack) / sizeof(float) + 4));
     d_pack3_ = reinterpret_cast<PwX3Pack*>(alloc((h_pack3_.size() + 1) * sizeof(PwX3Pack) / sizeof(float) + 4));
