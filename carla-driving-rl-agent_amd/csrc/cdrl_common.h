@@ -1,6 +1,7 @@
 // Common device/host helpers for libcdrl_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -53,6 +54,46 @@ int env_overrides(char* buf, int cap);      // "NAME=VALUE ..." of every CDRL_* 
     } while (0)
 
 #define CDRL_LAUNCH_CHECK() CDRL_HIP(hipGetLastError())
+
+// Tail events (round 6): a fork to another stream used to be hipEventRecord on the critical stream -- a barrier packet of its own in
+// the queue, a bubble in front of the next kernel, ~70 times per update-step.  hipExtLaunchKernelGGL binds a STOP EVENT to the kernel's
+// own dispatch packet instead (its completion signal), so the other stream can wait for "the newest kernel of the critical stream"
+// without anything being enqueued there.  A stop event on EVERY kernel costs more than the bubbles it removes (+0.16 ms per
+// update-step), so the launches that need one are LEARNED: while a thread has a TailEvents installed (Learner::launch), launch number i
+// of the body carries an event iff a fork followed launch i the last time this body ran (`need`); a fork that finds no event behind the
+// newest kernel (`last` null: first run, a changed sequence, a copy or memset behind the kernel) records one the old way and marks the
+// launch for the next run.  Always correct; converges after one run of each body.
+struct TailEvents {
+    hipStream_t stream = nullptr;
+    hipEvent_t ring[32] = {};
+    int n = 0;
+    unsigned head = 0;
+    hipEvent_t last = nullptr;      // stop event of the newest kernel on `stream`, if it carries one
+    int idx = 0;                    // launches of this body on `stream` so far
+    uint8_t* need = nullptr;        // per launch index of the current body: 1 = a fork followed it
+    int need_cap = 0;
+};
+extern thread_local TailEvents* tl_tail;
+
+template <typename... Args, typename... Act>
+inline void launch_tracked(void (*kernel)(Args...), dim3 grid, dim3 block, uint32_t lds, hipStream_t st, Act&&... args) {
+    TailEvents* t = tl_tail;
+    if (t && st == t->stream) {
+        const int i = t->idx++;
+        if (i < t->need_cap && t->need[i]) {
+            hipEvent_t ev = t->ring[t->head++ % (unsigned)t->n];
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, nullptr, ev, 0, static_cast<Args>(args)...);
+            t->last = ev;
+            return;
+        }
+        t->last = nullptr;
+    }
+    kernel<<<grid, block, lds, st>>>(static_cast<Args>(args)...);
+}
+inline void tail_invalidate(hipStream_t st) {
+    TailEvents* t = tl_tail;
+    if (t && st == t->stream) t->last = nullptr;
+}
 
 // "Set the dynamic-LDS attribute of this kernel once" guards: once PER DEVICE (a second engine on another device of the same process, or
 // the optional second enqueue thread racing the first launch, must not launch without it -- ADVICE r4): one flag per device and guard
@@ -155,3 +196,7 @@ inline VColGeom vcol_geom(int rows_per_group, int C, int max_blocks_per_group = 
 }
 
 }  // namespace cdrl
+
+// every launch of the library goes through launch_tracked (see TailEvents above)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) ::cdrl::launch_tracked(kernel, dim3(grid), dim3(block), (uint32_t)(lds), stream, __VA_ARGS__)

@@ -7,6 +7,7 @@
 namespace cdrl {
 
 static thread_local char g_err[1024] = "";
+thread_local TailEvents* tl_tail = nullptr;
 
 void set_error(const char* fmt, ...) {
     va_list ap;

@@ -367,11 +367,23 @@ private:
     std::unique_ptr<AuxWorker> aux_worker_;
     bool aux_inflight_ = false;
     int aux_wait();
+    TailEvents tail_;                                   // stop events of the critical stream's kernels (cdrl_common.h)
+    std::map<std::vector<uint64_t>, std::vector<uint8_t>> tail_need_;      // per body (launch key): which launches a fork follows
+    int mark_stream(hipStream_t st, hipEvent_t fallback, hipEvent_t* ev);
     hipEvent_t ev_main_[NSLOT] = {};
     hipEvent_t ev_side_[NSLOT] = {};
     hipEvent_t ev_join_ = nullptr;
     bool side_enabled_ = true;
     bool slot_used_[NSLOT] = {};
+    // numbered records of the side stream and what the critical stream has waited for (engine.hip: wait_side_record)
+    struct SideRec { hipEvent_t ev = nullptr; uint64_t seq = 0; };
+    static constexpr int SIDE_HIST = 32;
+    SideRec side_hist_[SIDE_HIST];
+    uint64_t side_seq_ = 0, main_waited_ = 0;
+    uint64_t slot_seq_[NSLOT] = {}, q_seq_[NQ] = {};
+    int side_lag_ = 4;
+    uint64_t note_side_record(hipEvent_t ev);
+    int wait_side_record(hipStream_t st, uint64_t need, hipEvent_t need_ev);
     int slot_ = 0;
     int next_slot(hipStream_t st);                       // main: claim a scratch slot (waits for its last side job)
     hipStream_t fork_side(hipStream_t st);               // main -> side dependency for the current slot

@@ -58,6 +58,8 @@ Learner::~Learner() {
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     for (int i = 0; i < NQ; ++i)
         if (ev_q_[i]) (void)hipEventDestroy(ev_q_[i]);
+    for (int i = 0; i < 32; ++i)
+        if (tail_.ring[i]) (void)hipEventDestroy(tail_.ring[i]);
     if (ev_tail_main_) (void)hipEventDestroy(ev_tail_main_);
     if (ev_tail_side_) (void)hipEventDestroy(ev_tail_side_);
     for (int i = 0; i < 3; ++i) {
@@ -141,7 +143,19 @@ int Learner::launch(hipStream_t caller, std::vector<uint64_t> key, bool graphabl
     CDRL_HIP(hipStreamWaitEvent(main_, ev_in_, 0));
     int rc = 0;
     if (!graphs_enabled_ || !graphable) {
+        // eager launches: kernels on the critical stream carry stop events (TailEvents, cdrl_common.h) while the body runs on this thread
+        if (tail_.n > 0) {
+            if (tail_need_.size() > 64) tail_need_.clear();
+            std::vector<uint8_t>& need = tail_need_[key];
+            if (need.empty()) need.assign(4096, 0);
+            tail_.need = need.data();
+            tail_.need_cap = (int)need.size();
+            tail_.idx = 0;
+            tail_.last = nullptr;
+            tl_tail = &tail_;
+        }
         rc = body(main_);
+        tl_tail = nullptr;
     } else {
         auto it = graphs_.find(key);
         if (it == graphs_.end()) {
@@ -178,20 +192,67 @@ int Learner::launch(hipStream_t caller, std::vector<uint64_t> key, bool graphabl
 static const int g_diag_skip_fin = cdrl_getenv("CDRL_DIAG_SKIP_FIN") ? atoi(cdrl_getenv("CDRL_DIAG_SKIP_FIN")) : 0;   // timing diagnostics only (stale statistics)
 static const int g_diag_noev = cdrl_getenv("CDRL_DIAG_NOEV") ? atoi(cdrl_getenv("CDRL_DIAG_NOEV")) : 0;   // timing diagnostics only (racy)
 
+// Records on the side stream are numbered (the stream is in order: whoever has waited for record s has waited for every record
+// before it), and the critical stream remembers the newest one it has waited for.  A scratch slot / partial-tile buffer is free once
+// the record of its last user is covered -- so instead of one hipStreamWaitEvent (a barrier packet of its own on the critical stream,
+// 0.23 ms per update-step for ~100 of them by the no-waits diagnostic) per claim, the critical stream waits for a record `side_lag_`
+// behind the newest one whenever the record it needs is not covered yet, and skips the claims that wait covers (round 6).
+uint64_t Learner::note_side_record(hipEvent_t ev) {
+    ++side_seq_;
+    side_hist_[side_seq_ % SIDE_HIST] = SideRec{ev, side_seq_};
+    return side_seq_;
+}
+
+int Learner::wait_side_record(hipStream_t st, uint64_t need, hipEvent_t need_ev) {
+    if (st != main_ || side_lag_ < 0) {              // another stream than the critical one (or the scheme off): the claim's own event
+        CDRL_HIP(hipStreamWaitEvent(st, need_ev, 0));
+        return 0;
+    }
+    if (need <= main_waited_) return 0;
+    uint64_t target = need;
+    if (side_seq_ > (uint64_t)side_lag_ && side_seq_ - (uint64_t)side_lag_ > target) target = side_seq_ - (uint64_t)side_lag_;
+    hipEvent_t ev = need_ev;
+    uint64_t covered = need;
+    if (side_seq_ - target < SIDE_HIST && side_hist_[target % SIDE_HIST].seq == target) {
+        ev = side_hist_[target % SIDE_HIST].ev;
+        covered = target;
+    }
+    for (int i = 0; i < SIDE_HIST; ++i)             // the event may have been recorded again since: waiting for it covers that record too
+        if (side_hist_[i].ev == ev && side_hist_[i].seq > covered) covered = side_hist_[i].seq;
+    CDRL_HIP(hipStreamWaitEvent(st, ev, 0));
+    main_waited_ = covered;
+    return 0;
+}
+
 int Learner::next_slot(hipStream_t st) {
     slot_ = (slot_ + 1) % NSLOT;
     if (g_diag_noev & 1) return 0;
-    if (side_enabled_ && slot_used_[slot_]) CDRL_HIP(hipStreamWaitEvent(st, ev_side_[slot_], 0));
+    if (side_enabled_ && slot_used_[slot_]) CDRL_TRY(wait_side_record(st, slot_seq_[slot_], ev_side_[slot_]));
     return 0;
 }
 
 hipStream_t Learner::fork_side(hipStream_t st) {
     if (!side_enabled_) return st;
     if (g_diag_noev & 2) return side_;
-    if (hipEventRecord(ev_main_[slot_], st) != hipSuccess) return st;
-    if (hipStreamWaitEvent(side_, ev_main_[slot_], 0) != hipSuccess) return st;
+    hipEvent_t ev = nullptr;
+    if (mark_stream(st, ev_main_[slot_], &ev) != 0) return st;
+    if (hipStreamWaitEvent(side_, ev, 0) != hipSuccess) return st;
     flush_deferred();
     return side_;
+}
+
+// An event that covers everything `st` holds so far: the stop event of its newest kernel when the tail events are on and nothing
+// else went in behind that kernel (nothing is enqueued on `st`), else `fallback` recorded on `st`.
+int Learner::mark_stream(hipStream_t st, hipEvent_t fallback, hipEvent_t* ev) {
+    TailEvents* t = tl_tail;
+    if (t && st == t->stream && t->last) {
+        *ev = t->last;
+        return 0;
+    }
+    if (t && st == t->stream && t->idx > 0 && t->idx <= t->need_cap) t->need[t->idx - 1] = 1;     // next run: a stop event on that launch
+    CDRL_HIP(hipEventRecord(fallback, st));
+    *ev = fallback;
+    return 0;
 }
 
 void Learner::flush_deferred() {
@@ -200,6 +261,7 @@ void Learner::flush_deferred() {
         if (rc != 0 && deferred_rc_ == 0) deferred_rc_ = rc;
         if (d.slot != slot_) {      // (a job of the current slot is covered by the done_side() that follows)
             if (hipEventRecord(ev_side_[d.slot], side_) != hipSuccess && deferred_rc_ == 0) deferred_rc_ = -3;
+            slot_seq_[d.slot] = note_side_record(ev_side_[d.slot]);
             slot_used_[d.slot] = true;
         }
     }
@@ -219,7 +281,7 @@ int Learner::defer_side(hipStream_t st, std::function<int(hipStream_t)> fn) {
 
 int Learner::next_q(hipStream_t st) {
     qi_ = (qi_ + 1) % NQ;
-    if (side_enabled_ && q_used_[qi_]) CDRL_HIP(hipStreamWaitEvent(st, ev_q_[qi_], 0));
+    if (side_enabled_ && q_used_[qi_]) CDRL_TRY(wait_side_record(st, q_seq_[qi_], ev_q_[qi_]));
     return 0;
 }
 
@@ -238,6 +300,7 @@ int Learner::done_side(hipStream_t side) {
     }
     if (g_diag_noev & 4) return 0;
     CDRL_HIP(hipEventRecord(ev_side_[slot_], side_));
+    slot_seq_[slot_] = note_side_record(ev_side_[slot_]);
     slot_used_[slot_] = true;
     return 0;
 }
@@ -250,6 +313,8 @@ int Learner::join_side(hipStream_t st) {
     }
     CDRL_HIP(hipEventRecord(ev_join_, side_));
     CDRL_HIP(hipStreamWaitEvent(st, ev_join_, 0));
+    const uint64_t js = note_side_record(ev_join_);
+    if (st == main_) main_waited_ = js;
     if (aux_pending_) {
         CDRL_TRY(aux_wait());
         CDRL_HIP(hipStreamWaitEvent(st, ev_aux_done_, 0));
@@ -338,10 +403,12 @@ int Learner::check_guards(hipStream_t st, int64_t* bad, int64_t* first_off) {
     const int n = (int)guard_off_.size();
     int64_t init[2] = {0, (int64_t)1 << 40};
     CDRL_HIP(hipMemcpyAsync(guard_tab_ + GUARD_TABLE_MAX, init, sizeof(init), hipMemcpyHostToDevice, st));
+    tail_invalidate(st);
     hipLaunchKernelGGL(guard_check_kernel, dim3(n), dim3(256), 0, st, ws_base_, guard_tab_, (int)(GUARD_BYTES / 4), guard_tab_ + GUARD_TABLE_MAX);
     CDRL_LAUNCH_CHECK();
     int64_t out[2];
     CDRL_HIP(hipMemcpyAsync(out, guard_tab_ + GUARD_TABLE_MAX, sizeof(out), hipMemcpyDeviceToHost, st));
+    tail_invalidate(st);
     CDRL_HIP(hipStreamSynchronize(st));
     if (bad) *bad = out[0];
     if (first_off) *first_off = out[0] ? guard_off_[(size_t)out[1]] : -1;
@@ -709,6 +776,7 @@ void Learner::add_pw(std::vector<Op>& ops, const std::string& prefix, View in, i
                 CDRL_TRY(pw_bwd_fused_reduce(f, sd));
                 if (side_enabled_ && sd == side_) {     // the buffer pair is free again once this reduce has run
                     CDRL_HIP(hipEventRecord(ev_q_[qi], sd));
+                    q_seq_[qi] = note_side_record(ev_q_[qi]);
                     q_used_[qi] = true;
                 }
                 return 0;
@@ -1009,11 +1077,12 @@ void Learner::add_aux_fork(std::vector<Op>& ops) {
     op.fwd = [=](hipStream_t st, int training) -> int {
         if (diag_skip_aux & 1) return 0;
         if (!side_enabled_) return run_fwd(aux_ops_, st, training);
-        CDRL_HIP(hipEventRecord(ev_aux_fork_, st));           // parameters / inputs produced on the main stream
+        hipEvent_t evf = nullptr;
+        CDRL_TRY(mark_stream(st, ev_aux_fork_, &evf));        // parameters / inputs produced on the main stream
         if (aux_worker_ && !graphs_enabled_) {
             CDRL_TRY(aux_wait());
-            aux_worker_->submit([this, training]() -> int {
-                CDRL_HIP(hipStreamWaitEvent(aux_, ev_aux_fork_, 0));
+            aux_worker_->submit([this, training, evf]() -> int {
+                CDRL_HIP(hipStreamWaitEvent(aux_, evf, 0));
                 CDRL_TRY(run_fwd(aux_ops_, aux_, training));
                 CDRL_HIP(hipEventRecord(ev_aux_done_, aux_));
                 return 0;
@@ -1021,7 +1090,7 @@ void Learner::add_aux_fork(std::vector<Op>& ops) {
             aux_inflight_ = true;
             return 0;
         }
-        CDRL_HIP(hipStreamWaitEvent(aux_, ev_aux_fork_, 0));
+        CDRL_HIP(hipStreamWaitEvent(aux_, evf, 0));
         CDRL_TRY(run_fwd(aux_ops_, aux_, training));
         CDRL_HIP(hipEventRecord(ev_aux_done_, aux_));
         return 0;
@@ -1045,12 +1114,13 @@ void Learner::add_aux_join(std::vector<Op>& ops) {
         if (!side_enabled_) return run_bwd(aux_ops_, st);
         // Own stream: ~90 tiny dependent kernels (0.8 ms).  On the filter-gradient side stream they blocked, in stream
         // order, the slot events the main stream waits on (measured: a 0.84 ms hole in the critical stream per pass).
-        CDRL_HIP(hipEventRecord(ev_aux_fork_, st));           // gradient of the concat is ready
+        hipEvent_t evf = nullptr;
+        CDRL_TRY(mark_stream(st, ev_aux_fork_, &evf));        // gradient of the concat is ready
         aux_pending_ = true;                                  // joined by join_side() at the end of the backward
         if (aux_worker_ && !graphs_enabled_) {
             CDRL_TRY(aux_wait());
-            aux_worker_->submit([this]() -> int {
-                CDRL_HIP(hipStreamWaitEvent(aux_, ev_aux_fork_, 0));
+            aux_worker_->submit([this, evf]() -> int {
+                CDRL_HIP(hipStreamWaitEvent(aux_, evf, 0));
                 CDRL_TRY(run_bwd(aux_ops_, aux_));
                 CDRL_HIP(hipEventRecord(ev_aux_done_, aux_));
                 return 0;
@@ -1058,7 +1128,7 @@ void Learner::add_aux_join(std::vector<Op>& ops) {
             aux_inflight_ = true;
             return 0;
         }
-        CDRL_HIP(hipStreamWaitEvent(aux_, ev_aux_fork_, 0));
+        CDRL_HIP(hipStreamWaitEvent(aux_, evf, 0));
         CDRL_TRY(run_bwd(aux_ops_, aux_));
         CDRL_HIP(hipEventRecord(ev_aux_done_, aux_));
         return 0;
@@ -1157,7 +1227,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
                 static const bool diag_skip = cdrl_getenv("CDRL_DIAG_SKIP_STEMF") && atoi(cdrl_getenv("CDRL_DIAG_SKIP_STEMF")) == 1;    // timing diagnostics only (no stem filter gradient)
                 if (!diag_skip)
-                    CDRL_TRY(stem_bwd_filter_fused(in_image_, ps, y.p, stem_stats, stem_coef, w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side, at));
+                    CDRL_TRY(stem_bwd_filter_fused(in_image_, ps, y.p, stem_stats, stem_coef, w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side, at, w.p, b.p));
                 return done_side(side);
             }
             hipStream_t side = fork_side(st);
@@ -1233,8 +1303,9 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                     Op fk;
                     fk.fwd = [=](hipStream_t st, int) -> int {
                         if (!side_enabled_) return 0;
-                        CDRL_HIP(hipEventRecord(ev_sc_fork_[sc_ev], st));
-                        CDRL_HIP(hipStreamWaitEvent(side_, ev_sc_fork_[sc_ev], 0));
+                        hipEvent_t evf = nullptr;
+                        CDRL_TRY(mark_stream(st, ev_sc_fork_[sc_ev], &evf));
+                        CDRL_HIP(hipStreamWaitEvent(side_, evf, 0));
                         return 0;
                     };
                     fk.bwd = [](hipStream_t) -> int { return 0; };
@@ -1448,6 +1519,8 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                             if (!side_enabled_) return 0;
                             CDRL_HIP(hipEventRecord(ev_sc_done_[sc_ev], side_));
                             CDRL_HIP(hipStreamWaitEvent(st, ev_sc_done_[sc_ev], 0));
+                            const uint64_t js = note_side_record(ev_sc_done_[sc_ev]);
+                            if (st == main_) main_waited_ = js;
                             return 0;
                         };
                         jn.bwd = [](hipStream_t) -> int { return 0; };
@@ -1532,7 +1605,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
             // joined, and a replay would never release it): the caller falls back to the single post-pass all-reduce
             if (!comm_ || graphs_enabled_) return 0;
             CDRL_TRY(aux_wait());
-            CDRL_HIP(hipEventRecord(ev_tail_main_, st));
+            CDRL_HIP(hipEventRecord(ev_tail_main_, st));          // (recorded, with its system-scope fence: the collectives read these bytes)
             CDRL_HIP(hipStreamWaitEvent(comm_, ev_tail_main_, 0));
             if (side_enabled_) {
                 CDRL_TRY(flush_side(st));       // (queued side jobs go out BEHIND an event of the critical stream, as everywhere else)
@@ -1799,24 +1872,45 @@ int Learner::bind(const Buffers& b) {
         // of 1.1 ms at E = 1 (tools/bench_rollout_rows.py).
         const int prio_lo = 0, prio_hi = 0;
         CDRL_HIP(hipStreamCreateWithPriority(&main_, hipStreamNonBlocking, prio_hi));
-        CDRL_HIP(hipEventCreateWithFlags(&ev_in_, hipEventDisableTiming));
-        CDRL_HIP(hipEventCreateWithFlags(&ev_out_, hipEventDisableTiming));
+        // Events between the engine's own streams carry no system-scope fence (hipEventDisableSystemFence): the marker packet of a default
+        // event writes the L2 back and invalidates it, in the middle of the critical stream.  The events that hand over to the communication
+        // stream (collectives: other devices read what they cover) keep it.  CDRL_EVENT_FENCE=1 -> default events everywhere (rounds 1-5).
+        const char* fe = cdrl_getenv("CDRL_EVENT_FENCE");
+        const unsigned evf_int = hipEventDisableTiming | ((fe && atoi(fe) == 1) ? 0u : (unsigned)hipEventDisableSystemFence);
+        CDRL_HIP(hipEventCreateWithFlags(&ev_in_, evf_int));      // (caller's stream: same device; what the host reads afterwards goes through a copy with its own fences)
+        CDRL_HIP(hipEventCreateWithFlags(&ev_out_, evf_int));
         CDRL_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, prio_lo));
         for (int i = 0; i < NSLOT; ++i) {
-            CDRL_HIP(hipEventCreateWithFlags(&ev_main_[i], hipEventDisableTiming));
-            CDRL_HIP(hipEventCreateWithFlags(&ev_side_[i], hipEventDisableTiming));
+            CDRL_HIP(hipEventCreateWithFlags(&ev_main_[i], evf_int));
+            CDRL_HIP(hipEventCreateWithFlags(&ev_side_[i], evf_int));
         }
-        CDRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-        for (int i = 0; i < NQ; ++i) CDRL_HIP(hipEventCreateWithFlags(&ev_q_[i], hipEventDisableTiming));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_join_, evf_int));
+        for (int i = 0; i < NQ; ++i) CDRL_HIP(hipEventCreateWithFlags(&ev_q_[i], evf_int));
+        {
+            // CDRL_SIDE_LAG=-1 -> every claim of a scratch slot waits for its own event (rounds 1-5); n >= 0: see wait_side_record
+            const char* le = cdrl_getenv("CDRL_SIDE_LAG");
+            side_lag_ = le ? atoi(le) : 4;
+        }
+        {
+            // CDRL_TAIL_EVENTS=0 -> forks by hipEventRecord on the critical stream (rounds 1-5)
+            const char* te = cdrl_getenv("CDRL_TAIL_EVENTS");
+            const bool tail_on = !(te && atoi(te) == 0) && !graphs_enabled_;
+            tail_.stream = main_;
+            tail_.n = 0;
+            if (tail_on) {
+                for (int i = 0; i < 32; ++i) CDRL_HIP(hipEventCreateWithFlags(&tail_.ring[i], evf_int));
+                tail_.n = 32;
+            }
+        }
         CDRL_HIP(hipEventCreateWithFlags(&ev_tail_main_, hipEventDisableTiming));
         CDRL_HIP(hipEventCreateWithFlags(&ev_tail_side_, hipEventDisableTiming));
         for (int i = 0; i < 3; ++i) {
-            CDRL_HIP(hipEventCreateWithFlags(&ev_sc_fork_[i], hipEventDisableTiming));
-            CDRL_HIP(hipEventCreateWithFlags(&ev_sc_done_[i], hipEventDisableTiming));
+            CDRL_HIP(hipEventCreateWithFlags(&ev_sc_fork_[i], evf_int));
+            CDRL_HIP(hipEventCreateWithFlags(&ev_sc_done_[i], evf_int));
         }
         CDRL_HIP(hipStreamCreateWithPriority(&aux_, hipStreamNonBlocking, prio_lo));
-        CDRL_HIP(hipEventCreateWithFlags(&ev_aux_fork_, hipEventDisableTiming));
-        CDRL_HIP(hipEventCreateWithFlags(&ev_aux_done_, hipEventDisableTiming));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_aux_fork_, evf_int));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_aux_done_, evf_int));
         const char* tenv = cdrl_getenv("CDRL_AUX_THREAD");
         // opt-in (CDRL_AUX_THREAD=1): measured 20.76 vs 20.83 ms/update-step at B=256 -- the host is 8 ms per step ahead of
         // the GPU in steady state, so the second enqueue thread only pays off for small images (host-bound below ~45x60)
@@ -1824,6 +1918,7 @@ int Learner::bind(const Buffers& b) {
             int dev = 0;
             CDRL_HIP(hipGetDevice(&dev));
             aux_worker_.reset(new AuxWorker(dev));
+            side_lag_ = -1;         // (two enqueue threads: the record bookkeeping is single-threaded)
         }
     }
     if (!hp_stage_) CDRL_HIP(hipHostMalloc(reinterpret_cast<void**>(&hp_stage_), sizeof(DevHP), 0));
@@ -1835,11 +1930,13 @@ int Learner::upload_hp(hipStream_t st) {
     // only the float block (lr / clip / entropy / betas); the Adam counters stay device-resident
     memcpy(hp_stage_, &hp_host_, sizeof(DevHP));
     CDRL_HIP(hipMemcpyAsync(hp_dev_, hp_stage_, offsetof(DevHP, t_policy), hipMemcpyHostToDevice, st));
+    tail_invalidate(st);
     return 0;
 }
 
 int Learner::reset_counters(hipStream_t st) {
     CDRL_HIP(hipMemsetAsync(reinterpret_cast<char*>(hp_dev_) + offsetof(DevHP, t_policy), 0, 3 * sizeof(int), st));
+    tail_invalidate(st);
     return 0;
 }
 
@@ -1994,6 +2091,7 @@ int Learner::update_old_policy_impl(hipStream_t st) {
                             tr_size_[M_POLICY] * sizeof(float), hipMemcpyDeviceToDevice, st));
     CDRL_HIP(hipMemcpyAsync(buf_.params + st_offset(M_OLD_POLICY), buf_.params + st_offset(M_POLICY),
                             st_size_[M_POLICY] * sizeof(float), hipMemcpyDeviceToDevice, st));
+    tail_invalidate(st);
     return 0;
 }
 
@@ -2051,6 +2149,7 @@ int Learner::predict_impl(const float* image, const float* road, const float* ve
     CDRL_TRY(value_act(lin_v_.p, value_out, cfg_.B, cfg_.exp_scale, st));
     if (dyn_out)
         CDRL_HIP(hipMemcpyAsync(dyn_out, dyn_.p, (size_t)cfg_.B * cfg_.dyn * sizeof(float), hipMemcpyDeviceToDevice, st));
+    tail_invalidate(st);
     return 0;
 }
 
