@@ -107,6 +107,8 @@ PROTOTYPES = {
     'cdrl_beta_sample_gammas': (_i, [_fp, _fp, _i, _i, _i, C.c_uint64, C.c_uint64, _fp, _fp]),
     'cdrl_philox_words': (_i, [C.c_uint64, C.c_uint64, C.c_uint64, _i, _i, _fp, _fp]),
     'cdrl_learner_policy_apply': (_i, [_L, _fp]),
+    'cdrl_learner_sequence_begin': (_i, [_L, _fp]),
+    'cdrl_learner_sequence_end': (_i, [_L, _fp]),
     'cdrl_learner_value_forward_backward': (_i, [_L, C.POINTER(ValueBatch), _f, _fp]),
     'cdrl_learner_value_apply': (_i, [_L, _fp]),
     'cdrl_learner_update_old_policy': (_i, [_L, _fp]),

@@ -332,6 +332,16 @@ int cdrl_philox_words(uint64_t seed, uint64_t offset, uint64_t idx0, int n, int 
     return philox_words(seed, offset, idx0, n, nblocks, out, S(stream));
 }
 
+int cdrl_learner_sequence_begin(cdrl_learner* l, void* stream) {
+    CHECK_L(l);
+    return l->impl->sequence_begin(S(stream));
+}
+
+int cdrl_learner_sequence_end(cdrl_learner* l, void* stream) {
+    CHECK_L(l);
+    return l->impl->sequence_end(S(stream));
+}
+
 int cdrl_learner_policy_apply(cdrl_learner* l, void* stream) {
     CHECK_L(l);
     return l->impl->policy_apply(S(stream));

@@ -147,6 +147,8 @@ public:
                                          hipStream_t st);
     float* sample_buffer() const { return sample_u_; }
     int policy_apply(hipStream_t st);
+    int sequence_begin(hipStream_t caller);
+    int sequence_end(hipStream_t caller);
     int value_forward_backward(const ValueBatch& b, float inv_world, hipStream_t st);
     int value_apply(hipStream_t st);
     int update_old_policy(hipStream_t st);
@@ -367,6 +369,8 @@ private:
     std::unique_ptr<AuxWorker> aux_worker_;
     bool aux_inflight_ = false;
     int aux_wait();
+    bool seq_open_ = false;                             // between sequence_begin and sequence_end on seq_caller_
+    hipStream_t seq_caller_ = nullptr;
     TailEvents tail_;                                   // stop events of the critical stream's kernels (cdrl_common.h)
     std::map<std::vector<uint64_t>, std::vector<uint8_t>> tail_need_;      // per body (launch key): which launches a fork follows
     int mark_stream(hipStream_t st, hipEvent_t fallback, hipEvent_t* ev);

@@ -139,8 +139,13 @@ int Learner::launch(hipStream_t caller, std::vector<uint64_t> key, bool graphabl
         set_error("learner not bound");
         return -1;
     }
-    CDRL_HIP(hipEventRecord(ev_in_, caller));
-    CDRL_HIP(hipStreamWaitEvent(main_, ev_in_, 0));
+    // inside a sequence (sequence_begin .. sequence_end on this stream) the hand-overs between the caller's stream and the engine's happen
+    // once, around the whole sequence
+    const bool in_seq = seq_open_ && caller == seq_caller_;
+    if (!in_seq) {
+        CDRL_HIP(hipEventRecord(ev_in_, caller));
+        CDRL_HIP(hipStreamWaitEvent(main_, ev_in_, 0));
+    }
     int rc = 0;
     if (!graphs_enabled_ || !graphable) {
         // eager launches: kernels on the critical stream carry stop events (TailEvents, cdrl_common.h) while the body runs on this thread
@@ -184,6 +189,38 @@ int Learner::launch(hipStream_t caller, std::vector<uint64_t> key, bool graphabl
         CDRL_HIP(hipGraphLaunch(it->second, main_));
     }
     if (rc != 0) return rc;
+    if (in_seq) return 0;
+    CDRL_HIP(hipEventRecord(ev_out_, main_));
+    CDRL_HIP(hipStreamWaitEvent(caller, ev_out_, 0));
+    return 0;
+}
+
+// A sequence of learner calls on ONE caller stream with nothing of the caller's own in between (an update-step on one GPU: policy pass,
+// apply, value pass, apply): every call used to hand the work from the caller's stream to the engine's and back -- two markers and two
+// barrier packets across two queues per call, ~10 us of signal latency each way with nothing to order.  Between begin and end the calls
+// on that stream skip the hand-overs; begin orders the engine behind the caller's stream, end the caller's stream behind the engine.
+int Learner::sequence_begin(hipStream_t caller) {
+    if (!main_) {
+        set_error("learner not bound");
+        return -1;
+    }
+    if (seq_open_) {
+        set_error("sequence_begin: a sequence is already open");
+        return -1;
+    }
+    CDRL_HIP(hipEventRecord(ev_in_, caller));
+    CDRL_HIP(hipStreamWaitEvent(main_, ev_in_, 0));
+    seq_open_ = true;
+    seq_caller_ = caller;
+    return 0;
+}
+
+int Learner::sequence_end(hipStream_t caller) {
+    if (!seq_open_ || caller != seq_caller_) {
+        set_error("sequence_end: no sequence open on this stream");
+        return -1;
+    }
+    seq_open_ = false;
     CDRL_HIP(hipEventRecord(ev_out_, main_));
     CDRL_HIP(hipStreamWaitEvent(caller, ev_out_, 0));
     return 0;

@@ -322,13 +322,37 @@ class LearnerEngine:
     def value_apply(self):
         _lib.check(self.lib.cdrl_learner_value_apply(self.h, self._stream()), 'value_apply')
 
+    def sequence(self):
+        """Context manager around a run of learner calls on the current stream with nothing of the caller's own between them (one
+        minibatch on one GPU: policy pass, apply, value pass, apply): the hand-overs between the caller's stream and the engine's
+        happen once, around the whole run (`cdrl_learner_sequence_begin / _end`).  Not for runs with collectives in between."""
+        eng = self
+
+        class _Seq:
+            def __enter__(self_inner):          # (re-entrant on the Python side: only the outermost level brackets)
+                depth = getattr(eng, '_seq_depth', 0)
+                if depth == 0:
+                    _lib.check(eng.lib.cdrl_learner_sequence_begin(eng.h, eng._stream()), 'sequence_begin')
+                eng._seq_depth = depth + 1
+                return eng
+
+            def __exit__(self_inner, *exc):
+                eng._seq_depth -= 1
+                if eng._seq_depth == 0:
+                    _lib.check(eng.lib.cdrl_learner_sequence_end(eng.h, eng._stream()), 'sequence_end')
+                return False
+
+        return _Seq()
+
     def policy_step(self, batch):
-        self.policy_forward_backward(batch)
-        self.policy_apply()
+        with self.sequence():
+            self.policy_forward_backward(batch)
+            self.policy_apply()
 
     def value_step(self, batch):
-        self.value_forward_backward(batch)
-        self.value_apply()
+        with self.sequence():
+            self.value_forward_backward(batch)
+            self.value_apply()
 
     def update_old_policy(self):
         _lib.check(self.lib.cdrl_learner_update_old_policy(self.h, self._stream()), 'update_old_policy')

@@ -187,6 +187,12 @@ class DataParallelLearner:
     def update_step(self, policy_batch, value_batch, resample=None):
         """One PPO update-step = one policy minibatch step + one value minibatch step
         (reference rl/agents/ppo.py:199-224)."""
+        if self.world == 1 and not self.force and os.environ.get('CDRL_SEQUENCE', '1') != '0':
+            # no collective between the four calls: one hand-over between the caller's stream and the engine's around all of them
+            with self.engine.sequence():
+                self.policy_step(policy_batch, resample)
+                self.value_step(value_batch, with_stats=True)
+            return
         self.policy_step(policy_batch, resample)
         if not self.value_step(value_batch, with_stats=True):
             self.sync_moving_statistics()

@@ -157,6 +157,13 @@ int cdrl_learner_policy_backward(cdrl_learner* l, const cdrl_policy_batch* b, fl
  * (seed, offset) select the Philox stream; the drawn sample is left in CDRL_BUF_SAMPLE. */
 int cdrl_learner_policy_forward_backward_resample(cdrl_learner* l, const cdrl_policy_batch* b, uint64_t seed,
                                                  uint64_t offset, float grad_scale, void* stream);
+/* Brackets a SEQUENCE of learner calls enqueued from one stream with nothing of the caller's own between them -- the four calls of
+ * one minibatch of PPOAgent.update on one GPU (rl/agents/ppo.py:190-226: policy gradients, apply, value gradients, apply).  Each
+ * learner call orders the engine's streams behind `stream` on entry and `stream` behind them on return; inside a sequence that
+ * happens once, in begin and in end.  Between the two, work the caller enqueues on `stream` is NOT ordered against the learner calls
+ * (collectives between a pass and its apply: do not bracket them).  Calls on other streams are unaffected.  No nesting. */
+int cdrl_learner_sequence_begin(cdrl_learner* l, void* stream);
+int cdrl_learner_sequence_end(cdrl_learner* l, void* stream);
 /* CARLAgent.apply_policy_gradients (core/carla_agent.py:375-388) + PPOAgent.apply_policy_gradients
  * (rl/agents/ppo.py:238-252): trunk Adam, per-tensor clip, old_policy <- policy, policy Adam. */
 int cdrl_learner_policy_apply(cdrl_learner* l, void* stream);
