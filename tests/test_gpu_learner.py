@@ -525,6 +525,37 @@ def test_determinism():
     assert torch.equal(g1, eng.grads)
 
 
+def test_sequence_of_calls_is_bit_identical():
+    """cdrl_learner_sequence_begin / _end (round 6): the four calls of an update-step inside ONE hand-over between the caller's stream
+    and the engine's give the parameters, optimizer moments and losses of the four separately bracketed calls bit for bit; the bracket
+    refuses nesting and an end without a begin."""
+    B, H, W = 8, 48, 64
+    _, e1 = make_pair(B, H, W, seed=13)
+    _, e2 = make_pair(B, H, W, seed=13)
+    pol, val = make_batches(B, H, W, seed=13)
+    dpol, dval = to_dev(pol), to_dev(val)
+    for it in range(3):
+        e1.policy_forward_backward(dpol)
+        e1.policy_apply()
+        e1.value_forward_backward(dval)
+        e1.value_apply()
+        with e2.sequence():
+            e2.policy_forward_backward(dpol)
+            e2.policy_apply()
+            with e2.sequence():                 # (the Python side is re-entrant: the inner level does not bracket)
+                e2.value_forward_backward(dval)
+            e2.value_apply()
+    torch.cuda.synchronize()
+    assert torch.equal(e1.params, e2.params)
+    assert torch.equal(e1.grads, e2.grads)
+    assert e1.metrics('policy')['loss'] == e2.metrics('policy')['loss'] and e1.metrics('value')['loss'] == e2.metrics('value')['loss']
+    st = e2._stream()
+    assert e2.lib.cdrl_learner_sequence_end(e2.h, st) != 0                  # nothing open
+    assert e2.lib.cdrl_learner_sequence_begin(e2.h, st) == 0
+    assert e2.lib.cdrl_learner_sequence_begin(e2.h, st) != 0                # no nesting at the C level
+    assert e2.lib.cdrl_learner_sequence_end(e2.h, st) == 0
+
+
 @pytest.mark.parametrize('H,W', [(90, 120), (90, 360)])
 def test_full_size_properties(H, W):
     """BASELINE.json's full size (B=256, T=4, 90x120x3; and the reference-faithful three-camera width 90x360) is too large for the CPU oracle in a test, so the engine is checked
