@@ -437,7 +437,8 @@ struct TensorSeg {      // one parameter tensor inside a flat arena
 };
 // sq-norm per tensor -> norms[ntensors]; deterministic two-stage reduction
 int tensor_sqnorms(const float* g, const TensorSeg* segs_dev, int ntensors, const int* chunk_tensor_dev,
-                   const int64_t* chunk_off_dev, int nchunks, double* chunk_part, float* sqnorms, hipStream_t st);
+                   const int64_t* chunk_off_dev, int nchunks, double* chunk_part, float* sqnorms, hipStream_t st,
+                   DevHP* tick_hp = nullptr, int tick = -1);    // tick_hp: also advances that Adam step counter (adam_tick folded in)
 // which: 0 policy, 1 value, 2 dynamics
 int clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const int* chunk_tensor_dev,
               const int64_t* chunk_off_dev, int nchunks, const TensorSeg* segs_dev, const float* sqnorms /*or null*/,

@@ -772,6 +772,8 @@ int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, con
     }
 #undef CDRL_STEM_BWD_LAUNCH
     CDRL_LAUNCH_CHECK();
+    // (the engine's arena holds the bias gradient right behind the filter gradient: one reduce over the 28 * Cout columns of a partial)
+    if (db == dw + 27 * Cout) return reduce_partials_f32(pf, nblk, (int64_t)28 * Cout, (int64_t)28 * Cout, dw, 0, st);
     CDRL_TRY(reduce_partials_f32(pf, nblk, (int64_t)27 * Cout, (int64_t)28 * Cout, dw, 0, st));
     return reduce_partials_f32(pf + 27 * Cout, nblk, Cout, (int64_t)28 * Cout, db, 0, st);
 }

@@ -586,8 +586,11 @@ void Learner::note_bn_inference(const float* gamma, const float* beta, const flo
 
 int Learner::run_trunk_fwd(hipStream_t st, int training) {
     if (!training) CDRL_TRY(bn_inference_stats_many(d_bninf_, (int)h_bninf_.size(), bninf_max_c_, st));
+    // this pass's weights in fragment order (fwd + bwd-data).  On the side stream beside the stem block, joined behind it: measured twice,
+    // 14.29 vs 14.30 ms with round 5's events and 12.46 vs 12.41 ms with round 6's -- three 10-us launches beside the bandwidth-bound stem
+    // conv plus a join packet cost what they save; they stay in front of the stem.
     CDRL_TRY(gemm_x3_pack_many(d_gpack_, (int)h_gpack_.size(), st));
-    CDRL_TRY(pw_pack_many(d_pack_, (int)h_pack_.size(), st));       // this pass's weights in fragment order (fwd + bwd-data)
+    CDRL_TRY(pw_pack_many(d_pack_, (int)h_pack_.size(), st));
     CDRL_TRY(pw_x3_pack_many(d_pack3_, (int)h_pack3_.size(), st));
     return run_fwd(trunk_ops_, st, training);
 }
@@ -2141,10 +2144,9 @@ int Learner::policy_apply_impl(hipStream_t st) {
     const int64_t to = tr_offset(M_TRUNK), po = tr_offset(M_POLICY);
     CDRL_TRY(clip_adam(buf_.params + to, buf_.grads + to, buf_.adam_m + to, buf_.adam_v + to, tr_size_[M_TRUNK], nullptr,
                        nullptr, 0, nullptr, nullptr, hp_dev_, 2, st));
-    CDRL_TRY(adam_tick(hp_dev_, 2, st));
     SegTable& s = seg_[M_POLICY];
     CDRL_TRY(tensor_sqnorms(buf_.grads + po, s.segs, s.ntensors, s.chunk_tensor, s.chunk_off, s.nchunks, s.chunk_part,
-                            s.sqnorms, st));
+                            s.sqnorms, st, hp_dev_, 2));        // (+ the trunk's Adam step counter: was a launch of its own)
     CDRL_TRY(update_old_policy_impl(st));
     CDRL_TRY(clip_adam(buf_.params + po, buf_.grads + po, buf_.adam_m + po, buf_.adam_v + po, tr_size_[M_POLICY],
                        s.chunk_tensor, s.chunk_off, s.nchunks, s.segs, s.sqnorms, hp_dev_, 0, st));
@@ -2159,10 +2161,9 @@ int Learner::value_apply_impl(hipStream_t st) {
     const int64_t to = tr_offset(M_TRUNK), vo = tr_offset(M_VALUE);
     CDRL_TRY(clip_adam(buf_.params + to, buf_.grads + to, buf_.adam_m + to, buf_.adam_v + to, tr_size_[M_TRUNK], nullptr,
                        nullptr, 0, nullptr, nullptr, hp_dev_, 2, st));
-    CDRL_TRY(adam_tick(hp_dev_, 2, st));
     SegTable& s = seg_[M_VALUE];
     CDRL_TRY(tensor_sqnorms(buf_.grads + vo, s.segs, s.ntensors, s.chunk_tensor, s.chunk_off, s.nchunks, s.chunk_part,
-                            s.sqnorms, st));
+                            s.sqnorms, st, hp_dev_, 2));
     CDRL_TRY(clip_adam(buf_.params + vo, buf_.grads + vo, buf_.adam_m + vo, buf_.adam_v + vo, tr_size_[M_VALUE],
                        s.chunk_tensor, s.chunk_off, s.nchunks, s.segs, s.sqnorms, hp_dev_, 1, st));
     return adam_tick(hp_dev_, 1, st);

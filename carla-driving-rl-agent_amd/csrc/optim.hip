@@ -19,9 +19,15 @@ __global__ void __launch_bounds__(256) sqnorm_chunk_kernel(const float* __restri
                                                            const TensorSeg* __restrict__ segs,
                                                            const int* __restrict__ chunk_tensor,
                                                            const int64_t* __restrict__ chunk_off,
-                                                           double* __restrict__ chunk_part) {
+                                                           double* __restrict__ chunk_part, DevHP* hp, int tick) {
     __shared__ double sm[256];
     const int c = blockIdx.x;
+    // the step counter of the Adam update that ran in FRONT of this kernel (the trunk's: nothing here reads it) -- it was a launch of its own
+    if (tick >= 0 && c == 0 && threadIdx.x == 0) {
+        if (tick == 0) hp->t_policy += 1;
+        else if (tick == 1) hp->t_value += 1;
+        else hp->t_dynamics += 1;
+    }
     const TensorSeg s = segs[chunk_tensor[c]];
     const int64_t beg = chunk_off[c];
     int64_t end = beg + CHUNK;
@@ -40,22 +46,28 @@ __global__ void __launch_bounds__(256) sqnorm_chunk_kernel(const float* __restri
     if (threadIdx.x == 0) chunk_part[c] = sm[0];
 }
 
-__global__ void sqnorm_final_kernel(const TensorSeg* __restrict__ segs, int ntensors,
-                                    const double* __restrict__ chunk_part, float* __restrict__ sqnorms) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per tensor: lane l sums the chunks l, l + 64, ... in order, then a fixed shuffle tree (one THREAD per tensor walked up to
+// 768 chunk partials one dependent load at a time: 17 us)
+__global__ void __launch_bounds__(256) sqnorm_final_kernel(const TensorSeg* __restrict__ segs, int ntensors,
+                                                           const double* __restrict__ chunk_part, float* __restrict__ sqnorms) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= ntensors) return;
     const TensorSeg s = segs[t];
     double acc = 0.0;
-    for (int c = 0; c < s.nchunks; ++c) acc += chunk_part[s.first_chunk + c];
-    sqnorms[t] = (float)acc;
+    for (int c = lane; c < s.nchunks; c += 64) acc += chunk_part[s.first_chunk + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) sqnorms[t] = (float)acc;
 }
 
 int tensor_sqnorms(const float* g, const TensorSeg* segs_dev, int ntensors, const int* chunk_tensor_dev,
-                   const int64_t* chunk_off_dev, int nchunks, double* chunk_part, float* sqnorms, hipStream_t st) {
+                   const int64_t* chunk_off_dev, int nchunks, double* chunk_part, float* sqnorms, hipStream_t st, DevHP* tick_hp,
+                   int tick) {
     hipLaunchKernelGGL(sqnorm_chunk_kernel, dim3(nchunks), dim3(256), 0, st, g, segs_dev, chunk_tensor_dev, chunk_off_dev,
-                       chunk_part);
+                       chunk_part, tick_hp, tick_hp ? tick : -1);
     CDRL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(cdiv(ntensors, 64)), dim3(64), 0, st, segs_dev, ntensors, chunk_part,
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(cdiv(ntensors, 4)), dim3(256), 0, st, segs_dev, ntensors, chunk_part,
                        sqnorms);
     CDRL_LAUNCH_CHECK();
     return 0;
