@@ -54,6 +54,7 @@ Learner::~Learner() {
     drop_graphs();
     if (ev_in_) (void)hipEventDestroy(ev_in_);
     if (ev_out_) (void)hipEventDestroy(ev_out_);
+    if (ev_out_sys_) (void)hipEventDestroy(ev_out_sys_);
     if (main_) (void)hipStreamDestroy(main_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     for (int i = 0; i < NQ; ++i)
@@ -190,8 +191,11 @@ int Learner::launch(hipStream_t caller, std::vector<uint64_t> key, bool graphabl
     }
     if (rc != 0) return rc;
     if (in_seq) return 0;
-    CDRL_HIP(hipEventRecord(ev_out_, main_));
-    CDRL_HIP(hipStreamWaitEvent(caller, ev_out_, 0));
+    // data-parallel use (a communication stream is set, or a pass ran with a gradient scale below 1): what the caller enqueues next may be a
+    // collective whose peers read these buffers -- the hand-back keeps the system-scope fence there (unmeasurable on one GPU: insurance)
+    hipEvent_t eo = (comm_ || dp_hint_) ? ev_out_sys_ : ev_out_;
+    CDRL_HIP(hipEventRecord(eo, main_));
+    CDRL_HIP(hipStreamWaitEvent(caller, eo, 0));
     return 0;
 }
 
@@ -221,8 +225,9 @@ int Learner::sequence_end(hipStream_t caller) {
         return -1;
     }
     seq_open_ = false;
-    CDRL_HIP(hipEventRecord(ev_out_, main_));
-    CDRL_HIP(hipStreamWaitEvent(caller, ev_out_, 0));
+    hipEvent_t eo = (comm_ || dp_hint_) ? ev_out_sys_ : ev_out_;
+    CDRL_HIP(hipEventRecord(eo, main_));
+    CDRL_HIP(hipStreamWaitEvent(caller, eo, 0));
     return 0;
 }
 
@@ -1919,6 +1924,7 @@ int Learner::bind(const Buffers& b) {
         const unsigned evf_int = hipEventDisableTiming | ((fe && atoi(fe) == 1) ? 0u : (unsigned)hipEventDisableSystemFence);
         CDRL_HIP(hipEventCreateWithFlags(&ev_in_, evf_int));      // (caller's stream: same device; what the host reads afterwards goes through a copy with its own fences)
         CDRL_HIP(hipEventCreateWithFlags(&ev_out_, evf_int));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_out_sys_, hipEventDisableTiming));
         CDRL_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, prio_lo));
         for (int i = 0; i < NSLOT; ++i) {
             CDRL_HIP(hipEventCreateWithFlags(&ev_main_[i], evf_int));
@@ -2032,6 +2038,7 @@ int Learner::policy_forward_impl(const float* image, const float* road, const fl
 }
 
 int Learner::policy_backward(const PolicyBatch& b, float inv_world, hipStream_t caller) {
+    if (inv_world != 1.0f) dp_hint_ = true;
     return launch(caller, {}, false, [&](hipStream_t st) -> int { return policy_backward_impl(b, inv_world, st); });
 }
 
@@ -2061,6 +2068,7 @@ int Learner::policy_backward_impl(const PolicyBatch& b, float inv_world, hipStre
 
 int Learner::policy_forward_backward_resample(const PolicyBatch& b, uint64_t seed, uint64_t offset, float inv_world,
                                               hipStream_t caller) {
+    if (inv_world != 1.0f) dp_hint_ = true;
     // (seed, offset) are kernel arguments that change every call -> eager, not graph-replayed
     return launch(caller, {}, false, [&](hipStream_t st) -> int {
         CDRL_TRY(policy_forward_impl(b.image, b.road, b.vehicle, b.navigation, st));
@@ -2082,6 +2090,7 @@ static inline uint64_t Kf(float f) {
 }
 
 int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipStream_t caller) {
+    if (inv_world != 1.0f) dp_hint_ = true;
     std::vector<uint64_t> key = {1, K(b.image), K(b.road), K(b.vehicle), K(b.navigation), K(b.adv), K(b.old_logp), K(b.speed),
                                  K(b.similarity), K(b.u), K(b.du_da), K(b.du_db), Kf(inv_world)};
     return launch(caller, key, true, [&](hipStream_t st) -> int {
@@ -2093,6 +2102,7 @@ int Learner::policy_forward_backward(const PolicyBatch& b, float inv_world, hipS
 }
 
 int Learner::value_forward_backward(const ValueBatch& b, float inv_world, hipStream_t caller) {
+    if (inv_world != 1.0f) dp_hint_ = true;
     std::vector<uint64_t> key = {2, K(b.image), K(b.road), K(b.vehicle), K(b.navigation), K(b.returns), K(b.speed),
                                  K(b.similarity), Kf(inv_world)};
     return launch(caller, key, true, [&](hipStream_t st) -> int { return value_forward_backward_impl(b, inv_world, st); });
