@@ -27,6 +27,32 @@ def _run(path, **env):
     return torch.load(path)
 
 
+def _run_steps(path, **env):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'path_consistency.py'), 'steps', path], env=e, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return torch.load(path)
+
+
+def test_stream_synchronisation_modes_are_bit_identical_over_update_steps(tmp_path):
+    """Round 6 changed HOW the engine's streams are ordered against each other, not what they compute: events without the system-scope
+    fence, forks through stop events bound to the kernels in front of them (learned per body: the first run of a body records the old
+    way), numbered side-stream records with lagged waits, one hand-over per update-step.  Twelve update-steps at the benchmark shape
+    (where the kernels take their real durations and the side stream really lags) must leave the parameters, the last gradients and the
+    losses bit-identical to (a) rounds 1-5's synchronisation -- default events, recorded forks, a wait per scratch claim, a hand-over
+    per call -- and (b) the most eager setting (waits for the newest record).  A missing edge shows up here as a different bit."""
+    new = _run_steps(str(tmp_path / 'new.pt'))
+    old = _run_steps(str(tmp_path / 'old.pt'), CDRL_EVENT_FENCE=1, CDRL_TAIL_EVENTS=0, CDRL_SIDE_LAG=-1, PC_SEQ=0)
+    lag0 = _run_steps(str(tmp_path / 'lag0.pt'), CDRL_SIDE_LAG=0, PC_SEQ=0)
+    for other in (old, lag0):
+        assert torch.equal(new['losses'], other['losses'])
+        assert torch.equal(new['params'], other['params'])
+        assert torch.equal(new['grads'], other['grads'])
+    assert torch.isfinite(new['params']).all() and len(new['losses']) == 6
+
+
 def _zero_gradient(name):
     """Parameters whose gradient is analytically zero (pure rounding residue in any implementation): biases in front of a
     train-mode BatchNorm, and the beta of a BatchNorm that is directly followed by another train-mode BatchNorm / conv + BN."""
