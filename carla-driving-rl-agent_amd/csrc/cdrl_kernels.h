@@ -444,6 +444,7 @@ int clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const int
               const int64_t* chunk_off_dev, int nchunks, const TensorSeg* segs_dev, const float* sqnorms /*or null*/,
               DevHP* hp, int which, hipStream_t st);
 int adam_tick(DevHP* hp, int which, hipStream_t st);
+int copy_two(float* d0, const float* s0, int64_t n0, float* d1, const float* s1, int64_t n1, hipStream_t st);
 
 // ---------------------------------------------------------------- GAE (gae.hip)
 // rewards [N+1] (bootstrap appended), values_be [N+1][2] -> returns_be [N][2], returns [N], adv_raw [N], adv [N]

@@ -2137,12 +2137,8 @@ int Learner::update_old_policy(hipStream_t caller) {
 int Learner::update_old_policy_impl(hipStream_t st) {
     // old_policy.set_weights(policy.get_weights()): all weights incl. BN moving statistics
     // (reference core/networks.py:281-285)
-    CDRL_HIP(hipMemcpyAsync(buf_.params + tr_offset(M_OLD_POLICY), buf_.params + tr_offset(M_POLICY),
-                            tr_size_[M_POLICY] * sizeof(float), hipMemcpyDeviceToDevice, st));
-    CDRL_HIP(hipMemcpyAsync(buf_.params + st_offset(M_OLD_POLICY), buf_.params + st_offset(M_POLICY),
-                            st_size_[M_POLICY] * sizeof(float), hipMemcpyDeviceToDevice, st));
-    tail_invalidate(st);
-    return 0;
+    return copy_two(buf_.params + tr_offset(M_OLD_POLICY), buf_.params + tr_offset(M_POLICY), tr_size_[M_POLICY],
+                    buf_.params + st_offset(M_OLD_POLICY), buf_.params + st_offset(M_POLICY), st_size_[M_POLICY], st);
 }
 
 int Learner::policy_apply(hipStream_t caller) {

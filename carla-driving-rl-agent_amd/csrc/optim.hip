@@ -127,6 +127,22 @@ int clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const int
     return 0;
 }
 
+// two device-to-device copies as ONE launch of the library's own (old_policy <- policy: trainable and state slices): hipMemcpyAsync ran
+// two blit kernels of the runtime with their own fences in the middle of the apply
+__global__ void __launch_bounds__(256) copy_two_kernel(float* __restrict__ d0, const float* __restrict__ s0, int64_t n0,
+                                                       float* __restrict__ d1, const float* __restrict__ s1, int64_t n1) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n0) d0[i] = s0[i];
+    else if (i < n0 + n1) d1[i - n0] = s1[i - n0];
+}
+
+int copy_two(float* d0, const float* s0, int64_t n0, float* d1, const float* s1, int64_t n1, hipStream_t st) {
+    if (n0 + n1 <= 0) return 0;
+    hipLaunchKernelGGL(copy_two_kernel, dim3((unsigned)cdiv64(n0 + n1, 256)), dim3(256), 0, st, d0, s0, n0, d1, s1, n1);
+    CDRL_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void adam_tick_kernel(DevHP* hp, int which) {
     if (which == 0) hp->t_policy += 1;
     else if (which == 1) hp->t_value += 1;
