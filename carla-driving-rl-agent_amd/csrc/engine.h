@@ -369,6 +369,7 @@ private:
     std::unique_ptr<AuxWorker> aux_worker_;
     bool aux_inflight_ = false;
     int aux_wait();
+    hipEvent_t ev_in_sys_ = nullptr;                    // hand-over from the caller's stream with the fence (data-parallel use)
     hipEvent_t ev_out_sys_ = nullptr;                   // hand-back to the caller's stream WITH the system-scope fence (data-parallel use)
     bool dp_hint_ = false;                              // a pass ran with a gradient scale below 1 (world size > 1)
     bool seq_open_ = false;                             // between sequence_begin and sequence_end on seq_caller_

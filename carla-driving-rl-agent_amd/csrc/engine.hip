@@ -55,6 +55,7 @@ Learner::~Learner() {
     if (ev_in_) (void)hipEventDestroy(ev_in_);
     if (ev_out_) (void)hipEventDestroy(ev_out_);
     if (ev_out_sys_) (void)hipEventDestroy(ev_out_sys_);
+    if (ev_in_sys_) (void)hipEventDestroy(ev_in_sys_);
     if (main_) (void)hipStreamDestroy(main_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     for (int i = 0; i < NQ; ++i)
@@ -144,8 +145,9 @@ int Learner::launch(hipStream_t caller, std::vector<uint64_t> key, bool graphabl
     // once, around the whole sequence
     const bool in_seq = seq_open_ && caller == seq_caller_;
     if (!in_seq) {
-        CDRL_HIP(hipEventRecord(ev_in_, caller));
-        CDRL_HIP(hipStreamWaitEvent(main_, ev_in_, 0));
+        hipEvent_t ei = (comm_ || dp_hint_) ? ev_in_sys_ : ev_in_;      // (data-parallel use: fenced both ways, see below)
+        CDRL_HIP(hipEventRecord(ei, caller));
+        CDRL_HIP(hipStreamWaitEvent(main_, ei, 0));
     }
     int rc = 0;
     if (!graphs_enabled_ || !graphable) {
@@ -191,8 +193,9 @@ int Learner::launch(hipStream_t caller, std::vector<uint64_t> key, bool graphabl
     }
     if (rc != 0) return rc;
     if (in_seq) return 0;
-    // data-parallel use (a communication stream is set, or a pass ran with a gradient scale below 1): what the caller enqueues next may be a
-    // collective whose peers read these buffers -- the hand-back keeps the system-scope fence there (unmeasurable on one GPU: insurance)
+    // data-parallel use (a communication stream is set, or a pass ran with a gradient scale below 1): what the caller enqueued before /
+    // enqueues next may be a collective whose peers write / read these buffers -- both hand-overs keep the system-scope fence there
+    // (unmeasurable on one GPU: insurance)
     hipEvent_t eo = (comm_ || dp_hint_) ? ev_out_sys_ : ev_out_;
     CDRL_HIP(hipEventRecord(eo, main_));
     CDRL_HIP(hipStreamWaitEvent(caller, eo, 0));
@@ -212,8 +215,9 @@ int Learner::sequence_begin(hipStream_t caller) {
         set_error("sequence_begin: a sequence is already open");
         return -1;
     }
-    CDRL_HIP(hipEventRecord(ev_in_, caller));
-    CDRL_HIP(hipStreamWaitEvent(main_, ev_in_, 0));
+    hipEvent_t ei = (comm_ || dp_hint_) ? ev_in_sys_ : ev_in_;
+    CDRL_HIP(hipEventRecord(ei, caller));
+    CDRL_HIP(hipStreamWaitEvent(main_, ei, 0));
     seq_open_ = true;
     seq_caller_ = caller;
     return 0;
@@ -1925,6 +1929,7 @@ int Learner::bind(const Buffers& b) {
         CDRL_HIP(hipEventCreateWithFlags(&ev_in_, evf_int));      // (caller's stream: same device; what the host reads afterwards goes through a copy with its own fences)
         CDRL_HIP(hipEventCreateWithFlags(&ev_out_, evf_int));
         CDRL_HIP(hipEventCreateWithFlags(&ev_out_sys_, hipEventDisableTiming));
+        CDRL_HIP(hipEventCreateWithFlags(&ev_in_sys_, hipEventDisableTiming));
         CDRL_HIP(hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, prio_lo));
         for (int i = 0; i < NSLOT; ++i) {
             CDRL_HIP(hipEventCreateWithFlags(&ev_main_[i], evf_int));
