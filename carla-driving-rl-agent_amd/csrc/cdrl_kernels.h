@@ -87,7 +87,10 @@ int gather_rows(const float* src, const int* idx, float* dst, int nrows, int64_t
 // splitk_ws (>= gemm_nn_splitk_elems floats, or null): enables split-K for small-M / long-K products
 int64_t gemm_nn_splitk_elems(int M, int N, int K);
 int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C, int M, int N, int K,
-            int accumulate, hipStream_t st, float* splitk_ws = nullptr);
+            int accumulate, hipStream_t st, float* splitk_ws = nullptr,
+            float* act_out = nullptr, int act = 0, bool* act_done = nullptr);
+// act_out / act / act_done: when the product goes through split-K, its reduce also writes act(C) to the dense [M][N] act_out and
+// sets *act_done (the caller runs act_fwd otherwise)
 // Cout[K,N] = sum_m A[m,K]^T * D[m,N]  (split over M; partial buffer `part` >= gemm_tn_part_elems)
 // G > 1: rows are G equal BatchNorm groups; pro_stats ([4][G][K]) != null applies A <- scale[g][k]*A + shift[g][k] on load.
 // dpro != null: D[m,n] <- k1*(dz - k2 - xhat*k3) on load (BatchNorm-backward apply; D views the gradient w.r.t. the BN
@@ -313,6 +316,9 @@ bool gemm_x3_supported(View A, int K);
 int64_t gemm_x3_packed_bytes(int N, int K);
 GemmX3Pack gemm_x3_pack_entry(const float* w, void* wp, int K, int N, int sbk, int sbn);
 int gemm_x3_pack_many(const GemmX3Pack* tab_dev, int n, hipStream_t st);
+// every pack table of a training pass + the W^T transposes of its backward in ONE launch (gemm_pw.hip, pack_bodies.h)
+int pack_all(const GemmX3Pack* tg, int ng, const PwPack* tp, int np, const PwX3Pack* t3, int n3, const PwTranspose* tt, int nt,
+             int transpose_tiles, hipStream_t st);
 // bf16_operands: one product per step on the first plane only (operands rounded to bf16: configuration 3's compute mode)
 int gemm_x3(View A, const void* Bp, const float* bias, View C, int M, int N, int K, int accumulate, hipStream_t st,
             bool bf16_operands = false, int at = 0);
@@ -438,11 +444,13 @@ struct TensorSeg {      // one parameter tensor inside a flat arena
 // sq-norm per tensor -> norms[ntensors]; deterministic two-stage reduction
 int tensor_sqnorms(const float* g, const TensorSeg* segs_dev, int ntensors, const int* chunk_tensor_dev,
                    const int64_t* chunk_off_dev, int nchunks, double* chunk_part, float* sqnorms, hipStream_t st,
-                   DevHP* tick_hp = nullptr, int tick = -1);    // tick_hp: also advances that Adam step counter (adam_tick folded in)
-// which: 0 policy, 1 value, 2 dynamics
-int clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const int* chunk_tensor_dev,
+                   DevHP* tick_hp = nullptr, int tick_mask = 0, bool fold_final = false);
+// tick_hp / tick_mask (1 policy, 2 value, 4 trunk): the chunk kernel also advances those Adam step counters; fold_final: no second
+// stage -- the consumer folds the chunk partials (clip_adam with chunk_part)
+int clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const int* chunk_tensor_dev /*or null*/,
               const int64_t* chunk_off_dev, int nchunks, const TensorSeg* segs_dev, const float* sqnorms /*or null*/,
-              DevHP* hp, int which, hipStream_t st);
+              DevHP* hp, int which, hipStream_t st, const double* chunk_part = nullptr, int ticked = 0);
+// chunk_part: per-tensor norms folded here from tensor_sqnorms' chunk partials; ticked: the step counter was advanced already
 int adam_tick(DevHP* hp, int which, hipStream_t st);
 int copy_two(float* d0, const float* s0, int64_t n0, float* d1, const float* s1, int64_t n1, hipStream_t st);
 

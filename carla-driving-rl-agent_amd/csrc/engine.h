@@ -372,6 +372,7 @@ private:
     hipEvent_t ev_in_sys_ = nullptr;                    // hand-over from the caller's stream with the fence (data-parallel use)
     hipEvent_t ev_out_sys_ = nullptr;                   // hand-back to the caller's stream WITH the system-scope fence (data-parallel use)
     bool dp_hint_ = false;                              // a pass ran with a gradient scale below 1 (world size > 1)
+    bool packs_have_wt_ = false;                        // the last forward's pack launch also wrote the W^T copies of the backward
     bool seq_open_ = false;                             // between sequence_begin and sequence_end on seq_caller_
     hipStream_t seq_caller_ = nullptr;
     TailEvents tail_;                                   // stop events of the critical stream's kernels (cdrl_common.h)

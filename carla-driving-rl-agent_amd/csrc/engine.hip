@@ -598,9 +598,11 @@ int Learner::run_trunk_fwd(hipStream_t st, int training) {
     // this pass's weights in fragment order (fwd + bwd-data).  On the side stream beside the stem block, joined behind it: measured twice,
     // 14.29 vs 14.30 ms with round 5's events and 12.46 vs 12.41 ms with round 6's -- three 10-us launches beside the bandwidth-bound stem
     // conv plus a join packet cost what they save; they stay in front of the stem.
-    CDRL_TRY(gemm_x3_pack_many(d_gpack_, (int)h_gpack_.size(), st));
-    CDRL_TRY(pw_pack_many(d_pack_, (int)h_pack_.size(), st));
-    CDRL_TRY(pw_x3_pack_many(d_pack3_, (int)h_pack3_.size(), st));
+    // ... and in ONE launch, with the W^T transposes of the backward (training passes) riding along: four dependent 4-13 us launches per
+    // pass became one (pack_all; the weights do not change between here and the backward)
+    packs_have_wt_ = training != 0;
+    CDRL_TRY(pack_all(d_gpack_, (int)h_gpack_.size(), d_pack_, (int)h_pack_.size(), d_pack3_, (int)h_pack3_.size(), d_pwt_,
+                      training ? (int)h_pwt_.size() : 0, pwt_tiles_, st));
     return run_fwd(trunk_ops_, st, training);
 }
 
@@ -1015,7 +1017,10 @@ void Learner::add_dense(std::vector<Op>& ops, int model, const std::string& pref
     Op op;
     op.fwd = [=](hipStream_t st, int) -> int {
         if (act == ACT_NONE) return gemm_nn(in, w.p, N, 1, b.p, out, M, N, K, 0, st, dsk);
-        CDRL_TRY(gemm_nn(in, w.p, N, 1, b.p, make_view(z, N), M, N, K, 0, st, dsk));
+        bool act_done = false;      // (split-K layers: the activation rides in the slab reduce)
+        const bool dense_out = out.ld == N && out.coff == 0;
+        CDRL_TRY(gemm_nn(in, w.p, N, 1, b.p, make_view(z, N), M, N, K, 0, st, dsk, dense_out ? out.p : nullptr, act, &act_done));
+        if (act_done) return 0;
         return act_fwd(z, out.p, (int64_t)M * N, act, st);
     };
     op.bwd = [=](hipStream_t st) -> int {
@@ -2066,7 +2071,7 @@ int Learner::policy_backward_impl(const PolicyBatch& b, float inv_world, hipStre
     a.inv_world = inv_world;
     CDRL_TRY(policy_loss(a, st));
     CDRL_TRY(run_bwd(policy_ops_, st));
-    CDRL_TRY(transpose_many(d_pwt_, (int)h_pwt_.size(), pwt_tiles_, st));      // W^T of the pointwise convs (weights of this pass)
+    if (!packs_have_wt_) CDRL_TRY(transpose_many(d_pwt_, (int)h_pwt_.size(), pwt_tiles_, st));      // W^T of the pointwise convs (normally packed with the forward's operands)
     CDRL_TRY(run_bwd(trunk_ops_, st));
     return join_side(st);
 }
@@ -2130,7 +2135,7 @@ int Learner::value_forward_backward_impl(const ValueBatch& b, float inv_world, h
     a.inv_world = inv_world;
     CDRL_TRY(value_loss(a, st));
     CDRL_TRY(run_bwd(value_ops_, st));
-    CDRL_TRY(transpose_many(d_pwt_, (int)h_pwt_.size(), pwt_tiles_, st));
+    if (!packs_have_wt_) CDRL_TRY(transpose_many(d_pwt_, (int)h_pwt_.size(), pwt_tiles_, st));
     CDRL_TRY(run_bwd(trunk_ops_, st));
     return join_side(st);
 }
@@ -2156,12 +2161,13 @@ int Learner::policy_apply_impl(hipStream_t st) {
     CDRL_TRY(clip_adam(buf_.params + to, buf_.grads + to, buf_.adam_m + to, buf_.adam_v + to, tr_size_[M_TRUNK], nullptr,
                        nullptr, 0, nullptr, nullptr, hp_dev_, 2, st));
     SegTable& s = seg_[M_POLICY];
+    // four launches instead of seven (round 6): the chunk kernel of the norms also advances the trunk's step counter (its update ran in front)
+    // and the policy's (its update runs behind and is told so); the per-tensor fold of the chunk partials happens inside clip_adam
     CDRL_TRY(tensor_sqnorms(buf_.grads + po, s.segs, s.ntensors, s.chunk_tensor, s.chunk_off, s.nchunks, s.chunk_part,
-                            s.sqnorms, st, hp_dev_, 2));        // (+ the trunk's Adam step counter: was a launch of its own)
+                            s.sqnorms, st, hp_dev_, 4 | 1, true));
     CDRL_TRY(update_old_policy_impl(st));
-    CDRL_TRY(clip_adam(buf_.params + po, buf_.grads + po, buf_.adam_m + po, buf_.adam_v + po, tr_size_[M_POLICY],
-                       s.chunk_tensor, s.chunk_off, s.nchunks, s.segs, s.sqnorms, hp_dev_, 0, st));
-    return adam_tick(hp_dev_, 0, st);
+    return clip_adam(buf_.params + po, buf_.grads + po, buf_.adam_m + po, buf_.adam_v + po, tr_size_[M_POLICY], s.chunk_tensor,
+                     s.chunk_off, s.nchunks, s.segs, nullptr, hp_dev_, 0, st, s.chunk_part, 1);
 }
 
 int Learner::value_apply(hipStream_t caller) {
@@ -2174,10 +2180,9 @@ int Learner::value_apply_impl(hipStream_t st) {
                        nullptr, 0, nullptr, nullptr, hp_dev_, 2, st));
     SegTable& s = seg_[M_VALUE];
     CDRL_TRY(tensor_sqnorms(buf_.grads + vo, s.segs, s.ntensors, s.chunk_tensor, s.chunk_off, s.nchunks, s.chunk_part,
-                            s.sqnorms, st, hp_dev_, 2));
-    CDRL_TRY(clip_adam(buf_.params + vo, buf_.grads + vo, buf_.adam_m + vo, buf_.adam_v + vo, tr_size_[M_VALUE],
-                       s.chunk_tensor, s.chunk_off, s.nchunks, s.segs, s.sqnorms, hp_dev_, 1, st));
-    return adam_tick(hp_dev_, 1, st);
+                            s.sqnorms, st, hp_dev_, 4 | 2, true));       // (see policy_apply_impl)
+    return clip_adam(buf_.params + vo, buf_.grads + vo, buf_.adam_m + vo, buf_.adam_v + vo, tr_size_[M_VALUE], s.chunk_tensor,
+                     s.chunk_off, s.nchunks, s.segs, nullptr, hp_dev_, 1, st, s.chunk_part, 1);
 }
 
 int Learner::predict(const float* image, const float* road, const float* vehicle, const float* navigation,

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "cdrl_kernels.h"
+#include "pack_bodies.h"
 
 namespace cdrl {
 
@@ -491,8 +492,10 @@ static void launch_nn(bool bt, bool vec, dim3 grid, hipStream_t st, View A, cons
 static int g_nn_bm64_threshold = -1;
 
 // C(view) (+)= bias + sum_z part[z]  (fixed order)
+// act_out (dense [M][N], optional): the layer's activation of the reduced value as well -- same expressions as act_fwd_kernel (bn.hip),
+// which was a launch of its own behind every split-K Dense layer
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int M, int N, const float* __restrict__ bias,
-                                     View C, int accumulate) {
+                                     View C, int accumulate, float* __restrict__ act_out, int act) {
     const int64_t n = (int64_t)M * N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / N;
@@ -500,7 +503,16 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit,
         float s = bias ? bias[c] : 0.0f;
         for (int z = 0; z < nsplit; ++z) s += part[(int64_t)z * n + i];
         float* o = &C.p[m * C.ld + C.coff + c];
-        *o = accumulate ? *o + s : s;
+        const float x = accumulate ? *o + s : s;
+        *o = x;
+        if (act_out) {
+            float a = x;
+            if (act == ACT_RELU6) a = fminf(fmaxf(x, 0.0f), 6.0f);
+            else if (act == ACT_SWISH6) a = fminf(x * (1.0f / (1.0f + expf(-x))), 6.0f);
+            else if (act == ACT_TANH) a = tanhf(x);
+            else if (act == ACT_SIGMOID) a = 1.0f / (1.0f + expf(-x));
+            act_out[i] = a;
+        }
     }
 }
 
@@ -510,7 +522,8 @@ int64_t gemm_nn_splitk_elems(int M, int N, int K) {
 }
 
 int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C, int M, int N, int K,
-            int accumulate, hipStream_t st, float* splitk_ws) {
+            int accumulate, hipStream_t st, float* splitk_ws, float* act_out, int act, bool* act_done) {
+    if (act_done) *act_done = false;
     if (M <= 0 || N <= 0) return 0;
     if (splitk_ws && gemm_nn_splitk_elems(M, N, K) > 0) {
         // few output tiles, long reduction (GRU projections: M = B or T*B, K = 256 / 768): split K over blockIdx.z so that
@@ -535,8 +548,9 @@ int gemm_nn(View A, const float* Bp, int sbk, int sbn, const float* bias, View C
                 CDRL_LAUNCH_CHECK();
                 const int64_t n = (int64_t)M * N;
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st,
-                                   splitk_ws, nsplit, M, N, bias, C, accumulate);
+                                   splitk_ws, nsplit, M, N, bias, C, accumulate, act_done ? act_out : nullptr, act);
                 CDRL_LAUNCH_CHECK();
+                if (act_done && act_out) *act_done = true;
                 return 0;
             }
         }
@@ -755,17 +769,7 @@ int reduce_partials_f32(const float* part, int nparts, int64_t n, int64_t stride
 __global__ void __launch_bounds__(256) transpose_many_kernel(const PwTranspose* __restrict__ tab) {
     __shared__ float t[32][33];
     const PwTranspose d = tab[blockIdx.y];
-    const int tk = (d.cin + 31) / 32, tn = (d.cout + 31) / 32;
-    if ((int)blockIdx.x >= tk * tn) return;
-    const int k0 = (blockIdx.x / tn) * 32, n0 = (blockIdx.x % tn) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-    for (int r = ty; r < 32; r += 8)
-        t[r][tx] = (k0 + r < d.cin && n0 + tx < d.cout) ? d.w[(int64_t)(k0 + r) * d.cout + n0 + tx] : 0.0f;
-    __syncthreads();
-#pragma unroll
-    for (int r = ty; r < 32; r += 8)
-        if (n0 + r < d.cout && k0 + tx < d.cin) d.wt[(int64_t)(n0 + r) * d.cin + k0 + tx] = t[tx][r];
+    transpose_body(d, blockIdx.x, t);
 }
 
 int transpose_many(const PwTranspose* tab_dev, int n, int tiles, hipStream_t st) {

@@ -22,6 +22,8 @@
 //                            output-gradient of (backward-data GEMM feeding a BN backward: no separate reduce pass).
 // Partials are double, one row per workgroup, combined in fixed order by bn_finalize / bn_bwd_finalize.
 #include "colreduce.h"
+#include "pack_bodies.h"
+#include <algorithm>
 
 namespace cdrl {
 
@@ -556,23 +558,47 @@ static int pw_ksm(int K) { return K <= 32 ? 16 : (K <= 64 ? 32 : (K <= 128 ? 64 
 // what lane (lrow = n & 31, lk) of the wave that owns column tile ct keeps in registers.  One launch for all convs of a pass.
 __global__ void __launch_bounds__(256) pw_pack_many_kernel(const PwPack* __restrict__ tab) {
     const PwPack d = tab[blockIdx.y];
-    const int total = d.ntiles * 2 * 32 * d.ksm;
-    if (d.bf16) {
-        // bf16 fragments of the BF variant: [ct][s = k / 16][lk][lrow][8], element e <-> k = 16 s + 8 lk + e (round-to-nearest-even)
-        __bf16* wb = reinterpret_cast<__bf16*>(d.wp);
-        const int ks = d.ksm / 8;
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-            const int e = i % 8, lrow = (i / 8) % 32, lk = (i / 256) % 2, s = (i / 512) % ks, ct = i / (512 * ks);
-            const int k = 16 * s + 8 * lk + e, n = ct * 32 + lrow;
-            wb[i] = (__bf16)((k < d.K && n < d.N) ? d.w[(int64_t)k * d.sbk + (int64_t)n * d.sbn] : 0.0f);
-        }
+    pw_pack_body(d, blockIdx.x, gridDim.x);
+}
+
+// All packing work of a training pass as ONE launch: blockIdx.y walks the split-precision GEMM packs, the float32-MFMA packs, the
+// split-precision conv packs and the W^T transposes of the backward (pack_bodies.h).
+__global__ void __launch_bounds__(256) pack_all_kernel(const GemmX3Pack* __restrict__ tg, int ng, const PwPack* __restrict__ tp, int np,
+                                                       const PwX3Pack* __restrict__ t3, int n3, const PwTranspose* __restrict__ tt, int nt) {
+    __shared__ float tile[32][33];
+    int y = blockIdx.y;
+    if (y < ng) {
+        const GemmX3Pack d = tg[y];
+        gemm_x3_pack_body(d, blockIdx.x, gridDim.x);
         return;
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int s = i % d.ksm, lrow = (i / d.ksm) % 32, lk = (i / (d.ksm * 32)) % 2, ct = i / (d.ksm * 64);
-        const int k = 2 * s + lk, n = ct * 32 + lrow;
-        d.wp[i] = (k < d.K && n < d.N) ? d.w[(int64_t)k * d.sbk + (int64_t)n * d.sbn] : 0.0f;
+    y -= ng;
+    if (y < np) {
+        const PwPack d = tp[y];
+        pw_pack_body(d, blockIdx.x, gridDim.x);
+        return;
     }
+    y -= np;
+    if (y < n3) {
+        const PwX3Pack d = t3[y];
+        pw_x3_pack_body(d, blockIdx.x, gridDim.x);
+        return;
+    }
+    y -= n3;
+    if (y < nt) {
+        const PwTranspose d = tt[y];
+        transpose_body(d, blockIdx.x, tile);
+    }
+}
+
+int pack_all(const GemmX3Pack* tg, int ng, const PwPack* tp, int np, const PwX3Pack* t3, int n3, const PwTranspose* tt, int nt,
+             int transpose_tiles, hipStream_t st) {
+    const int rows = ng + np + n3 + nt;
+    if (rows <= 0) return 0;
+    const int gx = std::max(32, nt > 0 ? transpose_tiles : 0);
+    hipLaunchKernelGGL(pack_all_kernel, dim3(gx, rows), dim3(256), 0, st, tg, ng, tp, np, t3, n3, tt, nt);
+    CDRL_LAUNCH_CHECK();
+    return 0;
 }
 
 int64_t pw_packed_elems(int N, int K) { return (int64_t)cdiv(N, 32) * 2 * 32 * pw_ksm(K); }

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "cdrl_kernels.h"
+#include "pack_bodies.h"
 
 namespace cdrl {
 
@@ -515,24 +516,7 @@ static inline int x3_nt(int N) { return N <= 32 ? 1 : (N <= 64 ? 2 : 4); }
 // B(k, n) = w[k * sbk + n * sbn] -> three bf16 planes of MFMA B fragments [3][KP/16][2][128][8]
 __global__ void pw_x3_pack_many_kernel(const PwX3Pack* __restrict__ tab) {
     const PwX3Pack d = tab[blockIdx.y];
-    const int ks = d.kp / 16, total = ks * 2 * 128, nblk = (d.N + 127) / 128;       // column blocks of 128: [block][3][KP/16][2][128][8]
-    for (int ii = blockIdx.x * 256 + threadIdx.x; ii < total * nblk; ii += gridDim.x * 256) {
-        const int blk = ii / total, i = ii % total;
-        const int nl = i % 128, n = blk * 128 + nl, lk = (i / 128) % 2, s = i / 256;
-        bf16x8 v[3];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 16 * s + 8 * lk + e;
-            const float x = (k < d.K && n < d.N) ? d.w[(int64_t)k * d.sbk + (int64_t)n * d.sbn] : 0.0f;
-            __bf16 h1, h2, h3;
-            split3(x, h1, h2, h3);
-            v[0][e] = h1;
-            v[1][e] = h2;
-            v[2][e] = h3;
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(d.wp + (((int64_t)blk * 3 + p) * total + i) * 8) = v[p];
-    }
+    pw_x3_pack_body(d, blockIdx.x, gridDim.x);
 }
 
 int64_t pw_x3_packed_bytes(int K) { return (int64_t)3 * (x3_kp(K) / 16) * 2 * 128 * 8 * 2; }      // one column block (N <= 128)

@@ -11,6 +11,7 @@
 //     buffered: the loads of stage i+1 are issued before the MFMAs of stage i;
 //   * 128 x 128 output tile per workgroup, 2 x 2 waves of 64 x 64 (four 32x32 accumulators each).
 #include "colreduce.h"
+#include "pack_bodies.h"
 
 namespace cdrl {
 
@@ -188,24 +189,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3_kernel(GemmX3Args a) {
 // B(k, n) = w[k * sbk + n * sbn] -> [3][KS][2][NP][8] bf16
 __global__ void gemm_x3_pack_kernel(const GemmX3Pack* __restrict__ tab) {
     const GemmX3Pack d = tab[blockIdx.y];
-    const int64_t plane = (int64_t)d.KS * 2 * d.NP * 8;
-    const int total = d.KS * 2 * d.NP;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int n = i % d.NP, lk = (i / d.NP) % 2, ks = i / (2 * d.NP);
-        bf16x8 v[3];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 16 * ks + 8 * lk + e;
-            const float x = (k < d.K && n < d.N) ? d.w[(int64_t)k * d.sbk + (int64_t)n * d.sbn] : 0.0f;
-            __bf16 h1, h2, h3;
-            gx3_split(x, h1, h2, h3);
-            v[0][e] = h1;
-            v[1][e] = h2;
-            v[2][e] = h3;
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(d.wp + p * plane + (int64_t)i * 8) = v[p];
-    }
+    gemm_x3_pack_body(d, blockIdx.x, gridDim.x);
 }
 
 int64_t gemm_x3_packed_bytes(int N, int K) { return (int64_t)3 * cdiv(K, 16) * 2 * (cdiv(N, 128) * 128) * 8 * 2; }

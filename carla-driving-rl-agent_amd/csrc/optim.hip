@@ -22,11 +22,13 @@ __global__ void __launch_bounds__(256) sqnorm_chunk_kernel(const float* __restri
                                                            double* __restrict__ chunk_part, DevHP* hp, int tick) {
     __shared__ double sm[256];
     const int c = blockIdx.x;
-    // the step counter of the Adam update that ran in FRONT of this kernel (the trunk's: nothing here reads it) -- it was a launch of its own
-    if (tick >= 0 && c == 0 && threadIdx.x == 0) {
-        if (tick == 0) hp->t_policy += 1;
-        else if (tick == 1) hp->t_value += 1;
-        else hp->t_dynamics += 1;
+    // Adam step counters advanced here instead of by launches of their own: the trunk's (its update ran in FRONT of this kernel) and the
+    // head's, whose update runs BEHIND it and is told so (clip_adam's `ticked`)
+    // (bit mask: 1 policy, 2 value, 4 trunk)
+    if (tick > 0 && c == 0 && threadIdx.x == 0) {
+        if (tick & 1) hp->t_policy += 1;
+        if (tick & 2) hp->t_value += 1;
+        if (tick & 4) hp->t_dynamics += 1;
     }
     const TensorSeg s = segs[chunk_tensor[c]];
     const int64_t beg = chunk_off[c];
@@ -63,10 +65,11 @@ __global__ void __launch_bounds__(256) sqnorm_final_kernel(const TensorSeg* __re
 
 int tensor_sqnorms(const float* g, const TensorSeg* segs_dev, int ntensors, const int* chunk_tensor_dev,
                    const int64_t* chunk_off_dev, int nchunks, double* chunk_part, float* sqnorms, hipStream_t st, DevHP* tick_hp,
-                   int tick) {
+                   int tick_mask, bool fold_final) {
     hipLaunchKernelGGL(sqnorm_chunk_kernel, dim3(nchunks), dim3(256), 0, st, g, segs_dev, chunk_tensor_dev, chunk_off_dev,
-                       chunk_part, tick_hp, tick_hp ? tick : -1);
+                       chunk_part, tick_hp, tick_hp ? tick_mask : 0);
     CDRL_LAUNCH_CHECK();
+    if (fold_final) return 0;           // the consumer (clip_adam with chunk_part) folds the chunk partials of its tensor itself
     hipLaunchKernelGGL(sqnorm_final_kernel, dim3(cdiv(ntensors, 4)), dim3(256), 0, st, segs_dev, ntensors, chunk_part,
                        sqnorms);
     CDRL_LAUNCH_CHECK();
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ p, c
                                                         const int64_t* __restrict__ chunk_off,
                                                         const TensorSeg* __restrict__ segs,
                                                         const float* __restrict__ sqnorms, const DevHP* __restrict__ hp,
-                                                        int which) {
+                                                        int which, const double* __restrict__ chunk_part, int ticked) {
     int64_t beg, end;
     float cn = 0.0f, denom = 1.0f;
     const float clip_norm = which == 0 ? hp->clip_norm_policy : (which == 1 ? hp->clip_norm_value : 0.0f);
@@ -90,8 +93,20 @@ __global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ p, c
         beg = chunk_off[c];
         end = beg + CHUNK;
         if (end > s.off + s.n) end = s.off + s.n;
-        if (sqnorms && clip_norm > 0.0f) {
-            const float l2 = sqnorms[t];
+        if ((sqnorms || chunk_part) && clip_norm > 0.0f) {
+            float l2;
+            if (chunk_part) {
+                // the tensor's squared norm from its chunk partials, exactly as sqnorm_final_kernel folds them (lane l: chunks l, l + 64,
+                // ... in order, fixed shuffle tree) -- every wave of every block of the tensor computes the same bits
+                const int lane = threadIdx.x & 63;
+                double acc = 0.0;
+                for (int cc = lane; cc < s.nchunks; cc += 64) acc += chunk_part[s.first_chunk + cc];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+                l2 = (float)__shfl(acc, 0, 64);
+            } else {
+                l2 = sqnorms[t];
+            }
             const float norm = l2 > 0.0f ? sqrtf(l2) : l2;
             cn = clip_norm;
             denom = fmaxf(norm, clip_norm);
@@ -102,7 +117,7 @@ __global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ p, c
         if (end > n) end = n;
     }
     const float lr = which == 0 ? hp->lr_policy : (which == 1 ? hp->lr_value : hp->lr_dynamics);
-    const int t1 = (which == 0 ? hp->t_policy : (which == 1 ? hp->t_value : hp->t_dynamics)) + 1;
+    const int t1 = (which == 0 ? hp->t_policy : (which == 1 ? hp->t_value : hp->t_dynamics)) + (ticked ? 0 : 1);
     const float b1 = hp->beta1, b2 = hp->beta2, eps = hp->eps;
     const float alpha = lr * sqrtf(1.0f - powf(b2, (float)t1)) / (1.0f - powf(b1, (float)t1));
     for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
@@ -119,10 +134,10 @@ __global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ p, c
 
 int clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const int* chunk_tensor_dev,
               const int64_t* chunk_off_dev, int nchunks, const TensorSeg* segs_dev, const float* sqnorms, DevHP* hp,
-              int which, hipStream_t st) {
+              int which, hipStream_t st, const double* chunk_part, int ticked) {
     const int grid = chunk_tensor_dev ? nchunks : (int)cdiv64(n, CHUNK);
     hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, chunk_tensor_dev, chunk_off_dev,
-                       segs_dev, sqnorms, hp, which);
+                       segs_dev, sqnorms, hp, which, chunk_part, ticked);
     CDRL_LAUNCH_CHECK();
     return 0;
 }
