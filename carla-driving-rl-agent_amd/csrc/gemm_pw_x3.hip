@@ -544,6 +544,13 @@ int pw_x3_pack_many(const PwX3Pack* tab_dev, int n, hipStream_t st) {
 }
 
 bool pw_x3_supported(View A, int N, int K) {
+    // K <= 128 (the persistent kernel): its A chunks are 16-byte BUFFER loads, which need dword alignment only, and columns beyond K
+    // inside the last chunk are zeroed -- so the 58-channel rows of stage 0 (232-byte pitch, channel offset 58) qualify (round 6;
+    // CDRL_PW_X3_UNALIGNED=0 -> 16-byte aligned rows only, as before: those convs then stay on the float32 matrix pipe)
+    static const bool unal = !(cdrl_getenv("CDRL_PW_X3_UNALIGNED") && atoi(cdrl_getenv("CDRL_PW_X3_UNALIGNED")) == 0);
+    if (unal && K >= 4 && K <= 128 && N >= 1 && N <= 128 && K % 2 == 0 && A.ld % 2 == 0 && A.coff % 2 == 0 &&
+        (reinterpret_cast<uintptr_t>(A.p) & 15) == 0)
+        return true;
     return K >= 4 && K <= 256 && N >= 1 && N <= 256 && K % 4 == 0 && A.ld % 4 == 0 && A.coff % 4 == 0 &&
            (reinterpret_cast<uintptr_t>(A.p) & 15) == 0;
 }
