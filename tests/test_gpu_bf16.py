@@ -238,7 +238,9 @@ def _cos(a, b):
     return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
 
 
-@pytest.mark.parametrize('B,H,W,A', [(64, 48, 64, 2), (32, 90, 120, 2)])
+# (round 6: the (32, 90, 120, 2) case, 52 s of CPU oracle, left the suite -- the operand mode at the real image size is held by
+#  test_config3_three_engines_at_batch_1024 and the full-size property tests; the suite stays under 15 minutes on the slowest boxes)
+@pytest.mark.parametrize('B,H,W,A', [(64, 48, 64, 2)])
 def test_bf16_operand_engine_vs_oracle(B, H, W, A):
     from oracle import model as OM
     from tests.util import make_pair, make_batches, oracle_batch, to_dev, rel_err, is_zero_gradient
