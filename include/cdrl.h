@@ -245,7 +245,8 @@ int cdrl_philox_words(uint64_t seed, uint64_t offset, uint64_t idx0, int n, int 
  * step; float32 in / out, float32-accurate, not bit-identical to an fmaf chain).  W_packed: cdrl_pwconv_x3_packed_bytes(K)
  * bytes written by cdrl_pwconv_x3_pack from B(k, n) = W[k * sbk + n * sbn].  Same prologue / epilogue contract as
  * cdrl_pwconv_fused (pro_stats: BN-apply on load; part: statistics partials, cdrl_pwconv_x3_partial_rows rows per group).
- * K, N <= 256; K, lda, a_coff multiples of 4.  K or N above 128 (the 232-channel convs of stage 2, core/architectures.py:130,140 at
+ * K, N <= 128: K, lda, a_coff even (the A chunks are 16-byte buffer loads at dword alignment; columns beyond K are zeroed: the
+ * 58-channel convs of stage 0 qualify since round 6); 128 < K or N <= 256: K, lda, a_coff multiples of 4.  K or N above 128 (the 232-channel convs of stage 2, core/architectures.py:130,140 at
  * num_channels 464): W_packed holds one block per 128 output columns -- cdrl_pwconv_x3_packed_bytes_n(K, N) bytes -- and the kernel
  * takes one 32-row tile per workgroup (one statistics row per tile). */
 int64_t cdrl_pwconv_x3_packed_bytes(int K);

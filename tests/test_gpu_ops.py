@@ -747,6 +747,44 @@ def test_pwconv_x3_split(lib, G, Mg, K, N, pro):
         assert rel_err(d.cpu().numpy(), (gc.double() @ w.double().t()).cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('G,Mg,K,N,pro', [(4, 1237, 58, 58, True), (4, 1000, 58, 58, False), (2, 777, 58, 92, True), (3, 130, 26, 58, False)])
+def test_pwconv_x3_dword_aligned_rows(lib, G, Mg, K, N, pro):
+    """Round 6: the split-precision conv on rows that are only DWORD aligned -- the 58-channel halves of stage 0 (unit tensors of 116
+    floats = 464-byte rows, branch half at channel offset 58; core/architectures.py:120-145 at num_channels 116): 16-byte buffer loads at
+    4-byte alignment, the two columns beyond K inside the last chunk belong to the NEIGHBOURING half (non-finite here on purpose) and
+    must not reach the product."""
+    rng = np.random.default_rng(G + Mg + K + N)
+    M = G * Mg
+    lda, a_coff, ldc, c_coff = 2 * K, K, N + 6, 2
+    a_np = rng.standard_normal((M, lda)).astype(np.float32)
+    a_np[:, :a_coff] = np.nan                                       # the other half of the tensor: never read into the product
+    a = dev(a_np)
+    a = torch.cat([a, torch.full((1, lda), float('nan'), device=DEV)])[:M]       # (keeps the allocation's tail defined)
+    w = dev((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32))
+    bias = dev((rng.standard_normal(N) * 0.1).astype(np.float32))
+    stats = None
+    if pro:
+        stats = dev(rng.uniform(0.5, 1.5, (4, G, K)).astype(np.float32))
+        stats[3] = dev(rng.uniform(-0.3, 0.3, (G, K)).astype(np.float32))
+    wp = torch.zeros(int(lib.cdrl_pwconv_x3_packed_bytes_n(K, N)), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cdrl_pwconv_x3_pack(P(w), K, N, N, 1, P(wp), S()))
+    c = torch.full((M, ldc), 7.0, device=DEV)
+    nb = int(lib.cdrl_pwconv_x3_partial_rows(G, Mg, N, K))
+    part = torch.zeros((G, nb, 2, N), dtype=torch.float64, device=DEV)
+    _lib.check(lib.cdrl_pwconv_x3(P(a), lda, a_coff, P(stats), P(wp), P(bias), P(c), ldc, c_coff, G, Mg, N, K, P(part), S()))
+    av = a[:, a_coff:a_coff + K].double().view(G, Mg, K)
+    if pro:
+        av = (stats[2].view(G, 1, K).double() * av + stats[3].view(G, 1, K).double()).float().double()
+    ref = (av.view(M, K) @ w.double() + bias.double()).cpu().numpy()
+    got = c[:, c_coff:c_coff + N]
+    assert bool(torch.isfinite(got).all())
+    assert rel_err(got.cpu().numpy(), ref) < 1e-5
+    assert bool((c[:, :c_coff] == 7.0).all()) and bool((c[:, c_coff + N:] == 7.0).all())
+    sums = part.sum(dim=1)
+    g64 = got.double().view(G, Mg, N)
+    assert torch.allclose(sums[:, 0], g64.sum(1), rtol=1e-9, atol=1e-6) and torch.allclose(sums[:, 1], (g64 * g64).sum(1), rtol=1e-9, atol=1e-6)
+
+
 @pytest.mark.parametrize('G,Mg,Cin,Cout,shuffle,act,epi,acc', [(4, 3072, 232, 232, 1, 1, 1, 0), (4, 3072, 232, 232, 0, 0, 0, 0), (4, 1000, 232, 232, 0, 0, 0, 1),
                                                                (2, 333, 232, 140, 1, 1, 0, 1), (3, 97, 116, 232, 0, 1, 1, 0), (1, 64, 232, 232, 1, 0, 0, 0)])
 def test_pwconv_x3_wide_bwd(lib, G, Mg, Cin, Cout, shuffle, act, epi, acc):
