@@ -50,7 +50,7 @@ def test_stream_synchronisation_modes_are_bit_identical_over_update_steps(tmp_pa
         assert torch.equal(new['losses'], other['losses'])
         assert torch.equal(new['params'], other['params'])
         assert torch.equal(new['grads'], other['grads'])
-    assert torch.isfinite(new['params']).all() and len(new['losses']) == 6
+    assert torch.isfinite(new['params']).all() and len(new['losses']) == 2 * (int(os.environ.get('PC_STEPS', 12)) // 4)     # (PC_STEPS: soak runs)
 
 
 def _zero_gradient(name):
