@@ -140,7 +140,6 @@ PROTOTYPES = {
     'cdrl_stem_block_bwd_workspace_doubles': (_i64, [_i] * 5),
     'cdrl_stem_block_bwd': (_i, [_fp] * 5 + [_i] * 5 + [_fp] * 7),
     'cdrl_stem_block_bwd_pooled': (_i, [_fp] * 6 + [_i] * 5 + [_fp] * 7),
-    'cdrl_stem_block_bwd_recompute': (_i, [_fp] * 8 + [_i] * 5 + [_fp] * 7),
     'cdrl_pwconv_fused_partial_rows': (_i, [_i, _i, _i, _i]),
     'cdrl_pwconv_fused': (_i, [_fp, _i, _i, _fp, _fp, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp]),
     'cdrl_pwconv_pack_elems': (_i64, [_i, _i]),
@@ -170,7 +169,7 @@ _lib = None
 # thread-local switch).  The prototypes above list the arguments WITHOUT it; it is spliced in here, and the binding object below offers
 # the tests a mode of its own (`lib.cdrl_set_op_activation_type(at)`, a Python attribute of the binding) that fills it in.
 ACT_TYPE_BEFORE_STREAM = ('cdrl_pwconv_bwd_fused', 'cdrl_gemm_tn', 'cdrl_gemm_x3', 'cdrl_stem_fwd_stats', 'cdrl_stem_block_bwd',
-                          'cdrl_stem_block_bwd_pooled', 'cdrl_stem_block_bwd_recompute', 'cdrl_pwconv_fused_packed', 'cdrl_pwconv_bn_bwd', 'cdrl_pwconv_bn_bwd_packed',
+                          'cdrl_stem_block_bwd_pooled', 'cdrl_pwconv_fused_packed', 'cdrl_pwconv_bn_bwd', 'cdrl_pwconv_bn_bwd_packed',
                           'cdrl_dwconv_bn_fwd', 'cdrl_dwconv_bn_bwd', 'cdrl_bn_train_fwd', 'cdrl_bn_train_bwd', 'cdrl_maxpool_bn_fwd')
 ACT_TYPE_LAST = ('cdrl_pwconv_bwd_fused_workspace',)
 for _n in ACT_TYPE_BEFORE_STREAM:

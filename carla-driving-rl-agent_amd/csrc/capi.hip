@@ -680,27 +680,6 @@ int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stat
     return stem_bwd_filter_fused(x, ps, y, stats, coef, dw, db, B, T, H, W, Cout, fpart, st, act_type);
 }
 
-int cdrl_stem_block_bwd_recompute(const float* x, const float* w, const float* bias, const float* y, const float* stats,
-                                  const uint8_t* argmax, const float* dp, const float* pooled, int B, int T, int H, int W, int Cout,
-                                  float* dgamma, float* dbeta, float* coef, float* dw, float* db, double* workspace, int act_type,
-                                  void* stream) {
-    if (!w || !bias || !pooled) {
-        set_error("cdrl_stem_block_bwd_recompute: w, bias and pooled are required");
-        return -1;
-    }
-    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    const int Hp = same_out(Ho, 2), Wp = same_out(Wo, 2);
-    hipStream_t st = S(stream);
-    PoolSrc ps = make_pool_src(argmax, dp, Ho, Wo);
-    ps.pa = pooled;
-    const int nb = vcol_geom(B * Hp * Wp, Cout).nb;
-    double* part = workspace;
-    double* fpart = workspace + (int64_t)T * nb * 2 * Cout;
-    CDRL_TRY(pool_bn_bwd_reduce(ps, y, T, B, Cout, stats, part, st, act_type));
-    CDRL_TRY(bn_bwd_finalize(part, nb, T, B * Ho * Wo, Cout, stats, dgamma, dbeta, coef, st));
-    return stem_bwd_filter_fused(x, ps, nullptr, stats, coef, dw, db, B, T, H, W, Cout, fpart, st, act_type, w, bias);
-}
-
 int cdrl_pwconv_fused_partial_rows(int G, int Mg, int N, int K) { return pw_nn_plan(G, Mg, N, K).nbpg; }
 
 int cdrl_pwconv_fused(const float* a, int lda, int a_coff, const float* pro_stats, const float* w, int sbk, int sbn,

@@ -170,9 +170,7 @@ int64_t stem_bwd_part_elems(int B, int T, int H, int W, int Cout);
 // never materialised); y: raw stem conv output, stats/coef: the stem BN's [4|3][T][Cout] blocks
 bool stem_bwd_fused_supported(int Cout);
 int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, const float* stats, const float* coef, float* dw,
-                          float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st, int at = 0,
-                          const float* w = nullptr, const float* bias = nullptr);
-// (w, bias given: y is recomputed from the image patches inside the kernel and may be null -- round 6)
+                          float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st, int at = 0);
 int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B, int T, int H, int W, int Cout,
                     double* part, hipStream_t st);
 // depthwise 3x3, TF 'SAME' (asymmetric) padding, stride 1|2.  N = frames.

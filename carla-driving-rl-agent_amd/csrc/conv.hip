@@ -466,8 +466,6 @@ struct StemBnBwd {
     const float* y;         // raw stem conv output [rows][Cout]
     const float* stats;     // [4][T][Cout]
     const float* coef;      // [3][T][Cout]
-    const float* w;         // RECOMP: the conv's filter [27][Cout] and bias [Cout] -- y is recomputed from the patch tile, not read
-    const float* bias;
 };
 
 // wave-private LDS tiles: ordering between a wave's own ds_write / ds_read needs no workgroup barrier
@@ -481,12 +479,7 @@ __device__ __forceinline__ void stem_wave_sync() {
 #define STEM_BWD_WGS 3      // waves per SIMD the register allocation aims at (153 + 16 registers sat one above the three-wave step: 180 -> 173 us)
 #endif
 // AT: element type of the pooled gradient and of the raw conv output y in the FUSED form (bf16 activation storage)
-// RECOMP (round 6): the raw conv output y is not read (255 MB of the kernel's 470 at the benchmark shape) but recomputed from the patch
-// tile the filter product needs anyway: y = [P | 1] [W ; b], 14 more float32 MFMA steps per 32 rows, handed from the accumulator layout
-// to the (row, channel chunk) lanes through the wave's D tile.  y enters only xhat (a VALUE: the float32-MFMA sum differs from the
-// forward's fmaf chain in the last bits); the ReLU6 DECISION comes from bit 7 of the argmax code, which the pool forward derived from
-// the activation it stored -- a gradient arrives only at argmax positions, so no other position needs a mask.
-template <bool FUSED, int NCH, class AT = float, bool RECOMP = false>
+template <bool FUSED, int NCH, class AT = float>
 __global__ void __launch_bounds__(256, STEM_BWD_WGS) stem_bwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ part, int B, int T, int H, int W, int Ho,
                                                             int Wo, int Cout, int rows, int rows_per, StemBnBwd bb) {
@@ -517,21 +510,13 @@ __global__ void __launch_bounds__(256, STEM_BWD_WGS) stem_bwd_mfma_kernel(const 
         }
         __syncthreads();
     }
-    __shared__ float WB[RECOMP ? 28 : 1][32];       // RECOMP: [W ; b], zero beyond Cout (B fragments of the y product: row 2 s + lk, column lcol)
-    if (RECOMP) {
-        for (int i = tid; i < 28 * 32; i += 256) {
-            const int k = i >> 5, c = i & 31;
-            WB[k][c] = c < Cout ? (k < 27 ? bb.w[k * Cout + c] : bb.bias[c]) : 0.0f;
-        }
-        __syncthreads();
-    }
     constexpr int nch = NCH;                         // 16-byte channel chunks per half-wave lane (3 for 24 channels)
     __amdgpu_buffer_rsrc_t rsDP, rsAM, rsY;
     if (FUSED) {
         const int64_t pel = (int64_t)B * T * bb.ps.Ho * bb.ps.Wo * Cout;
         rsDP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.ps.dp), 0, (int)(pel * sizeof(AT)), 0x00020000);
         rsAM = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bb.ps.argmax), 0, (int)pel, 0x00020000);
-        if (!RECOMP) rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.y), 0, (int)((int64_t)rows * Cout * sizeof(AT)), 0x00020000);
+        rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.y), 0, (int)((int64_t)rows * Cout * sizeof(AT)), 0x00020000);
     }
     for (int base = r0; base < r1; base += 128) {
         const int wrow0 = base + wave * 32;
@@ -563,16 +548,13 @@ __global__ void __launch_bounds__(256, STEM_BWD_WGS) stem_bwd_mfma_kernel(const 
             const int o1 = (j1 / 9) * W * 3 + (j1 % 9);
             pv[jj] = xp[half ? o1 : o0];
         }
-        auto store_patch = [&]() {
 #pragma unroll
-            for (int jj = 0; jj < 14; ++jj) {
-                float val = pv[jj];
-                if (jj == 13 && half) val = 1.0f;
-                if (!ok) val = 0.0f;
-                P[wave][r][half * 14 + jj] = val;
-            }
-        };
-        if (!(FUSED && RECOMP)) store_patch();
+        for (int jj = 0; jj < 14; ++jj) {
+            float val = pv[jj];
+            if (jj == 13 && half) val = 1.0f;
+            if (!ok) val = 0.0f;
+            P[wave][r][half * 14 + jj] = val;
+        }
         if (FUSED) {
             // gradient tile: the lane's nch chunks of 4 channels of its row.  dz is gathered from the pooled gradient through
             // the argmax (<= 4 candidate windows), masked by ReLU6, then dy = k1*(dz - k2 - xhat*k3).
@@ -625,22 +607,9 @@ __global__ void __launch_bounds__(256, STEM_BWD_WGS) stem_bwd_mfma_kernel(const 
                     gd[j][w4] = load4(rsDP, eo);
                     ga[j][w4] = __builtin_amdgcn_raw_buffer_load_b32(rsAM, eo, 0, 0);
                 }
-                if (!RECOMP) gy[j] = load4(rsY, (on && yo != OOR) ? yo + c0 : OOR);
+                gy[j] = load4(rsY, (on && yo != OOR) ? yo + c0 : OOR);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (RECOMP) {
-                // y tile of the wave's 32 rows while the gathers are in flight: [P | 1] [W ; b] in the accumulator layout -> D[row][channel]
-                store_patch();
-                stem_wave_sync();
-                f32x16_c ya;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) ya[i] = 0.0f;
-#pragma unroll
-                for (int s2 = 0; s2 < 14; ++s2) ya = __builtin_amdgcn_mfma_f32_32x32x2f32(P[wave][lcol][2 * s2 + lk], WB[2 * s2 + lk][lcol], ya, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) D[wave][(i & 3) + 8 * (i >> 2) + 4 * lk][lcol] = ya[i];
-                stem_wave_sync();
-            }
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const int c0 = (half * nch + j) * 4;
@@ -650,21 +619,13 @@ __global__ void __launch_bounds__(256, STEM_BWD_WGS) stem_bwd_mfma_kernel(const 
                 for (int i = 0; i < 4; ++i) {
                     float d = 0.0f;
 #pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4)       // (RECOMP: a code with bit 7 set -- ReLU6 closed at the winner -- matches no window)
-                        if (((ga[j][w4] >> (8 * i)) & (RECOMP ? 0xffu : 0x7fu)) == wk[w4]) d += __uint_as_float(gd[j][w4][i]);
-                    float v;
-                    if (RECOMP) {
-                        v = D[wave][r][c0 + i];
-                        if (sizeof(AT) == 2) v = (float)(bf16_t)v;      // bf16 storage: xhat from the value as it was stored
-                    } else {
-                        v = __uint_as_float(gy[j][i]);
-                    }
+                    for (int w4 = 0; w4 < 4; ++w4)
+                        if (((ga[j][w4] >> (8 * i)) & 0x7fu) == wk[w4]) d += __uint_as_float(gd[j][w4][i]);
+                    const float v = __uint_as_float(gy[j][i]);
                     const float mean = CF[gs][0][c0 + i], inv = CF[gs][1][c0 + i], sc = CF[gs][2][c0 + i], sh = CF[gs][3][c0 + i];
                     const float k1 = CF[gs][4][c0 + i], k2 = CF[gs][5][c0 + i], k3 = CF[gs][6][c0 + i];
-                    if (!RECOMP) {
-                        const float z = fmaf(sc, v, sh);
-                        if (!relu6_open(z)) d = 0.0f;
-                    }
+                    const float z = fmaf(sc, v, sh);
+                    if (!relu6_open(z)) d = 0.0f;
                     const float xh = (v - mean) * inv;
                     o[i] = ok ? k1 * (d - k2 - xh * k3) : 0.0f;
                 }
@@ -730,8 +691,7 @@ int stem_bwd_filter(const float* x, const float* dy, float* dw, float* db, int B
 bool stem_bwd_fused_supported(int Cout) { return Cout <= 32 && (Cout % 4) == 0; }
 
 int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, const float* stats, const float* coef, float* dw,
-                          float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st, int at, const float* w,
-                          const float* bias) {
+                          float* db, int B, int T, int H, int W, int Cout, double* part, hipStream_t st, int at) {
     if (!stem_bwd_fused_supported(Cout)) {
         set_error("stem_bwd_filter_fused: Cout=%d not supported", Cout);
         return -1;
@@ -745,32 +705,20 @@ int stem_bwd_filter_fused(const float* x, const PoolSrc& ps, const float* y, con
     float* pf = reinterpret_cast<float*>(part);
     int rows_per = cdiv(cdiv(rows, stem_nblk()), 128) * 128;
     const int nblk = cdiv(rows, rows_per);
-    StemBnBwd bb{ps, y, stats, coef, w, bias};
+    StemBnBwd bb{ps, y, stats, coef};
     const bool n3 = ((Cout >> 2) + 1) / 2 <= 3;
-    // y null (cdrl_stem_block_bwd_recompute) or CDRL_STEM_RECOMP=1: y is recomputed from the patch tile.  Measured in the update-step:
-    // 192.7 vs 169 us per launch, 13.31-13.35 vs 13.30-13.31 ms -- the kernel is bound by its gathers (41 load instructions per 32
-    // rows through one texture path per CU), not by the 255 MB the recompute saves, so the engine keeps reading y.
-    static const bool recomp_on = cdrl_getenv("CDRL_STEM_RECOMP") && atoi(cdrl_getenv("CDRL_STEM_RECOMP")) == 1;
-    const bool rc = w && bias && (recomp_on || !y);
-    if (!rc && !y) {
-        set_error("stem_bwd_filter_fused: neither y nor (w, bias) given");
-        return -1;
-    }
-#define CDRL_STEM_BWD_LAUNCH(NCHN, ATT, RC)                                                                                              \
-    hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, NCHN, ATT, RC>), dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, \
-                       rows, rows_per, bb)
-    if (rc) {
-        if (at && n3) CDRL_STEM_BWD_LAUNCH(3, bf16_t, true);
-        else if (at) CDRL_STEM_BWD_LAUNCH(4, bf16_t, true);
-        else if (n3) CDRL_STEM_BWD_LAUNCH(3, float, true);
-        else CDRL_STEM_BWD_LAUNCH(4, float, true);
-    } else {
-        if (at && n3) CDRL_STEM_BWD_LAUNCH(3, bf16_t, false);
-        else if (at) CDRL_STEM_BWD_LAUNCH(4, bf16_t, false);
-        else if (n3) CDRL_STEM_BWD_LAUNCH(3, float, false);
-        else CDRL_STEM_BWD_LAUNCH(4, float, false);
-    }
-#undef CDRL_STEM_BWD_LAUNCH
+    if (at && n3)
+        hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, 3, bf16_t>), dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                           rows_per, bb);
+    else if (at)
+        hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, 4, bf16_t>), dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                           rows_per, bb);
+    else if (n3)
+        hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, 3>), dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                           rows_per, bb);
+    else
+        hipLaunchKernelGGL((stem_bwd_mfma_kernel<true, 4>), dim3(nblk), dim3(256), 0, st, x, nullptr, pf, B, T, H, W, Ho, Wo, Cout, rows,
+                           rows_per, bb);
     CDRL_LAUNCH_CHECK();
     // (the engine's arena holds the bias gradient right behind the filter gradient: one reduce over the 28 * Cout columns of a partial)
     if (db == dw + 27 * Cout) return reduce_partials_f32(pf, nblk, (int64_t)28 * Cout, (int64_t)28 * Cout, dw, 0, st);

@@ -1281,7 +1281,7 @@ void Learner::build_trunk(std::vector<Op>& ops) {
                 PoolSrc ps = make_pool_src(argmax, pool.g, Hs, Ws);
                 static const bool diag_skip = cdrl_getenv("CDRL_DIAG_SKIP_STEMF") && atoi(cdrl_getenv("CDRL_DIAG_SKIP_STEMF")) == 1;    // timing diagnostics only (no stem filter gradient)
                 if (!diag_skip)
-                    CDRL_TRY(stem_bwd_filter_fused(in_image_, ps, y.p, stem_stats, stem_coef, w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side, at, w.p, b.p));
+                    CDRL_TRY(stem_bwd_filter_fused(in_image_, ps, y.p, stem_stats, stem_coef, w.g, b.g, B, T, H, W, Cs, fparts_[slot_], side, at));
                 return done_side(side);
             }
             hipStream_t side = fork_side(st);

@@ -466,15 +466,6 @@ int cdrl_stem_block_bwd(const float* x, const float* y, const float* stats, cons
 int cdrl_stem_block_bwd_pooled(const float* x, const float* y, const float* stats, const uint8_t* argmax, const float* dp,
                                const float* pooled, int B, int T, int H, int W, int Cout, float* dgamma, float* dbeta, float* coef,
                                float* dw, float* db, double* workspace, int act_type, void* stream);
-/* Same, with the filter gradient's operand load RECOMPUTING the raw conv output from the image patches it holds anyway
- * (y = [patch | 1] [w ; bias], float32 MFMA) instead of reading y: what the engine runs since round 6 (255 of the kernel's 470 MB at
- * B = 256, 4 x 90 x 120 x 3).  w: the conv's filter (3,3,3,Cout), bias (Cout).  y is read only by the BatchNorm sums' rare fallbacks
- * (channels with |gamma * invstd| < 0.05; bf16 storage: pooled values stored as exactly 6.0).  The ReLU6 decision comes from bit 7 of
- * the argmax codes cdrl_maxpool_bn_fwd wrote.  Agrees with cdrl_stem_block_bwd_pooled to float32 rounding, not bit-wise. */
-int cdrl_stem_block_bwd_recompute(const float* x, const float* w, const float* bias, const float* y, const float* stats,
-                                  const uint8_t* argmax, const float* dp, const float* pooled, int B, int T, int H, int W, int Cout,
-                                  float* dgamma, float* dbeta, float* coef, float* dw, float* db, double* workspace, int act_type,
-                                  void* stream);
 
 /* Rollout-time image augmentation of one observation stack (CARLAgent.augment, core/carla_agent.py:545-577; ops of
  * rl/augmentations/augmentations.py and simclr.color_jitter): color jitter (brightness -> contrast -> saturation -> hue ->

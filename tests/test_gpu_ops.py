@@ -511,16 +511,6 @@ def test_stem_block_bwd(lib, B, T, H, W):
     assert rel_err(dbt2.cpu().numpy(), p['b.beta'].grad.numpy()) < 2e-5
     assert rel_err(dw2.cpu().numpy(), wt.grad.numpy()) < 3e-5
     assert torch.equal(dbt, dbt2)                                       # sum dz: same decisions, same addends
-    # the recompute form (round 6: the filter-gradient kernel rebuilds y from its patch tile and takes the ReLU6 decision from bit 7
-    # of the argmax codes -- what the engine runs); the sums are those of the pooled form bit for bit, the filter gradient agrees to rounding
-    dg3, dbt3, coef3 = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(3 * T * Cc, device=DEV)
-    dw3, db3 = torch.zeros((3, 3, 3, Cc), device=DEV), torch.zeros(Cc, device=DEV)
-    _lib.check(lib.cdrl_stem_block_bwd_recompute(P(X), P(Wd), P(Bd), P(y), P(stats), P(am), P(DP), P(pool), B, T, H, W, Cc, P(dg3), P(dbt3),
-                                                 P(coef3), P(dw3), P(db3), P(ws), S()))
-    assert torch.equal(dg2, dg3) and torch.equal(dbt2, dbt3) and torch.equal(coef2, coef3)
-    assert rel_err(dw3.cpu().numpy(), wt.grad.numpy()) < 3e-5
-    assert rel_err(dw3.cpu().numpy(), dw2.cpu().numpy()) < 2e-6
-    assert np.abs(db3.cpu().numpy()).max() < 1e-4 * np.abs(dw3.cpu().numpy()).max()
     assert int((am >= 128).sum()) > 0 and int((am.to(torch.int32) & 127).max()) <= 8        # ReLU6 flag in bit 7 of the codes
 
 
